@@ -1,0 +1,263 @@
+"""Pins the CPU oracle against the golden vectors captured from the reference
+(tests/golden/gen_golden.py).  Runs on CPU; no GPU, no /root/reference."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import assert_close, GOLDEN
+
+
+def test_toy_hmm(oracle, golden):
+    g = golden("toy_hmm")
+    b = oracle.map_b(g["B"], g["obs"])
+    assert np.array_equal(b, g["b"])
+    alpha = oracle.forward(g["A"], g["pi"], b)
+    beta = oracle.backward(g["A"], b)
+    assert np.array_equal(alpha, g["alpha"]) and np.array_equal(beta, g["beta"])
+    v, bt, path = oracle.viterbi(g["A"], g["pi"], b)
+    assert np.array_equal(v, g["v"]) and np.array_equal(bt, g["bt"]) and np.array_equal(path, g["path"])
+    assert bt.dtype == np.uint32 and path.dtype == np.uint32
+    assert path.tolist() == [0, 1, 0]
+    xi, gamma = oracle.baumwelch(g["A"], b, alpha, beta)
+    assert_close(xi, g["xi"], 1e-14), assert_close(gamma, g["gamma"], 1e-14)
+    assert np.all(np.isneginf(gamma[-1]))
+    with np.errstate(all="ignore"):
+        est = oracle.estimate_discrete(g["obs"], 3, xi, gamma)
+    assert_close(est["A"], g["est_A"], 1e-13)
+    assert_close(est["B"], g["est_B"], 1e-13)
+    assert_close(est["pi"], g["est_pi"], 1e-13)
+    assert np.isneginf(est["B"][:, 1]).all()          # symbol 1 never observed
+    assert oracle.loglik(alpha) == g["calc_prob"]
+    assert abs(np.exp(g["calc_prob"]) - 0.028562) < 1e-9
+
+
+def test_hmm_train(oracle, golden):
+    g = golden("hmm_train_4x5")
+    obs = g["obs"]
+    b = oracle.map_b(g["B0"], obs)
+    alpha = oracle.forward(g["A0"], g["pi0"], b)
+    beta = oracle.backward(g["A0"], b)
+    assert np.array_equal(alpha, g["alpha"]) and np.array_equal(beta, g["beta"])
+    xi, gamma = oracle.baumwelch(g["A0"], b, alpha, beta)
+    assert_close(xi, g["xi"], 1e-13), assert_close(gamma, g["gamma"], 1e-13)
+    A, B, pi = g["A0"], g["B0"], g["pi0"]
+    log = []
+    for k in range(3):
+        A, B, pi = oracle.train_hmm_discrete(A, B, pi, obs, 1, 0.0, log)
+        assert_close(A, g["A%d" % (k + 1)], 1e-11), assert_close(B, g["B%d" % (k + 1)], 1e-11)
+        assert_close(pi, g["pi%d" % (k + 1)], 1e-11)
+    assert "\n".join(log) + "\n" == str(g["train_log"])
+    log3 = []
+    A3, _, _ = oracle.train_hmm_discrete(g["A0"], g["B0"], g["pi0"], obs, 3, 1e-4, log3)
+    assert "\n".join(log3) + "\n" == str(g["train3_log"])
+    assert_close(A3, g["train3_A"], 1e-11)
+    v, bt, path = oracle.viterbi(g["A3"], g["pi3"], oracle.map_b(g["B3"], obs))
+    assert np.array_equal(path, g["path3"]) and np.array_equal(bt, g["bt3"])
+    assert_close(v, g["v3"], 1e-12)
+
+
+def test_discrete_mid(oracle, golden):
+    g = golden("hmm_discrete_16x24")
+    b = oracle.map_b(g["B"], g["obs"])
+    alpha = oracle.forward(g["A"], g["pi"], b)
+    beta = oracle.backward(g["A"], b)
+    assert np.array_equal(alpha, g["alpha"]) and np.array_equal(beta, g["beta"])
+    v, bt, path = oracle.viterbi(g["A"], g["pi"], b)
+    assert np.array_equal(v, g["v"]) and np.array_equal(bt, g["bt"]) and np.array_equal(path, g["path"])
+    xi, gamma = oracle.baumwelch(g["A"], b, alpha, beta)
+    assert_close(gamma, g["gamma"], 1e-12)
+    assert_close(xi[0], g["xi_t0"], 1e-12), assert_close(xi[-2], g["xi_tlast"], 1e-12)
+    est = oracle.estimate_discrete(g["obs"], 24, xi, gamma)
+    assert_close(est["A"], g["est_A"], 1e-11), assert_close(est["B"], g["est_B"], 1e-11)
+
+
+@pytest.mark.parametrize("tag", ["", "_f32"])
+def test_gmmhmm_small(oracle, golden, tag):
+    g = golden("gmmhmm_small" + tag)
+    prec = np.float32 if tag else np.float64
+    tol = 2e-5 if tag else 1e-10
+    atol = 2e-5 if tag else 1e-12
+    b, bm = oracle.gmm_map_b(g["obs"], g["w"], g["mu"], g["si"], prec)
+    assert b.dtype == prec
+    assert_close(b, g["b"], tol, atol), assert_close(bm, g["bm"], tol, atol)
+    # trellises on the GOLDEN b: exact for Viterbi
+    alpha = oracle.forward(g["A"], g["pi"], g["b"], prec)
+    beta = oracle.backward(g["A"], g["b"], prec)
+    assert_close(alpha, g["alpha"], tol, atol), assert_close(beta, g["beta"], tol, atol)
+    v, bt, path = oracle.viterbi(g["A"], g["pi"], g["b"], prec)
+    assert np.array_equal(v, g["v"]) and np.array_equal(bt, g["bt"]) and np.array_equal(path, g["path"])
+    # end to end from the oracle's own b: path must still be identical
+    assert np.array_equal(oracle.viterbi(g["A"], g["pi"], b, prec)[2], g["path"])
+    xi, gamma = oracle.baumwelch(g["A"], g["b"], g["alpha"], g["beta"], prec)
+    assert_close(xi, g["xi"], 10 * tol, 10 * atol), assert_close(gamma, g["gamma"], 10 * tol, 10 * atol)
+    est = oracle.estimate_gmm(g["obs"], g["w"], g["mu"], g["bm"], g["alpha"], g["beta"], g["xi"], g["gamma"],
+                              precision=prec)
+    for k in ("A", "pi", "w", "mu", "si"):
+        assert_close(est[k], g["est_" + k], 50 * tol, 50 * atol, msg=k)
+    if not tag:
+        log = []
+        A, pi, w, mu, si = oracle.train_gmmhmm(g["A"], g["pi"], g["w"], g["mu"], g["si"], g["obs"], 3, 0.0, log)
+        assert "\n".join(log) + "\n" == str(g["train_log"])
+        for k, val in (("A", A), ("pi", pi), ("w", w), ("mu", mu), ("si", si)):
+            assert_close(val, g["train3_" + k], 1e-8, 1e-10, msg=k)
+        assert np.array_equal(oracle.viterbi(A, pi, oracle.gmm_map_b(g["obs"], w, mu, si)[0])[2], g["train3_decode"])
+
+
+@pytest.mark.parametrize("kind", ["diag", "full"])
+def test_gmmhmm_d39(oracle, golden, kind):
+    g = golden("gmmhmm_d39_" + kind)
+    if kind == "diag":
+        N, M, D = g["mu"].shape
+        si = np.zeros((N, M, D, D))
+        si[:, :, np.arange(D), np.arange(D)] = g["var"]
+        b2, bm2 = oracle.gmm_map_b_diag(g["obs"], g["w"], g["mu"], g["var"])
+        assert_close(b2, g["b"], 1e-12), assert_close(bm2, g["bm"], 1e-12)
+        assert np.array_equal(oracle.viterbi(g["A"], g["pi"], b2)[2], g["path"])
+    else:
+        si = g["si"]
+    b, bm = oracle.gmm_map_b(g["obs"], g["w"], g["mu"], si)
+    assert_close(b, g["b"], 1e-12), assert_close(bm, g["bm"], 1e-12)
+    alpha = oracle.forward(g["A"], g["pi"], g["b"])
+    beta = oracle.backward(g["A"], g["b"])
+    assert np.array_equal(alpha, g["alpha"]) and np.array_equal(beta, g["beta"])
+    v, bt, path = oracle.viterbi(g["A"], g["pi"], g["b"])
+    assert np.array_equal(v, g["v"]) and np.array_equal(bt, g["bt"]) and np.array_equal(path, g["path"])
+    assert np.array_equal(oracle.viterbi(g["A"], g["pi"], b)[2], g["path"])
+    assert oracle.loglik(alpha) == g["loglik"][0]
+    xi, gamma = oracle.baumwelch(g["A"], g["b"], alpha, beta)
+    assert_close(gamma, g["gamma"], 1e-11)
+    est = oracle.estimate_gmm(g["obs"], g["w"], g["mu"], g["bm"], alpha, beta, xi, gamma)
+    for k in ("A", "pi", "w", "mu", "si"):
+        assert_close(est[k], g["est_" + k], 1e-9, 1e-11, msg=k)
+
+
+def test_bw_stats_single_utterance_equals_estimate(oracle, golden):
+    """SURVEY 8e parity definition: with U=1 the accumulated statistics reproduce X3/H7."""
+    g = golden("gmmhmm_d39_diag")
+    st = oracle.bw_stats_diag([g["obs"]], g["A"], g["pi"], g["w"], g["mu"], g["var"])
+    m = oracle.mstep_from_stats(st)
+    assert_close(m["A"], g["est_A"], 1e-9), assert_close(m["pi"], g["est_pi"], 1e-9)
+    assert_close(m["w"], g["est_w"], 1e-9), assert_close(m["mu"], g["est_mu"], 1e-9)
+    D = g["mu"].shape[2]
+    assert_close(m["var"], g["est_si"][:, :, np.arange(D), np.arange(D)], 1e-9)
+    assert abs(st["loglik"] - g["loglik"][0]) < 1e-9
+
+
+def test_metric_slice(oracle, golden, synth):
+    """Metric config N=128, M=16, D=39, T=1000: bit-identical paths at scale."""
+    g = golden("gmmhmm_metric_slice")
+    N, M, D, T, U = g["shape"]
+    mdl = synth.synth_model(N, M, D, seed=1)
+    obs = synth.synth_obs(U, T, D, seed=1000)
+    assert obs.sum() == g["obs_sum"][0] and mdl["mu"].sum() == g["mu_sum"][0]   # input drift guard
+    for u in range(U):
+        b, bm = oracle.gmm_map_b_diag(obs[u], mdl["w"], mdl["mu"], mdl["var"])
+        assert_close(b[g["sample_j"], g["sample_t"]], g["b_sample"][u], 1e-12)
+        assert_close(bm[g["sample_j"], g["sample_m"], g["sample_t"]], g["bm_sample"][u], 1e-12)
+        assert abs(b.sum() - g["b_sum"][u]) < 1e-6
+        v, bt, path = oracle.viterbi(mdl["A"], mdl["pi"], b)
+        assert np.array_equal(path, g["path"][u])
+        assert_close(v[-1], g["v_last"][u], 1e-12)
+        ll = oracle.loglik(oracle.forward(mdl["A"], mdl["pi"], b[:, :32]))
+        assert abs(ll - g["loglik32"][u]) < 1e-9 * abs(ll)
+    # reference-shaped loop (CPU baseline line A) on a short prefix gives the same path prefix semantics
+    p_ref = oracle.decode_refshaped(obs[0][:20], mdl["A"], mdl["pi"], mdl["w"][:, :], mdl["mu"], mdl["si"])
+    p_vec = oracle.decode_diag(obs[0][:20], mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"])
+    assert np.array_equal(p_ref, p_vec)
+
+
+def test_gmm_funcs(oracle, golden):
+    g = golden("gmm_funcs")
+    assert_close(oracle.gaussian(g["x1"], 0, 4), g["g1"], 1e-14)
+    assert_close(oracle.gaussian_log(g["x1"], 0, 4), g["g1_log"], 1e-14)
+    mu0 = np.zeros(2)
+    assert_close(oracle.gaussian_multi(g["x2"], mu0, g["Sigma"]), g["g2"], 1e-13)
+    assert_close(oracle.gaussian_multi_log(g["x2"], mu0, g["Sigma"]), g["g2_log"], 1e-13)
+    gm = oracle.gaussian_mixture(g["c"], g["x3"], g["mu3"], g["Sigma3"])
+    assert gm.shape == g["gm"].shape == (1, 169)
+    assert_close(gm, g["gm"], 1e-13)
+    assert_close(oracle.gaussian_mixture_log(np.log(g["c"]), g["x3"], g["mu3"], g["Sigma3"]), g["gm_log"], 1e-13)
+    assert_close(oracle.gaussian_mixture_log(g["c39"], g["x39"], g["mu39"], g["Sigma39"]), g["gm39_log"], 1e-12)
+
+
+def test_lse_cases(oracle, golden):
+    g = golden("lse_cases")
+    a = g["a"]
+    i = np.array([0, 0, 1])
+    assert np.array_equal(oracle.lse2(a), g["lse2_all"])
+    assert np.array_equal(oracle.lse2(a, axis=0), g["lse2_0"])
+    assert np.array_equal(oracle.lse2(a, axis=2), g["lse2_2"])
+    assert np.array_equal(oracle.lse2(a, axis=(0, 2)), g["lse2_t02"])
+    assert np.array_equal(oracle.lse2(a[:, 2 == i, :], axis=1), g["lse2_sel2"])
+    assert np.array_equal(oracle.lse2(a[:, 0 == i, :], axis=1), g["lse2_sel0"])
+    assert np.array_equal(oracle.lse(a), g["lse_all"])
+    for ax, key in ((0, "lse_0"), (1, "lse_1"), (2, "lse_2"), ((0, 2), "lse_t02"), ((0, 1, 2), "lse_t012")):
+        assert np.array_equal(oracle.lse(a, axis=ax), g[key])
+    r = g["r"]
+    for ax, key in ((0, "r_lse0"), (1, "r_lse1"), (2, "r_lse2"), (None, "r_lse_all"), ((1, 2), "r_lse_t12")):
+        assert np.array_equal(oracle.lse(r, axis=ax), g[key]), key
+    assert np.array_equal(oracle.lse2(r, axis=1), g["r_lse2_1"])
+    assert np.isneginf(oracle.lse(r, axis=1)[2, 1]) and np.isneginf(oracle.lse(r, axis=2)[3, 5])
+    e = np.zeros((3, 0, 4))
+    out = oracle.lse(e, axis=1)
+    assert out.shape == tuple(g["empty_shape"]) and np.isneginf(out).all()
+    assert np.array_equal(oracle.lse(g["one"], axis=1), g["one_lse1"])
+
+
+def test_frames(oracle, golden):
+    g = golden("frames")
+    assert np.array_equal(oracle.split_frames(np.arange(30), 3, 2), g["f30"])
+    assert np.array_equal(oracle.create_hamming(400), g["ham400"])
+    assert np.array_equal(oracle.create_hamming(7), g["ham7"])
+    for n, nf, L in g["shapes"]:
+        f = oracle.split_frames(np.arange(n, dtype=np.float64), 400, 160)
+        assert f.shape == (nf, L)
+        key = "f_n%d" % n
+        if key in g.files:
+            assert np.array_equal(f, g[key])
+    assert np.array_equal(oracle.split_frames(np.arange(23.0), 5, 5), g["f_L5S5"])
+    assert np.array_equal(oracle.split_frames(np.arange(9.0), 4, 1), g["f_L4S1"])
+
+
+def test_mfcc_data_raw(oracle, golden):
+    g = golden("mfcc_data_raw")
+    sig = np.frombuffer(open(os.path.join(GOLDEN, "data.raw"), "rb").read(), dtype=np.int16)
+    assert len(sig) == g["n_samples"][0] == 21751
+    assert sig.astype(np.int64).sum() == g["sig_sum"][0]
+    cfg = oracle.MfccCfg()
+    assert np.array_equal(oracle.mel_bin_edges(cfg), g["bin_edges"])
+    fb = oracle.filter_bank(cfg)
+    assert np.array_equal(fb, g["fbank"])
+    assert (fb.max(axis=1) == 1.0).all() and (fb[:, 255:] == 0).all()
+    assert_close(oracle.mel([0.0, 700.0, 8000.0]), g["mel_pts"], 1e-15)
+    assert_close(oracle.mel_inv([0.0, 1000.0, 2595.0]), g["mel_inv_pts"], 1e-15)
+    assert np.array_equal(oracle.high_pass(sig.astype(np.float64), 0.97)[:8], g["hpf_head"])
+    power, cep, feat = oracle.mfcc(sig.astype(np.float64))
+    assert feat.shape == (135, 39) and cep.shape == (135, 40) and power.shape == (135, 257)
+    assert_close(power[:3], g["power_head"], 1e-11, 1e-9)
+    assert_close(power.sum(axis=1), g["power_rowsum"], 1e-12)
+    assert_close(cep, g["cepstrum"], 1e-10, 1e-10)
+    assert_close(feat, g["features"], 1e-10, 1e-10)
+    assert np.allclose(cep[:, 1:13].mean(axis=0), -1e-8, atol=1e-12)     # the view quirk (mfcc.py:155-156)
+    assert np.array_equal(feat[0, 13:26], feat[1, :13])                  # delta row 0 = features[1]
+
+
+def test_mfcc_synth(oracle, golden, synth):
+    g = golden("mfcc_synth_small")
+    p, c, f = oracle.mfcc(g["signal"])
+    assert_close(p, g["power"], 1e-10, 1e-7), assert_close(c, g["cepstrum"], 1e-10, 1e-10)
+    assert_close(f, g["features"], 1e-10, 1e-10)
+    assert_close(oracle.mfcc(g["signal_i16"].astype(np.float64))[2], g["features_i16"], 1e-10, 1e-10)
+    g = golden("mfcc_synth")
+    s = synth.synth_signal(int(g["n"][0]), seed=int(g["seed"][0]))
+    assert s.sum() == g["sig_sum"][0]
+    p, c, f = oracle.mfcc(s)
+    assert f.shape == (1000, 39)
+    assert_close(f, g["features"], 1e-10, 1e-10)
+    g = golden("mfcc_alt_params")
+    cfg = oracle.MfccCfg(fs=8000, frame_T=32e-3, frame_stride=16e-3, hpf_alpha=0.95, fft_N=256,
+                         mfbank_num=26, cepstrum_num=12)
+    assert np.array_equal(oracle.filter_bank(cfg), g["fbank"])
+    p, c, f = oracle.mfcc(g["signal"], cfg)
+    assert_close(c, g["cepstrum"], 1e-10, 1e-10), assert_close(f, g["features"], 1e-10, 1e-10)
