@@ -1,0 +1,198 @@
+/*
+ * lnasr_hip.h -- C-ABI of the MI355X (gfx950) GMM-HMM acoustic-scoring / decoding path.
+ *
+ * Drop-in boundary for yehuohan/ln-asr's numpy hot path.  The reference has no
+ * FFI of its own on this path: its boundary is the Python class /
+ * function surface.  Each entry point below therefore cites the reference
+ * function (file:line under the reference checkout) whose arithmetic it
+ * replaces; `ln-asr_amd/lnasr/_ffi.py` is the only caller (ctypes) and
+ * `INTEGRATION.md` shows the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns int: 0 = ok, negative = error (LNASR_E_*); the
+ *     message is available from lnasr_last_error() (thread-local).  No C++
+ *     exception crosses this boundary.
+ *   - one context = one process = one GPU (one HIP device, one compute stream).
+ *     Calls on one context are not re-entrant.
+ *   - data pointers are plain pointers to contiguous row-major arrays and may be
+ *     HOST or DEVICE memory (device memory from lnasr_dev_alloc); the library
+ *     detects which (hipPointerGetAttributes).  Host buffers are staged through
+ *     the context's workspace; device buffers are used in place.  Calls are
+ *     synchronous with respect to host buffers; with device buffers they only
+ *     enqueue on the context's stream (use lnasr_sync()).
+ *   - all probabilities are natural-log (hmm.py:27-33).  A[i*N+j] is i -> j.
+ *   - BATCH-FIRST, FRAME-MAJOR layouts (U utterances, T frames, N states,
+ *     M mixtures, D dims):   obs [U,T,D]   b [U,T,N]   bm [U,T,N,M]
+ *     alpha/beta/v [U,T,N]   bt [U,T,N] u32   path [U,T] u32   xi [U,T,N,N]
+ *     The reference's single-utterance arrays are views of these with U = 1
+ *     (its `b` [N,T] is b[0].T, its `bm` [N,M,T] is bm[0].transpose(1,2,0)).
+ *   - `lens` (optional, may be NULL): int32 [U] true length of each utterance
+ *     (1 <= lens[u] <= T); rows t >= lens[u] of the outputs are left untouched.
+ *   - `dtype`: storage type of b/bm/alpha/beta/v/xi/gamma buffers, LNASR_F64 or
+ *     LNASR_F32.  As in the reference (`precision=`, hmm.py:38) arithmetic is
+ *     fp64 either way (A, pi, w are fp64 there); F32 rounds at every store.
+ *     obs, model parameters, statistics and MFCC outputs are always fp64.
+ */
+#ifndef LNASR_HIP_H
+#define LNASR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LNASR_ABI_VERSION 1
+
+#define LNASR_F64 0
+#define LNASR_F32 1
+
+#define LNASR_OK 0
+#define LNASR_E_INVALID (-1)   /* bad argument / shape */
+#define LNASR_E_HIP (-2)       /* a HIP runtime call failed */
+#define LNASR_E_NOMODEL (-3)   /* no model uploaded for this call */
+#define LNASR_E_NODEVICE (-4)  /* no usable gfx950 device */
+#define LNASR_E_COMM (-5)      /* RCCL failure */
+#define LNASR_E_UNSUPPORTED (-6)
+
+typedef struct lnasr_ctx lnasr_ctx;
+
+/* ---- runtime ---------------------------------------------------------------- */
+int lnasr_abi_version(void);
+const char* lnasr_last_error(void);
+int lnasr_device_count(int* out);
+int lnasr_ctx_create(int device_id, lnasr_ctx** out);
+void lnasr_ctx_destroy(lnasr_ctx* ctx);
+int lnasr_sync(lnasr_ctx* ctx);
+int lnasr_device_info(lnasr_ctx* ctx, char* name, int name_cap, int* cu_count, size_t* hbm_bytes);
+
+/* device memory for HBM-resident inputs/outputs */
+int lnasr_dev_alloc(lnasr_ctx* ctx, size_t bytes, void** out);
+int lnasr_dev_free(lnasr_ctx* ctx, void* p);
+int lnasr_memcpy_h2d(lnasr_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int lnasr_memcpy_d2h(lnasr_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int lnasr_memset(lnasr_ctx* ctx, void* dst_dev, int byte, size_t bytes);
+
+/* per-kernel HIP-event timing on the context's own stream (bench.py roofline) */
+int lnasr_prof_enable(lnasr_ctx* ctx, int on);
+int lnasr_prof_reset(lnasr_ctx* ctx);
+int lnasr_prof_count(lnasr_ctx* ctx, int* n_kernels);
+int lnasr_prof_get(lnasr_ctx* ctx, int i, char* name, int name_cap, int64_t* launches, double* total_ms);
+
+/* ---- models ----------------------------------------------------------------- */
+/* GMM-HMM parameters: GMMHMM.__init__ (gmmhmm.py:34-44).  sigma_kind 0: full
+ * covariance [N,M,D,D] exactly as the reference stores `si` (inverted + log-det
+ * on the device with LU semantics, gmm.py:62-63; if every off-diagonal entry is
+ * exactly zero the diagonal kernels are used); sigma_kind 1: diagonal [N,M,D]. */
+int lnasr_model_upload(lnasr_ctx* ctx, int N, int M, int D,
+                       const double* logA, const double* logpi, const double* logw,
+                       const double* mu, const double* sigma, int sigma_kind);
+/* same, but never take the diagonal fast path (keeps the reference's full-Sigma arithmetic) */
+int lnasr_model_upload_full(lnasr_ctx* ctx, int N, int M, int D,
+                            const double* logA, const double* logpi, const double* logw,
+                            const double* mu, const double* sigma);
+/* transition-only model for the trellis entry points (HMM.__init__, hmm.py:36-45) */
+int lnasr_hmm_upload(lnasr_ctx* ctx, int N, const double* logA, const double* logpi);
+int lnasr_model_is_diag(lnasr_ctx* ctx, int* out);
+
+/* ---- emission --------------------------------------------------------------- */
+/* HMM._map_b (hmm.py:47-61): b[u,t,:] = B[:, obs[u,t]];  B is [N,K] */
+int lnasr_discrete_map_b(lnasr_ctx* ctx, const double* logB, int N, int K,
+                         const int32_t* obs, int U, int T, int dtype, void* b);
+/* GMMHMM._map_b (gmmhmm.py:46-67): b and (optionally) the per-mixture bm */
+int lnasr_gmm_logprob(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* lens,
+                      int dtype, void* b, void* bm_or_null);
+/* free functions of gmm.py (one Gaussian / one mixture, no HMM):
+ * gaussian_distribution{,_log} (gmm.py:16-30) */
+int lnasr_gauss1d(lnasr_ctx* ctx, const double* x, size_t L, double mu, double sigma2, int want_log, double* out);
+/* gaussian_multi_distribution{,_log} (gmm.py:32-68); Sigma [D,D], LU semantics */
+int lnasr_gauss_multi(lnasr_ctx* ctx, const double* x, size_t L, int D, const double* mu, const double* Sigma,
+                      int want_log, double* out);
+/* gaussian_mixture_distribution{,_log} (gmm.py:70-100); c is log-weights when want_log */
+int lnasr_gauss_mixture(lnasr_ctx* ctx, const double* c, int M, const double* x, size_t L, int D,
+                        const double* mu, const double* Sigma, int want_log, double* out);
+
+/* ---- trellises (use the uploaded logA / logpi) ---------------------------------- */
+/* HMM._viterbi (hmm.py:133-172): v, bt optional; path required.  best_score [U] optional. */
+int lnasr_viterbi(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* lens, int dtype,
+                  void* v_or_null, uint32_t* bt_or_null, uint32_t* path, double* best_score_or_null);
+/* GMMHMM.decode (hmm.py:276-283 -> gmmhmm.py:46-67 + hmm.py:133-172): emission + trellis +
+ * backtrace, b never leaves the device */
+int lnasr_decode(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* lens,
+                 uint32_t* path, double* best_score_or_null);
+/* HMM._forward (hmm.py:63-100) and calc_prob (hmm.py:268-274): alpha optional, loglik [U] optional */
+int lnasr_forward(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* lens, int dtype,
+                  void* alpha_or_null, double* loglik_or_null);
+/* HMM._backward (hmm.py:102-131) */
+int lnasr_backward(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* lens, int dtype, void* beta);
+/* GMMHMM.calc_prob: emission + forward, loglik [U] */
+int lnasr_calc_prob(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* lens, double* loglik);
+
+/* ---- Baum-Welch --------------------------------------------------------------- */
+/* HMM._baumwelch (hmm.py:174-200): xi [U,T,N,N], gamma [U,T,N]; frame lens-1 is -inf */
+int lnasr_baumwelch(lnasr_ctx* ctx, const void* b, const void* alpha, const void* beta,
+                    int U, int T, const int32_t* lens, int dtype, void* xi, void* gamma);
+/* HMM._estimate (hmm.py:202-225), single utterance: new logA [N,N], logB [N,K], logpi [N] */
+int lnasr_estimate_discrete(lnasr_ctx* ctx, const int32_t* obs, int T, int N, int K, int dtype,
+                            const void* xi, const void* gamma,
+                            void* logA_out, void* logB_out, void* logpi_out);
+/* GMMHMM._estimate (gmmhmm.py:69-156), single utterance, using the uploaded (old) w / mu:
+ * outputs logA [N,N], logpi [N], logw [N,M] in `dtype`; mu [N,M,D], si [N,M,D,D] fp64 */
+int lnasr_estimate_gmm(lnasr_ctx* ctx, const double* obs, int T, int dtype,
+                       const void* bm, const void* alpha, const void* beta,
+                       const void* xi, const void* gamma, double min_std,
+                       void* logA_out, void* logpi_out, void* logw_out, double* mu_out, double* si_out);
+
+/* Multi-utterance sufficient statistics (new): emission + forward + backward +
+ * posteriors accumulated on the device in the linear domain.  Packed fp64 layout of `stats`
+ * (length lnasr_bw_stats_len): xi_sum[N*N] gamma_sum[N] gamma0[N] mix[N*M] mix_x[N*M*D]
+ * mix_xx[N*M*D] (diagonal model) or [N*M*D*D] (full), loglik_sum[1], n_utt[1], n_frames[1]. */
+int lnasr_bw_stats_len(lnasr_ctx* ctx, size_t* n_doubles);
+int lnasr_bw_accumulate(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* lens, double* stats);
+/* M-step from (all-reduced) statistics: new logA, logpi, logw, mu, sigma (diag [N,M,D] or full) */
+int lnasr_bw_mstep(lnasr_ctx* ctx, const double* stats, double min_std,
+                   double* logA, double* logpi, double* logw, double* mu, double* sigma);
+
+/* ---- numeric utils ------------------------------------------------------------- */
+/* lse / lse2 (utils.py:140-204) along one axis of a 3-D view [outer, n, inner] -> [outer, inner] */
+int lnasr_lse(lnasr_ctx* ctx, const double* x, size_t outer, size_t n, size_t inner, int base2, double* out);
+
+/* ---- MFCC ------------------------------------------------------------------------ */
+typedef struct lnasr_mfcc_cfg {
+    int fs;            /* MFCC.__init__ (mfcc.py:23-48) */
+    int frame_len;     /* int(fs*frame_T)      = 400 */
+    int frame_step;    /* int(fs*frame_stride) = 160 */
+    int fft_n;         /* 512 (power of two, <= 4096) */
+    int n_mel;         /* 40 */
+    int n_cep;         /* 12 */
+    double hpf_alpha;  /* 0.97 */
+} lnasr_mfcc_cfg;
+/* split_frames frame count (utils.py:119) */
+int lnasr_num_frames(int64_t n_samples, int frame_len, int frame_step, int64_t* out);
+/* split_frames (utils.py:106-130): frames [Nf, L] fp64 */
+int lnasr_split_frames(lnasr_ctx* ctx, const double* signal, int64_t n, int L, int S, double* frames);
+/* MFCC.calc_mfcc (mfcc.py:108-175) over a batch of utterances concatenated in `signal`;
+ * offsets [U+1] (samples).  sample_kind 0: fp64 samples, 1: int16 PCM (read_pcm, utils.py:100-104).
+ * window [frame_len] and fbank [n_mel, fft_n/2+1] are the model constants (create_hamming
+ * utils.py:132-138, create_filter_bank mfcc.py:78-106).  Outputs are concatenated over
+ * utterances: power [sumNf, fft_n/2+1] (optional), cepstrum [sumNf, n_mel] (optional),
+ * features [sumNf, 3*(n_cep+1)]. */
+int lnasr_mfcc(lnasr_ctx* ctx, const void* signal, int sample_kind, const int64_t* offsets, int U,
+               const lnasr_mfcc_cfg* cfg, const double* window, const double* fbank,
+               double* power_or_null, double* cepstrum_or_null, double* features);
+
+/* ---- multi-GPU (one process per GPU, RCCL over xGMI) --------------------------------- */
+#define LNASR_UNIQUE_ID_BYTES 128
+int lnasr_comm_unique_id(void* id_out /* LNASR_UNIQUE_ID_BYTES */);
+int lnasr_comm_init(lnasr_ctx* ctx, const void* id, int rank, int nranks);
+int lnasr_comm_destroy(lnasr_ctx* ctx);
+/* gather of decoded state paths: every rank contributes count u32, receives nranks*count */
+int lnasr_allgather_u32(lnasr_ctx* ctx, const uint32_t* local, size_t count, uint32_t* all);
+/* sum all-reduce of packed Baum-Welch statistics, in place */
+int lnasr_allreduce_f64(lnasr_ctx* ctx, double* buf, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LNASR_HIP_H */

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Builds liblnasr_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python ln-asr_amd/build.py [--force] [--keep-temps]
+
+One object per csrc/*.hip (compiled in parallel, rebuilt only when stale), linked with RCCL
+into ln-asr_amd/lnasr/liblnasr_hip.so -- in-tree, so the library travels with the snapshot.
+"""
+import concurrent.futures as cf
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
+LIB = os.path.join(HERE, "lnasr", "liblnasr_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+         "-Wno-unused-variable", "-ffp-contract=on", "-I/opt/rocm/include"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, keep_temps=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
+    jobs = []
+    for s in srcs:
+        o = os.path.join(OBJ, os.path.basename(s)[:-4] + ".o")
+        if force or _stale(o, [s] + hdrs):
+            cmd = [HIPCC] + FLAGS + (["-save-temps=obj"] if keep_temps else []) + ["-c", s, "-o", o]
+            jobs.append((s, cmd))
+
+    def run(job):
+        s, cmd = job
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return s, r.returncode, r.stdout + r.stderr
+
+    failed = False
+    with cf.ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        for s, rc, out in ex.map(run, jobs):
+            if verbose or rc:
+                print("[hipcc] %s %s" % (os.path.basename(s), "ok" if rc == 0 else "FAILED"))
+            if out.strip() and (rc or verbose):
+                print(out)
+            failed |= rc != 0
+    if failed:
+        raise RuntimeError("hipcc failed")
+    objs = [os.path.join(OBJ, os.path.basename(s)[:-4] + ".o") for s in srcs]
+    if force or jobs or _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + \
+              ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode:
+            print(r.stdout + r.stderr)
+            raise RuntimeError("link failed")
+        if verbose:
+            print("[link] %s" % LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, keep_temps="--keep-temps" in sys.argv)

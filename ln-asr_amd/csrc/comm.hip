@@ -1,0 +1,77 @@
+// Multi-GPU exchange: one process per GPU, RCCL over xGMI.  Only two collectives exist on this
+// path: the gather of decoded state paths and the sum of Baum-Welch statistics.
+#include <rccl/rccl.h>
+
+#include "common.h"
+
+using namespace lnasr;
+
+#define LN_NCCL(expr)                                                                            \
+    do {                                                                                         \
+        ncclResult_t r__ = (expr);                                                               \
+        if (r__ != ncclSuccess)                                                                  \
+            return lnasr::fail(LNASR_E_COMM, "%s:%d %s -> %s", __FILE__, __LINE__, #expr,        \
+                               ncclGetErrorString(r__));                                         \
+    } while (0)
+
+static_assert(sizeof(ncclUniqueId) <= LNASR_UNIQUE_ID_BYTES, "unique id does not fit the ABI blob");
+
+extern "C" {
+
+int lnasr_comm_unique_id(void* id_out) {
+    LN_REQUIRE(id_out, "null id_out");
+    ncclUniqueId id;
+    LN_NCCL(ncclGetUniqueId(&id));
+    memset(id_out, 0, LNASR_UNIQUE_ID_BYTES);
+    memcpy(id_out, &id, sizeof(id));
+    return 0;
+}
+
+int lnasr_comm_init(lnasr_ctx* ctx, const void* idb, int rank, int nranks) {
+    LN_REQUIRE(ctx && idb, "null argument");
+    LN_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank %d / nranks %d", rank, nranks);
+    LN_REQUIRE(!ctx->comm, "communicator already initialised");
+    LN_HIP(hipSetDevice(ctx->device));
+    ncclUniqueId id;
+    memcpy(&id, idb, sizeof(id));
+    ncclComm_t comm;
+    LN_NCCL(ncclCommInitRank(&comm, nranks, id, rank));
+    ctx->comm = comm;
+    ctx->rank = rank;
+    ctx->nranks = nranks;
+    return 0;
+}
+
+int lnasr_comm_destroy(lnasr_ctx* ctx) {
+    if (!ctx || !ctx->comm) return 0;
+    (void)hipStreamSynchronize(ctx->stream);
+    ncclCommDestroy((ncclComm_t)ctx->comm);
+    ctx->comm = nullptr;
+    ctx->nranks = 1;
+    ctx->rank = 0;
+    return 0;
+}
+
+int lnasr_allgather_u32(lnasr_ctx* ctx, const uint32_t* local, size_t count, uint32_t* all) {
+    LN_REQUIRE(ctx && local && all, "null argument");
+    if (!ctx->comm) return fail(LNASR_E_COMM, "communicator not initialised (lnasr_comm_init)");
+    const size_t nr = (size_t)ctx->nranks;
+    const void* d_in;
+    void* d_out;
+    LN_TRY(stage_in(ctx, local, count * 4, ctx->ws_in5, &d_in));
+    LN_TRY(stage_out(ctx, all, count * nr * 4, ctx->ws_out3, &d_out));
+    LN_NCCL(ncclAllGather(d_in, d_out, count, ncclUint32, (ncclComm_t)ctx->comm, ctx->stream));
+    return finish_out(ctx, all, d_out, count * nr * 4);
+}
+
+int lnasr_allreduce_f64(lnasr_ctx* ctx, double* buf, size_t n) {
+    LN_REQUIRE(ctx && buf, "null argument");
+    if (!ctx->comm) return fail(LNASR_E_COMM, "communicator not initialised (lnasr_comm_init)");
+    const void* d_in;
+    LN_TRY(stage_in(ctx, buf, n * 8, ctx->ws_in5, &d_in));
+    void* d = const_cast<void*>(d_in);
+    LN_NCCL(ncclAllReduce(d, d, n, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));
+    return finish_out(ctx, buf, d, n * 8);
+}
+
+}  // extern "C"

@@ -1,0 +1,127 @@
+// Shared internals of liblnasr_hip.so (gfx950 only).  Not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/lnasr_hip.h"
+
+namespace lnasr {
+
+// ---- errors -------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int fail(int code, const char* fmt, ...);
+
+#define LN_HIP(expr)                                                                   \
+    do {                                                                               \
+        hipError_t e__ = (expr);                                                       \
+        if (e__ != hipSuccess)                                                         \
+            return lnasr::fail(LNASR_E_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #expr, \
+                               hipGetErrorString(e__));                                \
+    } while (0)
+
+#define LN_TRY(expr)            \
+    do {                        \
+        int rc__ = (expr);      \
+        if (rc__ != 0) return rc__; \
+    } while (0)
+
+#define LN_REQUIRE(cond, ...)                                      \
+    do {                                                           \
+        if (!(cond)) return lnasr::fail(LNASR_E_INVALID, __VA_ARGS__); \
+    } while (0)
+
+// ---- grow-only device buffer -----------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes);
+    void release();
+    template <typename T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// ---- uploaded model -----------------------------------------------------------------------
+struct Model {
+    int N = 0, M = 0, D = 0;
+    bool has_hmm = false;   // logA / logpi valid
+    bool has_gmm = false;   // mixture parameters valid
+    bool diag = false;      // diagonal fast path
+    DevBuf logA, logAT, logpi;   // [N,N], transposed [N,N], [N]
+    DevBuf expA, expAT;          // exp(logA) [N,N] and its transpose (linear-domain forward/backward)
+    DevBuf logw;                 // [N,M]
+    DevBuf mu;                   // [N,M,D]
+    DevBuf ivar;                 // diag: 1/var [N,M,D]
+    DevBuf var;                  // diag: var [N,M,D]
+    DevBuf prec;                 // full: Sigma^-1 [N,M,D,D]
+    DevBuf gconst;               // [N,M]: -0.5 (D ln 2pi + ln det Sigma)
+    DevBuf sigma_raw;            // full upload staging [N,M,D,D]
+    DevBuf wpack;                // MFMA-packed coefficient fragments (diag)
+    int wpack_Q = 0, wpack_KS = 0, wpack_NG = 0;
+    DevBuf flags;                // small int scratch (diag detection)
+    void release();
+};
+
+struct ProfRec {
+    int name_id;
+    hipEvent_t e0, e1;
+};
+
+}  // namespace lnasr
+
+struct lnasr_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t prop;
+    lnasr::Model model;
+    // workspace
+    lnasr::DevBuf ws_in, ws_in2, ws_in3, ws_in4, ws_in5;   // staged host inputs
+    lnasr::DevBuf ws_out, ws_out2, ws_out3;                // staged outputs
+    lnasr::DevBuf ws_b, ws_bm, ws_v, ws_alpha, ws_beta, ws_misc, ws_misc2, ws_lens, ws_stats;
+    // profiling
+    bool prof_on = false;
+    std::vector<std::string> prof_names;
+    std::vector<lnasr::ProfRec> prof_recs;
+    std::vector<hipEvent_t> event_pool;
+    std::vector<int64_t> prof_launches;
+    std::vector<double> prof_ms;
+    // comm
+    void* comm = nullptr;
+    int rank = 0, nranks = 1;
+};
+
+namespace lnasr {
+
+int prof_begin(lnasr_ctx* ctx, const char* name);   // returns record index or -1
+void prof_end(lnasr_ctx* ctx, int rec);
+
+// Launch wrapper: optional HIP-event bracket on the context's stream + launch error check.
+#define LN_LAUNCH(ctx, name, kernel, grid, block, shmem, ...)                                 \
+    do {                                                                                      \
+        int rec__ = (ctx)->prof_on ? lnasr::prof_begin((ctx), (name)) : -1;                   \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__);           \
+        if (rec__ >= 0) lnasr::prof_end((ctx), rec__);                                        \
+        hipError_t le__ = hipGetLastError();                                                  \
+        if (le__ != hipSuccess)                                                               \
+            return lnasr::fail(LNASR_E_HIP, "launch %s failed: %s", (name), hipGetErrorString(le__)); \
+    } while (0)
+
+// Is `p` device memory?  (host pointers from numpy are unregistered)
+bool is_device_ptr(const void* p);
+
+// Bring an input to the device (returns the device pointer to use; stages through `ws` if host).
+int stage_in(lnasr_ctx* ctx, const void* p, size_t bytes, DevBuf& ws, const void** out);
+// Prepare an output: returns device pointer to write; if host, `ws` is used and finish_out copies back.
+int stage_out(lnasr_ctx* ctx, void* p, size_t bytes, DevBuf& ws, void** out);
+int finish_out(lnasr_ctx* ctx, void* user, const void* dev, size_t bytes);
+
+inline size_t dtype_size(int dtype) { return dtype == LNASR_F32 ? 4 : 8; }
+
+}  // namespace lnasr

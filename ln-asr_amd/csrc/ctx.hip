@@ -1,0 +1,289 @@
+// Runtime: context, device memory, staging, per-kernel HIP-event profiling, errors.
+#include "common.h"
+
+namespace lnasr {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int DevBuf::reserve(size_t bytes) {
+    if (bytes <= cap && p) return 0;
+    if (p) {
+        hipError_t e = hipFree(p);
+        p = nullptr;
+        cap = 0;
+        if (e != hipSuccess) return fail(LNASR_E_HIP, "hipFree: %s", hipGetErrorString(e));
+    }
+    size_t want = bytes < 256 ? 256 : bytes;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+        p = nullptr;
+        return fail(LNASR_E_HIP, "hipMalloc(%zu): %s", want, hipGetErrorString(e));
+    }
+    cap = want;
+    return 0;
+}
+
+void DevBuf::release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+}
+
+void Model::release() {
+    DevBuf* all[] = {&logA, &logAT, &logpi, &expA, &expAT, &logw, &mu, &ivar, &var, &prec, &gconst, &sigma_raw, &wpack, &flags};
+    for (DevBuf* b : all) b->release();
+    has_hmm = has_gmm = false;
+}
+
+bool is_device_ptr(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();   // clear sticky "invalid value" for plain host memory
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+int stage_in(lnasr_ctx* ctx, const void* p, size_t bytes, DevBuf& ws, const void** out) {
+    if (bytes == 0) {
+        LN_TRY(ws.reserve(256));
+        *out = ws.p;
+        return 0;
+    }
+    if (!p) return fail(LNASR_E_INVALID, "null input pointer");
+    if (is_device_ptr(p)) {
+        *out = p;
+        return 0;
+    }
+    LN_TRY(ws.reserve(bytes));
+    LN_HIP(hipMemcpyAsync(ws.p, p, bytes, hipMemcpyHostToDevice, ctx->stream));
+    *out = ws.p;
+    return 0;
+}
+
+int stage_out(lnasr_ctx* ctx, void* p, size_t bytes, DevBuf& ws, void** out) {
+    if (p && is_device_ptr(p)) {
+        *out = p;
+        return 0;
+    }
+    LN_TRY(ws.reserve(bytes));
+    *out = ws.p;
+    return 0;
+}
+
+int finish_out(lnasr_ctx* ctx, void* user, const void* dev, size_t bytes) {
+    if (!user || user == dev || bytes == 0) return 0;
+    LN_HIP(hipMemcpyAsync(user, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    LN_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int prof_begin(lnasr_ctx* ctx, const char* name) {
+    int id = -1;
+    for (size_t i = 0; i < ctx->prof_names.size(); ++i)
+        if (ctx->prof_names[i] == name) { id = (int)i; break; }
+    if (id < 0) {
+        id = (int)ctx->prof_names.size();
+        ctx->prof_names.emplace_back(name);
+        ctx->prof_launches.push_back(0);
+        ctx->prof_ms.push_back(0.0);
+    }
+    hipEvent_t e[2];
+    for (int k = 0; k < 2; ++k) {
+        if (!ctx->event_pool.empty()) {
+            e[k] = ctx->event_pool.back();
+            ctx->event_pool.pop_back();
+        } else if (hipEventCreate(&e[k]) != hipSuccess) {
+            return -1;
+        }
+    }
+    if (hipEventRecord(e[0], ctx->stream) != hipSuccess) return -1;
+    ctx->prof_recs.push_back({id, e[0], e[1]});
+    return (int)ctx->prof_recs.size() - 1;
+}
+
+void prof_end(lnasr_ctx* ctx, int rec) { (void)hipEventRecord(ctx->prof_recs[rec].e1, ctx->stream); }
+
+static int prof_collect(lnasr_ctx* ctx) {
+    if (ctx->prof_recs.empty()) return 0;
+    LN_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto& r : ctx->prof_recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+            ctx->prof_ms[r.name_id] += ms;
+            ctx->prof_launches[r.name_id] += 1;
+        }
+        ctx->event_pool.push_back(r.e0);
+        ctx->event_pool.push_back(r.e1);
+    }
+    ctx->prof_recs.clear();
+    return 0;
+}
+
+}  // namespace lnasr
+
+using namespace lnasr;
+
+extern "C" {
+
+int lnasr_abi_version(void) { return LNASR_ABI_VERSION; }
+
+const char* lnasr_last_error(void) { return g_err; }
+
+int lnasr_device_count(int* out) {
+    LN_REQUIRE(out, "null out");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *out = n;
+    return 0;
+}
+
+int lnasr_ctx_create(int device_id, lnasr_ctx** out) {
+    LN_REQUIRE(out, "null out");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(LNASR_E_NODEVICE, "no HIP device visible (%s)", e == hipSuccess ? "count=0" : hipGetErrorString(e));
+    }
+    LN_REQUIRE(device_id >= 0 && device_id < n, "device_id %d out of range [0,%d)", device_id, n);
+    LN_HIP(hipSetDevice(device_id));
+    lnasr_ctx* ctx = new lnasr_ctx();
+    ctx->device = device_id;
+    LN_HIP(hipGetDeviceProperties(&ctx->prop, device_id));
+    if (strncmp(ctx->prop.gcnArchName, "gfx950", 6) != 0) {
+        std::string arch = ctx->prop.gcnArchName;
+        delete ctx;
+        return fail(LNASR_E_NODEVICE, "device %d is %s; this library is built for gfx950 only", device_id, arch.c_str());
+    }
+    LN_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    *out = ctx;
+    return 0;
+}
+
+void lnasr_ctx_destroy(lnasr_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    lnasr_comm_destroy(ctx);
+    ctx->model.release();
+    DevBuf* all[] = {&ctx->ws_in, &ctx->ws_in2, &ctx->ws_in3, &ctx->ws_in4, &ctx->ws_in5, &ctx->ws_out, &ctx->ws_out2,
+                     &ctx->ws_out3, &ctx->ws_b, &ctx->ws_bm, &ctx->ws_v, &ctx->ws_alpha, &ctx->ws_beta,
+                     &ctx->ws_misc, &ctx->ws_misc2, &ctx->ws_lens, &ctx->ws_stats};
+    for (DevBuf* b : all) b->release();
+    for (auto& r : ctx->prof_recs) {
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int lnasr_sync(lnasr_ctx* ctx) {
+    LN_REQUIRE(ctx, "null ctx");
+    LN_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int lnasr_device_info(lnasr_ctx* ctx, char* name, int name_cap, int* cu_count, size_t* hbm_bytes) {
+    LN_REQUIRE(ctx, "null ctx");
+    if (name && name_cap > 0) snprintf(name, name_cap, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+    if (cu_count) *cu_count = ctx->prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = ctx->prop.totalGlobalMem;
+    return 0;
+}
+
+int lnasr_dev_alloc(lnasr_ctx* ctx, size_t bytes, void** out) {
+    LN_REQUIRE(ctx && out, "null argument");
+    *out = nullptr;
+    LN_HIP(hipMalloc(out, bytes ? bytes : 256));
+    return 0;
+}
+
+int lnasr_dev_free(lnasr_ctx* ctx, void* p) {
+    LN_REQUIRE(ctx, "null ctx");
+    if (!p) return 0;
+    LN_HIP(hipStreamSynchronize(ctx->stream));
+    LN_HIP(hipFree(p));
+    return 0;
+}
+
+int lnasr_memcpy_h2d(lnasr_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    LN_REQUIRE(ctx && (bytes == 0 || (dst && src)), "null argument");
+    if (!bytes) return 0;
+    LN_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    LN_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int lnasr_memcpy_d2h(lnasr_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    LN_REQUIRE(ctx && (bytes == 0 || (dst && src)), "null argument");
+    if (!bytes) return 0;
+    LN_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    LN_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int lnasr_memset(lnasr_ctx* ctx, void* dst, int byte, size_t bytes) {
+    LN_REQUIRE(ctx && (bytes == 0 || dst), "null argument");
+    if (!bytes) return 0;
+    LN_HIP(hipMemsetAsync(dst, byte, bytes, ctx->stream));
+    return 0;
+}
+
+int lnasr_prof_enable(lnasr_ctx* ctx, int on) {
+    LN_REQUIRE(ctx, "null ctx");
+    if (!on) LN_TRY(prof_collect(ctx));
+    ctx->prof_on = on != 0;
+    return 0;
+}
+
+int lnasr_prof_reset(lnasr_ctx* ctx) {
+    LN_REQUIRE(ctx, "null ctx");
+    LN_TRY(prof_collect(ctx));
+    for (auto& v : ctx->prof_launches) v = 0;
+    for (auto& v : ctx->prof_ms) v = 0.0;
+    return 0;
+}
+
+int lnasr_prof_count(lnasr_ctx* ctx, int* n) {
+    LN_REQUIRE(ctx && n, "null argument");
+    LN_TRY(prof_collect(ctx));
+    *n = (int)ctx->prof_names.size();
+    return 0;
+}
+
+int lnasr_prof_get(lnasr_ctx* ctx, int i, char* name, int name_cap, int64_t* launches, double* total_ms) {
+    LN_REQUIRE(ctx, "null ctx");
+    LN_TRY(prof_collect(ctx));
+    LN_REQUIRE(i >= 0 && i < (int)ctx->prof_names.size(), "index %d out of range", i);
+    if (name && name_cap > 0) snprintf(name, name_cap, "%s", ctx->prof_names[i].c_str());
+    if (launches) *launches = ctx->prof_launches[i];
+    if (total_ms) *total_ms = ctx->prof_ms[i];
+    return 0;
+}
+
+}  // extern "C"

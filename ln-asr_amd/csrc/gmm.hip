@@ -1,0 +1,750 @@
+// Model upload and GMM emission scoring (gmm.py:16-100, gmmhmm.py:46-67).
+//
+// Kernels
+//   prep_diag_kernel      1/var, Gaussian constants                       (once per model)
+//   lu_invert_kernel      Sigma^-1 and log|det| with partial pivoting     (once per model)
+//   pack_wfrag_kernel     coefficient matrix in MFMA A-fragment order     (once per model)
+//   emit_diag_mfma        b = lse_m(w + N(o; mu, diag var)) as an fp64 MFMA GEMM
+//                         [x^2, x, 1] (frames x K) . [-1/2 iv, mu iv, const] (K x N*M)
+//                         with the M-way log-sum-exp fused in-lane          (hot kernel)
+//   emit_diag_generic     any N/M/D, fp64 VALU, direct (x-mu)^2/var form
+//   emit_full_generic     full covariance: (x-mu)^T P (x-mu)
+#include "common.h"
+#include "devmath.h"
+
+namespace lnasr {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------
+// model preparation
+// ------------------------------------------------------------------------------------------
+__global__ void transpose_exp_kernel(const double* __restrict__ A, double* __restrict__ AT,
+                                     double* __restrict__ E, double* __restrict__ ET, int N) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * N) return;
+    int i = idx / N, j = idx % N;
+    double a = A[idx];
+    AT[(size_t)j * N + i] = a;
+    const double e = exp(a);
+    E[idx] = e;
+    ET[(size_t)j * N + i] = e;
+}
+
+// flag[0] = 1 if any off-diagonal entry of any Sigma is not exactly zero
+__global__ void detect_offdiag_kernel(const double* __restrict__ S, size_t total, int D, int* flag) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    size_t e = idx % ((size_t)D * D);
+    int r = (int)(e / D), c = (int)(e % D);
+    if (r != c && !(S[idx] == 0.0)) atomicOr(flag, 1);
+}
+
+__global__ void extract_diag_kernel(const double* __restrict__ S, double* __restrict__ var, size_t NMD, int D) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= NMD) return;
+    size_t c = idx / D;
+    int d = (int)(idx % D);
+    var[idx] = S[c * D * D + (size_t)d * D + d];
+}
+
+// numpy.linalg.det returns sign * exp(sum log|u_ii|); the reference then takes log(det)
+// (gmm.py:62,65).  Keeping the exp/log round trip keeps its range behaviour (det overflow ->
+// +inf, underflow -> -inf, negative det -> NaN).
+__device__ __forceinline__ double log_of_det(double logabs, int sign) {
+    double det = (double)sign * exp(logabs);
+    return log(det);
+}
+
+// one thread per component
+__global__ void prep_diag_kernel(const double* __restrict__ var, double* __restrict__ ivar,
+                                 double* __restrict__ gconst, int NM, int D) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= NM) return;
+    double la = 0.0;
+    int sign = 1;
+    for (int d = 0; d < D; ++d) {
+        double v = var[(size_t)c * D + d];
+        ivar[(size_t)c * D + d] = 1.0 / v;
+        la += log(fabs(v));
+        if (v < 0.0) sign = -sign;
+        if (v == 0.0) sign = 0;
+    }
+    gconst[c] = -0.5 * ((double)D * kLog2Pi + log_of_det(la, sign));
+}
+
+// One block (64 threads) per component: Gauss-Jordan elimination with partial pivoting on
+// [Sigma | I] held in LDS.  LU semantics: Sigma need not be symmetric (test/gmm-test.py:42-43).
+__global__ void lu_invert_kernel(const double* __restrict__ S, double* __restrict__ P,
+                                 double* __restrict__ gconst, int D) {
+    extern __shared__ double lds[];
+    const int W = 2 * D;
+    double* a = lds;                          // [D][2D]
+    __shared__ int piv_row;
+    __shared__ double piv_val;
+    const int c = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const double* Sc = S + (size_t)c * D * D;
+    for (int e = tid; e < D * W; e += nt) {
+        int r = e / W, col = e % W;
+        a[e] = col < D ? Sc[(size_t)r * D + col] : (col - D == r ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    double logabs = 0.0;
+    int sign = 1;
+    for (int k = 0; k < D; ++k) {
+        if (tid == 0) {
+            int best = k;
+            double bv = fabs(a[k * W + k]);
+            for (int r = k + 1; r < D; ++r) {
+                double v = fabs(a[r * W + k]);
+                if (v > bv) { bv = v; best = r; }
+            }
+            piv_row = best;
+            piv_val = a[best * W + k];
+        }
+        __syncthreads();
+        const int pr = piv_row;
+        const double pv = piv_val;
+        if (pr != k) {
+            for (int col = tid; col < W; col += nt) {
+                double t = a[k * W + col];
+                a[k * W + col] = a[pr * W + col];
+                a[pr * W + col] = t;
+            }
+            sign = -sign;
+        }
+        logabs += log(fabs(pv));
+        if (pv < 0.0) sign = -sign;
+        if (pv == 0.0) sign = 0;
+        __syncthreads();
+        // eliminate column k from every other row (row k itself is scaled afterwards)
+        for (int e = tid; e < D * W; e += nt) {
+            int r = e / W, col = e % W;
+            if (r != k && col != k) {
+                double f = a[r * W + k] / pv;
+                a[e] -= f * a[k * W + col];
+            }
+        }
+        __syncthreads();
+        for (int r = tid; r < D; r += nt)
+            if (r != k) a[r * W + k] = 0.0;
+        for (int col = tid; col < W; col += nt) a[k * W + col] /= pv;
+        __syncthreads();
+    }
+    for (int e = tid; e < D * D; e += nt) {
+        int r = e / D, col = e % D;
+        P[(size_t)c * D * D + e] = a[r * W + D + col];
+    }
+    if (tid == 0) gconst[c] = -0.5 * ((double)D * kLog2Pi + log_of_det(logabs, sign));
+}
+
+// Coefficients of the expanded quadratic, laid out as MFMA A-operand fragments:
+//   wpack[((sg*Q + q)*KS + ks)*64 + lane]  = Wt[comp(sg, q, row = lane&15)][k = 4*ks + (lane>>4)]
+//   row r of tile q  <->  state 4*sg + (r&3), mixture 4*q + (r>>2)
+// so that after the MFMA, lane group (lane>>4) = g holds ALL mixtures of state 4*sg+g for
+// frame (lane&15) in its own registers and the M-way log-sum-exp needs no cross-lane traffic.
+//   k <  D      : -0.5 / var[d=k]
+//   D <= k < 2D : mu / var
+//   k == 2D     : log w + gconst - 0.5 * sum mu^2 / var
+//   k >  2D     : 0 (padding)
+__global__ void pack_wfrag_kernel(const double* __restrict__ mu, const double* __restrict__ ivar,
+                                  const double* __restrict__ gconst, const double* __restrict__ logw,
+                                  double* __restrict__ wpack, int N, int M, int D, int Q, int KS) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)(N / 4) * Q * KS * 64;
+    if (idx >= total) return;
+    int lane = (int)(idx & 63);
+    size_t r1 = idx >> 6;
+    int ks = (int)(r1 % KS);
+    r1 /= KS;
+    int q = (int)(r1 % Q);
+    int sg = (int)(r1 / Q);
+    int row = lane & 15, k = 4 * ks + (lane >> 4);
+    int state = 4 * sg + (row & 3), mix = 4 * q + (row >> 2);
+    size_t c = (size_t)state * M + mix;
+    double val = 0.0;
+    if (k < D) {
+        val = -0.5 * ivar[c * D + k];
+    } else if (k < 2 * D) {
+        int d = k - D;
+        val = mu[c * D + d] * ivar[c * D + d];
+    } else if (k == 2 * D) {
+        double s = 0.0;
+        for (int d = 0; d < D; ++d) {
+            double m = mu[c * D + d];
+            s += m * m * ivar[c * D + d];
+        }
+        val = logw[c] + gconst[c] - 0.5 * s;
+    }
+    wpack[idx] = val;
+}
+
+// ------------------------------------------------------------------------------------------
+// hot kernel: diagonal-covariance GMM bank on the fp64 matrix cores
+// ------------------------------------------------------------------------------------------
+// Block = 256 threads = 4 waves; wave w owns state group sg = 4*y + w (4 states, Q*4 = M
+// mixtures each) and keeps its coefficient fragments in registers for the whole launch
+// (Q*KS doubles per lane).  The block walks a chunk of 16-frame tiles: the tile's feature
+// matrix F[k][frame] (x^2 | x | 1) is built once in LDS (double buffered) and read as the
+// MFMA B operand by all four waves.  blockIdx is decoded XCD-aware: the GY blocks that share
+// a frame chunk sit on one XCD (b and b+8 share an XCD), so the obs tile is fetched from HBM
+// once and served to the other slabs from that XCD's L2.
+template <int Q, int KS, bool WRITE_BM>
+__global__ __launch_bounds__(256, 2) void emit_diag_mfma(
+    const double* __restrict__ obs, const double* __restrict__ wpack, const double* __restrict__ logw,
+    double* __restrict__ b, double* __restrict__ bm, long F, int N, int D, int NG, int GY,
+    long ntiles, int tiles_per_block, long nchunks) {
+    constexpr int KP = 4 * KS;
+    __shared__ double Fl[2][KP * 16];
+    __shared__ double ob[2][16 * 16];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const long bid = blockIdx.x;
+    const int xcd = (int)(bid & 7);
+    const long i = bid >> 3;
+    const int y = (int)(i % GY);
+    const long chunk = (i / GY) * 8 + xcd;
+    if (chunk >= nchunks) return;
+    const long tile0 = chunk * tiles_per_block;
+    long tile1 = tile0 + tiles_per_block;
+    if (tile1 > ntiles) tile1 = ntiles;
+    const int sg = 4 * y + w;
+    const bool active = sg < NG;
+    const int M = 4 * Q;
+
+    // stationary A fragments
+    double wr[Q][KS];
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            wr[q][ks] = active ? wpack[(((size_t)sg * Q + q) * KS + ks) * 64 + lane] : 0.0;
+
+    double lw[WRITE_BM ? Q * 4 : 1];
+    const int g = lane >> 4, fr = lane & 15;
+    const int my_state = 4 * sg + g;
+    if (WRITE_BM) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lw[q * 4 + r] = active ? logw[(size_t)my_state * M + 4 * q + r] : 0.0;
+    }
+
+    // constant rows of F (k >= 2D): 1 for k == 2D, 0 above
+    for (int e = tid; e < 2 * (KP - 2 * D) * 16; e += 256) {
+        int buf = e / ((KP - 2 * D) * 16);
+        int r = e % ((KP - 2 * D) * 16);
+        int k = 2 * D + r / 16;
+        Fl[buf][k * 16 + (r % 16)] = (k == 2 * D) ? 1.0 : 0.0;
+    }
+
+    const int EL = 16 * D;                      // obs elements per tile
+    constexpr int MAXLD = 4;                    // supports D <= 64
+    double pre[MAXLD];
+    auto load_tile = [&](long tile) {
+        const long base = tile * 16 * (long)D;
+        const long lim = F * (long)D;
+#pragma unroll
+        for (int r = 0; r < MAXLD; ++r) {
+            int e = tid + r * 256;
+            long ge = base + e;
+            pre[r] = (e < EL && ge < lim) ? obs[ge] : 0.0;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int r = 0; r < MAXLD; ++r) {
+            int e = tid + r * 256;
+            if (e < EL) {
+                int f = e / D, d = e - f * D;
+                double x = pre[r];
+                Fl[buf][d * 16 + f] = x * x;
+                Fl[buf][(D + d) * 16 + f] = x;
+            }
+        }
+    };
+
+    load_tile(tile0);
+    store_tile(0);
+    __syncthreads();
+
+    for (long tile = tile0; tile < tile1; ++tile) {
+        const int cur = (int)((tile - tile0) & 1);
+        const bool has_next = tile + 1 < tile1;
+        if (has_next) load_tile(tile + 1);
+
+        // flush the previous tile's staged outputs: 16 frames x 16 states, 128 B rows
+        if (tile > tile0) {
+            const int f = tid >> 4, s = tid & 15;
+            const long frame = (tile - 1) * 16 + f;
+            const int state = 16 * y + s;
+            if (frame < F && state < N) b[frame * N + state] = ob[cur ^ 1][tid];
+        }
+
+        double4_t acc[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) acc[q] = double4_t{0.0, 0.0, 0.0, 0.0};
+        const double* Fc = &Fl[cur][0];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const double bf = Fc[(4 * ks + g) * 16 + fr];
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+                acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(wr[q][ks], bf, acc[q], 0, 0, 0);
+        }
+
+        // in-lane M-way log-sum-exp: this lane holds c[q][r] = mixture 4q+r of state my_state
+        double mx = LN_NEG_INF;
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmax(mx, acc[q][r]);
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s += exp(acc[q][r] - mx);
+        double out = (mx == LN_NEG_INF) ? mx : mx + log(s);
+        ob[cur][fr * 16 + 4 * w + g] = out;
+
+        if (WRITE_BM) {
+            const long frame = tile * 16 + fr;
+            if (active && frame < F) {
+                double* dst = bm + ((size_t)frame * N + my_state) * M;
+#pragma unroll
+                for (int q = 0; q < Q; ++q)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dst[4 * q + r] = acc[q][r] - lw[q * 4 + r];
+            }
+        }
+
+        if (has_next) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+    // flush the last tile
+    {
+        const int cur = (int)((tile1 - 1 - tile0) & 1);
+        const int f = tid >> 4, s = tid & 15;
+        const long frame = (tile1 - 1) * 16 + f;
+        const int state = 16 * y + s;
+        if (tile1 > tile0 && frame < F && state < N) b[frame * N + state] = ob[cur][tid];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// generic VALU kernels (any N, M, D; fp64 arithmetic, TS storage)
+// ------------------------------------------------------------------------------------------
+// block = 256 threads: 64 frames (lanes) x 4 waves; wave w walks states w, w+4, ...
+template <typename TS>
+__global__ void emit_diag_generic(const double* __restrict__ obs, const double* __restrict__ mu,
+                                  const double* __restrict__ ivar, const double* __restrict__ gconst,
+                                  const double* __restrict__ logw, TS* __restrict__ b, TS* __restrict__ bm,
+                                  long F, int N, int M, int D) {
+    extern __shared__ double xs[];            // [D][64]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const long f0 = (long)blockIdx.x * 64;
+    for (int e = tid; e < 64 * D; e += blockDim.x) {
+        int f = e / D, d = e % D;
+        long fr = f0 + f;
+        xs[d * 64 + f] = fr < F ? obs[fr * D + d] : 0.0;
+    }
+    __syncthreads();
+    const long frame = f0 + lane;
+    for (int n = w; n < N; n += 4) {
+        Lse acc;
+        for (int m = 0; m < M; ++m) {
+            const size_t c = (size_t)n * M + m;
+            const double* mc = mu + c * D;
+            const double* ic = ivar + c * D;
+            double q = 0.0;
+            for (int d = 0; d < D; ++d) {
+                double xm = xs[d * 64 + lane] - mc[d];
+                q += (xm * ic[d]) * xm;
+            }
+            double val = gconst[c] - 0.5 * q;
+            if (bm && frame < F) st<TS>(bm, ((size_t)frame * N + n) * M + m, val);
+            acc.add(logw[c] + rnd<TS>(val));
+        }
+        if (frame < F) st<TS>(b, (size_t)frame * N + n, acc.value());
+    }
+}
+
+template <typename TS>
+__global__ void emit_full_generic(const double* __restrict__ obs, const double* __restrict__ mu,
+                                  const double* __restrict__ prec, const double* __restrict__ gconst,
+                                  const double* __restrict__ logw, TS* __restrict__ b, TS* __restrict__ bm,
+                                  long F, int N, int M, int D) {
+    extern __shared__ double xs[];            // [D][64]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const long f0 = (long)blockIdx.x * 64;
+    for (int e = tid; e < 64 * D; e += blockDim.x) {
+        int f = e / D, d = e % D;
+        long fr = f0 + f;
+        xs[d * 64 + f] = fr < F ? obs[fr * D + d] : 0.0;
+    }
+    __syncthreads();
+    const long frame = f0 + lane;
+    for (int n = w; n < N; n += 4) {
+        Lse acc;
+        for (int m = 0; m < M; ++m) {
+            const size_t c = (size_t)n * M + m;
+            const double* mc = mu + c * D;
+            const double* pc = prec + c * D * D;
+            double q = 0.0;
+            for (int d = 0; d < D; ++d) {
+                double t = 0.0;                                  // ((x-mu) P)[d]
+                for (int e = 0; e < D; ++e) t += (xs[e * 64 + lane] - mc[e]) * pc[(size_t)e * D + d];
+                q += t * (xs[d * 64 + lane] - mc[d]);
+            }
+            double val = gconst[c] - 0.5 * q;
+            if (bm && frame < F) st<TS>(bm, ((size_t)frame * N + n) * M + m, val);
+            acc.add(logw[c] + rnd<TS>(val));
+        }
+        if (frame < F) st<TS>(b, (size_t)frame * N + n, acc.value());
+    }
+}
+
+// free functions of gmm.py --------------------------------------------------------------
+__global__ void gauss1d_kernel(const double* __restrict__ x, size_t L, double mu, double s2, int want_log,
+                               double* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L) return;
+    double d = x[i] - mu;
+    if (want_log)
+        out[i] = -0.5 * (kLog2Pi + log(s2) + d * d / s2);                        // gmm.py:30
+    else
+        out[i] = 1.0 / sqrt(2.0 * M_PI * s2) * exp(-(d * d) / (2.0 * s2));       // gmm.py:26
+}
+
+// quad[m][l] for M components; linear pdf or log-pdf per component into comp[m*L + l]
+__global__ void gauss_multi_kernel(const double* __restrict__ x, size_t L, int D, int M,
+                                   const double* __restrict__ mu, const double* __restrict__ prec,
+                                   const double* __restrict__ gconst, int want_log, double* __restrict__ comp) {
+    size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= L) return;
+    const double* xl = x + l * D;
+    for (int m = 0; m < M; ++m) {
+        const double* mc = mu + (size_t)m * D;
+        const double* pc = prec + (size_t)m * D * D;
+        double q = 0.0;
+        for (int d = 0; d < D; ++d) {
+            double t = 0.0;
+            for (int e = 0; e < D; ++e) t += (xl[e] - mc[e]) * pc[(size_t)e * D + d];
+            q += t * (xl[d] - mc[d]);
+        }
+        if (want_log) {
+            comp[(size_t)m * L + l] = gconst[m] - 0.5 * q;                         // gmm.py:65-68
+        } else {
+            // r = 1 / ((2 pi)^(D/2) sqrt(det)) = exp(gconst)                      // gmm.py:46
+            comp[(size_t)m * L + l] = exp(gconst[m]) * exp(-0.5 * q);
+        }
+    }
+}
+
+__global__ void mixture_combine_kernel(const double* __restrict__ comp, const double* __restrict__ c, int M,
+                                       size_t L, int want_log, double* __restrict__ out) {
+    size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= L) return;
+    if (want_log) {                                                                // gmm.py:100
+        Lse acc;
+        for (int m = 0; m < M; ++m) acc.add(c[m] + comp[(size_t)m * L + l]);
+        out[l] = acc.value();
+    } else {                                                                       // gmm.py:88
+        double s = 0.0;
+        for (int m = 0; m < M; ++m) s += c[m] * comp[(size_t)m * L + l];
+        out[l] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static bool mfma_shape_supported(int N, int M, int D, int* Q, int* KS) {
+    if (N % 4 != 0 || M % 4 != 0) return false;
+    int q = M / 4, ks = (2 * D + 1 + 3) / 4;
+    if (!(q == 1 || q == 2 || q == 4)) return false;
+    if (!(ks == 20 || ks == 14 || ks == 7)) return false;     // D in {39,38}, {27,26}, {13,12}
+    if (D > 64) return false;
+    *Q = q;
+    *KS = ks;
+    return true;
+}
+
+int upload_hmm(lnasr_ctx* ctx, int N, const double* logA, const double* logpi) {
+    Model& md = ctx->model;
+    LN_REQUIRE(N >= 1 && N <= 4096, "N=%d out of range [1,4096]", N);
+    LN_REQUIRE(logA && logpi, "null model pointer");
+    size_t nn = (size_t)N * N * 8;
+    LN_TRY(md.logA.reserve(nn));
+    LN_TRY(md.logAT.reserve(nn));
+    LN_TRY(md.expA.reserve(nn));
+    LN_TRY(md.expAT.reserve(nn));
+    LN_TRY(md.logpi.reserve((size_t)N * 8));
+    hipMemcpyKind kA = is_device_ptr(logA) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    hipMemcpyKind kP = is_device_ptr(logpi) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    LN_HIP(hipMemcpyAsync(md.logA.p, logA, nn, kA, ctx->stream));
+    LN_HIP(hipMemcpyAsync(md.logpi.p, logpi, (size_t)N * 8, kP, ctx->stream));
+    int total = N * N;
+    LN_LAUNCH(ctx, "transpose_exp", transpose_exp_kernel, dim3((total + 255) / 256), dim3(256), 0,
+              md.logA.as<double>(), md.logAT.as<double>(), md.expA.as<double>(), md.expAT.as<double>(), N);
+    LN_HIP(hipStreamSynchronize(ctx->stream));   // host buffers may go away
+    md.N = N;
+    md.has_hmm = true;
+    return 0;
+}
+
+static int copy_in(lnasr_ctx* ctx, DevBuf& dst, const void* src, size_t bytes) {
+    LN_REQUIRE(src, "null model pointer");
+    LN_TRY(dst.reserve(bytes));
+    hipMemcpyKind k = is_device_ptr(src) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    LN_HIP(hipMemcpyAsync(dst.p, src, bytes, k, ctx->stream));
+    return 0;
+}
+
+static int model_upload_impl(lnasr_ctx* ctx, int N, int M, int D, const double* logA, const double* logpi,
+                             const double* logw, const double* mu, const double* sigma, int sigma_kind,
+                             bool allow_diag_detect) {
+    LN_REQUIRE(ctx, "null ctx");
+    LN_REQUIRE(M >= 1 && D >= 1 && M <= 4096 && D <= 1024, "M=%d D=%d out of range", M, D);
+    LN_REQUIRE(sigma_kind == 0 || sigma_kind == 1, "sigma_kind must be 0 (full) or 1 (diag)");
+    LN_REQUIRE(sigma, "null sigma");
+    Model& md = ctx->model;
+    md.has_gmm = false;
+    LN_TRY(upload_hmm(ctx, N, logA, logpi));
+    const size_t NM = (size_t)N * M, NMD = NM * D;
+    LN_TRY(copy_in(ctx, md.logw, logw, NM * 8));
+    LN_TRY(copy_in(ctx, md.mu, mu, NMD * 8));
+    LN_TRY(md.gconst.reserve(NM * 8));
+    bool diag = sigma_kind == 1;
+    if (sigma_kind == 1) {
+        LN_TRY(copy_in(ctx, md.var, sigma, NMD * 8));
+    } else {
+        LN_REQUIRE(D <= 88, "full covariance supports D <= 88 (got %d)", D);
+        LN_TRY(copy_in(ctx, md.sigma_raw, sigma, NMD * D * 8));
+        if (allow_diag_detect) {
+            LN_TRY(md.flags.reserve(256));
+            LN_HIP(hipMemsetAsync(md.flags.p, 0, 4, ctx->stream));
+            size_t total = NMD * D;
+            LN_LAUNCH(ctx, "detect_offdiag", detect_offdiag_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256),
+                      0, md.sigma_raw.as<double>(), total, D, md.flags.as<int>());
+            int flag = 0;
+            LN_HIP(hipMemcpyAsync(&flag, md.flags.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+            LN_HIP(hipStreamSynchronize(ctx->stream));
+            diag = flag == 0;
+        }
+        if (diag) {
+            LN_TRY(md.var.reserve(NMD * 8));
+            LN_LAUNCH(ctx, "extract_diag", extract_diag_kernel, dim3((unsigned)((NMD + 255) / 256)), dim3(256), 0,
+                      md.sigma_raw.as<double>(), md.var.as<double>(), NMD, D);
+        }
+    }
+    md.N = N;
+    md.M = M;
+    md.D = D;
+    md.diag = diag;
+    md.wpack_Q = md.wpack_KS = 0;
+    if (diag) {
+        LN_TRY(md.ivar.reserve(NMD * 8));
+        LN_LAUNCH(ctx, "prep_diag", prep_diag_kernel, dim3((unsigned)((NM + 127) / 128)), dim3(128), 0,
+                  md.var.as<double>(), md.ivar.as<double>(), md.gconst.as<double>(), (int)NM, D);
+        int Q = 0, KS = 0;
+        if (mfma_shape_supported(N, M, D, &Q, &KS)) {
+            size_t total = (size_t)(N / 4) * Q * KS * 64;
+            LN_TRY(md.wpack.reserve(total * 8));
+            LN_LAUNCH(ctx, "pack_wfrag", pack_wfrag_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                      md.mu.as<double>(), md.ivar.as<double>(), md.gconst.as<double>(), md.logw.as<double>(),
+                      md.wpack.as<double>(), N, M, D, Q, KS);
+            md.wpack_Q = Q;
+            md.wpack_KS = KS;
+            md.wpack_NG = N / 4;
+        }
+    } else {
+        LN_TRY(md.prec.reserve(NMD * D * 8));
+        size_t shmem = (size_t)D * 2 * D * 8;
+        LN_LAUNCH(ctx, "lu_invert", lu_invert_kernel, dim3((unsigned)NM), dim3(64), shmem, md.sigma_raw.as<double>(),
+                  md.prec.as<double>(), md.gconst.as<double>(), D);
+    }
+    LN_HIP(hipStreamSynchronize(ctx->stream));
+    md.has_gmm = true;
+    return 0;
+}
+
+template <int Q, int KS>
+static int launch_mfma(lnasr_ctx* ctx, const double* obs, long F, double* b, double* bm) {
+    Model& md = ctx->model;
+    const int N = md.N, D = md.D;
+    const int GY = (N + 15) / 16;
+    const long ntiles = (F + 15) / 16;
+    // ~2 blocks per CU resident; keep every block busy for many tiles so the fragment load amortises
+    const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+    long want_chunks = (2L * cus) / GY;
+    if (want_chunks < 8) want_chunks = 8;
+    want_chunks = (want_chunks / 8) * 8;
+    long tpb = (ntiles + want_chunks - 1) / want_chunks;
+    if (tpb < 1) tpb = 1;
+    const long nchunks = (ntiles + tpb - 1) / tpb;
+    const long grid = ((nchunks + 7) / 8) * 8 * GY;
+    if (bm) {
+        LN_LAUNCH(ctx, "emit_diag_mfma_bm", (emit_diag_mfma<Q, KS, true>), dim3((unsigned)grid), dim3(256), 0, obs,
+                  md.wpack.as<double>(), md.logw.as<double>(), b, bm, F, N, D, md.wpack_NG, GY, ntiles, (int)tpb,
+                  nchunks);
+    } else {
+        LN_LAUNCH(ctx, "emit_diag_mfma", (emit_diag_mfma<Q, KS, false>), dim3((unsigned)grid), dim3(256), 0, obs,
+                  md.wpack.as<double>(), md.logw.as<double>(), b, bm, F, N, D, md.wpack_NG, GY, ntiles, (int)tpb,
+                  nchunks);
+    }
+    return 0;
+}
+
+// device-resident emission over F = U*T flattened frames; b [F,N], bm [F,N,M] or null
+int emit_device(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, void* bm) {
+    Model& md = ctx->model;
+    if (!md.has_gmm) return fail(LNASR_E_NOMODEL, "no GMM-HMM model uploaded");
+    if (F <= 0) return 0;
+    const int N = md.N, M = md.M, D = md.D;
+    if (md.diag && dtype == LNASR_F64 && md.wpack_Q > 0 && !getenv("LNASR_NO_MFMA")) {
+        const int Q = md.wpack_Q, KS = md.wpack_KS;
+#define LN_CASE(q, ks) \
+    if (Q == q && KS == ks) return launch_mfma<q, ks>(ctx, obs, F, (double*)b, (double*)bm);
+        LN_CASE(4, 20) LN_CASE(2, 20) LN_CASE(1, 20) LN_CASE(4, 14) LN_CASE(2, 14) LN_CASE(1, 14)
+        LN_CASE(4, 7) LN_CASE(2, 7) LN_CASE(1, 7)
+#undef LN_CASE
+    }
+    const unsigned grid = (unsigned)((F + 63) / 64);
+    const size_t shmem = (size_t)D * 64 * 8;
+    LN_REQUIRE(shmem <= 160 * 1024, "D=%d too large for the generic emission kernel", D);
+    if (md.diag) {
+        if (dtype == LNASR_F32)
+            LN_LAUNCH(ctx, "emit_diag_generic_f32", emit_diag_generic<float>, dim3(grid), dim3(256), shmem, obs,
+                      md.mu.as<double>(), md.ivar.as<double>(), md.gconst.as<double>(), md.logw.as<double>(),
+                      (float*)b, (float*)bm, F, N, M, D);
+        else
+            LN_LAUNCH(ctx, "emit_diag_generic", emit_diag_generic<double>, dim3(grid), dim3(256), shmem, obs,
+                      md.mu.as<double>(), md.ivar.as<double>(), md.gconst.as<double>(), md.logw.as<double>(),
+                      (double*)b, (double*)bm, F, N, M, D);
+    } else {
+        if (dtype == LNASR_F32)
+            LN_LAUNCH(ctx, "emit_full_generic_f32", emit_full_generic<float>, dim3(grid), dim3(256), shmem, obs,
+                      md.mu.as<double>(), md.prec.as<double>(), md.gconst.as<double>(), md.logw.as<double>(),
+                      (float*)b, (float*)bm, F, N, M, D);
+        else
+            LN_LAUNCH(ctx, "emit_full_generic", emit_full_generic<double>, dim3(grid), dim3(256), shmem, obs,
+                      md.mu.as<double>(), md.prec.as<double>(), md.gconst.as<double>(), md.logw.as<double>(),
+                      (double*)b, (double*)bm, F, N, M, D);
+    }
+    return 0;
+}
+
+}  // namespace lnasr
+
+using namespace lnasr;
+
+extern "C" {
+
+int lnasr_model_upload(lnasr_ctx* ctx, int N, int M, int D, const double* logA, const double* logpi,
+                       const double* logw, const double* mu, const double* sigma, int sigma_kind) {
+    return model_upload_impl(ctx, N, M, D, logA, logpi, logw, mu, sigma, sigma_kind, true);
+}
+
+int lnasr_model_upload_full(lnasr_ctx* ctx, int N, int M, int D, const double* logA, const double* logpi,
+                            const double* logw, const double* mu, const double* sigma) {
+    return model_upload_impl(ctx, N, M, D, logA, logpi, logw, mu, sigma, 0, false);
+}
+
+int lnasr_hmm_upload(lnasr_ctx* ctx, int N, const double* logA, const double* logpi) {
+    LN_REQUIRE(ctx, "null ctx");
+    ctx->model.has_gmm = false;
+    return upload_hmm(ctx, N, logA, logpi);
+}
+
+int lnasr_model_is_diag(lnasr_ctx* ctx, int* out) {
+    LN_REQUIRE(ctx && out, "null argument");
+    if (!ctx->model.has_gmm) return fail(LNASR_E_NOMODEL, "no GMM-HMM model uploaded");
+    *out = ctx->model.diag ? 1 : 0;
+    return 0;
+}
+
+int lnasr_gmm_logprob(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* lens, int dtype, void* b,
+                      void* bm_or_null) {
+    LN_REQUIRE(ctx, "null ctx");
+    (void)lens;   // emission is per frame; padded frames are scored too and ignored downstream
+    LN_REQUIRE(U >= 0 && T >= 0, "negative batch shape");
+    LN_REQUIRE(dtype == LNASR_F64 || dtype == LNASR_F32, "bad dtype %d", dtype);
+    Model& md = ctx->model;
+    if (!md.has_gmm) return fail(LNASR_E_NOMODEL, "no GMM-HMM model uploaded");
+    const long F = (long)U * T;
+    if (F == 0) return 0;
+    LN_REQUIRE(b, "null b");
+    const size_t es = dtype_size(dtype);
+    const void* d_obs;
+    void *d_b, *d_bm = nullptr;
+    LN_TRY(stage_in(ctx, obs, (size_t)F * md.D * 8, ctx->ws_in, &d_obs));
+    LN_TRY(stage_out(ctx, b, (size_t)F * md.N * es, ctx->ws_out, &d_b));
+    if (bm_or_null) LN_TRY(stage_out(ctx, bm_or_null, (size_t)F * md.N * md.M * es, ctx->ws_out2, &d_bm));
+    LN_TRY(emit_device(ctx, (const double*)d_obs, F, dtype, d_b, d_bm));
+    LN_TRY(finish_out(ctx, b, d_b, (size_t)F * md.N * es));
+    if (bm_or_null) LN_TRY(finish_out(ctx, bm_or_null, d_bm, (size_t)F * md.N * md.M * es));
+    return 0;
+}
+
+int lnasr_gauss1d(lnasr_ctx* ctx, const double* x, size_t L, double mu, double sigma2, int want_log, double* out) {
+    LN_REQUIRE(ctx, "null ctx");
+    if (L == 0) return 0;
+    const void* d_x;
+    void* d_o;
+    LN_TRY(stage_in(ctx, x, L * 8, ctx->ws_in, &d_x));
+    LN_TRY(stage_out(ctx, out, L * 8, ctx->ws_out, &d_o));
+    LN_LAUNCH(ctx, "gauss1d", gauss1d_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, (const double*)d_x, L,
+              mu, sigma2, want_log, (double*)d_o);
+    return finish_out(ctx, out, d_o, L * 8);
+}
+
+static int gauss_components(lnasr_ctx* ctx, int M, const double* x, size_t L, int D, const double* mu,
+                            const double* Sigma, int want_log, const double** d_comp_out) {
+    LN_REQUIRE(D >= 1 && D <= 88, "D=%d out of range [1,88]", D);
+    const void *d_x, *d_mu, *d_S;
+    LN_TRY(stage_in(ctx, x, L * D * 8, ctx->ws_in, &d_x));
+    LN_TRY(stage_in(ctx, mu, (size_t)M * D * 8, ctx->ws_in2, &d_mu));
+    LN_TRY(stage_in(ctx, Sigma, (size_t)M * D * D * 8, ctx->ws_in3, &d_S));
+    LN_TRY(ctx->ws_misc.reserve((size_t)M * D * D * 8 + (size_t)M * 8));
+    double* d_P = ctx->ws_misc.as<double>();
+    double* d_g = d_P + (size_t)M * D * D;
+    LN_LAUNCH(ctx, "lu_invert", lu_invert_kernel, dim3((unsigned)M), dim3(64), (size_t)D * 2 * D * 8,
+              (const double*)d_S, d_P, d_g, D);
+    LN_TRY(ctx->ws_misc2.reserve((size_t)M * L * 8));
+    LN_LAUNCH(ctx, "gauss_multi", gauss_multi_kernel, dim3((unsigned)((L + 127) / 128)), dim3(128), 0,
+              (const double*)d_x, L, D, M, (const double*)d_mu, d_P, d_g, want_log, ctx->ws_misc2.as<double>());
+    *d_comp_out = ctx->ws_misc2.as<double>();
+    return 0;
+}
+
+int lnasr_gauss_multi(lnasr_ctx* ctx, const double* x, size_t L, int D, const double* mu, const double* Sigma,
+                      int want_log, double* out) {
+    LN_REQUIRE(ctx, "null ctx");
+    if (L == 0) return 0;
+    const double* d_comp;
+    LN_TRY(gauss_components(ctx, 1, x, L, D, mu, Sigma, want_log, &d_comp));
+    if (is_device_ptr(out)) {
+        LN_HIP(hipMemcpyAsync(out, d_comp, L * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        return 0;
+    }
+    return finish_out(ctx, out, d_comp, L * 8);
+}
+
+int lnasr_gauss_mixture(lnasr_ctx* ctx, const double* c, int M, const double* x, size_t L, int D, const double* mu,
+                        const double* Sigma, int want_log, double* out) {
+    LN_REQUIRE(ctx, "null ctx");
+    LN_REQUIRE(M >= 1, "M must be >= 1");
+    if (L == 0) return 0;
+    const double* d_comp;
+    LN_TRY(gauss_components(ctx, M, x, L, D, mu, Sigma, want_log, &d_comp));
+    const void* d_c;
+    void* d_o;
+    LN_TRY(stage_in(ctx, c, (size_t)M * 8, ctx->ws_in4, &d_c));
+    LN_TRY(stage_out(ctx, out, L * 8, ctx->ws_out, &d_o));
+    LN_LAUNCH(ctx, "mixture_combine", mixture_combine_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, d_comp,
+              (const double*)d_c, M, L, want_log, (double*)d_o);
+    return finish_out(ctx, out, d_o, L * 8);
+}
+
+}  // extern "C"

@@ -1,0 +1,741 @@
+// HMM trellises: Viterbi (+ lazy back-pointers / backtrace), forward, backward, Baum-Welch
+// posteriors (hmm.py:47-200, 268-283).
+//
+// Parallelism: utterances are independent; the frame recursion is sequential.  A block owns
+// UB utterances and walks their frames in lock-step (one or two barriers per frame).
+//
+// Viterbi keeps NO back-pointers in the recursion: v[t] is stored and the pointer actually
+// needed, bt[t+1, path[t+1]] = argmax_i(v[t,i] + A[i, path[t+1]]) (hmm.py:165,171), is
+// recomputed during the backtrace with the same fp64 additions, so the result is bit-identical
+// while the inner loop is one add + one max per (i, j).  The full bt matrix is produced by a
+// separate, fully parallel kernel only when the caller asks for it.
+#include "common.h"
+#include "devmath.h"
+
+namespace lnasr {
+
+int emit_device(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, void* bm);
+
+__global__ void fill_lens_kernel(int32_t* lens, int U, int T) {
+    int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u < U) lens[u] = T;
+}
+
+// HMM._map_b (hmm.py:47-61): b[u,t,:] = B[:, obs[u,t]]
+template <typename TS>
+__global__ void discrete_map_b_kernel(const double* __restrict__ logB, int N, int K, const int32_t* __restrict__ obs,
+                                      long F, TS* __restrict__ b) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= F * N) return;
+    long f = idx / N;
+    int j = (int)(idx % N);
+    int k = obs[f];
+    b[idx] = (TS)((k >= 0 && k < K) ? logB[(size_t)j * K + k] : __builtin_nan(""));
+}
+
+// ------------------------------------------------------------------------------------------
+// Viterbi, generic: any N, A streamed from L2
+// ------------------------------------------------------------------------------------------
+template <typename TS, int UB>
+__global__ void viterbi_generic(const TS* __restrict__ b, const double* __restrict__ A, const double* __restrict__ pi,
+                                const int32_t* __restrict__ lens, TS* __restrict__ v, int U, int T, int N) {
+    extern __shared__ double Vs[];            // [2][UB][N]
+    const int u0 = blockIdx.x * UB;
+    int len[UB], maxlen = 0;
+#pragma unroll
+    for (int k = 0; k < UB; ++k) {
+        len[k] = (u0 + k < U) ? lens[u0 + k] : 0;
+        maxlen = len[k] > maxlen ? len[k] : maxlen;
+    }
+    for (int j = threadIdx.x; j < N; j += blockDim.x) {
+#pragma unroll
+        for (int k = 0; k < UB; ++k) {
+            double val = LN_NEG_INF;
+            if (len[k] > 0) {
+                size_t o = ((size_t)(u0 + k) * T) * N + j;
+                val = rnd<TS>(pi[j] + ld(b, o));
+                st(v, o, val);
+            }
+            Vs[(0 * UB + k) * N + j] = val;
+        }
+    }
+    __syncthreads();
+    for (int t = 1; t < maxlen; ++t) {
+        const double* Vc = Vs + ((t - 1) & 1) * UB * N;
+        double* Vn = Vs + (t & 1) * UB * N;
+        for (int j = threadIdx.x; j < N; j += blockDim.x) {
+            double acc[UB];
+#pragma unroll
+            for (int k = 0; k < UB; ++k) acc[k] = LN_NEG_INF;
+            for (int i = 0; i < N; ++i) {
+                const double a = A[(size_t)i * N + j];
+#pragma unroll
+                for (int k = 0; k < UB; ++k) acc[k] = fmax(acc[k], Vc[k * N + i] + a);
+            }
+#pragma unroll
+            for (int k = 0; k < UB; ++k) {
+                double val = Vc[k * N + j];
+                if (t < len[k]) {
+                    size_t o = ((size_t)(u0 + k) * T + t) * N + j;
+                    val = rnd<TS>(acc[k] + ld(b, o));
+                    st(v, o, val);
+                }
+                Vn[k * N + j] = val;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Viterbi, register-resident transition matrix (N <= 64*CPT, N <= NW*RPT)
+// ------------------------------------------------------------------------------------------
+// Thread (wave w, lane l) keeps A[w*RPT + r][l + 64*c] for r < RPT, c < CPT in registers
+// (CPT*RPT doubles).  v[t-1] sits in LDS and is read as a broadcast; each read feeds CPT
+// add+max pairs.  Row slices are combined through LDS (NW > 1), then wave w finalises column
+// block(s) c = w, w+NW, ...: adds b, stores v[t] and publishes it for the next frame.
+template <int CPT, int NW, int RPT, int UB>
+__global__ __launch_bounds__(64 * NW, 2) void viterbi_reg(const double* __restrict__ b, const double* __restrict__ A,
+                                                          const double* __restrict__ pi,
+                                                          const int32_t* __restrict__ lens, double* __restrict__ v,
+                                                          int U, int T, int N) {
+    constexpr int NP = 64 * CPT;
+    __shared__ double Vs[2][UB][NP];
+    __shared__ double Ps[NW > 1 ? NW : 1][UB][NP];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int u0 = blockIdx.x * UB;
+
+    double areg[CPT][RPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c)
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const int i = w * RPT + r, j = lane + 64 * c;
+            areg[c][r] = (i < N && j < N) ? A[(size_t)i * N + j] : LN_NEG_INF;
+        }
+
+    int len[UB], maxlen = 0;
+#pragma unroll
+    for (int k = 0; k < UB; ++k) {
+        len[k] = (u0 + k < U) ? lens[u0 + k] : 0;
+        maxlen = len[k] > maxlen ? len[k] : maxlen;
+    }
+    // t = 0
+    for (int j = threadIdx.x; j < NP; j += 64 * NW) {
+#pragma unroll
+        for (int k = 0; k < UB; ++k) {
+            double val = LN_NEG_INF;
+            if (j < N && len[k] > 0) {
+                size_t o = ((size_t)(u0 + k) * T) * N + j;
+                val = pi[j] + b[o];
+                v[o] = val;
+            }
+            Vs[0][k][j] = val;
+        }
+    }
+    __syncthreads();
+
+    for (int t = 1; t < maxlen; ++t) {
+        const int cur = (t - 1) & 1, nxt = t & 1;
+        // emission for the columns this wave finalises (issued early; consumed after the loop)
+        double bv[UB][(CPT + NW - 1) / NW];
+#pragma unroll
+        for (int k = 0; k < UB; ++k)
+#pragma unroll
+            for (int cc = 0; cc < (CPT + NW - 1) / NW; ++cc) {
+                const int c = w + cc * NW, j = lane + 64 * c;
+                bv[k][cc] = (c < CPT && j < N && t < len[k]) ? b[((size_t)(u0 + k) * T + t) * N + j] : 0.0;
+            }
+
+        double acc[UB][CPT];
+#pragma unroll
+        for (int k = 0; k < UB; ++k)
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) acc[k][c] = LN_NEG_INF;
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+#pragma unroll
+            for (int k = 0; k < UB; ++k) {
+                const double vv = Vs[cur][k][w * RPT + r];
+#pragma unroll
+                for (int c = 0; c < CPT; ++c) acc[k][c] = fmax(acc[k][c], vv + areg[c][r]);
+            }
+        }
+        if (NW > 1) {
+#pragma unroll
+            for (int k = 0; k < UB; ++k)
+#pragma unroll
+                for (int c = 0; c < CPT; ++c) Ps[w][k][lane + 64 * c] = acc[k][c];
+            __syncthreads();
+        }
+#pragma unroll
+        for (int k = 0; k < UB; ++k)
+#pragma unroll
+            for (int cc = 0; cc < (CPT + NW - 1) / NW; ++cc) {
+                const int c = w + cc * NW;
+                if (c < CPT) {
+                    const int j = lane + 64 * c;
+                    double m;
+                    if (NW > 1) {
+                        m = Ps[0][k][j];
+#pragma unroll
+                        for (int ww = 1; ww < NW; ++ww) m = fmax(m, Ps[ww][k][j]);
+                    } else {
+                        m = acc[k][c];
+                    }
+                    double val = Vs[cur][k][j];
+                    if (j < N && t < len[k]) {
+                        val = m + bv[k][cc];
+                        v[((size_t)(u0 + k) * T + t) * N + j] = val;
+                    }
+                    Vs[nxt][k][j] = val;
+                }
+            }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// backtrace: one wave per utterance
+// ------------------------------------------------------------------------------------------
+template <typename TS>
+__global__ void backtrace_kernel(const TS* __restrict__ v, const double* __restrict__ AT,
+                                 const int32_t* __restrict__ lens, uint32_t* __restrict__ path,
+                                 double* __restrict__ best, int U, int T, int N) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int u = blockIdx.x * (blockDim.x >> 6) + w;
+    if (u >= U) return;
+    const int L = lens[u];
+    if (L <= 0) return;
+    const TS* vu = v + (size_t)u * T * N;
+    uint32_t* pu = path + (size_t)u * T;
+    double bv = LN_NEG_INF;
+    int bi = 0x7fffffff;
+    for (int j = lane; j < N; j += 64) argmax_combine(bv, bi, ld(vu, (size_t)(L - 1) * N + j), j);
+    wave_argmax(bv, bi);
+    int p = bi;
+    if (lane == 0) {
+        pu[L - 1] = (uint32_t)p;
+        if (best) best[u] = bv;
+    }
+    if (N <= 128) {
+        // two values per lane, next row prefetched while the dependent argmax chain runs
+        const int j0 = lane, j1 = lane + 64;
+        double n0 = LN_NEG_INF, n1 = LN_NEG_INF;
+        if (L >= 2) {
+            if (j0 < N) n0 = ld(vu, (size_t)(L - 2) * N + j0);
+            if (j1 < N) n1 = ld(vu, (size_t)(L - 2) * N + j1);
+        }
+        for (int t = L - 2; t >= 0; --t) {
+            const double c0 = n0, c1 = n1;
+            if (t > 0) {
+                if (j0 < N) n0 = ld(vu, (size_t)(t - 1) * N + j0);
+                if (j1 < N) n1 = ld(vu, (size_t)(t - 1) * N + j1);
+            }
+            const double* col = AT + (size_t)p * N;
+            double x = LN_NEG_INF;
+            int xi = 0x7fffffff;
+            if (j0 < N) { x = c0 + col[j0]; xi = j0; }
+            if (j1 < N) argmax_combine(x, xi, c1 + col[j1], j1);
+            wave_argmax(x, xi);
+            p = xi;
+            if (lane == 0) pu[t] = (uint32_t)p;
+        }
+    } else {
+        for (int t = L - 2; t >= 0; --t) {
+            const double* col = AT + (size_t)p * N;
+            double x = LN_NEG_INF;
+            int xi = 0x7fffffff;
+            for (int j = lane; j < N; j += 64) argmax_combine(x, xi, ld(vu, (size_t)t * N + j) + col[j], j);
+            wave_argmax(x, xi);
+            p = xi;
+            if (lane == 0) pu[t] = (uint32_t)p;
+        }
+    }
+}
+
+// full back-pointer matrix (hmm.py:165): bt[u,t,j] = argmax_i(v[u,t-1,i] + A[i,j]); bt[u,0,:] = 0
+template <typename TS>
+__global__ void bt_kernel(const TS* __restrict__ v, const double* __restrict__ A, const int32_t* __restrict__ lens,
+                          uint32_t* __restrict__ bt, int T, int N) {
+    extern __shared__ double vs[];            // [N]
+    const int u = blockIdx.y, t = blockIdx.x;
+    if (t >= lens[u]) return;
+    uint32_t* out = bt + ((size_t)u * T + t) * N;
+    if (t == 0) {
+        for (int j = threadIdx.x; j < N; j += blockDim.x) out[j] = 0;
+        return;
+    }
+    const TS* vp = v + ((size_t)u * T + (t - 1)) * N;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) vs[i] = ld(vp, i);
+    __syncthreads();
+    for (int j = threadIdx.x; j < N; j += blockDim.x) {
+        double best = vs[0] + A[j];
+        int bi = 0;
+        for (int i = 1; i < N; ++i) {
+            double val = vs[i] + A[(size_t)i * N + j];
+            if (val > best) { best = val; bi = i; }
+        }
+        out[j] = (uint32_t)bi;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward / backward (log domain)
+// ------------------------------------------------------------------------------------------
+// alpha[t,j] = lse_i(alpha[t-1,i] + A[i,j]) + b[t,j]                       (hmm.py:97-99)
+// Evaluated as s + log(sum_i exp(alpha[t-1,i] - s) * expA[i,j]) with s = max_i alpha[t-1,i]:
+// one exp per state per frame and an FMA per (i,j) instead of a transcendental per (i,j).
+// Columns whose linear-domain sum falls below kSafeSum (every contributor underflowed, or the
+// column is unreachable) are redone with the exact max-shifted log-domain sum, so the result
+// equals the reference's logaddexp fold to rounding for every input, including -inf entries.
+constexpr double kSafeSum = 1e-290;
+
+template <typename TS, bool BACKWARD>
+__global__ void fwdbwd_generic(const TS* __restrict__ b, const double* __restrict__ Alog,
+                               const double* __restrict__ Aexp, const double* __restrict__ pi,
+                               const int32_t* __restrict__ lens, TS* __restrict__ out, double* __restrict__ loglik,
+                               int U, int T, int N) {
+    // FORWARD : Alog = logA [i][j] (row i, col j), Aexp = expA;  thread j sums over i: Aexp[i*N+j]
+    // BACKWARD: Alog = logA^T [j][i], Aexp = expA^T;             thread i sums over j: Aexp[j*N+i]
+    extern __shared__ double sm[];
+    double* prev = sm;                 // [N]  previous row (forward: alpha[t-1]; backward: beta[t+1]+b[t+1])
+    double* ex = sm + N;               // [N]  exp(prev - s)
+    double* scratch = sm + 2 * N;      // [32]
+    const int u = blockIdx.x;
+    const int L = lens[u];
+    if (L <= 0) return;
+    const TS* bu = b + (size_t)u * T * N;
+    TS* ou = out ? out + (size_t)u * T * N : nullptr;
+
+    if (!BACKWARD) {
+        for (int j = threadIdx.x; j < N; j += blockDim.x) {
+            double val = rnd<TS>(pi[j] + ld(bu, j));
+            if (ou) st(ou, j, val);
+            prev[j] = val;
+        }
+    } else {
+        for (int j = threadIdx.x; j < N; j += blockDim.x) {
+            if (ou) st(ou, (size_t)(L - 1) * N + j, 0.0);
+            if (L >= 2) prev[j] = 0.0 + ld(bu, (size_t)(L - 1) * N + j);
+        }
+    }
+    __syncthreads();
+    const int steps = L - 1;
+    for (int sidx = 0; sidx < steps; ++sidx) {
+        const int t = BACKWARD ? (L - 2 - sidx) : (1 + sidx);
+        double lm = LN_NEG_INF;
+        for (int i = threadIdx.x; i < N; i += blockDim.x) lm = fmax(lm, prev[i]);
+        const double s = block_max(lm, scratch);
+        for (int i = threadIdx.x; i < N; i += blockDim.x) ex[i] = (s == LN_NEG_INF) ? 0.0 : exp(prev[i] - s);
+        __syncthreads();
+        double newv[4];                // up to 4 states per thread (N <= 4 * blockDim)
+        int cnt = 0;
+        for (int j = threadIdx.x; j < N; j += blockDim.x, ++cnt) {
+            double sum = 0.0;
+            for (int i = 0; i < N; ++i) sum += ex[i] * Aexp[(size_t)i * N + j];
+            double val;
+            if (sum >= kSafeSum && s != LN_NEG_INF) {
+                val = s + log(sum);
+            } else {
+                double mx = LN_NEG_INF;
+                for (int i = 0; i < N; ++i) mx = fmax(mx, prev[i] + Alog[(size_t)i * N + j]);
+                if (mx == LN_NEG_INF) {
+                    val = mx;
+                } else {
+                    double s2 = 0.0;
+                    for (int i = 0; i < N; ++i) s2 += exp(prev[i] + Alog[(size_t)i * N + j] - mx);
+                    val = mx + log(s2);
+                }
+            }
+            if (!BACKWARD) {
+                val = rnd<TS>(val + ld(bu, (size_t)t * N + j));
+                if (ou) st(ou, (size_t)t * N + j, val);
+                newv[cnt] = val;
+            } else {
+                val = rnd<TS>(val);
+                if (ou) st(ou, (size_t)t * N + j, val);
+                newv[cnt] = val + ld(bu, (size_t)t * N + j);     // feeds step t-1: beta[t] + b[t]
+            }
+        }
+        __syncthreads();
+        cnt = 0;
+        for (int j = threadIdx.x; j < N; j += blockDim.x, ++cnt) prev[j] = newv[cnt];
+        __syncthreads();
+    }
+    if (!BACKWARD && loglik) {
+        // calc_prob: lse(alpha[L-1])  (hmm.py:274)
+        double lm = LN_NEG_INF;
+        for (int i = threadIdx.x; i < N; i += blockDim.x) lm = fmax(lm, prev[i]);
+        const double s = block_max(lm, scratch);
+        double ls = 0.0;
+        for (int i = threadIdx.x; i < N; i += blockDim.x) ls += (s == LN_NEG_INF) ? 0.0 : exp(prev[i] - s);
+        const double tot = block_sum(ls, scratch);
+        if (threadIdx.x == 0) loglik[u] = (s == LN_NEG_INF) ? s : s + log(tot);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Baum-Welch posteriors (hmm.py:186-199): one block per (t, u)
+// ------------------------------------------------------------------------------------------
+template <typename TS>
+__global__ void baumwelch_kernel(const TS* __restrict__ b, const TS* __restrict__ alpha, const TS* __restrict__ beta,
+                                 const double* __restrict__ A, const int32_t* __restrict__ lens, TS* __restrict__ xi,
+                                 TS* __restrict__ gamma, int T, int N) {
+    extern __shared__ double sm[];
+    double* al = sm;                   // [N] alpha[t]
+    double* bb = sm + N;               // [N] b[t+1] , beta[t+1]
+    double* be = sm + 2 * N;
+    double* scratch = sm + 3 * N;      // [32]
+    const int t = blockIdx.x, u = blockIdx.y;
+    const int L = lens[u];
+    if (t >= L) return;
+    const size_t row = (size_t)u * T + t;
+    TS* xo = xi ? xi + row * N * N : nullptr;
+    TS* go = gamma + row * N;
+    const int NN = N * N;
+    if (t == L - 1) {                  // hmm.py:190,199: last frame stays -inf
+        if (xo) for (int e = threadIdx.x; e < NN; e += blockDim.x) st(xo, e, LN_NEG_INF);
+        for (int i = threadIdx.x; i < N; i += blockDim.x) st(go, i, LN_NEG_INF);
+        return;
+    }
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        al[i] = ld(alpha, row * N + i);
+        bb[i] = ld(b, (row + 1) * N + i);
+        be[i] = ld(beta, (row + 1) * N + i);
+    }
+    __syncthreads();
+    auto numer = [&](int e) {
+        const int i = e / N, j = e - i * N;
+        return ((al[i] + A[e]) + bb[j]) + be[j];                           // hmm.py:192-195 order
+    };
+    double lm = LN_NEG_INF;
+    for (int e = threadIdx.x; e < NN; e += blockDim.x) lm = fmax(lm, numer(e));
+    const double mx = block_max(lm, scratch);
+    double ls = 0.0;
+    if (mx != LN_NEG_INF)
+        for (int e = threadIdx.x; e < NN; e += blockDim.x) ls += exp(numer(e) - mx);
+    const double tot = block_sum(ls, scratch);
+    const double denom = (mx == LN_NEG_INF) ? mx : mx + log(tot);
+    if (xo)
+        for (int e = threadIdx.x; e < NN; e += blockDim.x) st(xo, e, numer(e) - denom);
+    // gamma[i] = lse_j xi[i,j]  (hmm.py:199); one wave per row
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int i = w; i < N; i += nw) {
+        double m = LN_NEG_INF;
+        for (int j = lane; j < N; j += 64) m = fmax(m, rnd<TS>(numer(i * N + j) - denom));
+        m = wave_max(m);
+        double s = 0.0;
+        if (m != LN_NEG_INF)
+            for (int j = lane; j < N; j += 64) s += exp(rnd<TS>(numer(i * N + j) - denom) - m);
+        s = wave_sum(s);
+        if (lane == 0) st(go, i, (m == LN_NEG_INF || m != m) ? m : m + log(s));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side drivers shared with other translation units
+// ------------------------------------------------------------------------------------------
+int device_lens(lnasr_ctx* ctx, const int32_t* lens, int U, int T, const int32_t** out) {
+    LN_TRY(ctx->ws_lens.reserve((size_t)(U > 0 ? U : 1) * 4));
+    int32_t* d = ctx->ws_lens.as<int32_t>();
+    if (lens) {
+        if (is_device_ptr(lens)) {
+            *out = lens;
+            return 0;
+        }
+        for (int u = 0; u < U; ++u)
+            LN_REQUIRE(lens[u] >= 1 && lens[u] <= T, "lens[%d]=%d out of range [1,%d]", u, lens[u], T);
+        LN_HIP(hipMemcpyAsync(d, lens, (size_t)U * 4, hipMemcpyHostToDevice, ctx->stream));
+        LN_HIP(hipStreamSynchronize(ctx->stream));
+    } else {
+        LN_LAUNCH(ctx, "fill_lens", fill_lens_kernel, dim3((U + 255) / 256), dim3(256), 0, d, U, T);
+    }
+    *out = d;
+    return 0;
+}
+
+// v [U,T,N] must be device memory
+int viterbi_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d_lens, int dtype, void* v) {
+    Model& md = ctx->model;
+    const int N = md.N;
+    const double* A = md.logA.as<double>();
+    const double* pi = md.logpi.as<double>();
+    if (dtype == LNASR_F64 && !getenv("LNASR_NO_REGVIT")) {
+        if (N <= 64) {
+            constexpr int UB = 2;
+            LN_LAUNCH(ctx, "viterbi_reg_n64", (viterbi_reg<1, 2, 32, UB>), dim3((U + UB - 1) / UB), dim3(128), 0,
+                      (const double*)b, A, pi, d_lens, (double*)v, U, T, N);
+            return 0;
+        }
+        if (N <= 128) {
+            if (U >= 1024) {
+                constexpr int UB = 2;
+                LN_LAUNCH(ctx, "viterbi_reg_n128", (viterbi_reg<2, 4, 32, UB>), dim3((U + UB - 1) / UB), dim3(256),
+                          0, (const double*)b, A, pi, d_lens, (double*)v, U, T, N);
+            } else {
+                constexpr int UB = 1;
+                LN_LAUNCH(ctx, "viterbi_reg_n128_u1", (viterbi_reg<2, 4, 32, UB>), dim3((U + UB - 1) / UB),
+                          dim3(256), 0, (const double*)b, A, pi, d_lens, (double*)v, U, T, N);
+            }
+            return 0;
+        }
+    }
+    constexpr int UB = 4;
+    int nt = ((N + 63) / 64) * 64;
+    if (nt > 1024) nt = 1024;
+    const size_t shmem = (size_t)2 * UB * N * 8;
+    LN_REQUIRE(shmem <= 160 * 1024, "N=%d too large for the Viterbi kernel", N);
+    if (dtype == LNASR_F32)
+        LN_LAUNCH(ctx, "viterbi_generic_f32", (viterbi_generic<float, UB>), dim3((U + UB - 1) / UB), dim3(nt), shmem,
+                  (const float*)b, A, pi, d_lens, (float*)v, U, T, N);
+    else
+        LN_LAUNCH(ctx, "viterbi_generic", (viterbi_generic<double, UB>), dim3((U + UB - 1) / UB), dim3(nt), shmem,
+                  (const double*)b, A, pi, d_lens, (double*)v, U, T, N);
+    return 0;
+}
+
+int backtrace_device(lnasr_ctx* ctx, const void* v, int U, int T, const int32_t* d_lens, int dtype, uint32_t* path,
+                     double* best) {
+    Model& md = ctx->model;
+    const int wpb = 4;
+    if (dtype == LNASR_F32)
+        LN_LAUNCH(ctx, "backtrace_f32", backtrace_kernel<float>, dim3((U + wpb - 1) / wpb), dim3(64 * wpb), 0,
+                  (const float*)v, md.logAT.as<double>(), d_lens, path, best, U, T, md.N);
+    else
+        LN_LAUNCH(ctx, "backtrace", backtrace_kernel<double>, dim3((U + wpb - 1) / wpb), dim3(64 * wpb), 0,
+                  (const double*)v, md.logAT.as<double>(), d_lens, path, best, U, T, md.N);
+    return 0;
+}
+
+int forward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d_lens, int dtype, void* alpha,
+                   double* loglik) {
+    Model& md = ctx->model;
+    const int N = md.N;
+    int nt = ((N + 63) / 64) * 64;
+    if (nt > 1024) nt = 1024;
+    LN_REQUIRE(N <= 4 * nt, "N=%d too large for the forward kernel", N);
+    const size_t shmem = (size_t)(2 * N + 32) * 8;
+    if (dtype == LNASR_F32)
+        LN_LAUNCH(ctx, "forward_f32", (fwdbwd_generic<float, false>), dim3(U), dim3(nt), shmem, (const float*)b,
+                  md.logA.as<double>(), md.expA.as<double>(), md.logpi.as<double>(), d_lens, (float*)alpha, loglik,
+                  U, T, N);
+    else
+        LN_LAUNCH(ctx, "forward", (fwdbwd_generic<double, false>), dim3(U), dim3(nt), shmem, (const double*)b,
+                  md.logA.as<double>(), md.expA.as<double>(), md.logpi.as<double>(), d_lens, (double*)alpha, loglik,
+                  U, T, N);
+    return 0;
+}
+
+int backward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d_lens, int dtype, void* beta) {
+    Model& md = ctx->model;
+    const int N = md.N;
+    int nt = ((N + 63) / 64) * 64;
+    if (nt > 1024) nt = 1024;
+    LN_REQUIRE(N <= 4 * nt, "N=%d too large for the backward kernel", N);
+    const double* expAT = md.expAT.as<double>();
+    const size_t shmem = (size_t)(2 * N + 32) * 8;
+    if (dtype == LNASR_F32)
+        LN_LAUNCH(ctx, "backward_f32", (fwdbwd_generic<float, true>), dim3(U), dim3(nt), shmem, (const float*)b,
+                  md.logAT.as<double>(), expAT, md.logpi.as<double>(), d_lens, (float*)beta, (double*)nullptr, U, T,
+                  N);
+    else
+        LN_LAUNCH(ctx, "backward", (fwdbwd_generic<double, true>), dim3(U), dim3(nt), shmem, (const double*)b,
+                  md.logAT.as<double>(), expAT, md.logpi.as<double>(), d_lens, (double*)beta, (double*)nullptr, U, T,
+                  N);
+    return 0;
+}
+
+int baumwelch_device(lnasr_ctx* ctx, const void* b, const void* alpha, const void* beta, int U, int T,
+                     const int32_t* d_lens, int dtype, void* xi, void* gamma) {
+    Model& md = ctx->model;
+    const int N = md.N;
+    const size_t shmem = (size_t)(3 * N + 32) * 8;
+    LN_REQUIRE(U <= 65535, "U=%d too large for one Baum-Welch launch", U);
+    if (dtype == LNASR_F32)
+        LN_LAUNCH(ctx, "baumwelch_f32", baumwelch_kernel<float>, dim3(T, U), dim3(256), shmem, (const float*)b,
+                  (const float*)alpha, (const float*)beta, md.logA.as<double>(), d_lens, (float*)xi, (float*)gamma, T,
+                  N);
+    else
+        LN_LAUNCH(ctx, "baumwelch", baumwelch_kernel<double>, dim3(T, U), dim3(256), shmem, (const double*)b,
+                  (const double*)alpha, (const double*)beta, md.logA.as<double>(), d_lens, (double*)xi,
+                  (double*)gamma, T, N);
+    return 0;
+}
+
+}  // namespace lnasr
+
+using namespace lnasr;
+
+#define LN_CHECK_BATCH(ctx, U, T, dtype)                                                      \
+    LN_REQUIRE(ctx, "null ctx");                                                              \
+    LN_REQUIRE((U) >= 0 && (T) >= 0, "negative batch shape");                                 \
+    LN_REQUIRE((dtype) == LNASR_F64 || (dtype) == LNASR_F32, "bad dtype %d", (dtype));        \
+    if (!(ctx)->model.has_hmm) return fail(LNASR_E_NOMODEL, "no HMM transition model uploaded")
+
+extern "C" {
+
+int lnasr_discrete_map_b(lnasr_ctx* ctx, const double* logB, int N, int K, const int32_t* obs, int U, int T,
+                         int dtype, void* b) {
+    LN_REQUIRE(ctx, "null ctx");
+    LN_REQUIRE(N >= 1 && K >= 1 && U >= 0 && T >= 0, "bad shape");
+    LN_REQUIRE(dtype == LNASR_F64 || dtype == LNASR_F32, "bad dtype %d", dtype);
+    const long F = (long)U * T;
+    if (F == 0) return 0;
+    if (!is_device_ptr(obs))
+        for (long f = 0; f < F; ++f)
+            LN_REQUIRE(obs[f] >= 0 && obs[f] < K, "obs[%ld]=%d outside the symbol set [0,%d)", f, obs[f], K);
+    const void *d_B, *d_obs;
+    void* d_b;
+    const size_t es = dtype_size(dtype);
+    LN_TRY(stage_in(ctx, logB, (size_t)N * K * 8, ctx->ws_in2, &d_B));
+    LN_TRY(stage_in(ctx, obs, (size_t)F * 4, ctx->ws_in, &d_obs));
+    LN_TRY(stage_out(ctx, b, (size_t)F * N * es, ctx->ws_out, &d_b));
+    const unsigned grid = (unsigned)((F * N + 255) / 256);
+    if (dtype == LNASR_F32)
+        LN_LAUNCH(ctx, "discrete_map_b_f32", discrete_map_b_kernel<float>, dim3(grid), dim3(256), 0,
+                  (const double*)d_B, N, K, (const int32_t*)d_obs, F, (float*)d_b);
+    else
+        LN_LAUNCH(ctx, "discrete_map_b", discrete_map_b_kernel<double>, dim3(grid), dim3(256), 0, (const double*)d_B,
+                  N, K, (const int32_t*)d_obs, F, (double*)d_b);
+    return finish_out(ctx, b, d_b, (size_t)F * N * es);
+}
+
+int lnasr_viterbi(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* lens, int dtype, void* v_or_null,
+                  uint32_t* bt_or_null, uint32_t* path, double* best_score_or_null) {
+    LN_CHECK_BATCH(ctx, U, T, dtype);
+    if (U == 0 || T == 0) return 0;
+    LN_REQUIRE(b && path, "null b/path");
+    const int N = ctx->model.N;
+    const size_t es = dtype_size(dtype), cells = (size_t)U * T * N;
+    const int32_t* d_lens;
+    LN_TRY(device_lens(ctx, lens, U, T, &d_lens));
+    const void* d_b;
+    void *d_v, *d_path, *d_bt = nullptr, *d_best = nullptr;
+    LN_TRY(stage_in(ctx, b, cells * es, ctx->ws_in, &d_b));
+    LN_TRY(stage_out(ctx, v_or_null, cells * es, ctx->ws_v, &d_v));
+    LN_TRY(stage_out(ctx, path, (size_t)U * T * 4, ctx->ws_out, &d_path));
+    if (best_score_or_null) LN_TRY(stage_out(ctx, best_score_or_null, (size_t)U * 8, ctx->ws_out2, &d_best));
+    LN_TRY(viterbi_device(ctx, d_b, U, T, d_lens, dtype, d_v));
+    LN_TRY(backtrace_device(ctx, d_v, U, T, d_lens, dtype, (uint32_t*)d_path, (double*)d_best));
+    if (bt_or_null) {
+        LN_TRY(stage_out(ctx, bt_or_null, cells * 4, ctx->ws_out3, &d_bt));
+        LN_REQUIRE(U <= 65535, "U=%d too large for the bt kernel", U);
+        int nt = ((N + 63) / 64) * 64;
+        if (nt > 256) nt = 256;
+        if (dtype == LNASR_F32)
+            LN_LAUNCH(ctx, "viterbi_bt_f32", bt_kernel<float>, dim3(T, U), dim3(nt), (size_t)N * 8, (const float*)d_v,
+                      ctx->model.logA.as<double>(), d_lens, (uint32_t*)d_bt, T, N);
+        else
+            LN_LAUNCH(ctx, "viterbi_bt", bt_kernel<double>, dim3(T, U), dim3(nt), (size_t)N * 8, (const double*)d_v,
+                      ctx->model.logA.as<double>(), d_lens, (uint32_t*)d_bt, T, N);
+    }
+    if (v_or_null) LN_TRY(finish_out(ctx, v_or_null, d_v, cells * es));
+    if (bt_or_null) LN_TRY(finish_out(ctx, bt_or_null, d_bt, cells * 4));
+    LN_TRY(finish_out(ctx, path, d_path, (size_t)U * T * 4));
+    if (best_score_or_null) LN_TRY(finish_out(ctx, best_score_or_null, d_best, (size_t)U * 8));
+    return 0;
+}
+
+int lnasr_decode(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* lens, uint32_t* path,
+                 double* best_score_or_null) {
+    LN_CHECK_BATCH(ctx, U, T, LNASR_F64);
+    if (!ctx->model.has_gmm) return fail(LNASR_E_NOMODEL, "no GMM-HMM model uploaded");
+    if (U == 0 || T == 0) return 0;
+    LN_REQUIRE(obs && path, "null obs/path");
+    Model& md = ctx->model;
+    const size_t cells = (size_t)U * T * md.N;
+    const int32_t* d_lens;
+    LN_TRY(device_lens(ctx, lens, U, T, &d_lens));
+    const void* d_obs;
+    void *d_path, *d_best = nullptr;
+    LN_TRY(stage_in(ctx, obs, (size_t)U * T * md.D * 8, ctx->ws_in, &d_obs));
+    LN_TRY(ctx->ws_b.reserve(cells * 8));
+    LN_TRY(ctx->ws_v.reserve(cells * 8));
+    LN_TRY(stage_out(ctx, path, (size_t)U * T * 4, ctx->ws_out, &d_path));
+    if (best_score_or_null) LN_TRY(stage_out(ctx, best_score_or_null, (size_t)U * 8, ctx->ws_out2, &d_best));
+    LN_TRY(emit_device(ctx, (const double*)d_obs, (long)U * T, LNASR_F64, ctx->ws_b.p, nullptr));
+    LN_TRY(viterbi_device(ctx, ctx->ws_b.p, U, T, d_lens, LNASR_F64, ctx->ws_v.p));
+    LN_TRY(backtrace_device(ctx, ctx->ws_v.p, U, T, d_lens, LNASR_F64, (uint32_t*)d_path, (double*)d_best));
+    LN_TRY(finish_out(ctx, path, d_path, (size_t)U * T * 4));
+    if (best_score_or_null) LN_TRY(finish_out(ctx, best_score_or_null, d_best, (size_t)U * 8));
+    return 0;
+}
+
+int lnasr_forward(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* lens, int dtype, void* alpha_or_null,
+                  double* loglik_or_null) {
+    LN_CHECK_BATCH(ctx, U, T, dtype);
+    if (U == 0 || T == 0) return 0;
+    LN_REQUIRE(b, "null b");
+    const int N = ctx->model.N;
+    const size_t es = dtype_size(dtype), cells = (size_t)U * T * N;
+    const int32_t* d_lens;
+    LN_TRY(device_lens(ctx, lens, U, T, &d_lens));
+    const void* d_b;
+    void *d_alpha = nullptr, *d_ll = nullptr;
+    LN_TRY(stage_in(ctx, b, cells * es, ctx->ws_in, &d_b));
+    if (alpha_or_null) LN_TRY(stage_out(ctx, alpha_or_null, cells * es, ctx->ws_alpha, &d_alpha));
+    if (loglik_or_null) LN_TRY(stage_out(ctx, loglik_or_null, (size_t)U * 8, ctx->ws_out2, &d_ll));
+    LN_TRY(forward_device(ctx, d_b, U, T, d_lens, dtype, d_alpha, (double*)d_ll));
+    if (alpha_or_null) LN_TRY(finish_out(ctx, alpha_or_null, d_alpha, cells * es));
+    if (loglik_or_null) LN_TRY(finish_out(ctx, loglik_or_null, d_ll, (size_t)U * 8));
+    return 0;
+}
+
+int lnasr_backward(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* lens, int dtype, void* beta) {
+    LN_CHECK_BATCH(ctx, U, T, dtype);
+    if (U == 0 || T == 0) return 0;
+    LN_REQUIRE(b && beta, "null b/beta");
+    const int N = ctx->model.N;
+    const size_t es = dtype_size(dtype), cells = (size_t)U * T * N;
+    const int32_t* d_lens;
+    LN_TRY(device_lens(ctx, lens, U, T, &d_lens));
+    const void* d_b;
+    void* d_beta;
+    LN_TRY(stage_in(ctx, b, cells * es, ctx->ws_in, &d_b));
+    LN_TRY(stage_out(ctx, beta, cells * es, ctx->ws_beta, &d_beta));
+    LN_TRY(backward_device(ctx, d_b, U, T, d_lens, dtype, d_beta));
+    return finish_out(ctx, beta, d_beta, cells * es);
+}
+
+int lnasr_calc_prob(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* lens, double* loglik) {
+    LN_CHECK_BATCH(ctx, U, T, LNASR_F64);
+    if (!ctx->model.has_gmm) return fail(LNASR_E_NOMODEL, "no GMM-HMM model uploaded");
+    if (U == 0 || T == 0) return 0;
+    LN_REQUIRE(obs && loglik, "null obs/loglik");
+    Model& md = ctx->model;
+    const size_t cells = (size_t)U * T * md.N;
+    const int32_t* d_lens;
+    LN_TRY(device_lens(ctx, lens, U, T, &d_lens));
+    const void* d_obs;
+    void* d_ll;
+    LN_TRY(stage_in(ctx, obs, (size_t)U * T * md.D * 8, ctx->ws_in, &d_obs));
+    LN_TRY(ctx->ws_b.reserve(cells * 8));
+    LN_TRY(stage_out(ctx, loglik, (size_t)U * 8, ctx->ws_out2, &d_ll));
+    LN_TRY(emit_device(ctx, (const double*)d_obs, (long)U * T, LNASR_F64, ctx->ws_b.p, nullptr));
+    LN_TRY(forward_device(ctx, ctx->ws_b.p, U, T, d_lens, LNASR_F64, nullptr, (double*)d_ll));
+    return finish_out(ctx, loglik, d_ll, (size_t)U * 8);
+}
+
+int lnasr_baumwelch(lnasr_ctx* ctx, const void* b, const void* alpha, const void* beta, int U, int T,
+                    const int32_t* lens, int dtype, void* xi, void* gamma) {
+    LN_CHECK_BATCH(ctx, U, T, dtype);
+    if (U == 0 || T == 0) return 0;
+    LN_REQUIRE(b && alpha && beta && gamma, "null argument");
+    const int N = ctx->model.N;
+    const size_t es = dtype_size(dtype), cells = (size_t)U * T * N;
+    const int32_t* d_lens;
+    LN_TRY(device_lens(ctx, lens, U, T, &d_lens));
+    const void *d_b, *d_al, *d_be;
+    void *d_xi = nullptr, *d_ga;
+    LN_TRY(stage_in(ctx, b, cells * es, ctx->ws_in, &d_b));
+    LN_TRY(stage_in(ctx, alpha, cells * es, ctx->ws_in2, &d_al));
+    LN_TRY(stage_in(ctx, beta, cells * es, ctx->ws_in3, &d_be));
+    if (xi) LN_TRY(stage_out(ctx, xi, cells * N * es, ctx->ws_out, &d_xi));
+    LN_TRY(stage_out(ctx, gamma, cells * es, ctx->ws_out2, &d_ga));
+    LN_TRY(baumwelch_device(ctx, d_b, d_al, d_be, U, T, d_lens, dtype, d_xi, d_ga));
+    if (xi) LN_TRY(finish_out(ctx, xi, d_xi, cells * N * es));
+    return finish_out(ctx, gamma, d_ga, cells * es);
+}
+
+}  // extern "C"

@@ -1,0 +1,554 @@
+"""ctypes binding of liblnasr_hip.so (include/lnasr_hip.h) -- the only caller of the C-ABI.
+
+There is NO CPU fallback: if the HIP library is missing or no gfx950 device is visible,
+every compute entry point raises.  Build the library with `python ln-asr_amd/build.py`.
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+F64, F32 = 0, 1
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liblnasr_hip.so")
+UNIQUE_ID_BYTES = 128
+
+
+class LnasrError(RuntimeError):
+    pass
+
+
+class MfccCfgStruct(C.Structure):
+    _fields_ = [("fs", C.c_int), ("frame_len", C.c_int), ("frame_step", C.c_int), ("fft_n", C.c_int),
+                ("n_mel", C.c_int), ("n_cep", C.c_int), ("hpf_alpha", C.c_double)]
+
+
+_vp, _i, _sz, _dbl, _i64 = C.c_void_p, C.c_int, C.c_size_t, C.c_double, C.c_int64
+_P = C.POINTER
+
+# name -> argtypes (every function returns int unless listed in _RESTYPES)
+SIGNATURES = {
+    "lnasr_abi_version": [],
+    "lnasr_last_error": [],
+    "lnasr_device_count": [_P(_i)],
+    "lnasr_ctx_create": [_i, _P(_vp)],
+    "lnasr_ctx_destroy": [_vp],
+    "lnasr_sync": [_vp],
+    "lnasr_device_info": [_vp, C.c_char_p, _i, _P(_i), _P(_sz)],
+    "lnasr_dev_alloc": [_vp, _sz, _P(_vp)],
+    "lnasr_dev_free": [_vp, _vp],
+    "lnasr_memcpy_h2d": [_vp, _vp, _vp, _sz],
+    "lnasr_memcpy_d2h": [_vp, _vp, _vp, _sz],
+    "lnasr_memset": [_vp, _vp, _i, _sz],
+    "lnasr_prof_enable": [_vp, _i],
+    "lnasr_prof_reset": [_vp],
+    "lnasr_prof_count": [_vp, _P(_i)],
+    "lnasr_prof_get": [_vp, _i, C.c_char_p, _i, _P(_i64), _P(_dbl)],
+    "lnasr_model_upload": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i],
+    "lnasr_model_upload_full": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "lnasr_hmm_upload": [_vp, _i, _vp, _vp],
+    "lnasr_model_is_diag": [_vp, _P(_i)],
+    "lnasr_discrete_map_b": [_vp, _vp, _i, _i, _vp, _i, _i, _i, _vp],
+    "lnasr_gmm_logprob": [_vp, _vp, _i, _i, _vp, _i, _vp, _vp],
+    "lnasr_gauss1d": [_vp, _vp, _sz, _dbl, _dbl, _i, _vp],
+    "lnasr_gauss_multi": [_vp, _vp, _sz, _i, _vp, _vp, _i, _vp],
+    "lnasr_gauss_mixture": [_vp, _vp, _i, _vp, _sz, _i, _vp, _vp, _i, _vp],
+    "lnasr_viterbi": [_vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp],
+    "lnasr_decode": [_vp, _vp, _i, _i, _vp, _vp, _vp],
+    "lnasr_forward": [_vp, _vp, _i, _i, _vp, _i, _vp, _vp],
+    "lnasr_backward": [_vp, _vp, _i, _i, _vp, _i, _vp],
+    "lnasr_calc_prob": [_vp, _vp, _i, _i, _vp, _vp],
+    "lnasr_baumwelch": [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp],
+    "lnasr_estimate_discrete": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "lnasr_estimate_gmm": [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _dbl, _vp, _vp, _vp, _vp, _vp],
+    "lnasr_bw_stats_len": [_vp, _P(_sz)],
+    "lnasr_bw_accumulate": [_vp, _vp, _i, _i, _vp, _vp],
+    "lnasr_bw_mstep": [_vp, _vp, _dbl, _vp, _vp, _vp, _vp, _vp],
+    "lnasr_lse": [_vp, _vp, _sz, _sz, _sz, _i, _vp],
+    "lnasr_num_frames": [_i64, _i, _i, _P(_i64)],
+    "lnasr_split_frames": [_vp, _vp, _i64, _i, _i, _vp],
+    "lnasr_mfcc": [_vp, _vp, _i, _vp, _i, _P(MfccCfgStruct), _vp, _vp, _vp, _vp, _vp],
+    "lnasr_comm_unique_id": [_vp],
+    "lnasr_comm_init": [_vp, _vp, _i, _i],
+    "lnasr_comm_destroy": [_vp],
+    "lnasr_allgather_u32": [_vp, _vp, _sz, _vp],
+    "lnasr_allreduce_f64": [_vp, _vp, _sz],
+}
+_RESTYPES = {"lnasr_last_error": C.c_char_p, "lnasr_ctx_destroy": None}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib():
+    """Load liblnasr_hip.so (once).  Raises LnasrError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(_LIB_PATH):
+                raise LnasrError("%s not found: build it with `python ln-asr_amd/build.py` "
+                                 "(there is no CPU fallback)" % _LIB_PATH)
+            l = C.CDLL(_LIB_PATH)
+            for name, args in SIGNATURES.items():
+                fn = getattr(l, name)
+                fn.argtypes = args
+                fn.restype = _RESTYPES.get(name, C.c_int)
+            if l.lnasr_abi_version() != 1:
+                raise LnasrError("ABI version mismatch")
+            _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().lnasr_last_error()
+        raise LnasrError("lnasr error %d: %s" % (rc, msg.decode() if msg else "?"))
+
+
+def np_dtype(code):
+    return np.float32 if code == F32 else np.float64
+
+
+def dtype_code(precision):
+    return F32 if np.dtype(precision) == np.float32 else F64
+
+
+class DeviceArray:
+    """A device-resident, C-contiguous array (HBM) owned by a Context."""
+
+    def __init__(self, ctx, shape, dtype):
+        self.ctx = ctx
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        p = C.c_void_p()
+        check(lib().lnasr_dev_alloc(ctx.handle, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    @classmethod
+    def from_host(cls, ctx, arr, dtype=None):
+        arr = np.ascontiguousarray(arr, dtype=dtype)
+        d = cls(ctx, arr.shape, arr.dtype)
+        check(lib().lnasr_memcpy_h2d(ctx.handle, d.ptr, arr.ctypes.data, d.nbytes))
+        return d
+
+    def to_host(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        check(lib().lnasr_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, self.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr and self.ctx.handle:
+            lib().lnasr_dev_free(self.ctx.handle, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _ptr(x):
+    """void* of a numpy array / DeviceArray / None."""
+    if x is None:
+        return None
+    if isinstance(x, DeviceArray):
+        return x.ptr
+    return x.ctypes.data
+
+
+def _in(x, dtype):
+    """Host arrays are made C-contiguous of `dtype`; DeviceArrays pass through."""
+    if isinstance(x, DeviceArray):
+        if x.dtype != np.dtype(dtype):
+            raise LnasrError("device array dtype %s, expected %s" % (x.dtype, np.dtype(dtype)))
+        return x
+    return np.ascontiguousarray(x, dtype=dtype)
+
+
+class Context:
+    """One process = one GPU = one Context (one HIP stream)."""
+
+    def __init__(self, device=None):
+        if device is None:
+            device = int(os.environ.get("LNASR_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        n = C.c_int(0)
+        check(lib().lnasr_device_count(C.byref(n)))
+        if n.value > 0:
+            device = device % n.value
+        h = C.c_void_p()
+        check(lib().lnasr_ctx_create(int(device), C.byref(h)))
+        self.handle = h.value
+        self.device = int(device)
+        self.model_owner = None       # (id(obj), version) of the model currently uploaded
+        self.model_shape = None       # (N, M, D) or (N,)
+
+    def close(self):
+        if self.handle:
+            lib().lnasr_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- runtime -----------------------------------------------------------------------
+    def sync(self):
+        check(lib().lnasr_sync(self.handle))
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cu = C.c_int(0)
+        mem = C.c_size_t(0)
+        check(lib().lnasr_device_info(self.handle, name, 256, C.byref(cu), C.byref(mem)))
+        return {"name": name.value.decode(), "cu_count": cu.value, "hbm_bytes": mem.value}
+
+    def empty(self, shape, dtype=np.float64):
+        return DeviceArray(self, shape, dtype)
+
+    def to_device(self, arr, dtype=None):
+        return DeviceArray.from_host(self, arr, dtype)
+
+    def prof_enable(self, on=True):
+        check(lib().lnasr_prof_enable(self.handle, 1 if on else 0))
+
+    def prof_reset(self):
+        check(lib().lnasr_prof_reset(self.handle))
+
+    def prof_report(self):
+        """{kernel name: (launches, total_ms)} from HIP events on this context's stream."""
+        n = C.c_int(0)
+        check(lib().lnasr_prof_count(self.handle, C.byref(n)))
+        out = {}
+        for i in range(n.value):
+            name = C.create_string_buffer(128)
+            cnt = C.c_int64(0)
+            ms = C.c_double(0)
+            check(lib().lnasr_prof_get(self.handle, i, name, 128, C.byref(cnt), C.byref(ms)))
+            if cnt.value:
+                out[name.value.decode()] = (cnt.value, ms.value)
+        return out
+
+    # -- models --------------------------------------------------------------------------
+    def upload_hmm(self, A, pi):
+        A = _in(A, np.float64)
+        pi = _in(pi, np.float64)
+        N = A.shape[0]
+        if A.shape != (N, N) or pi.shape != (N,):
+            raise ValueError("A must be [N,N] and pi [N]; got %s, %s" % (A.shape, pi.shape))
+        check(lib().lnasr_hmm_upload(self.handle, N, _ptr(A), _ptr(pi)))
+        self.model_shape = (N,)
+
+    def upload_gmmhmm(self, A, pi, w, mu, sigma, diag=False, force_full=False):
+        """sigma: [N,M,D,D] (diag=False) or [N,M,D] (diag=True)."""
+        A, pi, w, mu, sigma = (_in(x, np.float64) for x in (A, pi, w, mu, sigma))
+        N, M, D = mu.shape
+        if A.shape != (N, N) or pi.shape != (N,) or w.shape != (N, M):
+            raise ValueError("inconsistent GMM-HMM shapes")
+        if sigma.shape != ((N, M, D) if diag else (N, M, D, D)):
+            raise ValueError("sigma shape %s does not match (N,M,D)=%s" % (sigma.shape, (N, M, D)))
+        if force_full:
+            if diag:
+                raise ValueError("force_full needs a full covariance")
+            check(lib().lnasr_model_upload_full(self.handle, N, M, D, _ptr(A), _ptr(pi), _ptr(w), _ptr(mu), _ptr(sigma)))
+        else:
+            check(lib().lnasr_model_upload(self.handle, N, M, D, _ptr(A), _ptr(pi), _ptr(w), _ptr(mu), _ptr(sigma),
+                                           1 if diag else 0))
+        self.model_shape = (N, M, D)
+
+    def model_is_diag(self):
+        v = C.c_int(0)
+        check(lib().lnasr_model_is_diag(self.handle, C.byref(v)))
+        return bool(v.value)
+
+    # -- helpers ---------------------------------------------------------------------------
+    def _out(self, like_device, shape, dtype):
+        return DeviceArray(self, shape, dtype) if like_device else np.empty(shape, dtype=dtype)
+
+    @staticmethod
+    def _lens(lens, U):
+        if lens is None:
+            return None
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        if lens.shape != (U,):
+            raise ValueError("lens must have shape (U,)")
+        return lens
+
+    # -- emission ----------------------------------------------------------------------------
+    def discrete_map_b(self, logB, obs, precision=np.float64):
+        logB = _in(logB, np.float64)
+        obs = _in(obs, np.int32)
+        if obs.ndim == 1:
+            obs = obs.reshape(1, -1)
+        U, T = obs.shape
+        N, K = logB.shape
+        code = dtype_code(precision)
+        b = self._out(isinstance(obs, DeviceArray), (U, T, N), np_dtype(code))
+        check(lib().lnasr_discrete_map_b(self.handle, _ptr(logB), N, K, _ptr(obs), U, T, code, _ptr(b)))
+        return b
+
+    def gmm_logprob(self, obs, want_bm=False, precision=np.float64, lens=None):
+        obs = _in(obs, np.float64)
+        U, T, D = obs.shape
+        N, M, D0 = self.model_shape
+        if D != D0:
+            raise ValueError("obs has D=%d, model has D=%d" % (D, D0))
+        code = dtype_code(precision)
+        dev = isinstance(obs, DeviceArray)
+        b = self._out(dev, (U, T, N), np_dtype(code))
+        bm = self._out(dev, (U, T, N, M), np_dtype(code)) if want_bm else None
+        check(lib().lnasr_gmm_logprob(self.handle, _ptr(obs), U, T, _ptr(self._lens(lens, U)), code, _ptr(b), _ptr(bm)))
+        return (b, bm) if want_bm else b
+
+    def gauss1d(self, x, mu, sigma2, want_log):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        out = np.empty(x.shape, dtype=np.float64)
+        check(lib().lnasr_gauss1d(self.handle, _ptr(x), x.size, float(mu), float(sigma2), int(want_log), _ptr(out)))
+        return out
+
+    def gauss_multi(self, x, mu, Sigma, want_log):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        L, D = x.shape
+        mu = np.ascontiguousarray(np.asarray(mu, dtype=np.float64).reshape(D))
+        Sigma = np.ascontiguousarray(np.asarray(Sigma, dtype=np.float64).reshape(D, D))
+        out = np.empty(L, dtype=np.float64)
+        check(lib().lnasr_gauss_multi(self.handle, _ptr(x), L, D, _ptr(mu), _ptr(Sigma), int(want_log), _ptr(out)))
+        return out
+
+    def gauss_mixture(self, c, x, mu, Sigma, want_log):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        L, D = x.shape
+        c = np.ascontiguousarray(np.asarray(c, dtype=np.float64).ravel())
+        M = c.shape[0]
+        mu = np.ascontiguousarray(np.asarray(mu, dtype=np.float64).reshape(M, D))
+        Sigma = np.ascontiguousarray(np.asarray(Sigma, dtype=np.float64).reshape(M, D, D))
+        out = np.empty(L, dtype=np.float64)
+        check(lib().lnasr_gauss_mixture(self.handle, _ptr(c), M, _ptr(x), L, D, _ptr(mu), _ptr(Sigma), int(want_log),
+                                        _ptr(out)))
+        return out
+
+    # -- trellises -----------------------------------------------------------------------------
+    def viterbi(self, b, want_v=True, want_bt=True, want_score=False, lens=None):
+        """b [U,T,N] -> dict(path [U,T] u32, v, bt, score)."""
+        code = dtype_code(b.dtype)
+        b = _in(b, np_dtype(code))
+        U, T, N = b.shape
+        dev = isinstance(b, DeviceArray)
+        v = self._out(dev, (U, T, N), np_dtype(code)) if want_v else None
+        bt = self._out(dev, (U, T, N), np.uint32) if want_bt else None
+        path = self._out(dev, (U, T), np.uint32)
+        score = self._out(dev, (U,), np.float64) if want_score else None
+        if bt is not None and not dev:
+            bt[...] = 0
+        check(lib().lnasr_viterbi(self.handle, _ptr(b), U, T, _ptr(self._lens(lens, U)), code, _ptr(v), _ptr(bt),
+                                  _ptr(path), _ptr(score)))
+        return {"path": path, "v": v, "bt": bt, "score": score}
+
+    def decode(self, obs, want_score=False, lens=None, path_out=None, score_out=None):
+        obs = _in(obs, np.float64)
+        U, T, D = obs.shape
+        dev = isinstance(obs, DeviceArray)
+        path = path_out if path_out is not None else self._out(dev, (U, T), np.uint32)
+        score = score_out if score_out is not None else (self._out(dev, (U,), np.float64) if want_score else None)
+        check(lib().lnasr_decode(self.handle, _ptr(obs), U, T, _ptr(self._lens(lens, U)), _ptr(path), _ptr(score)))
+        return (path, score) if (want_score or score_out is not None) else path
+
+    def forward(self, b, want_alpha=True, want_loglik=True, lens=None):
+        code = dtype_code(b.dtype)
+        b = _in(b, np_dtype(code))
+        U, T, N = b.shape
+        dev = isinstance(b, DeviceArray)
+        alpha = self._out(dev, (U, T, N), np_dtype(code)) if want_alpha else None
+        ll = self._out(dev, (U,), np.float64) if want_loglik else None
+        check(lib().lnasr_forward(self.handle, _ptr(b), U, T, _ptr(self._lens(lens, U)), code, _ptr(alpha), _ptr(ll)))
+        return alpha, ll
+
+    def backward(self, b, lens=None):
+        code = dtype_code(b.dtype)
+        b = _in(b, np_dtype(code))
+        U, T, N = b.shape
+        beta = self._out(isinstance(b, DeviceArray), (U, T, N), np_dtype(code))
+        check(lib().lnasr_backward(self.handle, _ptr(b), U, T, _ptr(self._lens(lens, U)), code, _ptr(beta)))
+        return beta
+
+    def calc_prob(self, obs, lens=None):
+        obs = _in(obs, np.float64)
+        U, T, D = obs.shape
+        ll = self._out(isinstance(obs, DeviceArray), (U,), np.float64)
+        check(lib().lnasr_calc_prob(self.handle, _ptr(obs), U, T, _ptr(self._lens(lens, U)), _ptr(ll)))
+        return ll
+
+    def baumwelch(self, b, alpha, beta, want_xi=True, lens=None):
+        code = dtype_code(b.dtype)
+        dt = np_dtype(code)
+        b, alpha, beta = _in(b, dt), _in(alpha, dt), _in(beta, dt)
+        U, T, N = b.shape
+        dev = isinstance(b, DeviceArray)
+        xi = self._out(dev, (U, T, N, N), dt) if want_xi else None
+        gamma = self._out(dev, (U, T, N), dt)
+        check(lib().lnasr_baumwelch(self.handle, _ptr(b), _ptr(alpha), _ptr(beta), U, T, _ptr(self._lens(lens, U)),
+                                    code, _ptr(xi), _ptr(gamma)))
+        return xi, gamma
+
+    def estimate_discrete(self, obs, K, xi, gamma):
+        code = dtype_code(gamma.dtype)
+        dt = np_dtype(code)
+        obs = np.ascontiguousarray(obs, dtype=np.int32)
+        xi, gamma = _in(xi, dt), _in(gamma, dt)
+        T, N = gamma.shape
+        A = np.empty((N, N), dt)
+        B = np.empty((N, K), dt)
+        pi = np.empty(N, dt)
+        check(lib().lnasr_estimate_discrete(self.handle, _ptr(obs), T, N, K, code, _ptr(xi), _ptr(gamma), _ptr(A),
+                                            _ptr(B), _ptr(pi)))
+        return {"A": A, "B": B, "pi": pi}
+
+    def estimate_gmm(self, obs, bm, alpha, beta, xi, gamma, min_std):
+        """bm [T,N,M], alpha/beta/gamma [T,N], xi [T,N,N]; uses the uploaded (old) w and mu."""
+        code = dtype_code(gamma.dtype)
+        dt = np_dtype(code)
+        obs = np.ascontiguousarray(obs, dtype=np.float64)
+        bm, alpha, beta, xi, gamma = (_in(x, dt) for x in (bm, alpha, beta, xi, gamma))
+        T, D = obs.shape
+        N, M, _ = self.model_shape
+        A = np.empty((N, N), dt)
+        pi = np.empty(N, dt)
+        w = np.empty((N, M), dt)
+        mu = np.empty((N, M, D), np.float64)
+        si = np.empty((N, M, D, D), np.float64)
+        check(lib().lnasr_estimate_gmm(self.handle, _ptr(obs), T, code, _ptr(bm), _ptr(alpha), _ptr(beta), _ptr(xi),
+                                       _ptr(gamma), float(min_std), _ptr(A), _ptr(pi), _ptr(w), _ptr(mu), _ptr(si)))
+        return {"A": A, "pi": pi, "w": w, "mu": mu, "si": si}
+
+    def bw_stats_len(self):
+        n = C.c_size_t(0)
+        check(lib().lnasr_bw_stats_len(self.handle, C.byref(n)))
+        return n.value
+
+    def bw_accumulate(self, obs, lens=None, stats_out=None):
+        obs = _in(obs, np.float64)
+        U, T, D = obs.shape
+        stats = stats_out if stats_out is not None else np.zeros(self.bw_stats_len(), dtype=np.float64)
+        check(lib().lnasr_bw_accumulate(self.handle, _ptr(obs), U, T, _ptr(self._lens(lens, U)), _ptr(stats)))
+        return stats
+
+    def bw_mstep(self, stats, min_std=0.01):
+        N, M, D = self.model_shape
+        diag = self.model_is_diag()
+        A = np.empty((N, N))
+        pi = np.empty(N)
+        w = np.empty((N, M))
+        mu = np.empty((N, M, D))
+        sg = np.empty((N, M, D) if diag else (N, M, D, D))
+        stats = _in(stats, np.float64)
+        check(lib().lnasr_bw_mstep(self.handle, _ptr(stats), float(min_std), _ptr(A), _ptr(pi), _ptr(w), _ptr(mu), _ptr(sg)))
+        return {"A": A, "pi": pi, "w": w, "mu": mu, ("var" if diag else "si"): sg}
+
+    # -- numeric utils -------------------------------------------------------------------------
+    def lse3(self, x, base2=False):
+        """x [outer, n, inner] -> [outer, inner]."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        outer, n, inner = x.shape
+        out = np.empty((outer, inner), dtype=np.float64)
+        if out.size:
+            check(lib().lnasr_lse(self.handle, _ptr(x), outer, n, inner, 1 if base2 else 0, _ptr(out)))
+        return out
+
+    def split_frames(self, signal, L, S):
+        signal = np.ascontiguousarray(signal, dtype=np.float64)
+        nf = num_frames(len(signal), L, S)
+        out = np.empty((nf, L), dtype=np.float64)
+        check(lib().lnasr_split_frames(self.handle, _ptr(signal), len(signal), int(L), int(S), _ptr(out)))
+        return out
+
+    def mfcc(self, signal, offsets, cfg, window, fbank, want_power=True, want_cepstrum=True):
+        """signal: float64 or int16 samples (host or DeviceArray), utterances concatenated;
+        offsets int64 [U+1].  Returns (power|None, cepstrum|None, features, frame_offsets)."""
+        if isinstance(signal, DeviceArray):
+            kind = 1 if signal.dtype == np.int16 else 0
+        else:
+            signal = np.ascontiguousarray(signal)
+            if signal.dtype == np.int16:
+                kind = 1
+            else:
+                signal = np.ascontiguousarray(signal, dtype=np.float64)
+                kind = 0
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        U = len(offsets) - 1
+        nfs = [num_frames(int(offsets[u + 1] - offsets[u]), cfg.frame_len, cfg.frame_step) for u in range(U)]
+        foff = np.concatenate([[0], np.cumsum(nfs)]).astype(np.int64)
+        F = int(foff[-1])
+        dev = isinstance(signal, DeviceArray)
+        nbin = cfg.fft_n // 2 + 1
+        power = self._out(dev, (F, nbin), np.float64) if want_power else None
+        cep = self._out(dev, (F, cfg.n_mel), np.float64) if want_cepstrum else None
+        feat = self._out(dev, (F, 3 * (cfg.n_cep + 1)), np.float64)
+        window = np.ascontiguousarray(window, dtype=np.float64)
+        fbank = np.ascontiguousarray(fbank, dtype=np.float64)
+        check(lib().lnasr_mfcc(self.handle, _ptr(signal), kind, _ptr(offsets), U, C.byref(cfg), _ptr(window),
+                               _ptr(fbank), _ptr(power), _ptr(cep), _ptr(feat)))
+        return power, cep, feat, foff
+
+    # -- multi-GPU ---------------------------------------------------------------------------------
+    def comm_init(self, unique_id, rank, nranks):
+        buf = C.create_string_buffer(bytes(unique_id), UNIQUE_ID_BYTES)
+        check(lib().lnasr_comm_init(self.handle, buf, int(rank), int(nranks)))
+        self.rank, self.nranks = int(rank), int(nranks)
+
+    def comm_destroy(self):
+        check(lib().lnasr_comm_destroy(self.handle))
+        self.rank, self.nranks = 0, 1
+
+    def allgather_u32(self, local, out=None):
+        local = _in(local, np.uint32)
+        n = int(np.prod(local.shape))
+        nr = self.nranks
+        if out is None:
+            out = self._out(isinstance(local, DeviceArray), (nr,) + tuple(local.shape), np.uint32)
+        check(lib().lnasr_allgather_u32(self.handle, _ptr(local), n, _ptr(out)))
+        return out
+
+    def allreduce_f64(self, buf):
+        if not isinstance(buf, DeviceArray):
+            assert buf.dtype == np.float64 and buf.flags.c_contiguous
+        n = int(np.prod(buf.shape))
+        check(lib().lnasr_allreduce_f64(self.handle, _ptr(buf), n))
+        return buf
+
+    rank = 0
+    nranks = 1
+
+
+def comm_unique_id():
+    buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+    check(lib().lnasr_comm_unique_id(buf))
+    return buf.raw
+
+
+def num_frames(n, L, S):
+    out = C.c_int64(0)
+    check(lib().lnasr_num_frames(int(n), int(L), int(S), C.byref(out)))
+    return out.value
+
+
+_default = None
+
+
+def default_ctx():
+    """The process-wide context (device = $LNASR_DEVICE or $LOCAL_RANK or 0)."""
+    global _default
+    if _default is None:
+        _default = Context()
+    return _default
+
+
+def device_count():
+    n = C.c_int(0)
+    check(lib().lnasr_device_count(C.byref(n)))
+    return n.value

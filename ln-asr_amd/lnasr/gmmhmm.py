@@ -1,0 +1,134 @@
+"""GMM-HMM with the reference's call surface (lnasr/gmmhmm.py:17-208).
+
+n states, m Gaussians per state, d-dimensional observations; `A, pi, w` are natural-log
+probabilities, `mu [N,M,D]`, `si [N,M,D,D]` linear.  Emission scoring, the trellises and the
+Baum-Welch M-step all run in HIP kernels; `_map_b` leaves `self.b [N,T]` and
+`self.bm [N,M,T]` behind exactly like the reference so that `remap=False` calls work.
+
+Covariances that are exactly diagonal take the fp64-MFMA kernel automatically; anything else
+goes through the general (LU-inverse) kernel.  `si` may also be handed over already as the
+diagonal `[N,M,D]` (extension).
+
+Batch extras (not in the reference): `upload()`, `decode_batch`, `calc_prob_batch`,
+`accumulate` / `apply_stats` (multi-utterance Baum-Welch, statistics all-reducible over RCCL).
+"""
+import numpy as np
+
+from . import _ffi
+from .hmm import HMM, _save, _load
+
+
+class GMMHMM(HMM):
+
+    def __init__(self, n: int = 1, m: int = 1, d: int = 1, A=None, pi=None, w=None, mu=None, si=None,
+                 precision=np.double, *, ctx=None):
+        super().__init__(n, m, A, None, pi, precision, ctx=ctx)
+        self.d = d
+        self.w = w
+        self.mu = mu
+        self.si = si
+        self.min_std = 0.01
+
+    # ------------------------------------------------------------------ plumbing
+    def _upload_gmm(self):
+        """All parameters -> device (per call on the reference API; see `upload()` for batches)."""
+        si = np.asarray(self.si, dtype=np.float64)
+        mu = np.asarray(self.mu, dtype=np.float64)
+        self.ctx.upload_gmmhmm(np.asarray(self.A, dtype=np.float64), np.asarray(self.pi, dtype=np.float64),
+                               np.asarray(self.w, dtype=np.float64), mu, si, diag=(si.ndim == 3))
+
+    def upload(self):
+        """Upload once before a series of *_batch calls (parameters must not change in between)."""
+        self._upload_gmm()
+        return self
+
+    def _upload(self):
+        # trellis-only calls need just A / pi, but keeping the whole model resident lets
+        # `_estimate` read the old w / mu (gmmhmm.py:98,138) without another transfer
+        self._upload_gmm()
+
+    # ------------------------------------------------------------------ emission
+    def _map_b(self, obs: np.ndarray):
+        """bm[j,m,:] = log N(obs; mu[j,m], si[j,m]);  b[j,:] = lse_m(w[j,m] + bm[j,m,:])  (gmmhmm.py:46-67)."""
+        obs = np.asarray(obs, dtype=np.float64)
+        self._upload_gmm()
+        b, bm = self.ctx.gmm_logprob(obs[None], want_bm=True, precision=self.precision)
+        self.b = b[0].T                              # [N,T]
+        self.bm = bm[0].transpose(1, 2, 0)           # [N,M,T]
+
+    # ------------------------------------------------------------------ M-step
+    def _estimate(self, obs: np.ndarray, alpha, beta, xi, gamma):
+        """{'A','pi','w','mu','si'}  (gmmhmm.py:69-156).  Sigma is taken around the OLD mean and
+        gets `min_std * I` added, as in the reference."""
+        obs = np.asarray(obs, dtype=np.float64)
+        dt = np.float32 if np.asarray(gamma).dtype == np.float32 else np.float64
+        self._upload_gmm()
+        bm = np.ascontiguousarray(np.asarray(self.bm).transpose(2, 0, 1), dtype=dt)     # [T,N,M]
+        est = self.ctx.estimate_gmm(obs, bm, np.asarray(alpha, dtype=dt), np.asarray(beta, dtype=dt),
+                                    np.asarray(xi, dtype=dt), np.asarray(gamma, dtype=dt), self.min_std)
+        return est
+
+    def _updatemodel(self, model):
+        self.A = model["A"]
+        self.pi = model["pi"]
+        self.mu = model["mu"]
+        self.si = model["si"]
+        self.w = model["w"]
+
+    def reset(self, init_type):
+        """'uniform': zero means, identity Sigma; 'random': A, pi, w from the global numpy RNG,
+        mu ~ U(-0.3, 0.3), Sigma = I  (gmmhmm.py:166-188)."""
+        if init_type == "uniform":
+            self.A = np.log(np.ones((self.n, self.n), dtype=self.precision) * (1.0 / self.n))
+            self.pi = np.log(np.ones(self.n, dtype=self.precision) * (1.0 / self.n))
+            self.w = np.log(np.ones((self.n, self.m), dtype=self.precision) * (1.0 / self.m))
+            self.mu = np.zeros((self.n, self.m, self.d), dtype=self.precision)
+            self.si = np.zeros((self.n, self.m, self.d, self.d), dtype=self.precision)
+            self.si[:, :] = np.eye(self.d, dtype=self.precision)
+        elif init_type == "random":
+            a = np.random.random_sample((self.n, self.n))
+            pi = np.random.random_sample((self.n))
+            w = np.random.random_sample((self.n, self.m))
+            self.A = np.log(a / a.sum(axis=1)[:, np.newaxis])
+            self.pi = np.log(pi / np.sum(pi))
+            self.w = np.log(w / w.sum(axis=1)[:, np.newaxis])
+            self.mu = np.array(0.6 * np.random.random_sample((self.n, self.m, self.d)) - 0.3, dtype=self.precision)
+            self.si = np.zeros((self.n, self.m, self.d, self.d), dtype=self.precision)
+            self.si[:, :] = np.eye((self.d), dtype=self.precision)
+
+    def save(self, filename):
+        """Datasets 'A','pi','w','mu','si'  (gmmhmm.py:190-198)."""
+        _save(filename, {"A": self.A, "pi": self.pi, "w": self.w, "mu": self.mu, "si": self.si})
+
+    def load(self, filename):
+        """gmmhmm.py:200-208; n, m, d are inferred from mu's shape."""
+        d = _load(filename, ("A", "pi", "w", "mu", "si"))
+        self.A, self.pi, self.w, self.mu, self.si = d["A"], d["pi"], d["w"], d["mu"], d["si"]
+        self.n, self.m, self.d = self.mu.shape
+
+    # ------------------------------------------------------------------ public API
+    def calc_prob(self, obs: np.ndarray) -> float:
+        self._map_b(obs)
+        _, ll = self.ctx.forward(self._b_dev(), want_alpha=False, want_loglik=True)
+        return np.asarray(ll, dtype=self.precision)[0]
+
+    # ------------------------------------------------------------------ batch extras
+    def decode_batch(self, obs_batch, lens=None, want_score=False):
+        """obs [U,T,D] (numpy or DeviceArray) -> paths [U,T] uint32: emission + Viterbi +
+        backtrace fused on the device; call `upload()` first."""
+        return self.ctx.decode(obs_batch, want_score=want_score, lens=lens)
+
+    def calc_prob_batch(self, obs_batch, lens=None):
+        return self.ctx.calc_prob(obs_batch, lens=lens)
+
+    def accumulate(self, obs_batch, lens=None):
+        """Baum-Welch sufficient statistics of a batch (packed fp64 vector; sum over ranks
+        with Context.allreduce_f64, then `apply_stats`)."""
+        return self.ctx.bw_accumulate(obs_batch, lens=lens)
+
+    def apply_stats(self, stats):
+        """M-step from accumulated statistics; updates the parameters in place."""
+        m = self.ctx.bw_mstep(stats, self.min_std)
+        self.A, self.pi, self.w, self.mu = m["A"], m["pi"], m["w"], m["mu"]
+        self.si = m["var"] if "var" in m else m["si"]
+        return m

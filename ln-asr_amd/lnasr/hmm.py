@@ -1,0 +1,198 @@
+"""Discrete-observation HMM with the reference's call surface (lnasr/hmm.py:16-313).
+
+All probabilities (A, B, pi, b, alpha, beta, v, xi, gamma) are natural-log values; `A[i, j]`
+is the transition i -> j.  Every trellis below runs in HIP kernels (csrc/trellis.hip,
+csrc/estimate.hip); this class only keeps the reference's state (`self.b`), shapes, dtypes and
+print format.  Arrays returned are fresh numpy arrays in the reference's layouts:
+`b [N,T]`, `alpha/beta/v [T,N]`, `bt [T,N] uint32`, `path [T] uint32`, `xi [T,N,N]`.
+
+Extras (keyword-only / new methods, not in the reference): `ctx=` selects the GPU context,
+`decode_batch` / `calc_prob_batch` take `[U, T]` symbol batches.
+"""
+from typing import Tuple
+
+import numpy as np
+
+from . import _ffi
+from .utils import lse
+
+
+class HMM:
+    """n hidden states, m observation symbols, log-domain parameters (hmm.py:17-45)."""
+
+    def __init__(self, n: int = 1, m: int = 1, A=None, B=None, pi=None, precision=np.double, *, ctx=None):
+        self.n = n
+        self.m = m
+        self.A = A
+        self.B = B
+        self.pi = pi
+        self.precision = precision
+        self._ctx = ctx
+
+    # ------------------------------------------------------------------ plumbing
+    @property
+    def ctx(self):
+        if self._ctx is None:
+            self._ctx = _ffi.default_ctx()
+        return self._ctx
+
+    def _upload(self):
+        """Transition model -> device.  Done per call: N*N doubles, and the reference lets
+        callers mutate A / pi in place between calls."""
+        self.ctx.upload_hmm(np.asarray(self.A, dtype=np.float64), np.asarray(self.pi, dtype=np.float64))
+
+    def _b_dev(self):
+        """self.b [N,T] -> frame-major [1,T,N] of the storage dtype."""
+        b = np.asarray(self.b)
+        dt = np.float32 if b.dtype == np.float32 else np.float64
+        return np.ascontiguousarray(b.T, dtype=dt)[None]
+
+    # ------------------------------------------------------------------ emission
+    def _map_b(self, obs: np.ndarray):
+        """b[:, t] = B[:, obs[t]]  (hmm.py:47-61)."""
+        obs = np.asarray(obs)
+        b = self.ctx.discrete_map_b(np.asarray(self.B, dtype=np.float64), obs.astype(np.int32), self.precision)
+        self.b = b[0].T
+
+    # ------------------------------------------------------------------ trellises
+    def _forward(self, obs: np.ndarray, remap: bool = False) -> np.ndarray:
+        """alpha [T,N]: alpha[t,j] = lse_i(alpha[t-1,i] + A[i,j]) + b[j,t]  (hmm.py:63-100)."""
+        if remap:
+            self._map_b(obs)
+        self._upload()
+        alpha, _ = self.ctx.forward(self._b_dev(), want_alpha=True, want_loglik=False)
+        return alpha[0]
+
+    def _backward(self, obs: np.ndarray, remap: bool = False) -> np.ndarray:
+        """beta [T,N]: beta[t,i] = lse_j(beta[t+1,j] + A[i,j] + b[j,t+1])  (hmm.py:102-131)."""
+        if remap:
+            self._map_b(obs)
+        self._upload()
+        return self.ctx.backward(self._b_dev())[0]
+
+    def _viterbi(self, obs: np.ndarray, remap: bool = False) -> Tuple[np.ndarray]:
+        """(v [T,N], bt [T,N] uint32, path [T] uint32); ties -> first index  (hmm.py:133-172)."""
+        if remap:
+            self._map_b(obs)
+        self._upload()
+        r = self.ctx.viterbi(self._b_dev(), want_v=True, want_bt=True)
+        return (r["v"][0], r["bt"][0], r["path"][0])
+
+    def _baumwelch(self, obs: np.ndarray, alpha: np.ndarray, beta: np.ndarray, remap: bool = False) -> Tuple[np.ndarray]:
+        """(xi [T,N,N], gamma [T,N]); the last frame is -inf  (hmm.py:174-200)."""
+        if remap:
+            self._map_b(obs)
+        self._upload()
+        b = self._b_dev()
+        dt = b.dtype
+        xi, gamma = self.ctx.baumwelch(b, np.asarray(alpha, dtype=dt)[None], np.asarray(beta, dtype=dt)[None])
+        return xi[0], gamma[0]
+
+    def _estimate(self, obs: np.ndarray, alpha, beta, xi, gamma) -> dict:
+        """M-step {'A','B','pi'}; a symbol never observed gets a -inf column  (hmm.py:202-225)."""
+        dt = np.float32 if np.asarray(gamma).dtype == np.float32 else np.float64
+        return self.ctx.estimate_discrete(np.asarray(obs), self.m, np.asarray(xi, dtype=dt), np.asarray(gamma, dtype=dt))
+
+    def _updatemodel(self, model: dict):
+        self.A = model["A"]
+        self.B = model["B"]
+        self.pi = model["pi"]
+
+    def reset(self, init_type):
+        """'uniform' or 'random' initial parameters; anything else is a silent no-op (hmm.py:233-250).
+        Uses the global numpy RNG exactly like the reference, so seeding reproduces its draws."""
+        if init_type == "uniform":
+            self.A = np.log(np.ones((self.n, self.n), dtype=self.precision) * (1.0 / self.n))
+            self.B = np.log(np.ones((self.n, self.m), dtype=self.precision) * (1.0 / self.m))
+            self.pi = np.log(np.ones(self.n, dtype=self.precision) * (1.0 / self.n))
+        elif init_type == "random":
+            a = 1.0 - np.random.random_sample((self.n, self.n))     # (0, 1]: never log(0)
+            b = 1.0 - np.random.random_sample((self.n, self.m))
+            pi = 1.0 - np.random.random_sample((self.n))
+            self.A = np.log(a / a.sum(axis=1)[:, np.newaxis])
+            self.B = np.log(b / b.sum(axis=1)[:, np.newaxis])
+            self.pi = np.log(pi / np.sum(pi))
+
+    # ------------------------------------------------------------------ persistence
+    def save(self, filename):
+        """Datasets 'A','B','pi' (hmm.py:252-258): HDF5 when h5py is importable, else .npz."""
+        _save(filename, {"A": self.A, "B": self.B, "pi": self.pi})
+
+    def load(self, filename):
+        """hmm.py:260-266; unlike the reference the parameters come back as real ndarrays."""
+        d = _load(filename, ("A", "B", "pi"))
+        self.A, self.B, self.pi = d["A"], d["B"], d["pi"]
+        self.n, self.m = self.B.shape
+
+    # ------------------------------------------------------------------ public API
+    def calc_prob(self, obs: np.ndarray) -> float:
+        """log P(O | model) = lse(alpha[T-1])  (hmm.py:268-274)."""
+        self._map_b(obs)
+        self._upload()
+        _, ll = self.ctx.forward(self._b_dev(), want_alpha=False, want_loglik=True)
+        return np.asarray(ll, dtype=self.precision)[0]
+
+    def decode(self, obs: np.ndarray) -> np.ndarray:
+        """Most likely state sequence  (hmm.py:276-283)."""
+        _, _, path = self._viterbi(obs, True)
+        return path
+
+    def train(self, obs, iters=1, eps=0.0001, verbose: bool = True):
+        """Baum-Welch on one sequence, stopping when |delta loglik| < eps  (hmm.py:285-313)."""
+        for k in range(iters):
+            self._map_b(obs)
+            alpha = self._forward(obs)
+            beta = self._backward(obs)
+            xi, gamma = self._baumwelch(obs, alpha, beta)
+            model = self._estimate(obs, alpha, beta, xi, gamma)
+            prob_old = lse(alpha[-1])
+            self._updatemodel(model)
+            prob_new = self.calc_prob(obs)
+            prod_d = abs(prob_old - prob_new)
+            if verbose:
+                print("Iter: {:3},"
+                      " L(lambda|O) = {:.6e},"
+                      " L(lambda_new|O) = {:.6e},"
+                      " eps = {:.6f}"
+                      .format(k, prob_old, prob_new, prod_d))
+            if prod_d < eps:
+                break
+
+    # ------------------------------------------------------------------ batch extras
+    def decode_batch(self, obs_batch):
+        """[U,T] int symbols -> [U,T] uint32 paths."""
+        obs_batch = np.asarray(obs_batch, dtype=np.int32)
+        self._upload()
+        b = self.ctx.discrete_map_b(np.asarray(self.B, dtype=np.float64), obs_batch, self.precision)
+        return self.ctx.viterbi(b, want_v=False, want_bt=False)["path"]
+
+    def calc_prob_batch(self, obs_batch):
+        obs_batch = np.asarray(obs_batch, dtype=np.int32)
+        self._upload()
+        b = self.ctx.discrete_map_b(np.asarray(self.B, dtype=np.float64), obs_batch, self.precision)
+        return self.ctx.forward(b, want_alpha=False, want_loglik=True)[1]
+
+
+def _save(filename, arrays):
+    try:
+        import h5py
+    except ImportError:
+        h5py = None
+    if h5py is not None and not str(filename).endswith(".npz"):
+        with h5py.File(filename, "w") as f:
+            for k, v in arrays.items():
+                f.create_dataset(k, data=np.asarray(v))
+        return
+    with open(filename, "wb") as fp:
+        np.savez(fp, **{k: np.asarray(v) for k, v in arrays.items()})
+
+
+def _load(filename, keys):
+    with open(filename, "rb") as fp:
+        magic = fp.read(8)
+    if magic.startswith(b"\x89HDF"):
+        import h5py
+        with h5py.File(filename, "r") as f:
+            return {k: np.array(f[k]) for k in keys}
+    with np.load(filename) as z:
+        return {k: np.array(z[k]) for k in keys}

@@ -1,0 +1,165 @@
+"""GPU parity, decode path: emission (GMM log-likelihood) + Viterbi + backtrace through the
+C-ABI, against the golden vectors from the reference and against the CPU oracle."""
+import numpy as np
+import pytest
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from lnasr import _ffi
+    return _ffi.default_ctx()
+
+
+def test_toy_hmm_viterbi(golden):
+    from lnasr.hmm import HMM
+    g = golden("toy_hmm")
+    h = HMM(2, 3, g["A"], g["B"], g["pi"])
+    v, bt, path = h._viterbi(g["obs"], True)
+    assert np.array_equal(h.b, g["b"]) and h.b.shape == (2, 3)
+    assert np.array_equal(v, g["v"]) and np.array_equal(bt, g["bt"]) and np.array_equal(path, g["path"])
+    assert bt.dtype == np.uint32 and path.dtype == np.uint32 and v.dtype == np.float64
+    assert np.array_equal(h.decode(g["obs"]), g["decode"])
+
+
+def test_discrete_mid_viterbi(golden):
+    from lnasr.hmm import HMM
+    g = golden("hmm_discrete_16x24")
+    h = HMM(16, 24, g["A"], g["B"], g["pi"])
+    v, bt, path = h._viterbi(g["obs"], True)
+    assert np.array_equal(v, g["v"]) and np.array_equal(bt, g["bt"]) and np.array_equal(path, g["path"])
+
+
+@pytest.mark.parametrize("tag", ["", "_f32"])
+def test_gmmhmm_small(golden, tag):
+    from lnasr.gmmhmm import GMMHMM
+    g = golden("gmmhmm_small" + tag)
+    prec = np.float32 if tag else np.float64
+    gh = GMMHMM(5, 3, 2, g["A"], g["pi"], g["w"], g["mu"], g["si"], precision=prec)
+    gh._map_b(g["obs"])
+    assert gh.b.shape == (5, 40) and gh.bm.shape == (5, 3, 40) and gh.b.dtype == prec
+    tol = dict(rtol=2e-5, atol=2e-5) if tag else dict(rtol=1e-12, atol=1e-12)
+    assert_close(gh.b, g["b"], **tol), assert_close(gh.bm, g["bm"], **tol)
+    # trellis on the golden b: bit-identical
+    gh.b = g["b"]
+    v, bt, path = gh._viterbi(g["obs"])
+    assert v.dtype == prec
+    assert np.array_equal(v, g["v"]) and np.array_equal(bt, g["bt"]) and np.array_equal(path, g["path"])
+    # end to end
+    assert np.array_equal(gh.decode(g["obs"]), g["path"])
+
+
+@pytest.mark.parametrize("kind", ["diag", "full"])
+def test_gmmhmm_d39(golden, kind, ctx):
+    from lnasr.gmmhmm import GMMHMM
+    g = golden("gmmhmm_d39_" + kind)
+    N, M, D = g["mu"].shape
+    if kind == "diag":
+        si = np.zeros((N, M, D, D))
+        si[:, :, np.arange(D), np.arange(D)] = g["var"]
+    else:
+        si = g["si"]
+    gh = GMMHMM(N, M, D, g["A"], g["pi"], g["w"], g["mu"], si)
+    gh._map_b(g["obs"])
+    assert ctx.model_is_diag() == (kind == "diag")
+    assert_close(gh.b, g["b"], 1e-12), assert_close(gh.bm, g["bm"], 1e-12)
+    v, bt, path = gh._viterbi(g["obs"])
+    assert np.array_equal(path, g["path"]) and np.array_equal(bt, g["bt"])
+    assert_close(v, g["v"], 1e-12)
+    gh.b = g["b"]
+    v, bt, path = gh._viterbi(g["obs"])
+    assert np.array_equal(v, g["v"]) and np.array_equal(bt, g["bt"]) and np.array_equal(path, g["path"])
+    if kind == "diag":
+        # the three diagonal routes agree: [N,M,D] upload, generic VALU kernel, forced full-covariance kernel
+        gh2 = GMMHMM(N, M, D, g["A"], g["pi"], g["w"], g["mu"], g["var"])
+        assert np.array_equal(gh2.decode(g["obs"]), g["path"])
+        ctx.upload_gmmhmm(g["A"], g["pi"], g["w"], g["mu"], si, force_full=True)
+        assert not ctx.model_is_diag()
+        b_full = ctx.gmm_logprob(g["obs"][None])
+        assert_close(b_full[0].T, g["b"], 1e-12)
+        assert np.array_equal(ctx.decode(g["obs"][None])[0], g["path"])
+
+
+def test_metric_slice(golden, synth, oracle, ctx):
+    """N=128, M=16, D=39, T=1000: MFMA emission + register-resident Viterbi, bit-identical paths."""
+    g = golden("gmmhmm_metric_slice")
+    N, M, D, T, U = (int(x) for x in g["shape"])
+    mdl = synth.synth_model(N, M, D, seed=1)
+    obs = synth.synth_obs(U, T, D, seed=1000)
+    ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["si"])
+    assert ctx.model_is_diag()
+    b, bm = ctx.gmm_logprob(obs, want_bm=True)
+    for u in range(U):
+        assert_close(b[u][g["sample_t"], g["sample_j"]], g["b_sample"][u], 1e-12)
+        assert_close(bm[u][g["sample_t"], g["sample_j"], g["sample_m"]], g["bm_sample"][u], 1e-12)
+        assert abs(b[u].sum() - g["b_sum"][u]) < 1e-6
+    ob, obm = oracle.gmm_map_b_diag(obs[0], mdl["w"], mdl["mu"], mdl["var"])
+    assert_close(b[0].T, ob, 1e-12), assert_close(bm[0].transpose(1, 2, 0), obm, 1e-12)
+    path, score = ctx.decode(obs, want_score=True)
+    assert np.array_equal(path, g["path"])
+    assert_close(score, g["best_score"], 1e-13)
+    r = ctx.viterbi(b, want_v=True, want_bt=True, want_score=True)
+    assert np.array_equal(r["path"], g["path"])
+    assert_close(r["v"][:, -1, :], g["v_last"], 1e-13)
+    ov, obt, opath = oracle.viterbi(mdl["A"], mdl["pi"], np.ascontiguousarray(b[0].T))
+    assert np.array_equal(r["v"][0], ov) and np.array_equal(r["bt"][0], obt) and np.array_equal(r["path"][0], opath)
+    # generic kernels give the same answers as the MFMA / register-resident ones
+    import os
+    os.environ["LNASR_NO_MFMA"] = "1"
+    os.environ["LNASR_NO_REGVIT"] = "1"
+    try:
+        b2 = ctx.gmm_logprob(obs[:1])
+        assert_close(b2[0], b[0], 1e-13)
+        r2 = ctx.viterbi(b[:1], want_v=True, want_bt=False)
+        assert np.array_equal(r2["v"][0], r["v"][0]) and np.array_equal(r2["path"][0], r["path"][0])
+    finally:
+        del os.environ["LNASR_NO_MFMA"], os.environ["LNASR_NO_REGVIT"]
+
+
+def test_batch_ragged_and_device_resident(synth, oracle, ctx):
+    """Ragged batch (lens), HBM-resident inputs/outputs, odd shapes (N=6, M=3, D=5: generic kernels)."""
+    mdl = synth.synth_model(6, 3, 5, seed=2)
+    obs = synth.synth_obs(5, 33, 5, seed=77)
+    lens = np.array([33, 1, 17, 2, 30], dtype=np.int32)
+    ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
+    d_obs = ctx.to_device(obs)
+    path = ctx.decode(d_obs, lens=lens).to_host()
+    for u in range(5):
+        L = lens[u]
+        ref = oracle.decode_diag(obs[u, :L], mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"])
+        assert np.array_equal(path[u, :L], ref), u
+
+
+def test_viterbi_shapes(synth, oracle, ctx):
+    """N around the kernel-selection boundaries; T=1; ties resolve to the first index."""
+    rng = np.random.default_rng(5)
+    for N in (1, 2, 63, 64, 65, 127, 128, 129, 200):
+        d = synth.synth_discrete(N, 4, 9, seed=N)
+        ctx.upload_hmm(d["A"], d["pi"])
+        b = np.ascontiguousarray(rng.standard_normal((3, 9, N)))
+        r = ctx.viterbi(b, want_v=True, want_bt=True)
+        for u in range(3):
+            v, bt, path = oracle.viterbi(d["A"], d["pi"], np.ascontiguousarray(b[u].T))
+            assert np.array_equal(r["v"][u], v) and np.array_equal(r["bt"][u], bt) and np.array_equal(r["path"][u], path), N
+    # ties: uniform model, constant emissions -> every argmax is index 0
+    N = 70
+    ctx.upload_hmm(np.full((N, N), -np.log(N)), np.full(N, -np.log(N)))
+    r = ctx.viterbi(np.zeros((1, 5, N)), want_v=False, want_bt=True)
+    assert (r["path"] == 0).all() and (r["bt"] == 0).all()
+    # -inf transitions (left-to-right topology)
+    A = np.full((4, 4), -np.inf)
+    for i in range(4):
+        A[i, i] = np.log(0.5)
+        A[i, min(i + 1, 3)] = np.logaddexp(A[i, min(i + 1, 3)], np.log(0.5))
+    pi = np.array([0.0, -np.inf, -np.inf, -np.inf])
+    ctx.upload_hmm(A, pi)
+    b = np.ascontiguousarray(rng.standard_normal((1, 12, 4)))
+    r = ctx.viterbi(b)
+    v, bt, path = oracle.viterbi(A, pi, np.ascontiguousarray(b[0].T))
+    assert np.array_equal(r["v"][0], v) and np.array_equal(r["bt"][0], bt) and np.array_equal(r["path"][0], path)
+    # T = 1
+    r = ctx.viterbi(b[:, :1])
+    assert r["path"].shape == (1, 1) and r["path"][0, 0] == 0
