@@ -170,6 +170,8 @@ typedef struct lnasr_mfcc_cfg {
 } lnasr_mfcc_cfg;
 /* split_frames frame count (utils.py:119) */
 int lnasr_num_frames(int64_t n_samples, int frame_len, int frame_step, int64_t* out);
+/* MFCC.calc_high_pass_filter (mfcc.py:50-64): y[0]=x[0], y[t]=x[t]-alpha*x[t-1] */
+int lnasr_preemphasis(lnasr_ctx* ctx, const double* x, int64_t n, double alpha, double* y);
 /* split_frames (utils.py:106-130): frames [Nf, L] fp64 */
 int lnasr_split_frames(lnasr_ctx* ctx, const double* signal, int64_t n, int L, int S, double* frames);
 /* MFCC.calc_mfcc (mfcc.py:108-175) over a batch of utterances concatenated in `signal`;

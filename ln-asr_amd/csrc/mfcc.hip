@@ -1,0 +1,345 @@
+// MFCC front end (mfcc.py:108-175, utils.py:106-138): pre-emphasis -> framing -> Hamming ->
+// rFFT -> power -> mel filter bank -> 20 log10 -> mean norm -> DCT-II (ortho) -> cepstral mean
+// norm -> log-energy -> delta / delta-delta.  fp64 throughout, utterances batched by offsets.
+//
+// Kernels
+//   mfcc_frame_kernel   one block per frame: samples -> power [nbin], log-mel [n_mel], log-energy
+//   col_mean_kernel     per-utterance column means (the reference's two utterance-level means)
+//   dct_kernel          per frame: DCT-II of the mean-normalised log-mel row
+//   feat_kernel         per frame: second mean norm (applied to the returned cepstrum as well, as the
+//                       reference does through a view, mfcc.py:155-156), energy, delta, delta-delta
+#include "common.h"
+#include "devmath.h"
+
+namespace lnasr {
+
+constexpr int kMaxFft = 4096;
+
+__device__ __forceinline__ int find_utt(const int64_t* __restrict__ foff, int U, int64_t f) {
+    int lo = 0, hi = U;                 // foff[lo] <= f < foff[hi]
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (foff[mid] <= f) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+template <typename SAMPLE>
+__device__ __forceinline__ double sample_at(const SAMPLE* x, int64_t i) { return (double)x[i]; }
+
+// y[0] = x[0]; y[i] = x[i] - a x[i-1] (mfcc.py:63); zero beyond the utterance (utils.py:121-125)
+template <typename SAMPLE>
+__device__ __forceinline__ double preemph(const SAMPLE* __restrict__ x, int64_t n, int64_t i, double a) {
+    if (i >= n) return 0.0;
+    const double cur = sample_at(x, i);
+    return i == 0 ? cur : cur - a * sample_at(x, i - 1);
+}
+
+template <typename SAMPLE>
+__global__ void mfcc_frame_kernel(const SAMPLE* __restrict__ signal, const int64_t* __restrict__ soff,
+                                  const int64_t* __restrict__ foff, int U, int L, int S, int NFFT, int LOG2N,
+                                  int n_mel, double alpha, const double* __restrict__ window,
+                                  const double* __restrict__ fbank, const double* __restrict__ twid,
+                                  double* __restrict__ power_out, double* __restrict__ logmel,
+                                  double* __restrict__ energy) {
+    extern __shared__ double sm[];
+    double* re = sm;                    // [NFFT]
+    double* im = sm + NFFT;             // [NFFT]
+    double* pw = sm + 2 * NFFT;         // [NFFT/2 + 1]
+    double* red = pw + NFFT / 2 + 1;    // [32]
+    const int64_t f = blockIdx.x;
+    const int u = find_utt(foff, U, f);
+    const int64_t fl = f - foff[u];
+    const SAMPLE* x = signal + soff[u];
+    const int64_t n = soff[u + 1] - soff[u];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int nbin = NFFT / 2 + 1;
+
+    // windowed frame in bit-reversed order (np.fft.rfft(frames, NFFT) truncates / zero-pads to NFFT)
+    for (int k = tid; k < NFFT; k += nt) {
+        double v = 0.0;
+        if (k < L) v = preemph(x, n, fl * S + k, alpha) * window[k];
+        const int r = (int)(__brev((unsigned)k) >> (32 - LOG2N));
+        re[r] = v;
+        im[r] = 0.0;
+    }
+    __syncthreads();
+    // radix-2 decimation in time; twid[k] = (cos, -sin)(2 pi k / NFFT)
+    for (int s = 1; s <= LOG2N; ++s) {
+        const int half = 1 << (s - 1);
+        for (int bfly = tid; bfly < NFFT / 2; bfly += nt) {
+            const int grp = bfly >> (s - 1), pos = bfly & (half - 1);
+            const int i0 = (grp << s) + pos, i1 = i0 + half;
+            const int tw = pos << (LOG2N - s);
+            const double wr = twid[2 * tw], wi = twid[2 * tw + 1];
+            const double xr = re[i1], xi = im[i1];
+            const double tr = xr * wr - xi * wi, ti = xr * wi + xi * wr;
+            const double ur = re[i0], ui = im[i0];
+            re[i0] = ur + tr;
+            im[i0] = ui + ti;
+            re[i1] = ur - tr;
+            im[i1] = ui - ti;
+        }
+        __syncthreads();
+    }
+    // |X|^2 / NFFT  (mfcc.py:141-142: magnitude via np.abs, then squared)
+    double esum = 0.0;
+    for (int k = tid; k < nbin; k += nt) {
+        const double mag = hypot(re[k], im[k]);
+        const double p = (1.0 / NFFT) * (mag * mag);
+        pw[k] = p;
+        esum += p;
+        if (power_out) power_out[f * nbin + k] = p;
+    }
+    const double etot = block_sum(esum, red);
+    if (tid == 0) energy[f] = log(etot);                                   // mfcc.py:158-160
+    __syncthreads();
+    for (int m = tid; m < n_mel; m += nt) {
+        const double* fb = fbank + (size_t)m * nbin;
+        double s = 0.0;
+        for (int k = 0; k < nbin; ++k) s += pw[k] * fb[k];                   // mfcc.py:148
+        if (s == 0.0) s = 2.220446049250313e-16;                             // mfcc.py:149
+        logmel[f * n_mel + m] = 20.0 * log10(s);                             // mfcc.py:150
+    }
+}
+
+// mean over the frames of each utterance of columns [c0, c0+nc) of X [F, ld]; out[u*nc + c] = mean + 1e-8
+__global__ void col_mean_kernel(const double* __restrict__ X, const int64_t* __restrict__ foff, int ld, int c0,
+                                int nc, double* __restrict__ out) {
+    extern __shared__ double sm[];      // [slices][nc]
+    const int u = blockIdx.x;
+    const int64_t f0 = foff[u], f1 = foff[u + 1];
+    const int slices = blockDim.x / nc;
+    const int c = threadIdx.x % nc, sl = threadIdx.x / nc;
+    double s = 0.0;
+    if (sl < slices)
+        for (int64_t f = f0 + sl; f < f1; f += slices) s += X[f * ld + c0 + c];
+    if (sl < slices) sm[sl * nc + c] = s;
+    __syncthreads();
+    if (threadIdx.x < nc) {
+        double tot = 0.0;
+        for (int k = 0; k < slices; ++k) tot += sm[k * nc + threadIdx.x];
+        out[(size_t)u * nc + threadIdx.x] = tot / (double)(f1 - f0) + 1e-8;   // mfcc.py:151,156
+    }
+}
+
+// cep[f,k] = sum_m (logmel[f,m] - mean[u,m]) C[k,m];  C = DCT-II ortho matrix (mfcc.py:151-152)
+__global__ void dct_kernel(const double* __restrict__ logmel, const double* __restrict__ mean,
+                           const int64_t* __restrict__ foff, int U, int64_t F, int n_mel,
+                           const double* __restrict__ C, double* __restrict__ cep) {
+    extern __shared__ double row[];     // [rows][n_mel]
+    const int rows = blockDim.x / n_mel;
+    const int r = threadIdx.x / n_mel, k = threadIdx.x % n_mel;
+    const int64_t f = (int64_t)blockIdx.x * rows + r;
+    const bool ok = r < rows && f < F;
+    if (ok) {
+        const int u = find_utt(foff, U, f);
+        row[r * n_mel + k] = logmel[f * n_mel + k] - mean[(size_t)u * n_mel + k];
+    }
+    __syncthreads();
+    if (ok) {
+        double s = 0.0;
+        for (int m = 0; m < n_mel; ++m) s += row[r * n_mel + m] * C[(size_t)k * n_mel + m];
+        cep[f * n_mel + k] = s;
+    }
+}
+
+// features [F, 3*(nc+1)] and the returned cepstrum (cols 1..nc mean-normalised a second time)
+__global__ void feat_kernel(const double* __restrict__ cep, const double* __restrict__ mean2,
+                            const double* __restrict__ energy, const int64_t* __restrict__ foff, int U, int64_t F,
+                            int n_mel, int nc, double* __restrict__ cep_out, double* __restrict__ feat) {
+    const int W = nc + 1;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= F * W) return;
+    const int64_t f = idx / W;
+    const int c = (int)(idx % W);
+    const int u = find_utt(foff, U, f);
+    const int64_t f0 = foff[u];
+    const double* m2 = mean2 + (size_t)u * nc;
+    auto base = [&](int64_t ff) -> double {     // features[:, :13] of frame ff (mfcc.py:155-160)
+        return c < nc ? cep[ff * n_mel + 1 + c] - m2[c] : energy[ff];
+    };
+    auto delta = [&](int64_t ff) -> double {    // mfcc.py:162-166: row 0 is features[1]
+        return ff == f0 ? base(f0 + 1) : base(ff) - base(ff - 1);
+    };
+    const double v0 = base(f);
+    const double v1 = delta(f);
+    const double v2 = (f == f0) ? delta(f0 + 1) : delta(f) - delta(f - 1);      // mfcc.py:168-172
+    double* out = feat + f * 3 * W;
+    out[c] = v0;
+    out[W + c] = v1;
+    out[2 * W + c] = v2;
+    if (cep_out && c < nc) cep_out[f * n_mel + 1 + c] = v0;
+}
+
+__global__ void copy_cep_kernel(const double* __restrict__ cep, int64_t total, double* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) out[i] = cep[i];
+}
+
+// split_frames (utils.py:106-130)
+__global__ void split_frames_kernel(const double* __restrict__ x, int64_t n, int L, int S, int64_t nf,
+                                    double* __restrict__ out) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nf * L) return;
+    int64_t f = idx / L;
+    int k = (int)(idx % L);
+    int64_t i = f * S + k;
+    out[idx] = i < n ? x[i] : 0.0;
+}
+
+__global__ void preemph_kernel(const double* __restrict__ x, int64_t n, double a, double* __restrict__ y) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = preemph(x, n, i, a);
+}
+
+static int64_t num_frames_host(int64_t n, int L, int S) {
+    // int(np.ceil(np.abs(n - (L - S)) / S))  (utils.py:119)
+    int64_t a = n - (int64_t)(L - S);
+    if (a < 0) a = -a;
+    return (a + S - 1) / S;
+}
+
+}  // namespace lnasr
+
+using namespace lnasr;
+
+extern "C" {
+
+int lnasr_num_frames(int64_t n_samples, int frame_len, int frame_step, int64_t* out) {
+    LN_REQUIRE(out, "null out");
+    LN_REQUIRE(frame_len >= 1 && frame_step >= 1 && n_samples >= 0, "bad framing parameters");
+    *out = num_frames_host(n_samples, frame_len, frame_step);
+    return 0;
+}
+
+int lnasr_preemphasis(lnasr_ctx* ctx, const double* x, int64_t n, double alpha, double* y) {
+    LN_REQUIRE(ctx, "null ctx");
+    if (n <= 0) return 0;
+    LN_REQUIRE(x && y, "null argument");
+    const void* d_x;
+    void* d_y;
+    LN_TRY(stage_in(ctx, x, (size_t)n * 8, ctx->ws_in, &d_x));
+    LN_TRY(stage_out(ctx, y, (size_t)n * 8, ctx->ws_out, &d_y));
+    LN_LAUNCH(ctx, "preemphasis", preemph_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (const double*)d_x,
+              n, alpha, (double*)d_y);
+    return finish_out(ctx, y, d_y, (size_t)n * 8);
+}
+
+int lnasr_split_frames(lnasr_ctx* ctx, const double* signal, int64_t n, int L, int S, double* frames) {
+    LN_REQUIRE(ctx, "null ctx");
+    LN_REQUIRE(L >= 1 && S >= 1 && n >= 0, "bad framing parameters");
+    const int64_t nf = num_frames_host(n, L, S);
+    if (nf == 0) return 0;
+    LN_REQUIRE(frames, "null frames");
+    const void* d_x;
+    void* d_o;
+    LN_TRY(stage_in(ctx, signal, (size_t)n * 8, ctx->ws_in, &d_x));
+    LN_TRY(stage_out(ctx, frames, (size_t)nf * L * 8, ctx->ws_out, &d_o));
+    LN_LAUNCH(ctx, "split_frames", split_frames_kernel, dim3((unsigned)((nf * L + 255) / 256)), dim3(256), 0,
+              (const double*)d_x, n, L, S, nf, (double*)d_o);
+    return finish_out(ctx, frames, d_o, (size_t)nf * L * 8);
+}
+
+int lnasr_mfcc(lnasr_ctx* ctx, const void* signal, int sample_kind, const int64_t* offsets, int U,
+               const lnasr_mfcc_cfg* cfg, const double* window, const double* fbank, double* power_or_null,
+               double* cepstrum_or_null, double* features) {
+    LN_REQUIRE(ctx && cfg && offsets && window && fbank && features, "null argument");
+    LN_REQUIRE(U >= 1, "U must be >= 1");
+    LN_REQUIRE(sample_kind == 0 || sample_kind == 1, "sample_kind must be 0 (f64) or 1 (int16)");
+    const int L = cfg->frame_len, S = cfg->frame_step, NFFT = cfg->fft_n, n_mel = cfg->n_mel, nc = cfg->n_cep;
+    LN_REQUIRE(L >= 1 && S >= 1, "bad frame_len / frame_step");
+    int log2n = 0;
+    while ((1 << log2n) < NFFT) ++log2n;
+    LN_REQUIRE(NFFT >= 8 && NFFT <= kMaxFft && (1 << log2n) == NFFT, "fft_n=%d must be a power of two in [8,%d]",
+               NFFT, kMaxFft);
+    LN_REQUIRE(n_mel >= 1 && n_mel <= 256 && nc >= 1 && nc + 1 <= n_mel, "bad n_mel=%d / n_cep=%d", n_mel, nc);
+    LN_REQUIRE(!is_device_ptr(offsets), "offsets must be a host array");
+    const int nbin = NFFT / 2 + 1, W = nc + 1;
+    std::vector<int64_t> foff(U + 1, 0);
+    for (int u = 0; u < U; ++u) {
+        const int64_t n = offsets[u + 1] - offsets[u];
+        LN_REQUIRE(n >= 1, "utterance %d is empty", u);
+        const int64_t nf = num_frames_host(n, L, S);
+        // the reference indexes features[1] for the delta of row 0 (mfcc.py:164): one frame is an IndexError there
+        LN_REQUIRE(nf >= 2, "utterance %d yields %lld frame(s); MFCC deltas need at least 2", u, (long long)nf);
+        foff[u + 1] = foff[u] + nf;
+    }
+    const int64_t F = foff[U], NS = offsets[U] - offsets[0];
+    LN_REQUIRE(offsets[0] == 0, "offsets[0] must be 0");
+    const size_t ssz = sample_kind == 1 ? 2 : 8;
+    const void *d_sig, *d_win, *d_fb;
+    LN_TRY(stage_in(ctx, signal, (size_t)NS * ssz, ctx->ws_in, &d_sig));
+    LN_TRY(stage_in(ctx, window, (size_t)L * 8, ctx->ws_in2, &d_win));
+    LN_TRY(stage_in(ctx, fbank, (size_t)n_mel * nbin * 8, ctx->ws_in3, &d_fb));
+    // constants: sample offsets, frame offsets, twiddles, DCT matrix
+    std::vector<double> tw(NFFT), C((size_t)n_mel * n_mel);
+    for (int k = 0; k < NFFT / 2; ++k) {
+        const double a = 2.0 * M_PI * (double)k / (double)NFFT;
+        tw[2 * k] = cos(a);
+        tw[2 * k + 1] = -sin(a);
+    }
+    for (int k = 0; k < n_mel; ++k)
+        for (int m = 0; m < n_mel; ++m) {
+            // scipy.fftpack.dct(type=2, norm='ortho'): y_k = f_k * 2 sum_m x_m cos(pi k (2m+1) / (2N)),
+            // f_0 = sqrt(1/(4N)), f_k = sqrt(1/(2N))
+            const double f = k == 0 ? sqrt(1.0 / (4.0 * n_mel)) : sqrt(1.0 / (2.0 * n_mel));
+            C[(size_t)k * n_mel + m] = 2.0 * f * cos(M_PI * (double)k * (2.0 * m + 1.0) / (2.0 * n_mel));
+        }
+    const size_t cbytes = (size_t)(2 * (U + 1)) * 8 + (size_t)NFFT * 8 + C.size() * 8;
+    LN_TRY(ctx->ws_in4.reserve(cbytes));
+    int64_t* d_soff = ctx->ws_in4.as<int64_t>();
+    int64_t* d_foff = d_soff + (U + 1);
+    double* d_tw = reinterpret_cast<double*>(d_foff + (U + 1));
+    double* d_C = d_tw + NFFT;
+    LN_HIP(hipMemcpyAsync(d_soff, offsets, (size_t)(U + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    LN_HIP(hipMemcpyAsync(d_foff, foff.data(), (size_t)(U + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    LN_HIP(hipMemcpyAsync(d_tw, tw.data(), (size_t)NFFT * 8, hipMemcpyHostToDevice, ctx->stream));
+    LN_HIP(hipMemcpyAsync(d_C, C.data(), C.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    // workspaces: logmel [F,n_mel], cep [F,n_mel], energy [F], mean1 [U,n_mel], mean2 [U,nc]
+    LN_TRY(ctx->ws_misc.reserve(((size_t)F * n_mel * 2 + F + (size_t)U * n_mel + (size_t)U * nc) * 8));
+    double* logmel = ctx->ws_misc.as<double>();
+    double* cep = logmel + (size_t)F * n_mel;
+    double* energy = cep + (size_t)F * n_mel;
+    double* mean1 = energy + F;
+    double* mean2 = mean1 + (size_t)U * n_mel;
+    void *d_pow = nullptr, *d_cep = nullptr, *d_feat;
+    if (power_or_null) LN_TRY(stage_out(ctx, power_or_null, (size_t)F * nbin * 8, ctx->ws_out, &d_pow));
+    if (cepstrum_or_null) LN_TRY(stage_out(ctx, cepstrum_or_null, (size_t)F * n_mel * 8, ctx->ws_out2, &d_cep));
+    LN_TRY(stage_out(ctx, features, (size_t)F * 3 * W * 8, ctx->ws_out3, &d_feat));
+
+    const size_t shm = (size_t)(2 * NFFT + nbin + 32) * 8;
+    const int nt = NFFT / 2 < 256 ? (NFFT / 2 < 64 ? 64 : NFFT / 2) : 256;
+    if (sample_kind == 1)
+        LN_LAUNCH(ctx, "mfcc_frame_i16", mfcc_frame_kernel<int16_t>, dim3((unsigned)F), dim3(nt), shm,
+                  (const int16_t*)d_sig, d_soff, d_foff, U, L, S, NFFT, log2n, n_mel, cfg->hpf_alpha,
+                  (const double*)d_win, (const double*)d_fb, d_tw, (double*)d_pow, logmel, energy);
+    else
+        LN_LAUNCH(ctx, "mfcc_frame", mfcc_frame_kernel<double>, dim3((unsigned)F), dim3(nt), shm,
+                  (const double*)d_sig, d_soff, d_foff, U, L, S, NFFT, log2n, n_mel, cfg->hpf_alpha,
+                  (const double*)d_win, (const double*)d_fb, d_tw, (double*)d_pow, logmel, energy);
+    {
+        int threads = 256 - 256 % n_mel;
+        if (threads < n_mel) threads = n_mel;
+        LN_LAUNCH(ctx, "mfcc_col_mean", col_mean_kernel, dim3(U), dim3(threads), (size_t)threads * 8, logmel, d_foff,
+                  n_mel, 0, n_mel, mean1);
+        const int rows = threads / n_mel;
+        LN_LAUNCH(ctx, "mfcc_dct", dct_kernel, dim3((unsigned)((F + rows - 1) / rows)), dim3(threads),
+                  (size_t)threads * 8, logmel, mean1, d_foff, U, F, n_mel, d_C, cep);
+        int t2 = 256 - 256 % nc;
+        LN_LAUNCH(ctx, "mfcc_col_mean", col_mean_kernel, dim3(U), dim3(t2), (size_t)t2 * 8, cep, d_foff, n_mel, 1, nc,
+                  mean2);
+    }
+    if (d_cep)
+        LN_LAUNCH(ctx, "mfcc_copy_cep", copy_cep_kernel, dim3((unsigned)(((size_t)F * n_mel + 255) / 256)), dim3(256),
+                  0, cep, (int64_t)F * n_mel, (double*)d_cep);
+    LN_LAUNCH(ctx, "mfcc_feat", feat_kernel, dim3((unsigned)(((size_t)F * W + 255) / 256)), dim3(256), 0, cep, mean2,
+              energy, d_foff, U, F, n_mel, nc, (double*)d_cep, (double*)d_feat);
+    if (power_or_null) LN_TRY(finish_out(ctx, power_or_null, d_pow, (size_t)F * nbin * 8));
+    if (cepstrum_or_null) LN_TRY(finish_out(ctx, cepstrum_or_null, d_cep, (size_t)F * n_mel * 8));
+    LN_TRY(finish_out(ctx, features, d_feat, (size_t)F * 3 * W * 8));
+    LN_HIP(hipStreamSynchronize(ctx->stream));   // host-side constant vectors go out of scope
+    return 0;
+}
+
+}  // extern "C"

@@ -67,6 +67,7 @@ SIGNATURES = {
     "lnasr_bw_mstep": [_vp, _vp, _dbl, _vp, _vp, _vp, _vp, _vp],
     "lnasr_lse": [_vp, _vp, _sz, _sz, _sz, _i, _vp],
     "lnasr_num_frames": [_i64, _i, _i, _P(_i64)],
+    "lnasr_preemphasis": [_vp, _vp, _i64, _dbl, _vp],
     "lnasr_split_frames": [_vp, _vp, _i64, _i, _i, _vp],
     "lnasr_mfcc": [_vp, _vp, _i, _vp, _i, _P(MfccCfgStruct), _vp, _vp, _vp, _vp, _vp],
     "lnasr_comm_unique_id": [_vp],
@@ -458,6 +459,12 @@ class Context:
         out = np.empty((outer, inner), dtype=np.float64)
         if out.size:
             check(lib().lnasr_lse(self.handle, _ptr(x), outer, n, inner, 1 if base2 else 0, _ptr(out)))
+        return out
+
+    def preemphasis(self, signal, alpha):
+        signal = np.ascontiguousarray(signal, dtype=np.float64)
+        out = np.empty(signal.shape, dtype=np.float64)
+        check(lib().lnasr_preemphasis(self.handle, _ptr(signal), signal.size, float(alpha), _ptr(out)))
         return out
 
     def split_frames(self, signal, L, S):

@@ -1,0 +1,128 @@
+"""GPU parity: numeric utils (lse/lse2/split_frames), Gaussian free functions and the MFCC chain."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import assert_close, GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def test_lse_cases(golden):
+    from lnasr.utils import lse, lse2
+    g = golden("lse_cases")
+    a = g["a"]
+    i = np.array([0, 0, 1])
+    assert_close(lse2(a), g["lse2_all"], 1e-14), assert_close(lse2(a, axis=0), g["lse2_0"], 1e-14)
+    assert_close(lse2(a, axis=2), g["lse2_2"], 1e-14), assert_close(lse2(a, axis=(0, 2)), g["lse2_t02"], 1e-14)
+    assert_close(lse2(a[:, 2 == i, :], axis=1), g["lse2_sel2"], 1e-14)
+    assert_close(lse2(a[:, 0 == i, :], axis=1), g["lse2_sel0"], 1e-14)
+    assert_close(lse(a), g["lse_all"], 1e-14)
+    for ax, key in ((0, "lse_0"), (1, "lse_1"), (2, "lse_2"), ((0, 2), "lse_t02"), ((0, 1, 2), "lse_t012")):
+        assert_close(lse(a, axis=ax), g[key], 1e-14, msg=key)
+    r = g["r"]
+    for ax, key in ((0, "r_lse0"), (1, "r_lse1"), (2, "r_lse2"), (None, "r_lse_all"), ((1, 2), "r_lse_t12")):
+        assert_close(lse(r, axis=ax), g[key], 1e-13, msg=key)
+    assert_close(lse2(r, axis=1), g["r_lse2_1"], 1e-13)
+    assert np.isneginf(lse(r, axis=1)[2, 1]) and np.isneginf(lse(r, axis=2)[3, 5])
+    out = lse(np.zeros((3, 0, 4)), axis=1)
+    assert out.shape == tuple(g["empty_shape"]) and np.isneginf(out).all()
+    assert np.array_equal(lse(g["one"], axis=1), g["one_lse1"])
+
+
+def test_frames(golden):
+    from lnasr.utils import split_frames, create_hamming
+    g = golden("frames")
+    assert np.array_equal(split_frames(np.arange(30), 3, 2), g["f30"])
+    assert np.array_equal(create_hamming(400), g["ham400"]) and np.array_equal(create_hamming(7), g["ham7"])
+    for n, nf, L in g["shapes"]:
+        f = split_frames(np.arange(n, dtype=np.float64), 400, 160)
+        assert f.shape == (nf, L)
+        key = "f_n%d" % n
+        if key in g.files:
+            assert np.array_equal(f, g[key])
+    assert np.array_equal(split_frames(np.arange(23.0), 5, 5), g["f_L5S5"])
+    assert np.array_equal(split_frames(np.arange(9.0), 4, 1), g["f_L4S1"])
+
+
+def test_gmm_funcs(golden):
+    from lnasr import gmm
+    g = golden("gmm_funcs")
+    assert_close(gmm.gaussian_distribution(g["x1"], 0, 4), g["g1"], 1e-14)
+    assert_close(gmm.gaussian_distribution_log(g["x1"], 0, 4), g["g1_log"], 1e-14)
+    mu0 = np.zeros(2)
+    assert_close(gmm.gaussian_multi_distribution(g["x2"], mu0, g["Sigma"]), g["g2"], 1e-13)
+    assert_close(gmm.gaussian_multi_distribution_log(g["x2"], mu0, g["Sigma"]), g["g2_log"], 1e-13)
+    gm = gmm.gaussian_mixture_distribution(g["c"], g["x3"], g["mu3"], g["Sigma3"])
+    assert gm.shape == (1, 169)
+    assert_close(gm, g["gm"], 1e-13)
+    assert_close(gmm.gaussian_mixture_distribution_log(np.log(g["c"]), g["x3"], g["mu3"], g["Sigma3"]), g["gm_log"], 1e-13)
+    assert_close(gmm.gaussian_mixture_distribution_log(g["c39"], g["x39"], g["mu39"], g["Sigma39"]), g["gm39_log"], 1e-12)
+
+
+def test_mfcc_data_raw(golden):
+    from lnasr.mfcc import MFCC
+    from lnasr.utils import read_pcm
+    g = golden("mfcc_data_raw")
+    sig = read_pcm(os.path.join(GOLDEN, "data.raw"))
+    m = MFCC()
+    assert np.array_equal(m.create_filter_bank(), g["fbank"])
+    assert_close(m.calc_mel(np.array([0.0, 700.0, 8000.0])), g["mel_pts"], 1e-15)
+    assert_close(m.calc_mel_inv(np.array([0.0, 1000.0, 2595.0])), g["mel_inv_pts"], 1e-15)
+    assert np.array_equal(m.calc_high_pass_filter(sig.astype(np.float64))[:8], g["hpf_head"])
+    power, cep, feat = m.calc_mfcc(sig.astype(np.float64))
+    assert feat.shape == (135, 39) and cep.shape == (135, 40) and power.shape == (135, 257)
+    assert_close(power[:3], g["power_head"], 1e-10, 1e-7)
+    assert_close(power.sum(axis=1), g["power_rowsum"], 1e-11)
+    assert_close(cep, g["cepstrum"], 1e-9, 1e-9)
+    assert_close(feat, g["features"], 1e-9, 1e-9)
+    assert np.allclose(cep[:, 1:13].mean(axis=0), -1e-8, atol=1e-11)
+    assert np.array_equal(feat[0, 13:26], feat[1, :13])
+    # int16 PCM straight to the device gives the same features
+    _, _, feat_i16 = m.calc_mfcc(sig)
+    assert np.array_equal(feat_i16, feat)
+
+
+def test_mfcc_synth_and_batch(golden, synth, oracle):
+    from lnasr.mfcc import MFCC
+    g = golden("mfcc_synth_small")
+    p, c, f = MFCC().calc_mfcc(g["signal"])
+    assert_close(p, g["power"], 1e-9, 1e-6), assert_close(c, g["cepstrum"], 1e-9, 1e-9)
+    assert_close(f, g["features"], 1e-9, 1e-9)
+    g2 = golden("mfcc_synth")
+    s = synth.synth_signal(int(g2["n"][0]), seed=int(g2["seed"][0]))
+    _, _, f = MFCC().calc_mfcc(s)
+    assert f.shape == (1000, 39)
+    assert_close(f, g2["features"], 1e-9, 1e-9)
+    g3 = golden("mfcc_alt_params")
+    m = MFCC(fs=8000, frame_T=32e-3, frame_stride=16e-3, hpf_alpha=0.95, fft_N=256, mfbank_num=26, cepstrum_num=12)
+    assert np.array_equal(m.create_filter_bank(), g3["fbank"])
+    p, c, f = m.calc_mfcc(g3["signal"])
+    assert_close(c, g3["cepstrum"], 1e-9, 1e-9), assert_close(f, g3["features"], 1e-9, 1e-9)
+    # ragged batch == per-utterance results
+    sigs = [g["signal"], s[:5000], g["signal"][:1000]]
+    feat, foff = MFCC().calc_mfcc_batch(sigs)
+    for u, x in enumerate(sigs):
+        _, _, fu = MFCC().calc_mfcc(x)
+        assert np.array_equal(feat[foff[u]:foff[u + 1]], fu)
+        assert_close(fu, oracle.mfcc(x)[2], 1e-9, 1e-9)
+    # a single frame has no delta row in the reference (IndexError there): refused loudly here
+    from lnasr._ffi import LnasrError
+    with pytest.raises(LnasrError):
+        MFCC().calc_mfcc(np.ones(300))
+
+
+def test_recognizer_wiring(tmp_path, synth):
+    """Model persistence + Recognizer shell: PCM -> MFCC -> decode (parity unpinned upstream)."""
+    from lnasr.gmmhmm import GMMHMM
+    from lnasr.recognizer import Recognizer
+    mdl = synth.synth_model(4, 2, 39, seed=8)
+    gh = GMMHMM(4, 2, 39, mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["si"])
+    path = str(tmp_path / "gh.npz")
+    gh.save(path)
+    rec = Recognizer({"am": path, "lm": None})
+    assert (rec.am.gmmhmm.n, rec.am.gmmhmm.m, rec.am.gmmhmm.d) == (4, 2, 39)
+    pcm = np.clip(synth.synth_signal(8000, seed=1) * 5, -32768, 32767).astype(np.int16)
+    states = rec.recognize(pcm)
+    assert states.dtype == np.uint32 and states.shape == (49,) and states.max() < 4

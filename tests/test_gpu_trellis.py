@@ -1,0 +1,225 @@
+"""GPU parity: forward / backward / Baum-Welch posteriors / M-steps / train loops / statistics,
+against golden vectors from the reference and against the CPU oracle."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+# north_star tolerance: forward/backward log-likelihoods within 1e-4 relative; we hold 1e-11.
+LL_RTOL = 1e-11
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from lnasr import _ffi
+    return _ffi.default_ctx()
+
+
+def test_toy_hmm_full(golden):
+    from lnasr.hmm import HMM
+    g = golden("toy_hmm")
+    h = HMM(2, 3, g["A"], g["B"], g["pi"])
+    alpha = h._forward(g["obs"], True)
+    beta = h._backward(g["obs"])
+    assert_close(alpha, g["alpha"], 1e-14), assert_close(beta, g["beta"], 1e-14)
+    assert_close(np.exp(alpha), [[.32, .02], [.0404, .069], [.023496, .005066]], 1e-12)
+    xi, gamma = h._baumwelch(g["obs"], alpha, beta)
+    assert_close(xi, g["xi"], 1e-13), assert_close(gamma, g["gamma"], 1e-13)
+    assert np.isneginf(gamma[-1]).all() and np.isneginf(xi[-1]).all()
+    est = h._estimate(g["obs"], alpha, beta, xi, gamma)
+    assert_close(est["A"], g["est_A"], 1e-13), assert_close(est["B"], g["est_B"], 1e-13)
+    assert_close(est["pi"], g["est_pi"], 1e-13)
+    assert np.isneginf(est["B"][:, 1]).all()
+    p = h.calc_prob(g["obs"])
+    assert abs(p - g["calc_prob"]) < 1e-14 and abs(np.exp(p) - 0.028562) < 1e-9
+
+
+def test_hmm_train_matches_reference_log(golden):
+    from lnasr.hmm import HMM
+    g = golden("hmm_train_4x5")
+    h = HMM(4, 5, g["A0"], g["B0"], g["pi0"])
+    alpha = h._forward(g["obs"], True)
+    beta = h._backward(g["obs"])
+    assert_close(alpha, g["alpha"], 1e-12), assert_close(beta, g["beta"], 1e-12)
+    xi, gamma = h._baumwelch(g["obs"], alpha, beta)
+    assert_close(xi, g["xi"], 1e-11, 1e-12), assert_close(gamma, g["gamma"], 1e-11, 1e-12)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        h.train(g["obs"], 3, 1e-4, True)
+    assert buf.getvalue() == str(g["train3_log"])
+    assert_close(h.A, g["train3_A"], 1e-10)
+    # reset('random') consumes the global numpy RNG exactly like the reference
+    np.random.seed(0)
+    h2 = HMM(4, 5)
+    h2.reset("random")
+    assert np.array_equal(h2.A, g["A0"]) and np.array_equal(h2.B, g["B0"]) and np.array_equal(h2.pi, g["pi0"])
+    h2.reset("bogus")                      # silent no-op, as in the reference
+    assert np.array_equal(h2.A, g["A0"])
+
+
+def test_discrete_mid(golden):
+    from lnasr.hmm import HMM
+    g = golden("hmm_discrete_16x24")
+    h = HMM(16, 24, g["A"], g["B"], g["pi"])
+    alpha = h._forward(g["obs"], True)
+    beta = h._backward(g["obs"])
+    assert_close(alpha, g["alpha"], 1e-12), assert_close(beta, g["beta"], 1e-12)
+    xi, gamma = h._baumwelch(g["obs"], alpha, beta)
+    assert_close(gamma, g["gamma"], 1e-11)
+    assert_close(xi[0], g["xi_t0"], 1e-11), assert_close(xi[-2], g["xi_tlast"], 1e-11)
+    est = h._estimate(g["obs"], alpha, beta, xi, gamma)
+    assert_close(est["A"], g["est_A"], 1e-10), assert_close(est["B"], g["est_B"], 1e-10)
+    assert_close(est["pi"], g["est_pi"], 1e-10)
+    assert abs(h.calc_prob(g["obs"]) - g["calc_prob"][0]) < LL_RTOL * abs(g["calc_prob"][0])
+
+
+@pytest.mark.parametrize("tag", ["", "_f32"])
+def test_gmmhmm_small_bw(golden, tag):
+    from lnasr.gmmhmm import GMMHMM
+    g = golden("gmmhmm_small" + tag)
+    prec = np.float32 if tag else np.float64
+    tol = dict(rtol=3e-5, atol=3e-5) if tag else dict(rtol=1e-10, atol=1e-11)
+    gh = GMMHMM(5, 3, 2, g["A"], g["pi"], g["w"], g["mu"], g["si"], precision=prec)
+    gh._map_b(g["obs"])
+    gh.b, gh.bm = g["b"], g["bm"]                       # trellises on the golden emissions
+    alpha = gh._forward(g["obs"])
+    beta = gh._backward(g["obs"])
+    assert alpha.dtype == prec
+    assert_close(alpha, g["alpha"], **tol), assert_close(beta, g["beta"], **tol)
+    xi, gamma = gh._baumwelch(g["obs"], g["alpha"], g["beta"])
+    assert_close(xi, g["xi"], **tol), assert_close(gamma, g["gamma"], **tol)
+    est = gh._estimate(g["obs"], g["alpha"], g["beta"], g["xi"], g["gamma"])
+    big = dict(rtol=50 * tol["rtol"], atol=50 * tol["atol"])
+    for k in ("A", "pi", "w", "mu", "si"):
+        assert_close(est[k], g["est_" + k], msg=k, **big)
+    assert est["si"].shape == (5, 3, 2, 2)
+    if not tag:
+        gh = GMMHMM(5, 3, 2, g["A"], g["pi"], g["w"], g["mu"], g["si"])
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            gh.train(g["obs"], 3, 0.0, True)
+        assert buf.getvalue() == str(g["train_log"])
+        for k in ("A", "pi", "w", "mu", "si"):
+            assert_close(getattr(gh, k), g["train3_" + k], 1e-8, 1e-10, msg=k)
+        assert abs(gh.calc_prob(g["obs"]) - g["train3_loglik"][0]) < 1e-9
+        assert np.array_equal(gh.decode(g["obs"]), g["train3_decode"])
+        np.random.seed(0)
+        _ = np.array(0.6 * np.random.random_sample((40, 2)) - 0.3)
+        g2 = GMMHMM(5, 3, 2)
+        g2.reset("random")
+        assert np.array_equal(g2.A, g["A"]) and np.array_equal(g2.mu, g["mu"]) and np.array_equal(g2.si, g["si"])
+
+
+@pytest.mark.parametrize("kind", ["diag", "full"])
+def test_gmmhmm_d39_bw(golden, kind):
+    from lnasr.gmmhmm import GMMHMM
+    g = golden("gmmhmm_d39_" + kind)
+    N, M, D = g["mu"].shape
+    if kind == "diag":
+        si = np.zeros((N, M, D, D))
+        si[:, :, np.arange(D), np.arange(D)] = g["var"]
+    else:
+        si = g["si"]
+    gh = GMMHMM(N, M, D, g["A"], g["pi"], g["w"], g["mu"], si)
+    alpha = gh._forward(g["obs"], True)
+    beta = gh._backward(g["obs"])
+    assert_close(alpha, g["alpha"], 1e-12), assert_close(beta, g["beta"], 1e-12)
+    ll = gh.calc_prob(g["obs"])
+    assert abs(ll - g["loglik"][0]) < LL_RTOL * abs(ll)
+    xi, gamma = gh._baumwelch(g["obs"], alpha, beta)
+    assert_close(gamma, g["gamma"], 1e-10)
+    est = gh._estimate(g["obs"], alpha, beta, xi, gamma)
+    for k in ("A", "pi", "w", "mu", "si"):
+        assert_close(est[k], g["est_" + k], 1e-9, 1e-11, msg=k)
+
+
+def test_forward_backward_metric_shape(golden, synth, oracle, ctx):
+    """N=128: log-likelihood of the first 32 frames against the reference; alpha/beta against the oracle;
+    sum_j exp(alpha+beta) is the same likelihood at every frame (size-independent property)."""
+    g = golden("gmmhmm_metric_slice")
+    N, M, D, T, U = (int(x) for x in g["shape"])
+    mdl = synth.synth_model(N, M, D, seed=1)
+    obs = synth.synth_obs(U, T, D, seed=1000)
+    ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
+    ll32 = ctx.calc_prob(obs[:, :32])
+    assert_close(ll32, g["loglik32"], LL_RTOL)
+    b = ctx.gmm_logprob(obs[:, :200])
+    alpha, ll = ctx.forward(b)
+    beta = ctx.backward(b)
+    ob = np.ascontiguousarray(b[0].T)
+    assert_close(alpha[0], oracle.forward(mdl["A"], mdl["pi"], ob), 1e-12)
+    assert_close(beta[0], oracle.backward(mdl["A"], ob), 1e-12)
+    tot = oracle.lse(alpha + beta, axis=2)
+    assert np.abs(tot - ll[:, None]).max() < 1e-8
+    # ragged batch
+    lens = np.array([200, 57], dtype=np.int32)
+    _, ll_r = ctx.forward(b, lens=lens)
+    assert abs(ll_r[0] - ll[0]) < 1e-9
+    assert abs(ll_r[1] - oracle.loglik(oracle.forward(mdl["A"], mdl["pi"], np.ascontiguousarray(b[1, :57].T)))) < 1e-8
+
+
+def test_forward_underflow_fallback(ctx, oracle):
+    """Left-to-right model with huge emission gaps: the linear-domain sums underflow and the exact
+    log-domain fallback must take over; -inf transitions stay -inf."""
+    N, T = 6, 40
+    A = np.full((N, N), -np.inf)
+    for i in range(N):
+        A[i, i] = np.log(0.6)
+        if i + 1 < N:
+            A[i, i + 1] = np.log(0.4)
+    A[N - 1, N - 1] = 0.0
+    pi = np.full(N, -np.inf)
+    pi[0] = 0.0
+    rng = np.random.default_rng(3)
+    b = -2000.0 * rng.random((1, T, N))          # gaps of hundreds of nats between states
+    b[0, 5, 2] = -np.inf
+    ctx.upload_hmm(A, pi)
+    alpha, ll = ctx.forward(b)
+    beta = ctx.backward(b)
+    ob = np.ascontiguousarray(b[0].T)
+    with np.errstate(invalid="ignore"):
+        ra, rb = oracle.forward(A, pi, ob), oracle.backward(A, ob)
+    assert_close(alpha[0], ra, 1e-12), assert_close(beta[0], rb, 1e-12)
+    assert np.isfinite(ll[0]) and abs(ll[0] - oracle.loglik(ra)) < 1e-9 * abs(ll[0])
+    xi, gamma = ctx.baumwelch(b, alpha, beta)
+    rxi, rga = oracle.baumwelch(A, ob, ra, rb)
+    assert_close(gamma[0], rga, 1e-10, 1e-12), assert_close(xi[0], rxi, 1e-10, 1e-12)
+
+
+def test_bw_statistics(golden, synth, oracle, ctx):
+    """Multi-utterance sufficient statistics: U=1 reproduces the reference's single-sequence M-step
+    (SURVEY 8e), U>1 equals the oracle's sums, and accumulation is additive over batch splits."""
+    g = golden("gmmhmm_d39_diag")
+    ctx.upload_gmmhmm(g["A"], g["pi"], g["w"], g["mu"], g["var"], diag=True)
+    st = ctx.bw_accumulate(g["obs"][None])
+    m = ctx.bw_mstep(st)
+    D = g["mu"].shape[2]
+    assert_close(m["A"], g["est_A"], 1e-9), assert_close(m["pi"], g["est_pi"], 1e-9)
+    assert_close(m["w"], g["est_w"], 1e-9), assert_close(m["mu"], g["est_mu"], 1e-9)
+    assert_close(m["var"], g["est_si"][:, :, np.arange(D), np.arange(D)], 1e-9)
+    # U = 3 ragged, against the oracle's per-utterance sums
+    mdl = synth.synth_model(8, 4, 6, seed=4)
+    obs = synth.synth_obs(3, 50, 6, seed=55)
+    lens = np.array([50, 21, 37], dtype=np.int32)
+    ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
+    st = ctx.bw_accumulate(obs, lens=lens)
+    ref = oracle.bw_stats_diag([obs[u, :lens[u]] for u in range(3)], mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"])
+    N, M, Dd = 8, 4, 6
+    o = 0
+    for key, n in (("xi_sum", N * N), ("gamma_sum", N), ("gamma0", N), ("mix", N * M), ("mix_x", N * M * Dd),
+                   ("mix_xx", N * M * Dd)):
+        assert_close(st[o:o + n], np.asarray(ref[key]).ravel(), 1e-9, 1e-12, msg=key)
+        o += n
+    assert abs(st[o] - ref["loglik"]) < 1e-9 * abs(ref["loglik"]) and st[o + 1] == 3 and st[o + 2] == lens.sum()
+    st_a = ctx.bw_accumulate(obs[:2], lens=lens[:2])
+    st_b = ctx.bw_accumulate(obs[2:], lens=lens[2:])
+    assert_close(st_a + st_b, st, 1e-10, 1e-13)
+    m2 = ctx.bw_mstep(st)
+    mo = oracle.mstep_from_stats(ref)
+    for k in ("A", "pi", "w", "mu", "var"):
+        assert_close(m2[k], mo[k], 1e-9, 1e-12, msg=k)
