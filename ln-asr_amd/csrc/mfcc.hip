@@ -32,7 +32,8 @@ template <typename SAMPLE>
 __device__ __forceinline__ double preemph(const SAMPLE* __restrict__ x, int64_t n, int64_t i, double a) {
     if (i >= n) return 0.0;
     const double cur = sample_at(x, i);
-    return i == 0 ? cur : cur - a * sample_at(x, i - 1);
+    // separate multiply and subtract (no FMA contraction): bit-identical to numpy's x[1:] - a * x[:-1]
+    return i == 0 ? cur : __dsub_rn(cur, __dmul_rn(a, sample_at(x, i - 1)));
 }
 
 template <typename SAMPLE>

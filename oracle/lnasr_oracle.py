@@ -414,6 +414,32 @@ def decode_diag(obs, A, pi, w, mu, var):
     return viterbi(A, pi, b)[2]
 
 
+def prep_diag_fused(w, mu, var):
+    """Per-model constant for emit_b_fused: coefficient matrix [2D+1, N*M] of the expanded
+    quadratic, rows = (-1/2 iv | mu iv | log w + const)."""
+    N, M, D = mu.shape
+    iv = 1.0 / var
+    const = w - 0.5 * (D * LOG2PI + np.log(np.prod(var, axis=2)) + np.sum(mu * mu * iv, axis=2))
+    return np.ascontiguousarray(np.concatenate(
+        [(-0.5 * iv).reshape(N * M, D).T, (mu * iv).reshape(N * M, D).T, const.reshape(1, N * M)], axis=0))
+
+
+def emit_b_fused(obs, W, N, M):
+    """b [N,T] only (no bm): one GEMM [x^2 | x | 1] @ W followed by the M-way log-sum-exp --
+    the fastest numpy form of gmmhmm.py:46-67 for diagonal Sigma (CPU baseline line B)."""
+    T = obs.shape[0]
+    F = np.concatenate([obs * obs, obs, np.ones((T, 1))], axis=1)
+    z = (F @ W).reshape(T, N, M)
+    mx = z.max(axis=2)
+    z -= mx[:, :, None]
+    np.exp(z, out=z)
+    return np.ascontiguousarray((mx + np.log(z.sum(axis=2))).T)
+
+
+def decode_diag_fused(obs, A, pi, W, N, M):
+    return viterbi(A, pi, emit_b_fused(obs, W, N, M))[2]
+
+
 def decode_refshaped(obs, A, pi, w, mu, si):
     """Reference-SHAPED loop structure (per-(j,m) density calls, per-(t,j) trellis
     updates: gmmhmm.py:64-67, hmm.py:162-166) -- BASELINE.md section 3 line A.
