@@ -179,26 +179,71 @@ __global__ void pack_wfrag_kernel(const double* __restrict__ mu, const double* _
     wpack[idx] = val;
 }
 
+// Measured on MI355X (tools/ubench): v_mfma_f64_16x16x4 issues every 64.5 cycles per SIMD
+// (78 TFLOP/s chip-wide = the fp64 vector rate) and does NOT overlap with VALU work of the same
+// or of a co-resident wave -- the fp64 matrix op occupies the vector datapath.  The kernel's
+// time is therefore MFMA cycles + epilogue VALU cycles, and the epilogue is written to use as
+// few vector instructions as possible.
+
+// one-instruction max (the library fmax canonicalises MFMA results first)
+__device__ __forceinline__ double vmax_f64(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// exp(x) for x <= 0 (log-sum-exp terms after the max shift), ~1 ulp, 10 fp64 + 4 int instructions:
+//   x = k ln2/256 + r, |r| <= ln2/512   =>   exp(x) = 2^(k>>8) * 2^((k&255)/256) * (1 + r + r^2/2 + r^3/6 + r^4/24)
+// (remainder r^5/120 < 4e-17).  k comes out of the low mantissa bits of x*256/ln2 + 1.5*2^52; the
+// power of two is applied by adding to the exponent field of the table entry, which is safe
+// because x is clamped to >= -700 (e^-700 is 1e-304: no contribution to a sum whose largest term is 1).
+constexpr int kExpTab = 256;
+__device__ __forceinline__ double exp_nonpos(double x, const double* tab) {
+    constexpr double kInvStep = 369.32993046757463;          // 256 / ln 2
+    constexpr double kStepHi = 2.7076061740622863e-03;        // ln 2 / 256 (hi)
+    constexpr double kStepLo = 9.058776616587108e-20;         // ln 2 / 256 - hi
+    constexpr double kMagic = 6755399441055744.0;             // 1.5 * 2^52
+    x = vmax_f64(x, -700.0);
+    const double kp = fma(x, kInvStep, kMagic);
+    const int k = __double2loint(kp);
+    const double kd = kp - kMagic;
+    double r = fma(-kd, kStepHi, x);
+    r = fma(-kd, kStepLo, r);
+    double q = fma(r, 1.0 / 24.0, 1.0 / 6.0);
+    q = fma(q, r, 0.5);
+    const double p = fma(q, r * r, r);
+    const double t0 = tab[k & (kExpTab - 1)];
+    const int hi = __double2hiint(t0) + ((k >> 8) << 20);
+    const double t = __hiloint2double(hi, __double2loint(t0));
+    return fma(t, p, t);
+}
+
 // ------------------------------------------------------------------------------------------
 // hot kernel: diagonal-covariance GMM bank on the fp64 matrix cores
 // ------------------------------------------------------------------------------------------
-// Block = 256 threads = 4 waves; wave w owns state group sg = 4*y + w (4 states, Q*4 = M
-// mixtures each) and keeps its coefficient fragments in registers for the whole launch
-// (Q*KS doubles per lane).  The block walks a chunk of 16-frame tiles: the tile's feature
-// matrix F[k][frame] (x^2 | x | 1) is built once in LDS (double buffered) and read as the
-// MFMA B operand by all four waves.  blockIdx is decoded XCD-aware: the GY blocks that share
-// a frame chunk sit on one XCD (b and b+8 share an XCD), so the obs tile is fetched from HBM
-// once and served to the other slabs from that XCD's L2.
-template <int Q, int KS, bool WRITE_BM>
-__global__ __launch_bounds__(256, 2) void emit_diag_mfma(
+// Block = NWV waves; wave w owns state group sg = NWV*y + w (4 states, Q*4 = M mixtures each)
+// and keeps its coefficient fragments in registers for the whole launch (Q*KS doubles per
+// lane).  The block walks a chunk of 16-frame tiles, TPS tiles per barrier interval: the
+// tiles' feature matrices F[k][frame] (x^2 | x | 1) are built once in LDS (double buffered)
+// and read as the MFMA B operand by all waves.  blockIdx is decoded XCD-aware: the GY blocks
+// that share a frame chunk sit on one XCD (b and b+8 share an XCD), so the obs tile is fetched
+// from HBM once and served to the other slabs from that XCD's L2.
+template <int Q, int KS, int NWV, int TPS, bool WRITE_BM, int ABL = 0>
+__global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 2))) void emit_diag_mfma(
     const double* __restrict__ obs, const double* __restrict__ wpack, const double* __restrict__ logw,
     double* __restrict__ b, double* __restrict__ bm, long F, int N, int D, int NG, int GY,
     long ntiles, int tiles_per_block, long nchunks) {
     constexpr int KP = 4 * KS;
-    __shared__ double Fl[2][KP * 16];
-    __shared__ double ob[2][16 * 16];
+    constexpr int NT = 64 * NWV;
+    constexpr int SPB = 4 * NWV;                // states per block
+    constexpr int FS = 17;                      // padded row stride of F: conflict-free staging writes
+    __shared__ double Fl[2][TPS][KP * FS];
+    constexpr int OS = SPB + 1;                 // padded row stride of the staged outputs
+    __shared__ double ob[2][TPS][16 * OS];
+    __shared__ double etab[kExpTab];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int e = tid; e < kExpTab; e += NT) etab[e] = exp2((double)e * (1.0 / kExpTab));
     const long bid = blockIdx.x;
     const int xcd = (int)(bid & 7);
     const long i = bid >> 3;
@@ -208,8 +253,9 @@ __global__ __launch_bounds__(256, 2) void emit_diag_mfma(
     const long tile0 = chunk * tiles_per_block;
     long tile1 = tile0 + tiles_per_block;
     if (tile1 > ntiles) tile1 = ntiles;
-    const int sg = 4 * y + w;
+    const int sg = NWV * y + w;
     const bool active = sg < NG;
+    const int sgc = active ? sg : 0;
     const int M = 4 * Q;
 
     // stationary A fragments
@@ -217,117 +263,141 @@ __global__ __launch_bounds__(256, 2) void emit_diag_mfma(
 #pragma unroll
     for (int q = 0; q < Q; ++q)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-            wr[q][ks] = active ? wpack[(((size_t)sg * Q + q) * KS + ks) * 64 + lane] : 0.0;
+        for (int ks = 0; ks < KS; ++ks) wr[q][ks] = wpack[(((size_t)sgc * Q + q) * KS + ks) * 64 + lane];
 
     double lw[WRITE_BM ? Q * 4 : 1];
     const int g = lane >> 4, fr = lane & 15;
-    const int my_state = 4 * sg + g;
+    const int my_state = 4 * sgc + g;
     if (WRITE_BM) {
 #pragma unroll
         for (int q = 0; q < Q; ++q)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) lw[q * 4 + r] = active ? logw[(size_t)my_state * M + 4 * q + r] : 0.0;
+            for (int r = 0; r < 4; ++r) lw[q * 4 + r] = logw[(size_t)my_state * M + 4 * q + r];
     }
 
     // constant rows of F (k >= 2D): 1 for k == 2D, 0 above
-    for (int e = tid; e < 2 * (KP - 2 * D) * 16; e += 256) {
-        int buf = e / ((KP - 2 * D) * 16);
-        int r = e % ((KP - 2 * D) * 16);
-        int k = 2 * D + r / 16;
-        Fl[buf][k * 16 + (r % 16)] = (k == 2 * D) ? 1.0 : 0.0;
+    {
+        const int rows = KP - 2 * D;
+        for (int e = tid; e < 2 * TPS * rows * 16; e += NT) {
+            const int bt = e / (rows * 16), r = e % (rows * 16);
+            const int k = 2 * D + r / 16;
+            Fl[bt / TPS][bt % TPS][k * FS + (r % 16)] = (k == 2 * D) ? 1.0 : 0.0;
+        }
     }
 
-    const int EL = 16 * D;                      // obs elements per tile
-    constexpr int MAXLD = 4;                    // supports D <= 64
+    const int EL = TPS * 16 * D;                        // obs elements per stage
+    constexpr int MAXLD = (TPS * 16 * 64 + NT - 1) / NT;   // supports D <= 64
+    const long lim = F * (long)D;
     double pre[MAXLD];
-    auto load_tile = [&](long tile) {
+    int foff[MAXLD];                                    // LDS offset (doubles) of this thread's x^2 slot; -1: none
+#pragma unroll
+    for (int r = 0; r < MAXLD; ++r) {
+        const int e = tid + r * NT;
+        const int f = e / D, d = e - f * D;             // f = frame within the stage
+        foff[r] = e < EL ? (f >> 4) * (KP * FS) + d * FS + (f & 15) : -1;
+    }
+    auto load_stage = [&](long tile) {
         const long base = tile * 16 * (long)D;
-        const long lim = F * (long)D;
 #pragma unroll
         for (int r = 0; r < MAXLD; ++r) {
-            int e = tid + r * 256;
-            long ge = base + e;
-            pre[r] = (e < EL && ge < lim) ? obs[ge] : 0.0;
+            long ge = base + tid + r * NT;
+            ge = ge < lim ? ge : lim - 1;               // clamped, always a valid address
+            pre[r] = obs[ge];
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_stage = [&](int buf) {
+        double* Fd = &Fl[buf][0][0];
+        const int xo = D * FS;
 #pragma unroll
         for (int r = 0; r < MAXLD; ++r) {
-            int e = tid + r * 256;
-            if (e < EL) {
-                int f = e / D, d = e - f * D;
-                double x = pre[r];
-                Fl[buf][d * 16 + f] = x * x;
-                Fl[buf][(D + d) * 16 + f] = x;
+            if (foff[r] >= 0) {
+                const double x = pre[r];
+                Fd[foff[r]] = x * x;
+                Fd[foff[r] + xo] = x;
+            }
+        }
+    };
+    auto flush_stage = [&](int buf, long tile) {         // TPS*16 frames x SPB states, SPB*8-byte rows
+#pragma unroll
+        for (int r = 0; r < (TPS * 16 * SPB + NT - 1) / NT; ++r) {
+            const int e = tid + r * NT;
+            if (e < TPS * 16 * SPB) {
+                const int tt = e / (16 * SPB), rem = e % (16 * SPB);
+                const int f = rem / SPB, st = rem % SPB;
+                const long frame = (tile + tt) * 16 + f;
+                const int state = SPB * y + st;
+                if (tile + tt < tile1 && frame < F && state < N) b[frame * N + state] = ob[buf][tt][f * OS + st];
             }
         }
     };
 
-    load_tile(tile0);
-    store_tile(0);
+    load_stage(tile0);
+    store_stage(0);
     __syncthreads();
 
-    for (long tile = tile0; tile < tile1; ++tile) {
-        const int cur = (int)((tile - tile0) & 1);
-        const bool has_next = tile + 1 < tile1;
-        if (has_next) load_tile(tile + 1);
+    int cur = 0;
+    for (long tile = tile0; tile < tile1; tile += TPS, cur ^= 1) {
+        const bool has_next = tile + TPS < tile1;
+        if (has_next) load_stage(tile + TPS);
+        if (tile > tile0) flush_stage(cur ^ 1, tile - TPS);
 
-        // flush the previous tile's staged outputs: 16 frames x 16 states, 128 B rows
-        if (tile > tile0) {
-            const int f = tid >> 4, s = tid & 15;
-            const long frame = (tile - 1) * 16 + f;
-            const int state = 16 * y + s;
-            if (frame < F && state < N) b[frame * N + state] = ob[cur ^ 1][tid];
-        }
+#pragma unroll
+        for (int tt = 0; tt < TPS; ++tt) {
+            double4_t acc[Q];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) acc[q] = double4_t{0.0, 0.0, 0.0, 0.0};
+            const double* Fc = &Fl[cur][tt][0];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const double bf = Fc[(4 * ks + g) * FS + fr];
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    if (ABL == 2) acc[q][ks & 3] += bf * wr[q][ks];      // ablation: no matrix op
+                    else acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(wr[q][ks], bf, acc[q], 0, 0, 0);
+                }
+            }
+            if (ABL == 1) {                                              // ablation: no log-sum-exp
+                double sum = 0.0;
+#pragma unroll
+                for (int q = 0; q < Q; ++q) sum += acc[q][0] + acc[q][1] + acc[q][2] + acc[q][3];
+                ob[cur][tt][fr * OS + 4 * w + g] = sum;
+                continue;
+            }
 
-        double4_t acc[Q];
-#pragma unroll
-        for (int q = 0; q < Q; ++q) acc[q] = double4_t{0.0, 0.0, 0.0, 0.0};
-        const double* Fc = &Fl[cur][0];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const double bf = Fc[(4 * ks + g) * 16 + fr];
+            // in-lane M-way log-sum-exp: this lane holds c[q][r] = mixture 4q+r of state my_state
+            double mx = acc[0][0];
 #pragma unroll
             for (int q = 0; q < Q; ++q)
-                acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(wr[q][ks], bf, acc[q], 0, 0, 0);
-        }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (q + r > 0) mx = vmax_f64(mx, acc[q][r]);
+            double s = 0.0;
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s += exp_nonpos(acc[q][r] - mx, etab);
+            // mx = -inf: every term is NaN -> clamped -> s = 0 -> log gives -inf; mx = +inf/NaN propagate
+            ob[cur][tt][fr * OS + 4 * w + g] = (mx == LN_NEG_INF) ? mx : mx + log(s);
 
-        // in-lane M-way log-sum-exp: this lane holds c[q][r] = mixture 4q+r of state my_state
-        double mx = LN_NEG_INF;
+            if (WRITE_BM) {
+                const long frame = (tile + tt) * 16 + fr;
+                if (active && tile + tt < tile1 && frame < F) {
+                    double* dst = bm + ((size_t)frame * N + my_state) * M;
 #pragma unroll
-        for (int q = 0; q < Q; ++q)
+                    for (int q = 0; q < Q; ++q)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) mx = fmax(mx, acc[q][r]);
-        double s = 0.0;
-#pragma unroll
-        for (int q = 0; q < Q; ++q)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s += exp(acc[q][r] - mx);
-        double out = (mx == LN_NEG_INF) ? mx : mx + log(s);
-        ob[cur][fr * 16 + 4 * w + g] = out;
-
-        if (WRITE_BM) {
-            const long frame = tile * 16 + fr;
-            if (active && frame < F) {
-                double* dst = bm + ((size_t)frame * N + my_state) * M;
-#pragma unroll
-                for (int q = 0; q < Q; ++q)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) dst[4 * q + r] = acc[q][r] - lw[q * 4 + r];
+                        for (int r = 0; r < 4; ++r) dst[4 * q + r] = acc[q][r] - lw[q * 4 + r];
+                }
             }
         }
 
-        if (has_next) store_tile(cur ^ 1);
+        if (has_next) store_stage(cur ^ 1);
         __syncthreads();
     }
-    // flush the last tile
-    {
-        const int cur = (int)((tile1 - 1 - tile0) & 1);
-        const int f = tid >> 4, s = tid & 15;
-        const long frame = (tile1 - 1) * 16 + f;
-        const int state = 16 * y + s;
-        if (tile1 > tile0 && frame < F && state < N) b[frame * N + state] = ob[cur][tid];
+    // flush the last stage
+    if (tile1 > tile0) {
+        const long nst = (tile1 - tile0 + TPS - 1) / TPS;
+        flush_stage((int)((nst - 1) & 1), tile0 + (nst - 1) * TPS);
     }
 }
 
@@ -569,31 +639,62 @@ static int model_upload_impl(lnasr_ctx* ctx, int N, int M, int D, const double* 
     return 0;
 }
 
-template <int Q, int KS>
-static int launch_mfma(lnasr_ctx* ctx, const double* obs, long F, double* b, double* bm) {
+template <int Q, int KS, int NWV, int TPS>
+static int launch_mfma_cfg(lnasr_ctx* ctx, const double* obs, long F, double* b, double* bm) {
     Model& md = ctx->model;
     const int N = md.N, D = md.D;
-    const int GY = (N + 15) / 16;
+    constexpr int SPB = 4 * NWV;
+    const int GY = (N + SPB - 1) / SPB;
     const long ntiles = (F + 15) / 16;
-    // ~2 blocks per CU resident; keep every block busy for many tiles so the fragment load amortises
+    // one resident generation of blocks (2 waves per SIMD); every block walks many tiles so the
+    // fragment load amortises
     const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
-    long want_chunks = (2L * cus) / GY;
+    long want_chunks = ((long)cus * 8 / NWV) / GY;
     if (want_chunks < 8) want_chunks = 8;
     want_chunks = (want_chunks / 8) * 8;
     long tpb = (ntiles + want_chunks - 1) / want_chunks;
-    if (tpb < 1) tpb = 1;
+    tpb = ((tpb + TPS - 1) / TPS) * TPS;
+    if (tpb < TPS) tpb = TPS;
     const long nchunks = (ntiles + tpb - 1) / tpb;
     const long grid = ((nchunks + 7) / 8) * 8 * GY;
     if (bm) {
-        LN_LAUNCH(ctx, "emit_diag_mfma_bm", (emit_diag_mfma<Q, KS, true>), dim3((unsigned)grid), dim3(256), 0, obs,
-                  md.wpack.as<double>(), md.logw.as<double>(), b, bm, F, N, D, md.wpack_NG, GY, ntiles, (int)tpb,
-                  nchunks);
+        LN_LAUNCH(ctx, "emit_diag_mfma_bm", (emit_diag_mfma<Q, KS, NWV, TPS, true>), dim3((unsigned)grid),
+                  dim3(64 * NWV), 0, obs, md.wpack.as<double>(), md.logw.as<double>(), b, bm, F, N, D, md.wpack_NG, GY,
+                  ntiles, (int)tpb, nchunks);
     } else {
-        LN_LAUNCH(ctx, "emit_diag_mfma", (emit_diag_mfma<Q, KS, false>), dim3((unsigned)grid), dim3(256), 0, obs,
-                  md.wpack.as<double>(), md.logw.as<double>(), b, bm, F, N, D, md.wpack_NG, GY, ntiles, (int)tpb,
-                  nchunks);
+        LN_LAUNCH(ctx, "emit_diag_mfma", (emit_diag_mfma<Q, KS, NWV, TPS, false>), dim3((unsigned)grid),
+                  dim3(64 * NWV), 0, obs, md.wpack.as<double>(), md.logw.as<double>(), b, bm, F, N, D, md.wpack_NG, GY,
+                  ntiles, (int)tpb, nchunks);
     }
     return 0;
+}
+
+template <int Q, int KS>
+static int launch_mfma(lnasr_ctx* ctx, const double* obs, long F, double* b, double* bm) {
+    const char* var = getenv("LNASR_EMIT");
+    const char v = var ? var[0] : 'a';
+    if (Q == 4 && KS == 20) {      // metric shape: tuning variants
+        if (v == 'b') return launch_mfma_cfg<Q, KS, 4, 1>(ctx, obs, F, b, bm);
+        if (v == 'c') return launch_mfma_cfg<Q, KS, 4, 2>(ctx, obs, F, b, bm);
+        if (v == 'd') return launch_mfma_cfg<Q, KS, 8, 1>(ctx, obs, F, b, bm);
+        if (v == 'e') return launch_mfma_cfg<Q, KS, 8, 4>(ctx, obs, F, b, bm);
+        if (v == 'x' || v == 'y') {      // ablation builds (wrong results by design; timing only)
+            Model& md = ctx->model;
+            const int GY = (md.N + 31) / 32;
+            const long ntiles = (F + 15) / 16;
+            long tpb = (ntiles + 63) / 64;
+            const long nchunks = (ntiles + tpb - 1) / tpb;
+            const long grid = ((nchunks + 7) / 8) * 8 * GY;
+            if (v == 'x')
+                LN_LAUNCH(ctx, "emit_ablate_no_lse", (emit_diag_mfma<4, 20, 8, 1, false, 1>), dim3((unsigned)grid), dim3(512), 0,
+                          obs, md.wpack.as<double>(), md.logw.as<double>(), b, bm, F, md.N, md.D, md.wpack_NG, GY, ntiles, (int)tpb, nchunks);
+            else
+                LN_LAUNCH(ctx, "emit_ablate_no_mfma", (emit_diag_mfma<4, 20, 8, 1, false, 2>), dim3((unsigned)grid), dim3(512), 0,
+                          obs, md.wpack.as<double>(), md.logw.as<double>(), b, bm, F, md.N, md.D, md.wpack_NG, GY, ntiles, (int)tpb, nchunks);
+            return 0;
+        }
+    }
+    return launch_mfma_cfg<Q, KS, 8, 1>(ctx, obs, F, b, bm);
 }
 
 // device-resident emission over F = U*T flattened frames; b [F,N], bm [F,N,M] or null

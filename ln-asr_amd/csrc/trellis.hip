@@ -91,15 +91,18 @@ __global__ void viterbi_generic(const TS* __restrict__ b, const double* __restri
 // Viterbi, register-resident transition matrix (N <= 64*CPT, N <= NW*RPT)
 // ------------------------------------------------------------------------------------------
 // Thread (wave w, lane l) keeps A[w*RPT + r][l + 64*c] for r < RPT, c < CPT in registers
-// (CPT*RPT doubles).  v[t-1] sits in LDS and is read as a broadcast; each read feeds CPT
-// add+max pairs.  Row slices are combined through LDS (NW > 1), then wave w finalises column
-// block(s) c = w, w+NW, ...: adds b, stores v[t] and publishes it for the next frame.
-template <int CPT, int NW, int RPT, int UB>
-__global__ __launch_bounds__(64 * NW, 2) void viterbi_reg(const double* __restrict__ b, const double* __restrict__ A,
-                                                          const double* __restrict__ pi,
-                                                          const int32_t* __restrict__ lens, double* __restrict__ v,
-                                                          int U, int T, int N) {
+// (CPT*RPT doubles).  v[t-1] sits in LDS; each wave pulls its RPT-row slice into registers at
+// the top of the frame (broadcast reads) and every value feeds CPT add+max pairs.  Row slices
+// are combined through LDS (NW > 1); the CPT*UB (utterance, column-block) finalisation jobs are
+// dealt round-robin to the waves, each of which adds b (prefetched one frame ahead), stores
+// v[t] and publishes it for the next frame.  WPE = waves per SIMD the register budget targets.
+template <int CPT, int NW, int RPT, int UB, int WPE>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void viterbi_reg(
+    const double* __restrict__ b, const double* __restrict__ A, const double* __restrict__ pi,
+    const int32_t* __restrict__ lens, double* __restrict__ v, int U, int T, int N) {
     constexpr int NP = 64 * CPT;
+    constexpr int NJOB = CPT * UB;
+    constexpr int JPW = (NJOB + NW - 1) / NW;
     __shared__ double Vs[2][UB][NP];
     __shared__ double Ps[NW > 1 ? NW : 1][UB][NP];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -133,34 +136,48 @@ __global__ __launch_bounds__(64 * NW, 2) void viterbi_reg(const double* __restri
             Vs[0][k][j] = val;
         }
     }
+    // this wave's finalisation jobs and their emission stream (always a valid address: clamped)
+    int jk[JPW], jc[JPW];
+    const double* bp[JPW];
+    double bnext[JPW];
+#pragma unroll
+    for (int jj = 0; jj < JPW; ++jj) {
+        const int q = w + jj * NW;
+        jk[jj] = q / CPT;
+        jc[jj] = q % CPT;
+        const int uu = (u0 + jk[jj] < U) ? u0 + jk[jj] : U - 1;
+        const int j = lane + 64 * jc[jj];
+        bp[jj] = b + (size_t)uu * T * N + (j < N ? j : N - 1);
+        bnext[jj] = bp[jj][(size_t)(T > 1 ? 1 : 0) * N];
+    }
     __syncthreads();
 
     for (int t = 1; t < maxlen; ++t) {
         const int cur = (t - 1) & 1, nxt = t & 1;
-        // emission for the columns this wave finalises (issued early; consumed after the loop)
-        double bv[UB][(CPT + NW - 1) / NW];
+        double bcur[JPW];
+        const int tn = t + 1 < T ? t + 1 : T - 1;
+#pragma unroll
+        for (int jj = 0; jj < JPW; ++jj) {
+            bcur[jj] = bnext[jj];
+            bnext[jj] = bp[jj][(size_t)tn * N];
+        }
+        double vr[UB][RPT];
 #pragma unroll
         for (int k = 0; k < UB; ++k)
 #pragma unroll
-            for (int cc = 0; cc < (CPT + NW - 1) / NW; ++cc) {
-                const int c = w + cc * NW, j = lane + 64 * c;
-                bv[k][cc] = (c < CPT && j < N && t < len[k]) ? b[((size_t)(u0 + k) * T + t) * N + j] : 0.0;
-            }
+            for (int r = 0; r < RPT; ++r) vr[k][r] = Vs[cur][k][w * RPT + r];
 
         double acc[UB][CPT];
 #pragma unroll
         for (int k = 0; k < UB; ++k)
 #pragma unroll
-            for (int c = 0; c < CPT; ++c) acc[k][c] = LN_NEG_INF;
+            for (int c = 0; c < CPT; ++c) acc[k][c] = vr[k][0] + areg[c][0];
 #pragma unroll
-        for (int r = 0; r < RPT; ++r) {
+        for (int r = 1; r < RPT; ++r)
 #pragma unroll
-            for (int k = 0; k < UB; ++k) {
-                const double vv = Vs[cur][k][w * RPT + r];
+            for (int k = 0; k < UB; ++k)
 #pragma unroll
-                for (int c = 0; c < CPT; ++c) acc[k][c] = fmax(acc[k][c], vv + areg[c][r]);
-            }
-        }
+                for (int c = 0; c < CPT; ++c) acc[k][c] = fmax(acc[k][c], vr[k][r] + areg[c][r]);
         if (NW > 1) {
 #pragma unroll
             for (int k = 0; k < UB; ++k)
@@ -169,28 +186,26 @@ __global__ __launch_bounds__(64 * NW, 2) void viterbi_reg(const double* __restri
             __syncthreads();
         }
 #pragma unroll
-        for (int k = 0; k < UB; ++k)
+        for (int jj = 0; jj < JPW; ++jj) {
+            const int q = w + jj * NW;
+            if (q < NJOB) {
+                const int k = jk[jj], c = jc[jj], j = lane + 64 * c;
+                double m;
+                if (NW > 1) {
+                    m = Ps[0][k][j];
 #pragma unroll
-            for (int cc = 0; cc < (CPT + NW - 1) / NW; ++cc) {
-                const int c = w + cc * NW;
-                if (c < CPT) {
-                    const int j = lane + 64 * c;
-                    double m;
-                    if (NW > 1) {
-                        m = Ps[0][k][j];
-#pragma unroll
-                        for (int ww = 1; ww < NW; ++ww) m = fmax(m, Ps[ww][k][j]);
-                    } else {
-                        m = acc[k][c];
-                    }
-                    double val = Vs[cur][k][j];
-                    if (j < N && t < len[k]) {
-                        val = m + bv[k][cc];
-                        v[((size_t)(u0 + k) * T + t) * N + j] = val;
-                    }
-                    Vs[nxt][k][j] = val;
+                    for (int ww = 1; ww < NW; ++ww) m = fmax(m, Ps[ww][k][j]);
+                } else {
+                    m = acc[k][c];
                 }
+                double val = Vs[cur][k][j];
+                if (j < N && t < len[k]) {
+                    val = m + bcur[jj];
+                    v[((size_t)(u0 + k) * T + t) * N + j] = val;
+                }
+                Vs[nxt][k][j] = val;
             }
+        }
         __syncthreads();
     }
 }
@@ -250,6 +265,106 @@ __global__ void backtrace_kernel(const TS* __restrict__ v, const double* __restr
             wave_argmax(x, xi);
             p = xi;
             if (lane == 0) pu[t] = (uint32_t)p;
+        }
+    }
+}
+
+// wave64 max of a double through DPP (no LDS crossbar): quad_perm, half-mirror and mirror steps
+// leave every lane of a 16-lane row with the row's max; the four row results are then read as
+// scalars.  ctrl codes: quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_half_mirror = 0x141,
+// row_mirror = 0x140.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double x, int lane) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_max_dpp(double x) {
+    x = fmax(x, dpp_f64<0xB1>(x));
+    x = fmax(x, dpp_f64<0x4E>(x));
+    x = fmax(x, dpp_f64<0x141>(x));
+    x = fmax(x, dpp_f64<0x140>(x));
+    const double r0 = readlane_f64(x, 0), r1 = readlane_f64(x, 16), r2 = readlane_f64(x, 32),
+                 r3 = readlane_f64(x, 48);
+    return fmax(fmax(r0, r1), fmax(r2, r3));
+}
+
+// Backtrace for N <= 128 (fp64): A^T lives in LDS so the only dependent memory access per step is
+// an LDS row read; arg-max = DPP wave max, then the first lane holding the max (ballot + ffs),
+// which is numpy.argmax's first-index rule because lane l holds states l and l+64.  Decoded
+// states are collected 64 frames at a time and written as one coalesced 256-byte row.
+__global__ __launch_bounds__(256) void backtrace_lds_kernel(const double* __restrict__ v,
+                                                           const double* __restrict__ AT,
+                                                           const int32_t* __restrict__ lens,
+                                                           uint32_t* __restrict__ path, double* __restrict__ best,
+                                                           int U, int T, int N) {
+    extern __shared__ double ATs[];     // [N][N]: ATs[p*N + i] = A[i][p]
+    for (int e = threadIdx.x; e < N * N; e += blockDim.x) ATs[e] = AT[e];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int u = blockIdx.x * (blockDim.x >> 6) + w;
+    if (u >= U) return;
+    const int L = lens[u];
+    if (L <= 0) return;
+    const double* vu = v + (size_t)u * T * N;
+    uint32_t* pu = path + (size_t)u * T;
+    const int j0 = lane, j1 = lane + 64;
+    const bool ok0 = j0 < N, ok1 = j1 < N;
+    const int jj0 = ok0 ? j0 : 0, jj1 = ok1 ? j1 : 0;
+    auto pick = [&](double x0, double x1, double& mx) -> int {
+        mx = wave_max_dpp(fmax(x0, x1));
+        const unsigned long long m0 = __ballot(x0 == mx), m1 = __ballot(x1 == mx);
+        return m0 ? (__ffsll((long long)m0) - 1) : (m1 ? 63 + __ffsll((long long)m1) : 0);
+    };
+    double c0 = ok0 ? vu[(size_t)(L - 1) * N + jj0] : LN_NEG_INF;
+    double c1 = ok1 ? vu[(size_t)(L - 1) * N + jj1] : LN_NEG_INF;
+    double bestv;
+    int p = pick(c0, c1, bestv);
+    if (lane == 0 && best) best[u] = bestv;
+    uint32_t mine = 0;
+    if (lane == ((L - 1) & 63)) mine = (uint32_t)p;
+    if (((L - 1) & 63) == 0) pu[L - 1] = (uint32_t)p;      // single-entry top block
+    // v rows are streamed from HBM: keep PF frames in flight per wave (register ring) so that the
+    // dependent chain below only ever waits on LDS
+    constexpr int PF = 8;
+    double cur0[PF], cur1[PF], nxt0[PF], nxt1[PF];
+    auto load_rows = [&](int tstart, double* r0, double* r1) {     // frames tstart, tstart-1, ... (clamped at 0)
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const int tt = tstart - k > 0 ? tstart - k : 0;
+            r0[k] = ok0 ? vu[(size_t)tt * N + jj0] : LN_NEG_INF;
+            r1[k] = ok1 ? vu[(size_t)tt * N + jj1] : LN_NEG_INF;
+        }
+    };
+    load_rows(L - 2 > 0 ? L - 2 : 0, cur0, cur1);
+    for (int tb = L - 2; tb >= 0; tb -= PF) {
+        load_rows(tb - PF > 0 ? tb - PF : 0, nxt0, nxt1);
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const int t = tb - k;
+            if (t >= 0) {
+                const double* col = ATs + p * N;
+                const double x0 = ok0 ? cur0[k] + col[jj0] : LN_NEG_INF;
+                const double x1 = ok1 ? cur1[k] + col[jj1] : LN_NEG_INF;
+                double mx;
+                p = pick(x0, x1, mx);
+                if (lane == (t & 63)) mine = (uint32_t)p;
+                if ((t & 63) == 0) {
+                    // frames t .. min(t+63, L-1) are complete: lane l holds frame t + l
+                    if (t + lane < L) pu[t + lane] = mine;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            cur0[k] = nxt0[k];
+            cur1[k] = nxt1[k];
         }
     }
 }
@@ -462,24 +577,23 @@ int viterbi_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
     const double* A = md.logA.as<double>();
     const double* pi = md.logpi.as<double>();
     if (dtype == LNASR_F64 && !getenv("LNASR_NO_REGVIT")) {
-        if (N <= 64) {
-            constexpr int UB = 2;
-            LN_LAUNCH(ctx, "viterbi_reg_n64", (viterbi_reg<1, 2, 32, UB>), dim3((U + UB - 1) / UB), dim3(128), 0,
-                      (const double*)b, A, pi, d_lens, (double*)v, U, T, N);
-            return 0;
-        }
+        const char* var = getenv("LNASR_VIT");
+        const char vsel = var ? var[0] : 'a';
+#define LN_VIT(name, CPT, NW, RPT, UB, WPE)                                                                  \
+    do {                                                                                                     \
+        LN_LAUNCH(ctx, name, (viterbi_reg<CPT, NW, RPT, UB, WPE>), dim3((U + UB - 1) / UB), dim3(64 * NW), 0, \
+                  (const double*)b, A, pi, d_lens, (double*)v, U, T, N);                                     \
+        return 0;                                                                                            \
+    } while (0)
+        if (N <= 64) LN_VIT("viterbi_reg_n64", 1, 2, 32, 2, 4);
         if (N <= 128) {
-            if (U >= 1024) {
-                constexpr int UB = 2;
-                LN_LAUNCH(ctx, "viterbi_reg_n128", (viterbi_reg<2, 4, 32, UB>), dim3((U + UB - 1) / UB), dim3(256),
-                          0, (const double*)b, A, pi, d_lens, (double*)v, U, T, N);
-            } else {
-                constexpr int UB = 1;
-                LN_LAUNCH(ctx, "viterbi_reg_n128_u1", (viterbi_reg<2, 4, 32, UB>), dim3((U + UB - 1) / UB),
-                          dim3(256), 0, (const double*)b, A, pi, d_lens, (double*)v, U, T, N);
-            }
-            return 0;
+            if (U < 512) LN_VIT("viterbi_reg_n128_u1", 2, 8, 16, 1, 4);
+            if (vsel == 'b') LN_VIT("viterbi_reg_n128_b", 2, 4, 32, 2, 2);
+            if (vsel == 'c') LN_VIT("viterbi_reg_n128_c", 2, 8, 16, 4, 2);
+            if (vsel == 'd') LN_VIT("viterbi_reg_n128_d", 2, 8, 16, 1, 4);
+            LN_VIT("viterbi_reg_n128", 2, 8, 16, 2, 4);
         }
+#undef LN_VIT
     }
     constexpr int UB = 4;
     int nt = ((N + 63) / 64) * 64;
@@ -499,6 +613,11 @@ int backtrace_device(lnasr_ctx* ctx, const void* v, int U, int T, const int32_t*
                      double* best) {
     Model& md = ctx->model;
     const int wpb = 4;
+    if (dtype == LNASR_F64 && md.N <= 128 && !getenv("LNASR_NO_LDSBT")) {
+        LN_LAUNCH(ctx, "backtrace_lds", backtrace_lds_kernel, dim3((U + wpb - 1) / wpb), dim3(64 * wpb),
+                  (size_t)md.N * md.N * 8, (const double*)v, md.logAT.as<double>(), d_lens, path, best, U, T, md.N);
+        return 0;
+    }
     if (dtype == LNASR_F32)
         LN_LAUNCH(ctx, "backtrace_f32", backtrace_kernel<float>, dim3((U + wpb - 1) / wpb), dim3(64 * wpb), 0,
                   (const float*)v, md.logAT.as<double>(), d_lens, path, best, U, T, md.N);
