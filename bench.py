@@ -70,8 +70,10 @@ def cpu_baseline():
     """Line B of BASELINE.md: best vectorised numpy form, one process per host core, one BLAS
     thread each, disjoint utterances; plus line A (reference-shaped loops, 1 core) as context."""
     import multiprocessing as mp
-    cores = len(os.sched_getaffinity(0))
-    per = 6
+    avail = len(os.sched_getaffinity(0))
+    # a 1-GPU box owns 16 of the host's logical CPUs (pool guidance); LNASR_CPU_WORKERS overrides
+    cores = max(1, min(avail, int(os.environ.get("LNASR_CPU_WORKERS", "16"))))
+    per = 40
     ctx = mp.get_context("fork")
     with ctx.Pool(cores) as pool:
         pool.map(_cpu_worker, [(5000 + i, 1) for i in range(cores)])          # warm caches / imports
@@ -81,8 +83,8 @@ def cpu_baseline():
     frames = cores * per * T_FRAMES
     out = {"value": frames / wall, "unit": "frames/s", "cores": cores, "kind": "port",
            "sample": "%d utterances x %d frames (same synthetic model/shape), oracle decode_diag_fused "
-                     "(numpy GEMM emission + vectorised Viterbi), %d worker processes x 1 BLAS thread, %.1f s wall"
-                     % (cores * per, T_FRAMES, cores, wall)}
+                     "(numpy GEMM emission + vectorised Viterbi), %d worker processes x 1 BLAS thread "
+                     "(%d logical CPUs visible), %.1f s wall" % (cores * per, T_FRAMES, cores, avail, wall)}
     # line A: reference-shaped loop structure, single core, short prefix
     from lnasr import synth
     o = _load_oracle()

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
         const int uu = (u0 + jk[jj] < U) ? u0 + jk[jj] : U - 1;
         const int j = lane + 64 * jc[jj];
         bp[jj] = b + (size_t)uu * T * N + (j < N ? j : N - 1);
-        bnext[jj] = bp[jj][(size_t)(T > 1 ? 1 : 0) * N];
+        bnext[jj] = (q < NJOB) ? bp[jj][(size_t)(T > 1 ? 1 : 0) * N] : 0.0;   // wave-uniform: idle waves load nothing
     }
     __syncthreads();
 
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
 #pragma unroll
         for (int jj = 0; jj < JPW; ++jj) {
             bcur[jj] = bnext[jj];
-            bnext[jj] = bp[jj][(size_t)tn * N];
+            if (w + jj * NW < NJOB) bnext[jj] = bp[jj][(size_t)tn * N];
         }
         double vr[UB][RPT];
 #pragma unroll

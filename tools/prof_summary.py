@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output directories (gpurun_out/...) into the small files committed under profiles/.
+
+    python tools/prof_summary.py <tag> <trace_dir> [<fetch_dir> <write_dir>]
+
+Writes profiles/<tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats summary, verbatim) and, when the
+two --pmc passes are given, profiles/<tag>_pmc.csv plus profiles/pmc_traffic.json (HBM bytes per launch:
+(2 * FETCH_SIZE + WRITE_SIZE) KiB -- FETCH_SIZE reads exactly half of a coalesced streaming read on
+gfx950 (MI355X_MICROARCH.md, HBM); checked here against the known sizes of obs / b / v)."""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, trace = sys.argv[1], sys.argv[2]
+os.makedirs(os.path.join(REPO, "profiles"), exist_ok=True)
+ks = glob.glob(os.path.join(trace, "**", "*_kernel_stats.csv"), recursive=True)[0]
+shutil.copy(ks, os.path.join(REPO, "profiles", tag + "_kernel_stats.csv"))
+print(open(ks).read()[:1500])
+
+
+def short(name):
+    m = re.search(r"lnasr::([a-z_0-9]+)", name)
+    return m.group(1) if m else name[:40]
+
+
+if len(sys.argv) >= 5:
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for d in sys.argv[3:5]:
+        f = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)[0]
+        for r in csv.DictReader(open(f)):
+            agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    out = {}
+    with open(os.path.join(REPO, "profiles", tag + "_pmc.csv"), "w") as fp:
+        fp.write("kernel,launches,FETCH_SIZE_KiB_avg,WRITE_SIZE_KiB_avg,hbm_bytes_per_launch(2*FETCH+WRITE)\n")
+        for k, c in sorted(agg.items()):
+            fe = sum(c.get("FETCH_SIZE", [0])) / max(1, len(c.get("FETCH_SIZE", [0])))
+            wr = sum(c.get("WRITE_SIZE", [0])) / max(1, len(c.get("WRITE_SIZE", [0])))
+            hbm = (2 * fe + wr) * 1024
+            fp.write("%s,%d,%.1f,%.1f,%.0f\n" % (k, len(c.get("FETCH_SIZE", [])), fe, wr, hbm))
+            out[k] = {"fetch_kib": fe, "write_kib": wr, "hbm_bytes_per_launch": hbm}
+    key_map = {"emit_diag_mfma": "emit_diag_mfma", "viterbi_reg": "viterbi_reg_n128", "backtrace_lds_kernel": "backtrace_lds"}
+    traffic = {v: out[k] for k, v in key_map.items() if k in out}
+    traffic["_source"] = "%s: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of bench.py (U=1024, T=1000)" % tag
+    json.dump(traffic, open(os.path.join(REPO, "profiles", "pmc_traffic.json"), "w"), indent=1)
+    print(open(os.path.join(REPO, "profiles", tag + "_pmc.csv")).read())
