@@ -491,6 +491,228 @@ __global__ void fwdbwd_generic(const TS* __restrict__ b, const double* __restric
 }
 
 // ------------------------------------------------------------------------------------------
+// forward / backward, register-resident exp(A) (N <= 64*CPT, N <= NW*RPT; fp64 storage)
+// ------------------------------------------------------------------------------------------
+// Same blocking as viterbi_reg: thread (wave w, lane l) keeps expA[w*RPT + r][l + 64c] (forward) or
+// expA^T (backward) in registers, UB utterances walk in lock-step, row slices are combined through
+// LDS and the CPT*UB (utterance, column-block) jobs are finalised by one wave each:
+//     prev_t[j] = S + log(sum_i e[i] * expA[i,j])  (+ b[t,j] for forward)
+//     e_t[j]    = exp(prev_t[j] - S'),   S' = max_j prev_{t-1}[j]
+// The shift S' lags one frame (the max of the frame just consumed), so no extra block-wide
+// reduction sits on the critical path: any shift is exact in floating point as long as nothing
+// over/underflows, and sums outside [1e-290, 1e290] (or NaN) fall back to the exact max-shifted
+// log-domain evaluation of that column, as in fwdbwd_generic.
+template <bool BACKWARD, int CPT, int NW, int RPT, int UB, int WPE>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void fwdbwd_reg(
+    const double* __restrict__ b, const double* __restrict__ Aexp, const double* __restrict__ Alog,
+    const double* __restrict__ pi, const int32_t* __restrict__ lens, double* __restrict__ out,
+    double* __restrict__ loglik, int U, int T, int N) {
+    constexpr int NP = 64 * CPT;
+    constexpr int NJOB = CPT * UB;
+    constexpr int JPW = (NJOB + NW - 1) / NW;
+    __shared__ double Es[2][UB][NP];      // exp(prev - shift) of the frame being consumed
+    __shared__ double Cs[2][UB][NP];      // prev itself (log domain) for the exact fallback
+    __shared__ double Ps[NW > 1 ? NW : 1][UB][NP];
+    __shared__ double Ms[2][UB][CPT];     // per column-block max of prev
+    __shared__ double Ss[2][UB];          // shift the e values of this buffer were computed with
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int u0 = blockIdx.x * UB;
+
+    double areg[CPT][RPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c)
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const int i = w * RPT + r, j = lane + 64 * c;
+            areg[c][r] = (i < N && j < N) ? Aexp[(size_t)i * N + j] : 0.0;
+        }
+
+    int len[UB], maxlen = 0;
+#pragma unroll
+    for (int k = 0; k < UB; ++k) {
+        len[k] = (u0 + k < U) ? lens[u0 + k] : 0;
+        maxlen = len[k] > maxlen ? len[k] : maxlen;
+    }
+    // jobs of this wave
+    int jk[JPW], jc[JPW], jlen[JPW];
+    const double* bp[JPW];
+    double* op[JPW];
+    bool jvalid[JPW];
+#pragma unroll
+    for (int jj = 0; jj < JPW; ++jj) {
+        const int q = w + jj * NW;
+        jvalid[jj] = q < NJOB;
+        jk[jj] = jvalid[jj] ? q / CPT : 0;
+        jc[jj] = q % CPT;
+        const int uu = (u0 + jk[jj] < U) ? u0 + jk[jj] : U - 1;
+        const int j = lane + 64 * jc[jj];
+        bp[jj] = b + (size_t)uu * T * N + (j < N ? j : N - 1);
+        op[jj] = out ? out + (size_t)uu * T * N + (j < N ? j : N - 1) : nullptr;
+        jlen[jj] = 0;
+#pragma unroll
+        for (int k = 0; k < UB; ++k)
+            if (k == jk[jj]) jlen[jj] = len[k];
+    }
+    // frame of utterance-job jj at step s:  forward t = s;  backward t = L-1-s
+    auto frame_of = [&](int jj, int step) { return BACKWARD ? jlen[jj] - 1 - step : step; };
+
+    // step 0: prev_0 and its per-block max
+#pragma unroll
+    for (int jj = 0; jj < JPW; ++jj) {
+        if (jvalid[jj]) {
+            const int k = jk[jj], c = jc[jj], j = lane + 64 * c;
+            double prev = LN_NEG_INF;
+            if (j < N && jlen[jj] > 0) {
+                const int t0 = frame_of(jj, 0);
+                const double bv = bp[jj][(size_t)t0 * N];
+                if (BACKWARD) {
+                    if (op[jj]) op[jj][(size_t)t0 * N] = 0.0;
+                    prev = 0.0 + bv;
+                } else {
+                    prev = pi[j] + bv;
+                    if (op[jj]) op[jj][0] = prev;
+                }
+            }
+            Cs[0][k][j] = prev;
+            const double m = wave_max_dpp(prev);
+            if (lane == 0) Ms[0][k][c] = m;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int jj = 0; jj < JPW; ++jj) {
+        if (jvalid[jj]) {
+            const int k = jk[jj], c = jc[jj], j = lane + 64 * c;
+            double S = Ms[0][k][0];
+#pragma unroll
+            for (int cc = 1; cc < CPT; ++cc) S = fmax(S, Ms[0][k][cc]);
+            const double prev = Cs[0][k][j];
+            Es[0][k][j] = (S == LN_NEG_INF || prev == LN_NEG_INF) ? 0.0 : exp(prev - S);
+            if (c == 0 && lane == 0) Ss[0][k] = S;
+        }
+    }
+    double bnext[JPW];
+#pragma unroll
+    for (int jj = 0; jj < JPW; ++jj) {
+        int t1 = frame_of(jj, 1);
+        t1 = t1 < 0 ? 0 : (t1 > T - 1 ? T - 1 : t1);
+        bnext[jj] = jvalid[jj] ? bp[jj][(size_t)t1 * N] : 0.0;
+    }
+    __syncthreads();
+
+    for (int step = 1; step < maxlen; ++step) {
+        const int cur = (step - 1) & 1, nxt = step & 1;
+        double bcur[JPW];
+#pragma unroll
+        for (int jj = 0; jj < JPW; ++jj) {
+            bcur[jj] = bnext[jj];
+            int tn = frame_of(jj, step + 1);
+            tn = tn < 0 ? 0 : (tn > T - 1 ? T - 1 : tn);
+            if (jvalid[jj]) bnext[jj] = bp[jj][(size_t)tn * N];
+        }
+        double er[UB][RPT];
+#pragma unroll
+        for (int k = 0; k < UB; ++k)
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) er[k][r] = Es[cur][k][w * RPT + r];
+        double acc[UB][CPT];
+#pragma unroll
+        for (int k = 0; k < UB; ++k)
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) acc[k][c] = er[k][0] * areg[c][0];
+#pragma unroll
+        for (int r = 1; r < RPT; ++r)
+#pragma unroll
+            for (int k = 0; k < UB; ++k)
+#pragma unroll
+                for (int c = 0; c < CPT; ++c) acc[k][c] = fma(er[k][r], areg[c][r], acc[k][c]);
+        if (NW > 1) {
+#pragma unroll
+            for (int k = 0; k < UB; ++k)
+#pragma unroll
+                for (int c = 0; c < CPT; ++c) Ps[w][k][lane + 64 * c] = acc[k][c];
+            __syncthreads();
+        }
+#pragma unroll
+        for (int jj = 0; jj < JPW; ++jj) {
+            if (jvalid[jj]) {
+                const int k = jk[jj], c = jc[jj], j = lane + 64 * c;
+                if (step < jlen[jj]) {
+                    double sum;
+                    if (NW > 1) {
+                        sum = Ps[0][k][j];
+#pragma unroll
+                        for (int ww = 1; ww < NW; ++ww) sum += Ps[ww][k][j];
+                    } else {
+                        sum = acc[k][c];
+                    }
+                    const double Sc = Ss[cur][k];
+                    double val;
+                    if (sum >= kSafeSum && sum <= 1e290 && Sc != LN_NEG_INF) {
+                        val = Sc + log(sum);
+                    } else {                       // exact log-domain column (rare)
+                        const int jcl = j < N ? j : N - 1;
+                        double mx = LN_NEG_INF;
+                        for (int i = 0; i < N; ++i) mx = fmax(mx, Cs[cur][k][i] + Alog[(size_t)i * N + jcl]);
+                        if (mx == LN_NEG_INF || mx != mx) {
+                            val = mx;
+                        } else {
+                            double s2 = 0.0;
+                            for (int i = 0; i < N; ++i) s2 += exp(Cs[cur][k][i] + Alog[(size_t)i * N + jcl] - mx);
+                            val = mx + log(s2);
+                        }
+                    }
+                    const int t = frame_of(jj, step);
+                    double prev;
+                    if (BACKWARD) {
+                        if (j < N && op[jj]) op[jj][(size_t)t * N] = val;
+                        prev = val + bcur[jj];
+                    } else {
+                        prev = val + bcur[jj];
+                        if (j < N && op[jj]) op[jj][(size_t)t * N] = prev;
+                    }
+                    if (j >= N) prev = LN_NEG_INF;
+                    double S = Ms[cur][k][0];
+#pragma unroll
+                    for (int cc = 1; cc < CPT; ++cc) S = fmax(S, Ms[cur][k][cc]);
+                    Cs[nxt][k][j] = prev;
+                    Es[nxt][k][j] = (S == LN_NEG_INF || prev == LN_NEG_INF) ? 0.0 : exp(prev - S);
+                    const double m = wave_max_dpp(prev);
+                    if (lane == 0) Ms[nxt][k][c] = m;
+                    if (c == 0 && lane == 0) Ss[nxt][k] = S;
+                } else {                           // this utterance has ended: carry its state
+                    Cs[nxt][k][j] = Cs[cur][k][j];
+                    Es[nxt][k][j] = Es[cur][k][j];
+                    if (lane == 0) Ms[nxt][k][c] = Ms[cur][k][c];
+                    if (c == 0 && lane == 0) Ss[nxt][k] = Ss[cur][k];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // calc_prob: lse_j alpha[L-1, j]  (hmm.py:274)
+    if (!BACKWARD && loglik && w == 0) {
+        const int fin = (maxlen > 0 ? maxlen - 1 : 0) & 1;
+#pragma unroll
+        for (int k = 0; k < UB; ++k) {
+            if (u0 + k < U && len[k] > 0) {
+                double mx = Ms[fin][k][0];
+#pragma unroll
+                for (int cc = 1; cc < CPT; ++cc) mx = fmax(mx, Ms[fin][k][cc]);
+                double sacc = 0.0;
+#pragma unroll
+                for (int c = 0; c < CPT; ++c) {
+                    const double pv = Cs[fin][k][lane + 64 * c];
+                    sacc += (mx == LN_NEG_INF || pv == LN_NEG_INF) ? 0.0 : exp(pv - mx);
+                }
+                sacc = wave_sum(sacc);
+                if (lane == 0) loglik[u0 + k] = (mx == LN_NEG_INF) ? mx : mx + log(sacc);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Baum-Welch posteriors (hmm.py:186-199): one block per (t, u)
 // ------------------------------------------------------------------------------------------
 template <typename TS>
@@ -631,6 +853,17 @@ int forward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
                    double* loglik) {
     Model& md = ctx->model;
     const int N = md.N;
+    if (dtype == LNASR_F64 && N <= 128 && !getenv("LNASR_NO_REGFWD")) {
+        if (N <= 64)
+            LN_LAUNCH(ctx, "forward_reg_n64", (fwdbwd_reg<false, 1, 2, 32, 2, 3>), dim3((U + 1) / 2), dim3(128), 0,
+                      (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
+                      (double*)alpha, loglik, U, T, N);
+        else
+            LN_LAUNCH(ctx, "forward_reg_n128", (fwdbwd_reg<false, 2, 8, 16, 2, 3>), dim3((U + 1) / 2), dim3(512), 0,
+                      (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
+                      (double*)alpha, loglik, U, T, N);
+        return 0;
+    }
     int nt = ((N + 63) / 64) * 64;
     if (nt > 1024) nt = 1024;
     LN_REQUIRE(N <= 4 * nt, "N=%d too large for the forward kernel", N);
@@ -649,10 +882,21 @@ int forward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
 int backward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d_lens, int dtype, void* beta) {
     Model& md = ctx->model;
     const int N = md.N;
+    const double* expAT = md.expAT.as<double>();
+    if (dtype == LNASR_F64 && N <= 128 && !getenv("LNASR_NO_REGFWD")) {
+        if (N <= 64)
+            LN_LAUNCH(ctx, "backward_reg_n64", (fwdbwd_reg<true, 1, 2, 32, 2, 3>), dim3((U + 1) / 2), dim3(128), 0,
+                      (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
+                      (double*)nullptr, U, T, N);
+        else
+            LN_LAUNCH(ctx, "backward_reg_n128", (fwdbwd_reg<true, 2, 8, 16, 2, 3>), dim3((U + 1) / 2), dim3(512), 0,
+                      (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
+                      (double*)nullptr, U, T, N);
+        return 0;
+    }
     int nt = ((N + 63) / 64) * 64;
     if (nt > 1024) nt = 1024;
     LN_REQUIRE(N <= 4 * nt, "N=%d too large for the backward kernel", N);
-    const double* expAT = md.expAT.as<double>();
     const size_t shmem = (size_t)(2 * N + 32) * 8;
     if (dtype == LNASR_F32)
         LN_LAUNCH(ctx, "backward_f32", (fwdbwd_generic<float, true>), dim3(U), dim3(nt), shmem, (const float*)b,

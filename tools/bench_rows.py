@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Per-row measurements of the other BASELINE.json configs on one GPU (development / DESIGN.md numbers;
+the driver-facing benchmark is bench.py).  Inputs resident in HBM, HIP-event kernel times.
+
+    python tools/bench_rows.py [mfcc] [gmm] [fwd] [bw] [all]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ln-asr_amd"))
+from lnasr import _ffi, synth  # noqa: E402
+from lnasr.mfcc import MFCC  # noqa: E402
+
+what = set(sys.argv[1:]) or {"all"}
+ctx = _ffi.default_ctx()
+print(ctx.device_info())
+
+
+def timed(label, fn, units, unit_name, reps=5, algo_bytes=None, algo_flop=None):
+    fn()
+    ctx.sync()
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    ctx.sync()
+    dt = (time.perf_counter() - t0) / reps
+    ctx.prof_enable(False)
+    rep = ctx.prof_report()
+    extra = ""
+    if algo_bytes:
+        extra += "  %.1f GB/s algorithmic (%.1f%% of 8 TB/s)" % (algo_bytes / dt / 1e9, algo_bytes / dt / 8e12 * 100)
+    if algo_flop:
+        extra += "  %.2f TFLOP/s algorithmic (%.1f%% of 78.6)" % (algo_flop / dt / 1e12, algo_flop / dt / 78.6e12 * 100)
+    print("%-34s %9.3f ms  %.3e %s/s%s" % (label, dt * 1e3, units / dt, unit_name, extra))
+    for k, (n, ms) in sorted(rep.items(), key=lambda kv: -kv[1][1])[:6]:
+        print("      %-28s %5.1f launches/step %9.3f ms avg" % (k, n / reps, ms / n))
+
+
+if what & {"mfcc", "all"}:
+    # config 2: 16 kHz, 25/10 ms, 40 mel, 13 cepstra -> D=39; n = 160,240 samples -> 1000 frames; U utterances
+    U, n = 256, 160240
+    sig = synth.synth_signal(n, seed=7)
+    batch = np.tile(sig, U)
+    offs = (np.arange(U + 1) * n).astype(np.int64)
+    m = MFCC()
+    cfg, win, bank = m._cfg()
+    d_sig = ctx.to_device(batch)
+    frames = U * 1000
+    timed("mfcc f64 samples (U=%d)" % U, lambda: ctx.mfcc(d_sig, offs, cfg, win, bank, False, False), frames, "frames",
+          algo_bytes=frames * 1592.0)
+    d_i16 = ctx.to_device(np.clip(batch, -32768, 32767).astype(np.int16))
+    timed("mfcc int16 PCM (U=%d)" % U, lambda: ctx.mfcc(d_i16, offs, cfg, win, bank, False, False), frames, "frames",
+          algo_bytes=frames * 632.0)
+
+if what & {"gmm", "all"}:
+    # config 3: T=1000, M=16, D=39, U=1024; single GMM (N=1) and the 128-state bank
+    U, T, M, D = 1024, 1000, 16, 39
+    obs = ctx.to_device(synth.synth_obs(U, T, D, seed=1000))
+    for N in (1, 128):
+        mdl = synth.synth_model(N, M, D, seed=1)
+        ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
+        b = ctx.empty((U, T, N), np.float64)
+        lib = _ffi.lib()
+        fn = lambda: _ffi.check(lib.lnasr_gmm_logprob(ctx.handle, obs.ptr, U, T, None, 0, b.ptr, None))
+        timed("gmm log-likelihood N=%d" % N, fn, U * T, "frames", algo_bytes=U * T * (312.0 + 8 * N),
+              algo_flop=U * T * 3.0 * N * M * D)
+
+if what & {"fwd", "all"}:
+    U, T, N, M, D = 1024, 1000, 128, 16, 39
+    mdl = synth.synth_model(N, M, D, seed=1)
+    ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
+    obs = ctx.to_device(synth.synth_obs(U, T, D, seed=1000))
+    b = ctx.gmm_logprob(obs)
+    al = ctx.empty((U, T, N), np.float64)
+    ll = ctx.empty((U,), np.float64)
+    lib = _ffi.lib()
+    timed("forward N=128 (alpha + loglik)", lambda: _ffi.check(lib.lnasr_forward(ctx.handle, b.ptr, U, T, None, 0, al.ptr, ll.ptr)),
+          U * T, "frames", algo_flop=U * T * 3.0 * N * N)
+    timed("backward N=128", lambda: _ffi.check(lib.lnasr_backward(ctx.handle, b.ptr, U, T, None, 0, al.ptr)), U * T, "frames",
+          algo_flop=U * T * 3.0 * N * N)
+    timed("calc_prob (emission + forward)", lambda: _ffi.check(lib.lnasr_calc_prob(ctx.handle, obs.ptr, U, T, None, ll.ptr)),
+          U * T, "frames")
+
+if what & {"bw", "all"}:
+    # config 5: N=256, M=32, T=2000, D=39, 64 utterances per GPU
+    U, T, N, M, D = 64, 2000, 256, 32, 39
+    mdl = synth.synth_model(N, M, D, seed=1)
+    ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
+    obs = ctx.to_device(synth.synth_obs(U, T, D, seed=1000))
+    stats = ctx.empty((ctx.bw_stats_len(),), np.float64)
+    lib = _ffi.lib()
+    timed("Baum-Welch statistics N=256 M=32", lambda: _ffi.check(lib.lnasr_bw_accumulate(ctx.handle, obs.ptr, U, T, None, stats.ptr)),
+          U * T, "frames", reps=2)
