@@ -859,7 +859,7 @@ int forward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
                       (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
                       (double*)alpha, loglik, U, T, N);
         else
-            LN_LAUNCH(ctx, "forward_reg_n128", (fwdbwd_reg<false, 2, 8, 16, 2, 3>), dim3((U + 1) / 2), dim3(512), 0,
+            LN_LAUNCH(ctx, "forward_reg_n128", (fwdbwd_reg<false, 2, 8, 16, 4, 2>), dim3((U + 3) / 4), dim3(512), 0,
                       (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
                       (double*)alpha, loglik, U, T, N);
         return 0;
@@ -889,7 +889,7 @@ int backward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* 
                       (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
                       (double*)nullptr, U, T, N);
         else
-            LN_LAUNCH(ctx, "backward_reg_n128", (fwdbwd_reg<true, 2, 8, 16, 2, 3>), dim3((U + 1) / 2), dim3(512), 0,
+            LN_LAUNCH(ctx, "backward_reg_n128", (fwdbwd_reg<true, 2, 8, 16, 4, 2>), dim3((U + 3) / 4), dim3(512), 0,
                       (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
                       (double*)nullptr, U, T, N);
         return 0;
