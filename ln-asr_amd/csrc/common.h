@@ -63,8 +63,9 @@ struct Model {
     DevBuf prec;                 // full: Sigma^-1 [N,M,D,D]
     DevBuf gconst;               // [N,M]: -0.5 (D ln 2pi + ln det Sigma)
     DevBuf sigma_raw;            // full upload staging [N,M,D,D]
-    DevBuf wpack;                // MFMA-packed coefficient fragments (diag)
+    DevBuf wpack, wpack_nw;      // MFMA-packed coefficient fragments (diag): with / without log w folded in
     int wpack_Q = 0, wpack_KS = 0, wpack_NG = 0;
+    int wpack_virt = 1;          // M = 16*virt mixtures are scored as `virt` virtual 16-mixture states, then merged
     DevBuf flags;                // small int scratch (diag detection)
     void release();
 };

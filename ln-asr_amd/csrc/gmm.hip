@@ -149,7 +149,7 @@ __global__ void lu_invert_kernel(const double* __restrict__ S, double* __restric
 //   k >  2D     : 0 (padding)
 __global__ void pack_wfrag_kernel(const double* __restrict__ mu, const double* __restrict__ ivar,
                                   const double* __restrict__ gconst, const double* __restrict__ logw,
-                                  double* __restrict__ wpack, int N, int M, int D, int Q, int KS) {
+                                  double* __restrict__ wpack, int N, int M, int D, int Q, int KS, int fold_w) {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t total = (size_t)(N / 4) * Q * KS * 64;
     if (idx >= total) return;
@@ -174,7 +174,7 @@ __global__ void pack_wfrag_kernel(const double* __restrict__ mu, const double* _
             double m = mu[c * D + d];
             s += m * m * ivar[c * D + d];
         }
-        val = logw[c] + gconst[c] - 0.5 * s;
+        val = (fold_w ? logw[c] : 0.0) + gconst[c] - 0.5 * s;
     }
     wpack[idx] = val;
 }
@@ -364,6 +364,20 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 2))
                 continue;
             }
 
+            if (WRITE_BM) {     // coefficients carry no log w here: bm is the raw component log-density
+                const long frame = (tile + tt) * 16 + fr;
+                if (active && tile + tt < tile1 && frame < F) {
+                    double* dst = bm + ((size_t)frame * N + my_state) * M;
+#pragma unroll
+                    for (int q = 0; q < Q; ++q)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) dst[4 * q + r] = acc[q][r];
+                }
+#pragma unroll
+                for (int q = 0; q < Q; ++q)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[q][r] += lw[q * 4 + r];
+            }
             // in-lane M-way log-sum-exp: this lane holds c[q][r] = mixture 4q+r of state my_state
             double mx = acc[0][0];
 #pragma unroll
@@ -379,16 +393,6 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 2))
             // mx = -inf: every term is NaN -> clamped -> s = 0 -> log gives -inf; mx = +inf/NaN propagate
             ob[cur][tt][fr * OS + 4 * w + g] = (mx == LN_NEG_INF) ? mx : mx + log(s);
 
-            if (WRITE_BM) {
-                const long frame = (tile + tt) * 16 + fr;
-                if (active && tile + tt < tile1 && frame < F) {
-                    double* dst = bm + ((size_t)frame * N + my_state) * M;
-#pragma unroll
-                    for (int q = 0; q < Q; ++q)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) dst[4 * q + r] = acc[q][r] - lw[q * 4 + r];
-                }
-            }
         }
 
         if (has_next) store_stage(cur ^ 1);
@@ -472,6 +476,15 @@ __global__ void emit_full_generic(const double* __restrict__ obs, const double* 
         }
         if (frame < F) st<TS>(b, (size_t)frame * N + n, acc.value());
     }
+}
+
+// b[f,n] = lse_h b'[f, n*k + h]: merges the k virtual 16-mixture states of each state
+__global__ void merge_virtual_kernel(const double* __restrict__ bv, size_t cells, int k, double* __restrict__ b) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= cells) return;
+    Lse acc;
+    for (int h = 0; h < k; ++h) acc.add(bv[idx * k + h]);
+    b[idx] = acc.value();
 }
 
 // free functions of gmm.py --------------------------------------------------------------
@@ -618,15 +631,24 @@ static int model_upload_impl(lnasr_ctx* ctx, int N, int M, int D, const double* 
         LN_LAUNCH(ctx, "prep_diag", prep_diag_kernel, dim3((unsigned)((NM + 127) / 128)), dim3(128), 0,
                   md.var.as<double>(), md.ivar.as<double>(), md.gconst.as<double>(), (int)NM, D);
         int Q = 0, KS = 0;
-        if (mfma_shape_supported(N, M, D, &Q, &KS)) {
-            size_t total = (size_t)(N / 4) * Q * KS * 64;
+        // M = 16*k mixtures: score k virtual 16-mixture states per state ([N,M,D] is [N*k,16,D] in memory)
+        const int virt = (M > 16 && M % 16 == 0) ? M / 16 : 1;
+        const int Nv = N * virt, Mv = M / virt;
+        md.wpack_virt = 1;
+        if (mfma_shape_supported(Nv, Mv, D, &Q, &KS)) {
+            size_t total = (size_t)(Nv / 4) * Q * KS * 64;
             LN_TRY(md.wpack.reserve(total * 8));
+            LN_TRY(md.wpack_nw.reserve(total * 8));
             LN_LAUNCH(ctx, "pack_wfrag", pack_wfrag_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                       md.mu.as<double>(), md.ivar.as<double>(), md.gconst.as<double>(), md.logw.as<double>(),
-                      md.wpack.as<double>(), N, M, D, Q, KS);
+                      md.wpack.as<double>(), Nv, Mv, D, Q, KS, 1);
+            LN_LAUNCH(ctx, "pack_wfrag", pack_wfrag_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                      md.mu.as<double>(), md.ivar.as<double>(), md.gconst.as<double>(), md.logw.as<double>(),
+                      md.wpack_nw.as<double>(), Nv, Mv, D, Q, KS, 0);
             md.wpack_Q = Q;
             md.wpack_KS = KS;
-            md.wpack_NG = N / 4;
+            md.wpack_NG = Nv / 4;
+            md.wpack_virt = virt;
         }
     } else {
         LN_TRY(md.prec.reserve(NMD * D * 8));
@@ -642,7 +664,7 @@ static int model_upload_impl(lnasr_ctx* ctx, int N, int M, int D, const double* 
 template <int Q, int KS, int NWV, int TPS>
 static int launch_mfma_cfg(lnasr_ctx* ctx, const double* obs, long F, double* b, double* bm) {
     Model& md = ctx->model;
-    const int N = md.N, D = md.D;
+    const int N = md.N * md.wpack_virt, D = md.D;      // (virtual) states scored by this launch
     constexpr int SPB = 4 * NWV;
     const int GY = (N + SPB - 1) / SPB;
     const long ntiles = (F + 15) / 16;
@@ -659,7 +681,7 @@ static int launch_mfma_cfg(lnasr_ctx* ctx, const double* obs, long F, double* b,
     const long grid = ((nchunks + 7) / 8) * 8 * GY;
     if (bm) {
         LN_LAUNCH(ctx, "emit_diag_mfma_bm", (emit_diag_mfma<Q, KS, NWV, TPS, true>), dim3((unsigned)grid),
-                  dim3(64 * NWV), 0, obs, md.wpack.as<double>(), md.logw.as<double>(), b, bm, F, N, D, md.wpack_NG, GY,
+                  dim3(64 * NWV), 0, obs, md.wpack_nw.as<double>(), md.logw.as<double>(), b, bm, F, N, D, md.wpack_NG, GY,
                   ntiles, (int)tpb, nchunks);
     } else {
         LN_LAUNCH(ctx, "emit_diag_mfma", (emit_diag_mfma<Q, KS, NWV, TPS, false>), dim3((unsigned)grid),
@@ -705,11 +727,24 @@ int emit_device(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, v
     const int N = md.N, M = md.M, D = md.D;
     if (md.diag && dtype == LNASR_F64 && md.wpack_Q > 0 && !getenv("LNASR_NO_MFMA")) {
         const int Q = md.wpack_Q, KS = md.wpack_KS;
+        double* bdst = (double*)b;
+        if (md.wpack_virt > 1) {
+            LN_TRY(ctx->ws_misc2.reserve((size_t)F * N * md.wpack_virt * 8));
+            bdst = ctx->ws_misc2.as<double>();
+        }
+        int rc = LNASR_E_UNSUPPORTED;
 #define LN_CASE(q, ks) \
-    if (Q == q && KS == ks) return launch_mfma<q, ks>(ctx, obs, F, (double*)b, (double*)bm);
+    if (Q == q && KS == ks) rc = launch_mfma<q, ks>(ctx, obs, F, bdst, (double*)bm);
         LN_CASE(4, 20) LN_CASE(2, 20) LN_CASE(1, 20) LN_CASE(4, 14) LN_CASE(2, 14) LN_CASE(1, 14)
         LN_CASE(4, 7) LN_CASE(2, 7) LN_CASE(1, 7)
 #undef LN_CASE
+        LN_TRY(rc);
+        if (md.wpack_virt > 1) {
+            const size_t cells = (size_t)F * N;
+            LN_LAUNCH(ctx, "merge_virtual_states", merge_virtual_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256),
+                      0, bdst, cells, md.wpack_virt, (double*)b);
+        }
+        return 0;
     }
     const unsigned grid = (unsigned)((F + 63) / 64);
     const size_t shmem = (size_t)D * 64 * 8;

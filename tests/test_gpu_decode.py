@@ -163,3 +163,25 @@ def test_viterbi_shapes(synth, oracle, ctx):
     # T = 1
     r = ctx.viterbi(b[:, :1])
     assert r["path"].shape == (1, 1) and r["path"][0, 0] == 0
+
+
+def test_mfma_virtual_states(synth, oracle, ctx):
+    """M = 32 / 48 mixtures run the fp64-MFMA kernel as 2 / 3 virtual 16-mixture states per state."""
+    for M in (32, 48):
+        N, D, T = 8, 39, 37
+        mdl = synth.synth_model(N, M, D, seed=6)
+        mdl["w"][2, 5] = -np.inf                        # a zero-weight mixture
+        obs = synth.synth_obs(2, T, D, seed=9)
+        ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
+        b, bm = ctx.gmm_logprob(obs, want_bm=True)
+        for u in range(2):
+            with np.errstate(divide="ignore"):
+                ob, obm = oracle.gmm_map_b_diag(obs[u], mdl["w"], mdl["mu"], mdl["var"])
+            assert_close(b[u].T, ob, 1e-12), assert_close(bm[u].transpose(1, 2, 0), obm, 1e-12)
+        import os
+        os.environ["LNASR_NO_MFMA"] = "1"
+        try:
+            b2 = ctx.gmm_logprob(obs)
+        finally:
+            del os.environ["LNASR_NO_MFMA"]
+        assert_close(b2, b, 1e-13)
