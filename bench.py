@@ -165,18 +165,41 @@ def main():
     d_path = ctx.empty((U, T), np.uint32)
     d_score = ctx.empty((U,), np.float64)
     d_all = None
+    hung = False
 
     # RCCL communicator for the gather of paths (N > 1)
     gather = "n/a (single GPU)"
     if world > 1:
+        import threading
         ok = 1
+        state = {}
+
+        def _init_comm():
+            # communicator + one rehearsal gather; run under a watchdog so a wedged bootstrap cannot hang the bench
+            try:
+                ctx.comm_init(state["id"], rank, world)
+                buf = ctx.empty((world, U, T), np.uint32)
+                ctx.allgather_u32(d_path, out=buf)
+                ctx.sync()
+                state["buf"] = buf
+            except Exception as e:                                   # noqa: BLE001
+                state["err"] = e
+
         try:
             ids = [_ffi.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(ids, src=0)
-            ctx.comm_init(ids[0], rank, world)
-            d_all = ctx.empty((world, U, T), np.uint32)
+            state["id"] = ids[0]
+            th = threading.Thread(target=_init_comm, daemon=True)
+            th.start()
+            th.join(float(os.environ.get("LNASR_COMM_TIMEOUT", "180")))
+            if th.is_alive():
+                raise RuntimeError("RCCL bootstrap / first all-gather did not finish in time")
+            if "err" in state:
+                raise state["err"]
+            d_all = state["buf"]
         except Exception as e:                                       # noqa: BLE001
             ok = 0
+            hung = True
             sys.stderr.write("[rank %d] RCCL init failed: %s\n" % (rank, e))
         flag = torch.tensor([ok], dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -265,6 +288,9 @@ def main():
             out["gpu_over_cpu"] = value / cpu["value"]
         print(json.dumps(out))
     barrier()
+    if hung:
+        sys.stdout.flush()
+        os._exit(0)          # a wedged RCCL thread must not keep the process alive
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
