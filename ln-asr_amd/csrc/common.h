@@ -65,6 +65,8 @@ struct Model {
     DevBuf sigma_raw;            // full upload staging [N,M,D,D]
     DevBuf wpack, wpack_nw;      // MFMA-packed coefficient fragments (diag): with / without log w folded in
     int wpack_Q = 0, wpack_KS = 0, wpack_NG = 0;
+    DevBuf wsingle;              // N = 1: coefficient fragments of the single mixture
+    int wsingle_KS = 0;
     int wpack_virt = 1;          // M = 16*virt mixtures are scored as `virt` virtual 16-mixture states, then merged
     DevBuf flags;                // small int scratch (diag detection)
     void release();

@@ -406,6 +406,125 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 2))
 }
 
 // ------------------------------------------------------------------------------------------
+// single GMM (N = 1, M <= 16): HBM-bound row of the path (gmm.py:90-100 over a batch)
+// ------------------------------------------------------------------------------------------
+// 320 B of traffic per frame against 20 MFMAs: the kernel is laid out for bytes in flight, not
+// for FLOPs.  Every wave is independent (no block barriers): it owns a private LDS feature tile,
+// walks 16-frame tiles with the next tile's observations already in registers, runs the
+// 16-component x 16-frame MFMA chain and reduces the 16 mixtures across its four 16-lane rows.
+// wsingle[ks*64 + lane] = coefficient of component (lane & 15), k = 4*ks + (lane >> 4), log w excluded.
+__global__ void pack_single_kernel(const double* __restrict__ mu, const double* __restrict__ ivar,
+                                   const double* __restrict__ gconst, double* __restrict__ wsingle, int M, int D,
+                                   int KS) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= KS * 64) return;
+    const int lane = idx & 63, ks = idx >> 6;
+    const int m = lane & 15, k = 4 * ks + (lane >> 4);
+    double val = 0.0;
+    if (m < M) {
+        if (k < D) {
+            val = -0.5 * ivar[(size_t)m * D + k];
+        } else if (k < 2 * D) {
+            val = mu[(size_t)m * D + k - D] * ivar[(size_t)m * D + k - D];
+        } else if (k == 2 * D) {
+            double sq = 0.0;
+            for (int d = 0; d < D; ++d) sq += mu[(size_t)m * D + d] * mu[(size_t)m * D + d] * ivar[(size_t)m * D + d];
+            val = gconst[m] - 0.5 * sq;
+        }
+    } else if (k == 2 * D) {
+        val = LN_NEG_INF;                      // padding component: contributes exp(-inf) = 0
+    }
+    wsingle[idx] = val;
+}
+
+template <int KS, bool WRITE_BM>
+__global__ __launch_bounds__(256) void emit_single_mfma(const double* __restrict__ obs,
+                                                        const double* __restrict__ wsingle,
+                                                        const double* __restrict__ logw, double* __restrict__ b,
+                                                        double* __restrict__ bm, long F, int M, int D, long ntiles) {
+    constexpr int KP = 4 * KS, FS = 17;
+    constexpr int MAXLD = (16 * ((KP - 1) / 2) + 63) / 64;     // loads per lane for one 16-frame tile
+    __shared__ double Fl[4][KP * FS];
+    __shared__ double etab[kExpTab];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int e = tid; e < kExpTab; e += 256) etab[e] = exp2((double)e * (1.0 / kExpTab));
+    double* Fw = &Fl[w][0];
+    for (int e = lane; e < (KP - 2 * D) * 16; e += 64) {
+        const int k = 2 * D + e / 16;
+        Fw[k * FS + (e % 16)] = (k == 2 * D) ? 1.0 : 0.0;
+    }
+    __syncthreads();                           // table ready; from here on waves never synchronise
+
+    double wr[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) wr[ks] = wsingle[ks * 64 + lane];
+    const int g = lane >> 4, fr = lane & 15;
+    double lw[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) lw[r] = (g + 4 * r < M) ? logw[g + 4 * r] : 0.0;
+
+    const int EL = 16 * D;
+    const int nld = (EL + 63) / 64;
+    const long lim = F * (long)D;
+    int foff[MAXLD];
+#pragma unroll
+    for (int r = 0; r < MAXLD; ++r) {
+        const int e = lane + r * 64;
+        const int f = e / D, d = e - f * D;
+        foff[r] = e < EL ? d * FS + f : -1;
+    }
+    double pre[MAXLD];
+    auto load_tile = [&](long tile) {
+        const long base = tile * 16 * (long)D;
+#pragma unroll
+        for (int r = 0; r < MAXLD; ++r)
+            if (r < nld) {
+                long ge = base + lane + r * 64;
+                ge = ge < lim ? ge : lim - 1;
+                pre[r] = obs[ge];
+            }
+    };
+    const long wid = (long)blockIdx.x * 4 + w, nw = (long)gridDim.x * 4;
+    long tile = wid;
+    if (tile < ntiles) load_tile(tile);
+    for (; tile < ntiles; tile += nw) {
+        const int xo = D * FS;
+#pragma unroll
+        for (int r = 0; r < MAXLD; ++r)
+            if (r < nld && foff[r] >= 0) {
+                const double x = pre[r];
+                Fw[foff[r]] = x * x;
+                Fw[foff[r] + xo] = x;
+            }
+        if (tile + nw < ntiles) load_tile(tile + nw);
+        __builtin_amdgcn_wave_barrier();       // wave-private tile: ordering within the wave is enough
+        double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wr[ks], Fw[(4 * ks + g) * FS + fr], acc, 0, 0, 0);
+        __builtin_amdgcn_wave_barrier();
+        const long frame = tile * 16 + fr;
+        if (WRITE_BM && frame < F) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (g + 4 * r < M) bm[(size_t)frame * M + g + 4 * r] = acc[r];
+        }
+        double c[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[r] = acc[r] + lw[r];
+        double mx = vmax_f64(vmax_f64(c[0], c[1]), vmax_f64(c[2], c[3]));
+        mx = fmax(mx, shfl_xor_f64(mx, 16));
+        mx = fmax(mx, shfl_xor_f64(mx, 32));
+        double sacc = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sacc += exp_nonpos(c[r] - mx, etab);
+        sacc += shfl_xor_f64(sacc, 16);
+        sacc += shfl_xor_f64(sacc, 32);
+        if (g == 0 && frame < F) b[frame] = (mx == LN_NEG_INF) ? mx : mx + log(sacc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // generic VALU kernels (any N, M, D; fp64 arithmetic, TS storage)
 // ------------------------------------------------------------------------------------------
 // block = 256 threads: 64 frames (lanes) x 4 waves; wave w walks states w, w+4, ...
@@ -413,18 +532,21 @@ template <typename TS>
 __global__ void emit_diag_generic(const double* __restrict__ obs, const double* __restrict__ mu,
                                   const double* __restrict__ ivar, const double* __restrict__ gconst,
                                   const double* __restrict__ logw, TS* __restrict__ b, TS* __restrict__ bm,
-                                  long F, int N, int M, int D) {
-    extern __shared__ double xs[];            // [D][64]
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const long f0 = (long)blockIdx.x * 64;
-    for (int e = tid; e < 64 * D; e += blockDim.x) {
+                                  long F, int N, int M, int D, int fw) {
+    // fw = 1: the 4 waves share one 64-frame tile and split the states (N >= 4);
+    // fw = 4: every wave scores all states of its own 64-frame tile (single GMM / tiny N)
+    extern __shared__ double xs_all[];        // [fw][D][64]
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: parameter reads become s_loads
+    const long fb = (long)blockIdx.x * 64 * fw;
+    for (int e = tid; e < 64 * fw * D; e += blockDim.x) {
         int f = e / D, d = e % D;
-        long fr = f0 + f;
-        xs[d * 64 + f] = fr < F ? obs[fr * D + d] : 0.0;
+        long fr = fb + f;
+        xs_all[((f >> 6) * D + d) * 64 + (f & 63)] = fr < F ? obs[fr * D + d] : 0.0;
     }
     __syncthreads();
-    const long frame = f0 + lane;
-    for (int n = w; n < N; n += 4) {
+    const double* xs = xs_all + (size_t)(w % fw) * D * 64;
+    const long frame = fb + (long)(w % fw) * 64 + lane;
+    for (int n = w / fw; n < N; n += 4 / fw) {
         Lse acc;
         for (int m = 0; m < M; ++m) {
             const size_t c = (size_t)n * M + m;
@@ -447,18 +569,21 @@ template <typename TS>
 __global__ void emit_full_generic(const double* __restrict__ obs, const double* __restrict__ mu,
                                   const double* __restrict__ prec, const double* __restrict__ gconst,
                                   const double* __restrict__ logw, TS* __restrict__ b, TS* __restrict__ bm,
-                                  long F, int N, int M, int D) {
-    extern __shared__ double xs[];            // [D][64]
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const long f0 = (long)blockIdx.x * 64;
-    for (int e = tid; e < 64 * D; e += blockDim.x) {
+                                  long F, int N, int M, int D, int fw) {
+    // fw = 1: the 4 waves share one 64-frame tile and split the states (N >= 4);
+    // fw = 4: every wave scores all states of its own 64-frame tile (single GMM / tiny N)
+    extern __shared__ double xs_all[];        // [fw][D][64]
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long fb = (long)blockIdx.x * 64 * fw;
+    for (int e = tid; e < 64 * fw * D; e += blockDim.x) {
         int f = e / D, d = e % D;
-        long fr = f0 + f;
-        xs[d * 64 + f] = fr < F ? obs[fr * D + d] : 0.0;
+        long fr = fb + f;
+        xs_all[((f >> 6) * D + d) * 64 + (f & 63)] = fr < F ? obs[fr * D + d] : 0.0;
     }
     __syncthreads();
-    const long frame = f0 + lane;
-    for (int n = w; n < N; n += 4) {
+    const double* xs = xs_all + (size_t)(w % fw) * D * 64;
+    const long frame = fb + (long)(w % fw) * 64 + lane;
+    for (int n = w / fw; n < N; n += 4 / fw) {
         Lse acc;
         for (int m = 0; m < M; ++m) {
             const size_t c = (size_t)n * M + m;
@@ -631,6 +756,17 @@ static int model_upload_impl(lnasr_ctx* ctx, int N, int M, int D, const double* 
         LN_LAUNCH(ctx, "prep_diag", prep_diag_kernel, dim3((unsigned)((NM + 127) / 128)), dim3(128), 0,
                   md.var.as<double>(), md.ivar.as<double>(), md.gconst.as<double>(), (int)NM, D);
         int Q = 0, KS = 0;
+        md.wsingle_KS = 0;
+        if (N == 1 && M <= 16 && D <= 64) {
+            const int ks1 = (2 * D + 1 + 3) / 4;
+            if (ks1 == 20 || ks1 == 14 || ks1 == 7) {
+                LN_TRY(md.wsingle.reserve((size_t)ks1 * 64 * 8));
+                LN_LAUNCH(ctx, "pack_single", pack_single_kernel, dim3((ks1 * 64 + 255) / 256), dim3(256), 0,
+                          md.mu.as<double>(), md.ivar.as<double>(), md.gconst.as<double>(), md.wsingle.as<double>(), M,
+                          D, ks1);
+                md.wsingle_KS = ks1;
+            }
+        }
         // M = 16*k mixtures: score k virtual 16-mixture states per state ([N,M,D] is [N*k,16,D] in memory)
         const int virt = (M > 16 && M % 16 == 0) ? M / 16 : 1;
         const int Nv = N * virt, Mv = M / virt;
@@ -725,6 +861,24 @@ int emit_device(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, v
     if (!md.has_gmm) return fail(LNASR_E_NOMODEL, "no GMM-HMM model uploaded");
     if (F <= 0) return 0;
     const int N = md.N, M = md.M, D = md.D;
+    if (md.diag && dtype == LNASR_F64 && md.wsingle_KS > 0 && !getenv("LNASR_NO_MFMA")) {
+        const long ntiles = (F + 15) / 16;
+        const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+        long grid = (ntiles + 3) / 4;
+        if (grid > (long)cus * 4) grid = (long)cus * 4;      // 16 waves per CU, grid-stride over tiles
+#define LN_SCASE(ks)                                                                                              \
+    if (md.wsingle_KS == ks) {                                                                                    \
+        if (bm)                                                                                                   \
+            LN_LAUNCH(ctx, "emit_single_mfma_bm", (emit_single_mfma<ks, true>), dim3((unsigned)grid), dim3(256), 0, obs, \
+                      md.wsingle.as<double>(), md.logw.as<double>(), (double*)b, (double*)bm, F, M, D, ntiles);   \
+        else                                                                                                      \
+            LN_LAUNCH(ctx, "emit_single_mfma", (emit_single_mfma<ks, false>), dim3((unsigned)grid), dim3(256), 0, obs, \
+                      md.wsingle.as<double>(), md.logw.as<double>(), (double*)b, (double*)bm, F, M, D, ntiles);   \
+        return 0;                                                                                                 \
+    }
+        LN_SCASE(20) LN_SCASE(14) LN_SCASE(7)
+#undef LN_SCASE
+    }
     if (md.diag && dtype == LNASR_F64 && md.wpack_Q > 0 && !getenv("LNASR_NO_MFMA")) {
         const int Q = md.wpack_Q, KS = md.wpack_KS;
         double* bdst = (double*)b;
@@ -746,27 +900,28 @@ int emit_device(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, v
         }
         return 0;
     }
-    const unsigned grid = (unsigned)((F + 63) / 64);
-    const size_t shmem = (size_t)D * 64 * 8;
+    const int fw = N >= 4 ? 1 : 4;
+    const unsigned grid = (unsigned)((F + 64 * fw - 1) / (64 * fw));
+    const size_t shmem = (size_t)D * 64 * 8 * fw;
     LN_REQUIRE(shmem <= 160 * 1024, "D=%d too large for the generic emission kernel", D);
     if (md.diag) {
         if (dtype == LNASR_F32)
             LN_LAUNCH(ctx, "emit_diag_generic_f32", emit_diag_generic<float>, dim3(grid), dim3(256), shmem, obs,
                       md.mu.as<double>(), md.ivar.as<double>(), md.gconst.as<double>(), md.logw.as<double>(),
-                      (float*)b, (float*)bm, F, N, M, D);
+                      (float*)b, (float*)bm, F, N, M, D, fw);
         else
             LN_LAUNCH(ctx, "emit_diag_generic", emit_diag_generic<double>, dim3(grid), dim3(256), shmem, obs,
                       md.mu.as<double>(), md.ivar.as<double>(), md.gconst.as<double>(), md.logw.as<double>(),
-                      (double*)b, (double*)bm, F, N, M, D);
+                      (double*)b, (double*)bm, F, N, M, D, fw);
     } else {
         if (dtype == LNASR_F32)
             LN_LAUNCH(ctx, "emit_full_generic_f32", emit_full_generic<float>, dim3(grid), dim3(256), shmem, obs,
                       md.mu.as<double>(), md.prec.as<double>(), md.gconst.as<double>(), md.logw.as<double>(),
-                      (float*)b, (float*)bm, F, N, M, D);
+                      (float*)b, (float*)bm, F, N, M, D, fw);
         else
             LN_LAUNCH(ctx, "emit_full_generic", emit_full_generic<double>, dim3(grid), dim3(256), shmem, obs,
                       md.mu.as<double>(), md.prec.as<double>(), md.gconst.as<double>(), md.logw.as<double>(),
-                      (double*)b, (double*)bm, F, N, M, D);
+                      (double*)b, (double*)bm, F, N, M, D, fw);
     }
     return 0;
 }

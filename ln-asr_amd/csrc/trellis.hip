@@ -713,6 +713,217 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
 }
 
 // ------------------------------------------------------------------------------------------
+// N > 128: the transition matrix no longer fits the register file of a CU.  It is streamed from
+// L2 once per frame and shared by UB utterances; thread (column jc, row slice rs) accumulates over
+// its slice of rows, slices are combined through LDS and the UB*NP (utterance, column) results are
+// finalised by all threads.  Same arithmetic as the register-resident kernels.
+// ------------------------------------------------------------------------------------------
+template <int UB>
+__global__ __launch_bounds__(1024) void viterbi_stream(const double* __restrict__ b, const double* __restrict__ A,
+                                                       const double* __restrict__ pi,
+                                                       const int32_t* __restrict__ lens, double* __restrict__ v,
+                                                       int U, int T, int N, int NP, int RS, int RPS) {
+    extern __shared__ double sm[];
+    double* Vs = sm;                           // [2][UB][NP]
+    double* Ps = sm + 2 * UB * NP;             // [RS][UB][NP]
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int jc = tid % NP, rs = tid / NP;
+    const int u0 = blockIdx.x * UB;
+    int len[UB], maxlen = 0;
+#pragma unroll
+    for (int k = 0; k < UB; ++k) {
+        len[k] = (u0 + k < U) ? lens[u0 + k] : 0;
+        maxlen = len[k] > maxlen ? len[k] : maxlen;
+    }
+    for (int q = tid; q < UB * NP; q += nt) {
+        const int k = q / NP, j = q % NP;
+        double val = LN_NEG_INF;
+        if (j < N && len[k] > 0) {
+            const size_t o = ((size_t)(u0 + k) * T) * N + j;
+            val = pi[j] + b[o];
+            v[o] = val;
+        }
+        Vs[k * NP + j] = val;
+    }
+    __syncthreads();
+    const int i0 = rs * RPS, i1 = (i0 + RPS < N) ? i0 + RPS : N;
+    const int jcl = jc < N ? jc : N - 1;
+    for (int t = 1; t < maxlen; ++t) {
+        const double* Vc = Vs + ((t - 1) & 1) * UB * NP;
+        double* Vn = Vs + (t & 1) * UB * NP;
+        if (rs < RS) {
+            double acc[UB];
+#pragma unroll
+            for (int k = 0; k < UB; ++k) acc[k] = LN_NEG_INF;
+#pragma unroll 8
+            for (int i = i0; i < i1; ++i) {
+                const double a = A[(size_t)i * N + jcl];
+#pragma unroll
+                for (int k = 0; k < UB; ++k) acc[k] = fmax(acc[k], Vc[k * NP + i] + a);
+            }
+#pragma unroll
+            for (int k = 0; k < UB; ++k) Ps[(rs * UB + k) * NP + jc] = acc[k];
+        }
+        __syncthreads();
+        for (int q = tid; q < UB * NP; q += nt) {
+            const int k = q / NP, j = q % NP;
+            double val = Vc[k * NP + j];
+            if (j < N && t < len[k]) {
+                double m = Ps[k * NP + j];
+                for (int r = 1; r < RS; ++r) m = fmax(m, Ps[(r * UB + k) * NP + j]);
+                const size_t o = ((size_t)(u0 + k) * T + t) * N + j;
+                val = m + b[o];
+                v[o] = val;
+            }
+            Vn[k * NP + j] = val;
+        }
+        __syncthreads();
+    }
+}
+
+template <bool BACKWARD, int UB>
+__global__ __launch_bounds__(1024) void fwdbwd_stream(const double* __restrict__ b, const double* __restrict__ Aexp,
+                                                      const double* __restrict__ Alog, const double* __restrict__ pi,
+                                                      const int32_t* __restrict__ lens, double* __restrict__ out,
+                                                      double* __restrict__ loglik, int U, int T, int N, int NP, int RS,
+                                                      int RPS) {
+    extern __shared__ double sm[];
+    const int NB = NP / 64;                    // 64-column blocks
+    double* Es = sm;                           // [2][UB][NP]
+    double* Cs = Es + 2 * UB * NP;             // [2][UB][NP]
+    double* Ps = Cs + 2 * UB * NP;             // [RS][UB][NP]
+    double* Ms = Ps + RS * UB * NP;            // [2][UB][NB]
+    double* Ss = Ms + 2 * UB * NB;             // [2][UB]
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63;
+    const int jc = tid % NP, rs = tid / NP;
+    const int u0 = blockIdx.x * UB;
+    int len[UB], maxlen = 0;
+#pragma unroll
+    for (int k = 0; k < UB; ++k) {
+        len[k] = (u0 + k < U) ? lens[u0 + k] : 0;
+        maxlen = len[k] > maxlen ? len[k] : maxlen;
+    }
+    auto frame_of = [&](int k, int step) { return BACKWARD ? len[k] - 1 - step : step; };
+    // step 0 (jobs: q -> (k = q / NP, j = q % NP); a wave never straddles two utterances since NP % 64 == 0)
+    for (int q = tid; q < UB * NP; q += nt) {
+        const int k = q / NP, j = q % NP;
+        double prev = LN_NEG_INF;
+        if (j < N && len[k] > 0) {
+            const int t0 = frame_of(k, 0);
+            const size_t o = ((size_t)(u0 + k) * T + t0) * N + j;
+            if (BACKWARD) {
+                if (out) out[o] = 0.0;
+                prev = 0.0 + b[o];
+            } else {
+                prev = pi[j] + b[o];
+                if (out) out[o] = prev;
+            }
+        }
+        Cs[k * NP + j] = prev;
+        const double m = wave_max_dpp(prev);
+        if (lane == 0) Ms[k * NB + (j >> 6)] = m;
+    }
+    __syncthreads();
+    for (int q = tid; q < UB * NP; q += nt) {
+        const int k = q / NP, j = q % NP;
+        double S = Ms[k * NB];
+        for (int c = 1; c < NB; ++c) S = fmax(S, Ms[k * NB + c]);
+        const double prev = Cs[k * NP + j];
+        Es[k * NP + j] = (S == LN_NEG_INF || prev == LN_NEG_INF) ? 0.0 : exp(prev - S);
+        if (j == 0) Ss[k] = S;
+    }
+    __syncthreads();
+    const int i0 = rs * RPS, i1 = (i0 + RPS < N) ? i0 + RPS : N;
+    const int jcl = jc < N ? jc : N - 1;
+    for (int step = 1; step < maxlen; ++step) {
+        const int cur = (step - 1) & 1, nxt = step & 1;
+        const double* Ec = Es + cur * UB * NP;
+        const double* Cc = Cs + cur * UB * NP;
+        if (rs < RS) {
+            double acc[UB];
+#pragma unroll
+            for (int k = 0; k < UB; ++k) acc[k] = 0.0;
+#pragma unroll 8
+            for (int i = i0; i < i1; ++i) {
+                const double a = Aexp[(size_t)i * N + jcl];
+#pragma unroll
+                for (int k = 0; k < UB; ++k) acc[k] = fma(Ec[k * NP + i], a, acc[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < UB; ++k) Ps[(rs * UB + k) * NP + jc] = acc[k];
+        }
+        __syncthreads();
+        for (int q = tid; q < UB * NP; q += nt) {
+            const int k = q / NP, j = q % NP;
+            double* En = Es + nxt * UB * NP;
+            double* Cn = Cs + nxt * UB * NP;
+            if (step < len[k]) {
+                double sum = Ps[k * NP + j];
+                for (int r = 1; r < RS; ++r) sum += Ps[(r * UB + k) * NP + j];
+                const double Sc = Ss[cur * UB + k];
+                double val;
+                if (sum >= kSafeSum && sum <= 1e290 && Sc != LN_NEG_INF) {
+                    val = Sc + log(sum);
+                } else {
+                    const int jl = j < N ? j : N - 1;
+                    double mx = LN_NEG_INF;
+                    for (int i = 0; i < N; ++i) mx = fmax(mx, Cc[k * NP + i] + Alog[(size_t)i * N + jl]);
+                    if (mx == LN_NEG_INF || mx != mx) {
+                        val = mx;
+                    } else {
+                        double s2 = 0.0;
+                        for (int i = 0; i < N; ++i) s2 += exp(Cc[k * NP + i] + Alog[(size_t)i * N + jl] - mx);
+                        val = mx + log(s2);
+                    }
+                }
+                const int t = frame_of(k, step);
+                double prev = LN_NEG_INF;
+                if (j < N) {
+                    const size_t o = ((size_t)(u0 + k) * T + t) * N + j;
+                    const double bv = b[o];
+                    if (BACKWARD) {
+                        if (out) out[o] = val;
+                        prev = val + bv;
+                    } else {
+                        prev = val + bv;
+                        if (out) out[o] = prev;
+                    }
+                }
+                double S = Ms[(cur * UB + k) * NB];
+                for (int c = 1; c < NB; ++c) S = fmax(S, Ms[(cur * UB + k) * NB + c]);
+                Cn[k * NP + j] = prev;
+                En[k * NP + j] = (S == LN_NEG_INF || prev == LN_NEG_INF) ? 0.0 : exp(prev - S);
+                const double m = wave_max_dpp(prev);
+                if (lane == 0) Ms[(nxt * UB + k) * NB + (j >> 6)] = m;
+                if (j == 0) Ss[nxt * UB + k] = S;
+            } else {
+                Cn[k * NP + j] = Cc[k * NP + j];
+                En[k * NP + j] = Ec[k * NP + j];
+                if (lane == 0) Ms[(nxt * UB + k) * NB + (j >> 6)] = Ms[(cur * UB + k) * NB + (j >> 6)];
+                if (j == 0) Ss[nxt * UB + k] = Ss[cur * UB + k];
+            }
+        }
+        __syncthreads();
+    }
+    if (!BACKWARD && loglik && tid < 64) {
+        const int fin = (maxlen > 0 ? maxlen - 1 : 0) & 1;
+        for (int k = 0; k < UB; ++k) {
+            if (u0 + k < U && len[k] > 0) {
+                double mx = Ms[(fin * UB + k) * NB];
+                for (int c = 1; c < NB; ++c) mx = fmax(mx, Ms[(fin * UB + k) * NB + c]);
+                double sacc = 0.0;
+                for (int j = lane; j < NP; j += 64) {
+                    const double pv = Cs[(fin * UB + k) * NP + j];
+                    sacc += (mx == LN_NEG_INF || pv == LN_NEG_INF) ? 0.0 : exp(pv - mx);
+                }
+                sacc = wave_sum(sacc);
+                if (lane == 0) loglik[u0 + k] = (mx == LN_NEG_INF) ? mx : mx + log(sacc);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Baum-Welch posteriors (hmm.py:186-199): one block per (t, u)
 // ------------------------------------------------------------------------------------------
 template <typename TS>
@@ -818,6 +1029,13 @@ int viterbi_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
 #undef LN_VIT
     }
     constexpr int UB = 4;
+    if (dtype == LNASR_F64 && N > 128 && N <= 1024 && !getenv("LNASR_NO_STREAM")) {
+        const int NP = ((N + 63) / 64) * 64, RS = 1024 / NP, RPS = (N + RS - 1) / RS;
+        const size_t shm = (size_t)(2 + RS) * UB * NP * 8;
+        LN_LAUNCH(ctx, "viterbi_stream", (viterbi_stream<UB>), dim3((U + UB - 1) / UB), dim3(NP * RS), shm,
+                  (const double*)b, A, pi, d_lens, (double*)v, U, T, N, NP, RS, RPS);
+        return 0;
+    }
     int nt = ((N + 63) / 64) * 64;
     if (nt > 1024) nt = 1024;
     const size_t shmem = (size_t)2 * UB * N * 8;
@@ -864,6 +1082,15 @@ int forward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
                       (double*)alpha, loglik, U, T, N);
         return 0;
     }
+    if (dtype == LNASR_F64 && N > 128 && N <= 1024 && !getenv("LNASR_NO_STREAM")) {
+        constexpr int UB = 4;
+        const int NP = ((N + 63) / 64) * 64, RS = 1024 / NP, RPS = (N + RS - 1) / RS, NB = NP / 64;
+        const size_t shm = ((size_t)(4 + RS) * UB * NP + 2 * UB * NB + 2 * UB) * 8;
+        LN_LAUNCH(ctx, "forward_stream", (fwdbwd_stream<false, UB>), dim3((U + UB - 1) / UB), dim3(NP * RS), shm,
+                  (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
+                  (double*)alpha, loglik, U, T, N, NP, RS, RPS);
+        return 0;
+    }
     int nt = ((N + 63) / 64) * 64;
     if (nt > 1024) nt = 1024;
     LN_REQUIRE(N <= 4 * nt, "N=%d too large for the forward kernel", N);
@@ -892,6 +1119,15 @@ int backward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* 
             LN_LAUNCH(ctx, "backward_reg_n128", (fwdbwd_reg<true, 2, 8, 16, 4, 2>), dim3((U + 3) / 4), dim3(512), 0,
                       (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
                       (double*)nullptr, U, T, N);
+        return 0;
+    }
+    if (dtype == LNASR_F64 && N > 128 && N <= 1024 && !getenv("LNASR_NO_STREAM")) {
+        constexpr int UB = 4;
+        const int NP = ((N + 63) / 64) * 64, RS = 1024 / NP, RPS = (N + RS - 1) / RS, NB = NP / 64;
+        const size_t shm = ((size_t)(4 + RS) * UB * NP + 2 * UB * NB + 2 * UB) * 8;
+        LN_LAUNCH(ctx, "backward_stream", (fwdbwd_stream<true, UB>), dim3((U + UB - 1) / UB), dim3(NP * RS), shm,
+                  (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
+                  (double*)nullptr, U, T, N, NP, RS, RPS);
         return 0;
     }
     int nt = ((N + 63) / 64) * 64;

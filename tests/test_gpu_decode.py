@@ -185,3 +185,21 @@ def test_mfma_virtual_states(synth, oracle, ctx):
         finally:
             del os.environ["LNASR_NO_MFMA"]
         assert_close(b2, b, 1e-13)
+
+
+def test_single_gmm_batch(synth, oracle, ctx):
+    """Config-3 shape: one 16-mixture GMM (N=1) over a batch -- the HBM-bound MFMA kernel; also M < 16."""
+    for M in (16, 5):
+        mdl = synth.synth_model(1, M, 39, seed=12)
+        obs = synth.synth_obs(3, 101, 39, seed=13)
+        ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
+        b, bm = ctx.gmm_logprob(obs, want_bm=True)
+        b_only = ctx.gmm_logprob(obs)
+        assert np.array_equal(b, b_only)
+        for u in range(3):
+            ob, obm = oracle.gmm_map_b_diag(obs[u], mdl["w"], mdl["mu"], mdl["var"])
+            assert_close(b[u].T, ob, 1e-12), assert_close(bm[u].transpose(1, 2, 0), obm, 1e-12)
+            si = np.zeros((M, 39, 39))
+            si[:, np.arange(39), np.arange(39)] = mdl["var"][0]
+            ref = oracle.gaussian_mixture_log(mdl["w"][0], obs[u], mdl["mu"][0], si)
+            assert_close(b[u, :, 0], ref, 1e-12)

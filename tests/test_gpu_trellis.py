@@ -223,3 +223,32 @@ def test_bw_statistics(golden, synth, oracle, ctx):
     mo = oracle.mstep_from_stats(ref)
     for k in ("A", "pi", "w", "mu", "var"):
         assert_close(m2[k], mo[k], 1e-9, 1e-12, msg=k)
+
+
+def test_forward_backward_large_n(synth, oracle, ctx):
+    """N > 128 (streaming kernels): alpha / beta / loglik / posteriors against the oracle, ragged batch."""
+    rng = np.random.default_rng(17)
+    for N in (129, 200, 256):
+        d = synth.synth_discrete(N, 4, 8, seed=N)
+        A = d["A"].copy()
+        A[3, :] = -np.inf
+        A[3, 5] = 0.0                                   # a deterministic transition
+        A[:, 7] = -np.inf                               # an unreachable state
+        ctx.upload_hmm(A, d["pi"])
+        T = 21
+        b = np.ascontiguousarray(-30.0 * rng.random((5, T, N)))
+        lens = np.array([T, 1, 9, 2, 20], dtype=np.int32)
+        alpha, ll = ctx.forward(b, lens=lens)
+        beta = ctx.backward(b, lens=lens)
+        r = ctx.viterbi(b, lens=lens)
+        for u in range(5):
+            L = lens[u]
+            ob = np.ascontiguousarray(b[u, :L].T)
+            with np.errstate(invalid="ignore"):
+                ra, rb = oracle.forward(A, d["pi"], ob), oracle.backward(A, ob)
+            assert_close(alpha[u, :L], ra, 1e-12, msg="alpha N=%d u=%d" % (N, u))
+            assert_close(beta[u, :L], rb, 1e-12, msg="beta N=%d u=%d" % (N, u))
+            assert abs(ll[u] - oracle.loglik(ra)) <= 1e-11 * abs(ll[u])
+            v, bt, path = oracle.viterbi(A, d["pi"], ob)
+            assert np.array_equal(r["v"][u, :L], v) and np.array_equal(r["path"][u, :L], path)
+            assert np.array_equal(r["bt"][u, :L], bt)
