@@ -36,12 +36,28 @@ __device__ __forceinline__ double preemph(const SAMPLE* __restrict__ x, int64_t 
     return i == 0 ? cur : __dsub_rn(cur, __dmul_rn(a, sample_at(x, i - 1)));
 }
 
+// [lo, hi) of the non-zero taps of every mel filter (zeros add nothing to the dot product of mfcc.py:148)
+__global__ void mel_range_kernel(const double* __restrict__ fbank, int n_mel, int nbin, int* __restrict__ range) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n_mel) return;
+    const double* fb = fbank + (size_t)m * nbin;
+    int lo = nbin, hi = 0;
+    for (int k = 0; k < nbin; ++k)
+        if (fb[k] != 0.0) {
+            if (k < lo) lo = k;
+            hi = k + 1;
+        }
+    if (hi == 0) lo = 0;
+    range[2 * m] = lo;
+    range[2 * m + 1] = hi;
+}
+
 template <typename SAMPLE>
 __global__ void mfcc_frame_kernel(const SAMPLE* __restrict__ signal, const int64_t* __restrict__ soff,
                                   const int64_t* __restrict__ foff, int U, int L, int S, int NFFT, int LOG2N,
                                   int n_mel, double alpha, const double* __restrict__ window,
-                                  const double* __restrict__ fbank, const double* __restrict__ twid,
-                                  double* __restrict__ power_out, double* __restrict__ logmel,
+                                  const double* __restrict__ fbank, const int* __restrict__ mel_range,
+                                  const double* __restrict__ twid, double* __restrict__ power_out, double* __restrict__ logmel,
                                   double* __restrict__ energy) {
     extern __shared__ double sm[];
     double* re = sm;                    // [NFFT]
@@ -98,7 +114,8 @@ __global__ void mfcc_frame_kernel(const SAMPLE* __restrict__ signal, const int64
     for (int m = tid; m < n_mel; m += nt) {
         const double* fb = fbank + (size_t)m * nbin;
         double s = 0.0;
-        for (int k = 0; k < nbin; ++k) s += pw[k] * fb[k];                   // mfcc.py:148
+        const int hi = mel_range[2 * m + 1];
+        for (int k = mel_range[2 * m]; k < hi; ++k) s += pw[k] * fb[k];      // mfcc.py:148
         if (s == 0.0) s = 2.220446049250313e-16;                             // mfcc.py:149
         logmel[f * n_mel + m] = 20.0 * log10(s);                             // mfcc.py:150
     }
@@ -287,12 +304,13 @@ int lnasr_mfcc(lnasr_ctx* ctx, const void* signal, int sample_kind, const int64_
             const double f = k == 0 ? sqrt(1.0 / (4.0 * n_mel)) : sqrt(1.0 / (2.0 * n_mel));
             C[(size_t)k * n_mel + m] = 2.0 * f * cos(M_PI * (double)k * (2.0 * m + 1.0) / (2.0 * n_mel));
         }
-    const size_t cbytes = (size_t)(2 * (U + 1)) * 8 + (size_t)NFFT * 8 + C.size() * 8;
+    const size_t cbytes = (size_t)(2 * (U + 1)) * 8 + (size_t)NFFT * 8 + C.size() * 8 + (size_t)2 * n_mel * 4;
     LN_TRY(ctx->ws_in4.reserve(cbytes));
     int64_t* d_soff = ctx->ws_in4.as<int64_t>();
     int64_t* d_foff = d_soff + (U + 1);
     double* d_tw = reinterpret_cast<double*>(d_foff + (U + 1));
     double* d_C = d_tw + NFFT;
+    int* d_range = reinterpret_cast<int*>(d_C + C.size());
     LN_HIP(hipMemcpyAsync(d_soff, offsets, (size_t)(U + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     LN_HIP(hipMemcpyAsync(d_foff, foff.data(), (size_t)(U + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     LN_HIP(hipMemcpyAsync(d_tw, tw.data(), (size_t)NFFT * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -309,16 +327,18 @@ int lnasr_mfcc(lnasr_ctx* ctx, const void* signal, int sample_kind, const int64_
     if (cepstrum_or_null) LN_TRY(stage_out(ctx, cepstrum_or_null, (size_t)F * n_mel * 8, ctx->ws_out2, &d_cep));
     LN_TRY(stage_out(ctx, features, (size_t)F * 3 * W * 8, ctx->ws_out3, &d_feat));
 
+    LN_LAUNCH(ctx, "mfcc_mel_range", mel_range_kernel, dim3((n_mel + 63) / 64), dim3(64), 0, (const double*)d_fb, n_mel,
+              nbin, d_range);
     const size_t shm = (size_t)(2 * NFFT + nbin + 32) * 8;
     const int nt = NFFT / 2 < 256 ? (NFFT / 2 < 64 ? 64 : NFFT / 2) : 256;
     if (sample_kind == 1)
         LN_LAUNCH(ctx, "mfcc_frame_i16", mfcc_frame_kernel<int16_t>, dim3((unsigned)F), dim3(nt), shm,
                   (const int16_t*)d_sig, d_soff, d_foff, U, L, S, NFFT, log2n, n_mel, cfg->hpf_alpha,
-                  (const double*)d_win, (const double*)d_fb, d_tw, (double*)d_pow, logmel, energy);
+                  (const double*)d_win, (const double*)d_fb, d_range, d_tw, (double*)d_pow, logmel, energy);
     else
         LN_LAUNCH(ctx, "mfcc_frame", mfcc_frame_kernel<double>, dim3((unsigned)F), dim3(nt), shm,
                   (const double*)d_sig, d_soff, d_foff, U, L, S, NFFT, log2n, n_mel, cfg->hpf_alpha,
-                  (const double*)d_win, (const double*)d_fb, d_tw, (double*)d_pow, logmel, energy);
+                  (const double*)d_win, (const double*)d_fb, d_range, d_tw, (double*)d_pow, logmel, energy);
     {
         int threads = 256 - 256 % n_mel;
         if (threads < n_mel) threads = n_mel;

@@ -269,6 +269,126 @@ __global__ void backtrace_kernel(const TS* __restrict__ v, const double* __restr
     }
 }
 
+// Single-barrier variant: b[t,j] is added to every row-slice maximum before the slices meet
+// (rounding is monotonic, so max_i((v_i + A_ij) + b_j) == max_i(v_i + A_ij) + b_j bit for bit) and
+// the slices are merged with LDS floating-point atomic max into a triple-buffered v row: one
+// barrier per frame, no partial-maximum round trip.
+template <int CPT, int NW, int RPT, int UB, int WPE>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void viterbi_reg1b(
+    const double* __restrict__ b, const double* __restrict__ A, const double* __restrict__ pi,
+    const int32_t* __restrict__ lens, double* __restrict__ v, int U, int T, int N) {
+    constexpr int NP = 64 * CPT;
+    __shared__ double Vs[3][UB][NP];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int u0 = blockIdx.x * UB;
+
+    double areg[CPT][RPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c)
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const int i = w * RPT + r, j = lane + 64 * c;
+            areg[c][r] = (i < N && j < N) ? A[(size_t)i * N + j] : LN_NEG_INF;
+        }
+    int len[UB], maxlen = 0;
+#pragma unroll
+    for (int k = 0; k < UB; ++k) {
+        len[k] = (u0 + k < U) ? lens[u0 + k] : 0;
+        maxlen = len[k] > maxlen ? len[k] : maxlen;
+    }
+    for (int j = threadIdx.x; j < NP; j += 64 * NW) {
+#pragma unroll
+        for (int k = 0; k < UB; ++k) {
+            double val = LN_NEG_INF;
+            if (j < N && len[k] > 0) {
+                size_t o = ((size_t)(u0 + k) * T) * N + j;
+                val = pi[j] + b[o];
+                v[o] = val;
+            }
+            Vs[0][k][j] = val;
+            Vs[1][k][j] = LN_NEG_INF;
+            Vs[2][k][j] = LN_NEG_INF;
+        }
+    }
+    // emission streams of this wave's columns (every wave needs b for all UB*CPT column blocks):
+    // one per-lane pointer per column block, utterance/frame offsets stay scalar
+    const double* pl[CPT];
+    size_t uoff[UB];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+        const int j = lane + 64 * c;
+        pl[c] = b + (j < N ? j : N - 1);
+    }
+#pragma unroll
+    for (int k = 0; k < UB; ++k) uoff[k] = (size_t)((u0 + k < U) ? u0 + k : U - 1) * T;
+    double bnext[UB][CPT];
+#pragma unroll
+    for (int k = 0; k < UB; ++k)
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) bnext[k][c] = pl[c][(uoff[k] + (T > 1 ? 1 : 0)) * N];
+    // store duty: (utterance, column block) q = w + jj*NW written to global one frame late
+    constexpr int NJOB = CPT * UB;
+    __syncthreads();
+
+    int cur = 0;                                   // buffer holding v[t-1]
+    for (int t = 1; t < maxlen; ++t) {
+        const int nxt = cur == 2 ? 0 : cur + 1, rst = nxt == 2 ? 0 : nxt + 1;
+        double bcur[UB][CPT];
+        const int tn = t + 1 < T ? t + 1 : T - 1;
+#pragma unroll
+        for (int k = 0; k < UB; ++k)
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) {
+                bcur[k][c] = bnext[k][c];
+                bnext[k][c] = pl[c][(uoff[k] + tn) * N];
+            }
+        // v[t-1] of the columns this wave stores to global (complete since the last barrier)
+        if (t > 1 && w < NJOB) {
+            const int k = w / CPT, c = w % CPT, j = lane + 64 * c;
+            if (j < N && t - 1 < len[k]) v[((size_t)(u0 + k) * T + (t - 1)) * N + j] = Vs[cur][k][j];
+        }
+        // reset the buffer that frame t+1 will accumulate into
+        if (w == NW - 1) {
+#pragma unroll
+            for (int k = 0; k < UB; ++k)
+#pragma unroll
+                for (int c = 0; c < CPT; ++c) Vs[rst][k][lane + 64 * c] = LN_NEG_INF;
+        }
+        double acc[UB][CPT];
+        constexpr int HR = RPT / 2;                // two half slices keep the live v values to UB*HR doubles
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            double vr[UB][HR];
+#pragma unroll
+            for (int k = 0; k < UB; ++k)
+#pragma unroll
+                for (int r = 0; r < HR; ++r) vr[k][r] = Vs[cur][k][w * RPT + h * HR + r];
+#pragma unroll
+            for (int r = 0; r < HR; ++r)
+#pragma unroll
+                for (int k = 0; k < UB; ++k)
+#pragma unroll
+                    for (int c = 0; c < CPT; ++c) {
+                        const double cand = vr[k][r] + areg[c][h * HR + r];
+                        acc[k][c] = (h == 0 && r == 0) ? cand : fmax(acc[k][c], cand);
+                    }
+        }
+#pragma unroll
+        for (int k = 0; k < UB; ++k)
+#pragma unroll
+            for (int c = 0; c < CPT; ++c)
+                __hip_atomic_fetch_max(&Vs[nxt][k][lane + 64 * c], acc[k][c] + bcur[k][c], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+        __syncthreads();
+        cur = nxt;
+    }
+    // last frame
+    if (maxlen > 1 && w < NJOB) {
+        const int k = w / CPT, c = w % CPT, j = lane + 64 * c;
+        if (j < N && maxlen - 1 < len[k]) v[((size_t)(u0 + k) * T + (maxlen - 1)) * N + j] = Vs[cur][k][j];
+    }
+}
+
 // wave64 max of a double through DPP (no LDS crossbar): quad_perm, half-mirror and mirror steps
 // leave every lane of a 16-lane row with the row's max; the four row results are then read as
 // scalars.  ctrl codes: quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_half_mirror = 0x141,
@@ -1011,7 +1131,7 @@ int viterbi_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
     const double* pi = md.logpi.as<double>();
     if (dtype == LNASR_F64 && !getenv("LNASR_NO_REGVIT")) {
         const char* var = getenv("LNASR_VIT");
-        const char vsel = var ? var[0] : 'a';
+        const char vsel = var ? var[0] : 'e';
 #define LN_VIT(name, CPT, NW, RPT, UB, WPE)                                                                  \
     do {                                                                                                     \
         LN_LAUNCH(ctx, name, (viterbi_reg<CPT, NW, RPT, UB, WPE>), dim3((U + UB - 1) / UB), dim3(64 * NW), 0, \
@@ -1020,11 +1140,17 @@ int viterbi_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
     } while (0)
         if (N <= 64) LN_VIT("viterbi_reg_n64", 1, 2, 32, 2, 4);
         if (N <= 128) {
-            if (U < 512) LN_VIT("viterbi_reg_n128_u1", 2, 8, 16, 1, 4);
-            if (vsel == 'b') LN_VIT("viterbi_reg_n128_b", 2, 4, 32, 2, 2);
-            if (vsel == 'c') LN_VIT("viterbi_reg_n128_c", 2, 8, 16, 4, 2);
-            if (vsel == 'd') LN_VIT("viterbi_reg_n128_d", 2, 8, 16, 1, 4);
-            LN_VIT("viterbi_reg_n128", 2, 8, 16, 2, 4);
+            // default: single-barrier kernel (LDS atomic max); LNASR_VIT=a selects the two-barrier one
+            if (vsel == 'a' && U < 512) LN_VIT("viterbi_reg_n128_u1", 2, 8, 16, 1, 4);
+            if (vsel == 'a') LN_VIT("viterbi_reg_n128", 2, 8, 16, 2, 4);
+            if (U < 512) {
+                LN_LAUNCH(ctx, "viterbi_reg1b_n128_u1", (viterbi_reg1b<2, 8, 16, 1, 4>), dim3(U), dim3(512), 0,
+                          (const double*)b, A, pi, d_lens, (double*)v, U, T, N);
+            } else {
+                LN_LAUNCH(ctx, "viterbi_reg1b_n128", (viterbi_reg1b<2, 8, 16, 2, 4>), dim3((U + 1) / 2), dim3(512), 0,
+                          (const double*)b, A, pi, d_lens, (double*)v, U, T, N);
+            }
+            return 0;
         }
 #undef LN_VIT
     }
