@@ -16,6 +16,14 @@ __device__ __forceinline__ void st(TS* p, size_t i, double v) { p[i] = (TS)v; }
 template <typename TS>
 __device__ __forceinline__ double rnd(double v) { return (double)(TS)v; }
 
+// one-instruction max: the library fmax first canonicalises operands the compiler cannot prove quiet
+// (MFMA results, LDS / global loads), which doubles the instruction count of max chains
+__device__ __forceinline__ double vmax_f64(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __shfl_xor(lo, mask, 64);

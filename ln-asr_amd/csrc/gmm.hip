@@ -185,13 +185,6 @@ __global__ void pack_wfrag_kernel(const double* __restrict__ mu, const double* _
 // time is therefore MFMA cycles + epilogue VALU cycles, and the epilogue is written to use as
 // few vector instructions as possible.
 
-// one-instruction max (the library fmax canonicalises MFMA results first)
-__device__ __forceinline__ double vmax_f64(double a, double b) {
-    double r;
-    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
 // exp(x) for x <= 0 (log-sum-exp terms after the max shift), ~1 ulp, 10 fp64 + 4 int instructions:
 //   x = k ln2/256 + r, |r| <= ln2/512   =>   exp(x) = 2^(k>>8) * 2^((k&255)/256) * (1 + r + r^2/2 + r^3/6 + r^4/24)
 // (remainder r^5/120 < 4e-17).  k comes out of the low mantissa bits of x*256/ln2 + 1.5*2^52; the

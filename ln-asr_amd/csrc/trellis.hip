@@ -370,7 +370,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
 #pragma unroll
                     for (int c = 0; c < CPT; ++c) {
                         const double cand = vr[k][r] + areg[c][h * HR + r];
-                        acc[k][c] = (h == 0 && r == 0) ? cand : fmax(acc[k][c], cand);
+                        acc[k][c] = (h == 0 && r == 0) ? cand : vmax_f64(acc[k][c], cand);
                     }
         }
 #pragma unroll
@@ -406,13 +406,13 @@ __device__ __forceinline__ double readlane_f64(double x, int lane) {
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double wave_max_dpp(double x) {
-    x = fmax(x, dpp_f64<0xB1>(x));
-    x = fmax(x, dpp_f64<0x4E>(x));
-    x = fmax(x, dpp_f64<0x141>(x));
-    x = fmax(x, dpp_f64<0x140>(x));
+    x = vmax_f64(x, dpp_f64<0xB1>(x));
+    x = vmax_f64(x, dpp_f64<0x4E>(x));
+    x = vmax_f64(x, dpp_f64<0x141>(x));
+    x = vmax_f64(x, dpp_f64<0x140>(x));
     const double r0 = readlane_f64(x, 0), r1 = readlane_f64(x, 16), r2 = readlane_f64(x, 32),
                  r3 = readlane_f64(x, 48);
-    return fmax(fmax(r0, r1), fmax(r2, r3));
+    return vmax_f64(vmax_f64(r0, r1), vmax_f64(r2, r3));
 }
 
 // Backtrace for N <= 128 (fp64): A^T lives in LDS so the only dependent memory access per step is
@@ -436,16 +436,16 @@ __global__ __launch_bounds__(256) void backtrace_lds_kernel(const double* __rest
     uint32_t* pu = path + (size_t)u * T;
     const int j0 = lane, j1 = lane + 64;
     const bool ok0 = j0 < N, ok1 = j1 < N;
-    const int jj0 = ok0 ? j0 : 0, jj1 = ok1 ? j1 : 0;
+    const int jj0 = ok0 ? j0 : 0, jj1 = ok1 ? j1 : 0;        // clamped: every load is a valid address
     auto pick = [&](double x0, double x1, double& mx) -> int {
-        mx = wave_max_dpp(fmax(x0, x1));
+        mx = wave_max_dpp(vmax_f64(x0, x1));
         const unsigned long long m0 = __ballot(x0 == mx), m1 = __ballot(x1 == mx);
         return m0 ? (__ffsll((long long)m0) - 1) : (m1 ? 63 + __ffsll((long long)m1) : 0);
     };
-    double c0 = ok0 ? vu[(size_t)(L - 1) * N + jj0] : LN_NEG_INF;
-    double c1 = ok1 ? vu[(size_t)(L - 1) * N + jj1] : LN_NEG_INF;
+    auto mask0 = [&](double x) { return ok0 ? x : LN_NEG_INF; };
+    auto mask1 = [&](double x) { return ok1 ? x : LN_NEG_INF; };
     double bestv;
-    int p = pick(c0, c1, bestv);
+    int p = pick(mask0(vu[(size_t)(L - 1) * N + jj0]), mask1(vu[(size_t)(L - 1) * N + jj1]), bestv);
     if (lane == 0 && best) best[u] = bestv;
     uint32_t mine = 0;
     if (lane == ((L - 1) & 63)) mine = (uint32_t)p;
@@ -458,8 +458,8 @@ __global__ __launch_bounds__(256) void backtrace_lds_kernel(const double* __rest
 #pragma unroll
         for (int k = 0; k < PF; ++k) {
             const int tt = tstart - k > 0 ? tstart - k : 0;
-            r0[k] = ok0 ? vu[(size_t)tt * N + jj0] : LN_NEG_INF;
-            r1[k] = ok1 ? vu[(size_t)tt * N + jj1] : LN_NEG_INF;
+            r0[k] = vu[(size_t)tt * N + jj0];
+            r1[k] = vu[(size_t)tt * N + jj1];
         }
     };
     load_rows(L - 2 > 0 ? L - 2 : 0, cur0, cur1);
@@ -468,10 +468,10 @@ __global__ __launch_bounds__(256) void backtrace_lds_kernel(const double* __rest
 #pragma unroll
         for (int k = 0; k < PF; ++k) {
             const int t = tb - k;
-            if (t >= 0) {
+            if (t >= 0) {                                   // wave-uniform
                 const double* col = ATs + p * N;
-                const double x0 = ok0 ? cur0[k] + col[jj0] : LN_NEG_INF;
-                const double x1 = ok1 ? cur1[k] + col[jj1] : LN_NEG_INF;
+                const double x0 = mask0(cur0[k] + col[jj0]);
+                const double x1 = mask1(cur1[k] + col[jj1]);
                 double mx;
                 p = pick(x0, x1, mx);
                 if (lane == (t & 63)) mine = (uint32_t)p;
