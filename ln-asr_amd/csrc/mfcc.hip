@@ -121,6 +121,197 @@ __global__ void mfcc_frame_kernel(const SAMPLE* __restrict__ signal, const int64
     }
 }
 
+// fft_n = 512 fast path: ONE WAVE PER FRAME, no block-level barriers.
+//   real 512-point FFT = 256-point complex FFT of z[n] = y[2n] + i y[2n+1] (Stockham radix-4, four
+//   stages, one radix-4 butterfly per lane per stage, ping-pong buffers in the wave's private LDS
+//   slice) followed by the even/odd split  X[k] = E[k] + W512^k O[k].
+// tw512[k] = (cos, -sin)(2 pi k / 512), k < 256; the 256-point twiddles are tw512[2m].
+struct cplx {
+    double re, im;
+};
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return {a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ cplx csub(cplx a, cplx b) { return {a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ cplx mul_neg_i(cplx a) { return {a.im, -a.re}; }          // a * (-i)
+
+__device__ __forceinline__ void radix4(cplx v[4]) {
+    const cplx t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]);
+    const cplx t2 = cadd(v[1], v[3]), t3 = mul_neg_i(csub(v[1], v[3]));
+    v[0] = cadd(t0, t2);
+    v[1] = cadd(t1, t3);
+    v[2] = csub(t0, t2);
+    v[3] = csub(t1, t3);
+}
+
+template <typename SAMPLE>
+__global__ __launch_bounds__(256) void mfcc_frame512_kernel(
+    const SAMPLE* __restrict__ signal, const int64_t* __restrict__ soff, const int64_t* __restrict__ foff, int U,
+    int64_t F, int L, int S, int n_mel, double alpha, const double* __restrict__ window,
+    const double* __restrict__ fbank, const int* __restrict__ mel_range, const double* __restrict__ tw512,
+    double* __restrict__ power_out, double* __restrict__ logmel, double* __restrict__ energy) {
+    constexpr int NC = 256, NBIN = 257, MAXTAP = 1024, MAXMEL = 128;
+    __shared__ double tws[2 * NC];                 // tw512, shared by the block
+    __shared__ double wins[2 * NC];                // window (L <= 512)
+    __shared__ double taps[MAXTAP];                // non-zero filter taps, filter after filter
+    __shared__ int tap_off[MAXMEL + 1];
+    __shared__ double bufs[4][2 * NC];             // per wave: FFT buffer (re, im interleaved), then power
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int e = tid; e < 2 * NC; e += 256) {
+        tws[e] = tw512[e];
+        wins[e] = e < L ? window[e] : 0.0;
+    }
+    if (tid < n_mel) tap_off[tid + 1] = mel_range[2 * tid + 1] - mel_range[2 * tid];
+    __syncthreads();
+    if (tid == 0) {                                // exclusive prefix of the tap counts, in LDS
+        int o = 0;
+        for (int m = 0; m < n_mel; ++m) {
+            const int c = tap_off[m + 1];
+            tap_off[m] = o;
+            o += c;
+        }
+        tap_off[n_mel] = o;
+    }
+    __syncthreads();
+    const bool taps_in_lds = tap_off[n_mel] <= MAXTAP;
+    if (taps_in_lds)
+        for (int m = w; m < n_mel; m += 4) {
+            const int lo = mel_range[2 * m], cnt = mel_range[2 * m + 1] - lo;
+            for (int e = lane; e < cnt; e += 64) taps[tap_off[m] + e] = fbank[(size_t)m * NBIN + lo + e];
+        }
+    __syncthreads();                               // last block-level barrier: waves are independent from here
+    // raw samples of one frame, fetched one iteration ahead so that HBM latency hides behind the FFT
+    struct Raw {
+        double xm[4], x0[4], x1[4];
+        int64_t base, n;
+    };
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    int64_t f = (int64_t)blockIdx.x * 4 + w;
+    if (f >= F) return;
+    int u = find_utt(foff, U, f);
+    auto fetch = [&](int64_t ff, Raw& rw) {
+        while (foff[u + 1] <= ff) ++u;             // frames visited by a wave are increasing
+        const SAMPLE* x = signal + soff[u];
+        rw.n = soff[u + 1] - soff[u];
+        rw.base = (ff - foff[u]) * S;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t i0 = rw.base + 2 * (lane + 64 * r);
+            const int64_t last = rw.n - 1;
+            const int64_t im = i0 - 1 < 0 ? 0 : (i0 - 1 > last ? last : i0 - 1);
+            const int64_t ia = i0 > last ? last : i0, ib = i0 + 1 > last ? last : i0 + 1;
+            rw.xm[r] = sample_at(x, im);           // clamped addresses: loads are unconditional
+            rw.x0[r] = sample_at(x, ia);
+            rw.x1[r] = sample_at(x, ib);
+        }
+    };
+    Raw cur;
+    fetch(f, cur);
+    double* A = &bufs[w][0];
+    for (; f < F; f += stride) {
+    Raw nxt = cur;
+    if (f + stride < F) fetch(f + stride, nxt);
+
+    // stage 0 (Ns = 1): v[r] = z[lane + 64 r] = (y[2n], y[2n+1]) * window, y = pre-emphasised signal
+    cplx v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int k0 = 2 * (lane + 64 * r);
+        const int64_t i0 = cur.base + k0;
+        // y[i] = x[i] - alpha x[i-1] (mfcc.py:63), y[0] = x[0]; zero beyond the utterance (utils.py:121-125)
+        double a = i0 == 0 ? cur.x0[r] : __dsub_rn(cur.x0[r], __dmul_rn(alpha, cur.xm[r]));
+        double c = __dsub_rn(cur.x1[r], __dmul_rn(alpha, cur.x0[r]));
+        if (i0 >= cur.n) a = 0.0;
+        if (i0 + 1 >= cur.n) c = 0.0;
+        v[r] = {a * wins[k0], c * wins[k0 + 1]};   // wins is zero beyond the frame length
+    }
+    radix4(v);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        A[2 * (4 * lane + r)] = v[r].re;
+        A[2 * (4 * lane + r) + 1] = v[r].im;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // stages Ns = 4, 16, 64: all reads of a stage happen before its writes, so one buffer is enough
+#pragma unroll
+    for (int Ns = 4; Ns < NC; Ns *= 4) {
+        const int k = lane & (Ns - 1);
+        const int step = NC / (Ns * 4);            // twiddle index stride in units of 2 pi / 256
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int src = lane + 64 * r;
+            cplx z = {A[2 * src], A[2 * src + 1]};
+            if (r > 0) {
+                const int m2 = 2 * k * r * step;   // W256^m = tw512[2m]; the table holds half a turn:
+                const int idx = m2 & (NC - 1);     // tw512[i + 256] = -tw512[i]
+                const double sg = m2 >= NC ? -1.0 : 1.0;
+                const cplx tw = {sg * tws[2 * idx], sg * tws[2 * idx + 1]};
+                z = cmul(z, tw);
+            }
+            v[r] = z;
+        }
+        radix4(v);
+        __builtin_amdgcn_wave_barrier();
+        const int j0 = (lane / Ns) * Ns * 4 + k;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            A[2 * (j0 + r * Ns)] = v[r].re;
+            A[2 * (j0 + r * Ns) + 1] = v[r].im;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // Z = A[0..255]; X[k] for k = 0..256; power |X|^2 / 512 (mfcc.py:141-142)
+    double pk[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const int k = lane + 64 * q;
+        pk[q] = 0.0;
+        if (k < NBIN) {
+            const int ka = k & (NC - 1), kb = (NC - k) & (NC - 1);
+            const cplx zk = {A[2 * ka], A[2 * ka + 1]};
+            const cplx zc = {A[2 * kb], -A[2 * kb + 1]};
+            const cplx e = {0.5 * (zk.re + zc.re), 0.5 * (zk.im + zc.im)};
+            const cplx d = csub(zk, zc);
+            const cplx o = {0.5 * d.im, -0.5 * d.re};                // -(i/2) (zk - zc)
+            const cplx tw = k < NC ? cplx{tws[2 * k], tws[2 * k + 1]} : cplx{-1.0, 0.0};
+            const cplx xk = cadd(e, cmul(o, tw));
+            // |X|^2 directly (the reference squares np.abs: same value to an ulp, a fraction of the instructions)
+            pk[q] = (1.0 / 512.0) * fma(xk.re, xk.re, xk.im * xk.im);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    double* pw = A;                                // the FFT buffer is dead: reuse it for the power spectrum
+    double esum = 0.0;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const int k = lane + 64 * q;
+        if (k < NBIN) {
+            pw[k] = pk[q];
+            esum += pk[q];
+            if (power_out) power_out[f * NBIN + k] = pk[q];
+        }
+    }
+    esum = wave_sum(esum);
+    if (lane == 0) energy[f] = log(esum);                               // mfcc.py:158-160
+    __builtin_amdgcn_wave_barrier();
+    for (int m = lane; m < n_mel; m += 64) {
+        const int lo = mel_range[2 * m], hi = mel_range[2 * m + 1];
+        double s = 0.0;
+        if (taps_in_lds) {
+            const double* tp = taps + tap_off[m] - lo;
+#pragma unroll 4
+            for (int k = lo; k < hi; ++k) s += pw[k] * tp[k];           // mfcc.py:148
+        } else {
+            const double* fb = fbank + (size_t)m * NBIN;
+            for (int k = lo; k < hi; ++k) s += pw[k] * fb[k];
+        }
+        if (s == 0.0) s = 2.220446049250313e-16;                         // mfcc.py:149
+        logmel[f * n_mel + m] = 20.0 * log10(s);                         // mfcc.py:150
+    }
+    __builtin_amdgcn_wave_barrier();               // the next frame overwrites this wave's buffer
+    cur = nxt;
+    }
+}
+
 // mean over the frames of each utterance of columns [c0, c0+nc) of X [F, ld]; out[u*nc + c] = mean + 1e-8
 __global__ void col_mean_kernel(const double* __restrict__ X, const int64_t* __restrict__ foff, int ld, int c0,
                                 int nc, double* __restrict__ out) {
@@ -331,7 +522,21 @@ int lnasr_mfcc(lnasr_ctx* ctx, const void* signal, int sample_kind, const int64_
               nbin, d_range);
     const size_t shm = (size_t)(2 * NFFT + nbin + 32) * 8;
     const int nt = NFFT / 2 < 256 ? (NFFT / 2 < 64 ? 64 : NFFT / 2) : 256;
-    if (sample_kind == 1)
+    if (NFFT == 512 && L <= 512 && n_mel <= 128 && !getenv("LNASR_NO_FFT512")) {
+        // persistent waves (4 blocks of 4 waves per CU), each walking frames with a grid stride
+        const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+        int64_t want = (F + 3) / 4;
+        if (want > (int64_t)cus * 4) want = (int64_t)cus * 4;
+        const unsigned grid = (unsigned)want;
+        if (sample_kind == 1)
+            LN_LAUNCH(ctx, "mfcc_frame512_i16", mfcc_frame512_kernel<int16_t>, dim3(grid), dim3(256), 0,
+                      (const int16_t*)d_sig, d_soff, d_foff, U, F, L, S, n_mel, cfg->hpf_alpha, (const double*)d_win,
+                      (const double*)d_fb, d_range, d_tw, (double*)d_pow, logmel, energy);
+        else
+            LN_LAUNCH(ctx, "mfcc_frame512", mfcc_frame512_kernel<double>, dim3(grid), dim3(256), 0,
+                      (const double*)d_sig, d_soff, d_foff, U, F, L, S, n_mel, cfg->hpf_alpha, (const double*)d_win,
+                      (const double*)d_fb, d_range, d_tw, (double*)d_pow, logmel, energy);
+    } else if (sample_kind == 1)
         LN_LAUNCH(ctx, "mfcc_frame_i16", mfcc_frame_kernel<int16_t>, dim3((unsigned)F), dim3(nt), shm,
                   (const int16_t*)d_sig, d_soff, d_foff, U, L, S, NFFT, log2n, n_mel, cfg->hpf_alpha,
                   (const double*)d_win, (const double*)d_fb, d_range, d_tw, (double*)d_pow, logmel, energy);
