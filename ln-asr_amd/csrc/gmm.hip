@@ -822,14 +822,11 @@ static int launch_mfma_cfg(lnasr_ctx* ctx, const double* obs, long F, double* b,
 
 template <int Q, int KS>
 static int launch_mfma(lnasr_ctx* ctx, const double* obs, long F, double* b, double* bm) {
+#ifdef LNASR_ABLATION_BUILD          // developer builds only: -DLNASR_ABLATION_BUILD + LNASR_EMIT=x|y
     const char* var = getenv("LNASR_EMIT");
     const char v = var ? var[0] : 'a';
-    if (Q == 4 && KS == 20) {      // metric shape: tuning variants
-        if (v == 'b') return launch_mfma_cfg<Q, KS, 4, 1>(ctx, obs, F, b, bm);
-        if (v == 'c') return launch_mfma_cfg<Q, KS, 4, 2>(ctx, obs, F, b, bm);
-        if (v == 'd') return launch_mfma_cfg<Q, KS, 8, 1>(ctx, obs, F, b, bm);
-        if (v == 'e') return launch_mfma_cfg<Q, KS, 8, 4>(ctx, obs, F, b, bm);
-        if (v == 'x' || v == 'y') {      // ablation builds (wrong results by design; timing only)
+    if (Q == 4 && KS == 20) {
+        if (v == 'x' || v == 'y') {      // ablation kernels (wrong results by design; timing only)
             Model& md = ctx->model;
             const int GY = (md.N + 31) / 32;
             const long ntiles = (F + 15) / 16;
@@ -845,6 +842,9 @@ static int launch_mfma(lnasr_ctx* ctx, const double* obs, long F, double* b, dou
             return 0;
         }
     }
+#endif
+    // 8 waves per block (32 states), one 16-frame tile per barrier interval: fastest of the tilings tried
+    // (4 or 8 waves x 1, 2, 4 tiles per interval) on MI355X
     return launch_mfma_cfg<Q, KS, 8, 1>(ctx, obs, F, b, bm);
 }
 
