@@ -384,6 +384,72 @@ __global__ void acc_mix_diag_kernel(const double* __restrict__ obs, const double
     }
 }
 
+// full covariance: one block per (component c, utterance u).  Posteriors g[t] of the whole utterance sit in
+// LDS, observations stream through in 64-frame chunks, every thread keeps up to kPairAcc (d,e) pairs of the
+// D x D second-moment matrix (around the OLD mean, gmmhmm.py:138) in registers; one atomic per pair per block.
+__global__ void acc_full_kernel(const double* __restrict__ obs, const double* __restrict__ alpha,
+                                const double* __restrict__ beta, const double* __restrict__ b,
+                                const double* __restrict__ bm, const double* __restrict__ c1,
+                                const double* __restrict__ logw, const double* __restrict__ mu,
+                                const int32_t* __restrict__ lens, int T, int N, int M, int D,
+                                double* __restrict__ mix, double* __restrict__ mix_x, double* __restrict__ mix_xx) {
+    extern __shared__ double sm[];
+    constexpr int CH = 64;
+    double* g = sm;                    // [T]
+    double* dt = sm + T;               // [CH][D]
+    const int c = blockIdx.x, u = blockIdx.y;
+    const int j = c / M, m = c % M;
+    const int L = lens[u];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const size_t fbase = (size_t)u * T;
+    const double* mo = mu + (size_t)c * D;
+    for (int t = tid; t < L; t += nt) {
+        const size_t fr = fbase + t, fj = fr * N + j;
+        const double z = (alpha[fj] + beta[fj] - c1[fr]) + (logw[c] + bm[fj * M + m] - b[fj]);
+        g[t] = (z == LN_NEG_INF || z != z) ? 0.0 : exp(z);
+    }
+    __syncthreads();
+    const int DD = D * D;
+    const int npass = (DD + nt * kPairAcc - 1) / (nt * kPairAcc);
+    for (int pass = 0; pass < npass; ++pass) {
+        double acc[kPairAcc];
+        double macc = 0.0, gacc = 0.0;
+#pragma unroll
+        for (int r = 0; r < kPairAcc; ++r) acc[r] = 0.0;
+        for (int t0 = 0; t0 < L; t0 += CH) {
+            const int nch = (L - t0) < CH ? (L - t0) : CH;
+            __syncthreads();
+            for (int e = tid; e < nch * D; e += nt) dt[e] = obs[(fbase + t0) * D + e] - mo[e % D];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < kPairAcc; ++r) {
+                const int p = pass * nt * kPairAcc + r * nt + tid;
+                if (p < DD) {
+                    const int d = p / D, e = p % D;
+                    double a = acc[r];
+                    for (int f = 0; f < nch; ++f) a += g[t0 + f] * (dt[f * D + d] * dt[f * D + e]);
+                    acc[r] = a;
+                }
+            }
+            if (pass == 0) {
+                if (tid < D)
+                    for (int f = 0; f < nch; ++f) macc += g[t0 + f] * obs[(fbase + t0 + f) * D + tid];
+                if (tid == D)
+                    for (int f = 0; f < nch; ++f) gacc += g[t0 + f];
+            }
+        }
+        if (pass == 0) {
+            if (tid < D) atomicAdd(&mix_x[(size_t)c * D + tid], macc);
+            if (tid == D) atomicAdd(&mix[c], gacc);
+        }
+#pragma unroll
+        for (int r = 0; r < kPairAcc; ++r) {
+            const int p = pass * nt * kPairAcc + r * nt + tid;
+            if (p < DD) atomicAdd(&mix_xx[(size_t)c * DD + p], acc[r]);
+        }
+    }
+}
+
 __global__ void rowsum_kernel(const double* __restrict__ X, int N, double* __restrict__ out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
@@ -393,7 +459,8 @@ __global__ void rowsum_kernel(const double* __restrict__ X, int N, double* __res
 }
 
 // M-step on (all-reduced) statistics, diagonal model
-__global__ void mstep_stats_kernel(const double* __restrict__ st, StatsLayout L, int N, int M, int D, double min_std,
+__global__ void mstep_stats_kernel(const double* __restrict__ st, StatsLayout L, int N, int M, int D, int diag,
+                                   double min_std,
                                    double* __restrict__ A, double* __restrict__ pi, double* __restrict__ w,
                                    double* __restrict__ mu, double* __restrict__ var) {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -408,7 +475,11 @@ __global__ void mstep_stats_kernel(const double* __restrict__ st, StatsLayout L,
     if (idx < (size_t)N * M * D) {
         double g = st[L.mix + idx / D];
         mu[idx] = st[L.mix_x + idx] / g;
-        var[idx] = st[L.mix_xx + idx] / g + min_std;
+        if (diag) var[idx] = st[L.mix_xx + idx] / g + min_std;
+    }
+    if (!diag && idx < (size_t)N * M * D * D) {
+        const size_t c = idx / ((size_t)D * D), de = idx % ((size_t)D * D);
+        var[idx] = st[L.mix_xx + idx] / st[L.mix + c] + ((de / D == de % D) ? min_std : 0.0);   // gmmhmm.py:147
     }
 }
 
@@ -592,11 +663,9 @@ int lnasr_bw_accumulate(lnasr_ctx* ctx, const double* obs, int U, int T, const i
     LN_REQUIRE(ctx && stats, "null argument");
     Model& md = ctx->model;
     if (!md.has_gmm) return fail(LNASR_E_NOMODEL, "no GMM-HMM model uploaded");
-    if (!md.diag)
-        return fail(LNASR_E_UNSUPPORTED, "lnasr_bw_accumulate: full-covariance statistics are not implemented yet");
     LN_REQUIRE(U >= 1 && T >= 1 && obs, "bad batch");
     const int N = md.N, M = md.M, D = md.D;
-    const StatsLayout L = stats_layout(N, M, D, true);
+    const StatsLayout L = stats_layout(N, M, D, md.diag);
     const int32_t* d_lens;
     LN_TRY(device_lens(ctx, lens, U, T, &d_lens));
     const void* d_obs;
@@ -630,11 +699,19 @@ int lnasr_bw_accumulate(lnasr_ctx* ctx, const double* obs, int U, int T, const i
     // frames past an utterance's length hold stale alpha/beta; ab_lse covers them but acc_mix skips them
     LN_LAUNCH(ctx, "ab_lse", ab_lse_kernel<double>, dim3((unsigned)(((size_t)U * T + 3) / 4)), dim3(256), 0, al, be,
               (long)U * T, N, c1);
-    const size_t shmem = (size_t)kMixCH * (M + D) * 8;
-    LN_REQUIRE(shmem <= 160 * 1024, "M=%d, D=%d too large for the statistics kernel", M, D);
-    LN_LAUNCH(ctx, "acc_mix_diag", acc_mix_diag_kernel, dim3(N, (T + kMixCH - 1) / kMixCH, U), dim3(256), shmem,
-              (const double*)d_obs, al, be, b, bm, c1, md.logw.as<double>(), md.mu.as<double>(), d_lens, T, N, M, D,
-              st + L.mix, st + L.mix_x, st + L.mix_xx);
+    if (md.diag) {
+        const size_t shmem = (size_t)kMixCH * (M + D) * 8;
+        LN_REQUIRE(shmem <= 160 * 1024, "M=%d, D=%d too large for the statistics kernel", M, D);
+        LN_LAUNCH(ctx, "acc_mix_diag", acc_mix_diag_kernel, dim3(N, (T + kMixCH - 1) / kMixCH, U), dim3(256), shmem,
+                  (const double*)d_obs, al, be, b, bm, c1, md.logw.as<double>(), md.mu.as<double>(), d_lens, T, N, M,
+                  D, st + L.mix, st + L.mix_x, st + L.mix_xx);
+    } else {
+        const size_t shmem = ((size_t)T + 64 * (size_t)D) * 8;
+        LN_REQUIRE(shmem <= 160 * 1024, "T=%d too long for the full-covariance statistics kernel", T);
+        LN_LAUNCH(ctx, "acc_full", acc_full_kernel, dim3(N * M, U), dim3(256), shmem, (const double*)d_obs, al, be, b,
+                  bm, c1, md.logw.as<double>(), md.mu.as<double>(), d_lens, T, N, M, D, st + L.mix, st + L.mix_x,
+                  st + L.mix_xx);
+    }
     return finish_out(ctx, stats, d_st, L.total * 8);
 }
 
@@ -643,24 +720,24 @@ int lnasr_bw_mstep(lnasr_ctx* ctx, const double* stats, double min_std, double* 
     LN_REQUIRE(ctx && stats && logA && logpi && logw && mu && sigma, "null argument");
     Model& md = ctx->model;
     if (!md.has_gmm) return fail(LNASR_E_NOMODEL, "no GMM-HMM model uploaded");
-    if (!md.diag) return fail(LNASR_E_UNSUPPORTED, "lnasr_bw_mstep: full-covariance statistics are not implemented yet");
     const int N = md.N, M = md.M, D = md.D;
-    const StatsLayout L = stats_layout(N, M, D, true);
+    const StatsLayout L = stats_layout(N, M, D, md.diag);
     const void* d_st;
     LN_TRY(stage_in(ctx, stats, L.total * 8, ctx->ws_in, &d_st));
     const size_t NM = (size_t)N * M;
-    LN_TRY(ctx->ws_misc.reserve(((size_t)N * N + N + NM + 2 * NM * D) * 8));
+    const size_t nsig = md.diag ? NM * D : NM * D * D;
+    LN_TRY(ctx->ws_misc.reserve(((size_t)N * N + N + NM + NM * D + nsig) * 8));
     double* dA = ctx->ws_misc.as<double>();
     double* dpi = dA + (size_t)N * N;
     double* dw = dpi + N;
     double* dmu = dw + NM;
     double* dvar = dmu + NM * D;
     size_t big = (size_t)N * N;
-    if (NM * D > big) big = NM * D;
+    if (nsig > big) big = nsig;
     LN_LAUNCH(ctx, "mstep_stats", mstep_stats_kernel, dim3((unsigned)((big + 255) / 256)), dim3(256), 0,
-              (const double*)d_st, L, N, M, D, min_std, dA, dpi, dw, dmu, dvar);
+              (const double*)d_st, L, N, M, D, md.diag ? 1 : 0, min_std, dA, dpi, dw, dmu, dvar);
     struct { double* user; double* dev; size_t n; } outs[] = {
-        {logA, dA, (size_t)N * N}, {logpi, dpi, (size_t)N}, {logw, dw, NM}, {mu, dmu, NM * D}, {sigma, dvar, NM * D}};
+        {logA, dA, (size_t)N * N}, {logpi, dpi, (size_t)N}, {logw, dw, NM}, {mu, dmu, NM * D}, {sigma, dvar, nsig}};
     for (auto& o : outs) {
         hipMemcpyKind k = is_device_ptr(o.user) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
         LN_HIP(hipMemcpyAsync(o.user, o.dev, o.n * 8, k, ctx->stream));

@@ -252,3 +252,23 @@ def test_forward_backward_large_n(synth, oracle, ctx):
             v, bt, path = oracle.viterbi(A, d["pi"], ob)
             assert np.array_equal(r["v"][u, :L], v) and np.array_equal(r["path"][u, :L], path)
             assert np.array_equal(r["bt"][u, :L], bt)
+
+
+def test_bw_statistics_full_covariance(golden, ctx):
+    """Full-covariance statistics: U=1 reproduces the reference's M-step (old-mean Sigma + min_std I);
+    accumulation is additive."""
+    g = golden("gmmhmm_d39_full")
+    ctx.upload_gmmhmm(g["A"], g["pi"], g["w"], g["mu"], g["si"])
+    assert not ctx.model_is_diag()
+    N, M, D = g["mu"].shape
+    st = ctx.bw_accumulate(g["obs"][None])
+    assert st.shape == (N * N + 2 * N + N * M + N * M * D + N * M * D * D + 3,)
+    m = ctx.bw_mstep(st)
+    assert_close(m["A"], g["est_A"], 1e-9), assert_close(m["pi"], g["est_pi"], 1e-9)
+    assert_close(m["w"], g["est_w"], 1e-9), assert_close(m["mu"], g["est_mu"], 1e-9, 1e-12)
+    assert m["si"].shape == (N, M, D, D)
+    assert_close(m["si"], g["est_si"], 1e-9, 1e-12)
+    two = np.stack([g["obs"], g["obs"][::-1].copy()])
+    st2 = ctx.bw_accumulate(two)
+    st_b = ctx.bw_accumulate(two[1:])
+    assert_close(st + st_b, st2, 1e-10, 1e-12)
