@@ -38,18 +38,26 @@ __device__ __forceinline__ double preemph(const SAMPLE* __restrict__ x, int64_t 
 
 // [lo, hi) of the non-zero taps of every mel filter (zeros add nothing to the dot product of mfcc.py:148)
 __global__ void mel_range_kernel(const double* __restrict__ fbank, int n_mel, int nbin, int* __restrict__ range) {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= n_mel) return;
+    // one wave per filter: lanes scan the bins with a 64-stride, min / max over the wave
+    const int m = blockIdx.x, lane = threadIdx.x;
     const double* fb = fbank + (size_t)m * nbin;
     int lo = nbin, hi = 0;
-    for (int k = 0; k < nbin; ++k)
+    for (int k = lane; k < nbin; k += 64)
         if (fb[k] != 0.0) {
             if (k < lo) lo = k;
             hi = k + 1;
         }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        const int olo = __shfl_xor(lo, s, 64), ohi = __shfl_xor(hi, s, 64);
+        lo = olo < lo ? olo : lo;
+        hi = ohi > hi ? ohi : hi;
+    }
     if (hi == 0) lo = 0;
-    range[2 * m] = lo;
-    range[2 * m + 1] = hi;
+    if (lane == 0) {
+        range[2 * m] = lo;
+        range[2 * m + 1] = hi;
+    }
 }
 
 template <typename SAMPLE>
@@ -148,18 +156,21 @@ __global__ __launch_bounds__(256) void mfcc_frame512_kernel(
     const SAMPLE* __restrict__ signal, const int64_t* __restrict__ soff, const int64_t* __restrict__ foff, int U,
     int64_t F, int L, int S, int n_mel, double alpha, const double* __restrict__ window,
     const double* __restrict__ fbank, const int* __restrict__ mel_range, const double* __restrict__ tw512,
-    double* __restrict__ power_out, double* __restrict__ logmel, double* __restrict__ energy) {
-    constexpr int NC = 256, NBIN = 257, MAXTAP = 1024, MAXMEL = 128;
+    const double* __restrict__ dctC, double* __restrict__ power_out, double* __restrict__ cepraw,
+    double* __restrict__ energy) {
+    constexpr int NC = 256, NBIN = 257, MAXTAP = 1024, MAXMEL = 48;
     __shared__ double tws[2 * NC];                 // tw512, shared by the block
     __shared__ double wins[2 * NC];                // window (L <= 512)
     __shared__ double taps[MAXTAP];                // non-zero filter taps, filter after filter
+    __shared__ double Ct[MAXMEL * MAXMEL];         // DCT matrix, transposed: Ct[m][k] = C[k][m]
     __shared__ int tap_off[MAXMEL + 1];
-    __shared__ double bufs[4][2 * NC];             // per wave: FFT buffer (re, im interleaved), then power
+    __shared__ double bufs[4][2 * NC];             // per wave: FFT buffer (re, im interleaved), then power | log-mel
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     for (int e = tid; e < 2 * NC; e += 256) {
         tws[e] = tw512[e];
         wins[e] = e < L ? window[e] : 0.0;
     }
+    for (int e = tid; e < n_mel * n_mel; e += 256) Ct[(e % n_mel) * n_mel + e / n_mel] = dctC[e];
     if (tid < n_mel) tap_off[tid + 1] = mel_range[2 * tid + 1] - mel_range[2 * tid];
     __syncthreads();
     if (tid == 0) {                                // exclusive prefix of the tap counts, in LDS
@@ -207,6 +218,7 @@ __global__ __launch_bounds__(256) void mfcc_frame512_kernel(
     Raw cur;
     fetch(f, cur);
     double* A = &bufs[w][0];
+    double* lm = A + 320;                          // log-mel row: beyond the 257 power bins
     for (; f < F; f += stride) {
     Raw nxt = cur;
     if (f + stride < F) fetch(f + stride, nxt);
@@ -305,14 +317,24 @@ __global__ __launch_bounds__(256) void mfcc_frame512_kernel(
             for (int k = lo; k < hi; ++k) s += pw[k] * fb[k];
         }
         if (s == 0.0) s = 2.220446049250313e-16;                         // mfcc.py:149
-        logmel[f * n_mel + m] = 20.0 * log10(s);                         // mfcc.py:150
+        lm[m] = 20.0 * log10(s);                                         // mfcc.py:150
+    }
+    __builtin_amdgcn_wave_barrier();
+    // DCT-II (ortho) of the RAW log-mel row.  The reference subtracts the utterance mean first
+    // (mfcc.py:151-152); the DCT is linear, so that subtraction is applied to the transformed
+    // row by feat_kernel and the frame kernel needs no utterance-level quantity.
+    for (int k = lane; k < n_mel; k += 64) {
+        double s = 0.0;
+#pragma unroll 4
+        for (int m = 0; m < n_mel; ++m) s += lm[m] * Ct[m * n_mel + k];
+        cepraw[f * n_mel + k] = s;
     }
     __builtin_amdgcn_wave_barrier();               // the next frame overwrites this wave's buffer
     cur = nxt;
     }
 }
 
-// mean over the frames of each utterance of columns [c0, c0+nc) of X [F, ld]; out[u*nc + c] = mean + 1e-8
+// mean over the frames of each utterance of columns [c0, c0+nc) of X [F, ld]
 __global__ void col_mean_kernel(const double* __restrict__ X, const int64_t* __restrict__ foff, int ld, int c0,
                                 int nc, double* __restrict__ out) {
     extern __shared__ double sm[];      // [slices][nc]
@@ -328,23 +350,19 @@ __global__ void col_mean_kernel(const double* __restrict__ X, const int64_t* __r
     if (threadIdx.x < nc) {
         double tot = 0.0;
         for (int k = 0; k < slices; ++k) tot += sm[k * nc + threadIdx.x];
-        out[(size_t)u * nc + threadIdx.x] = tot / (double)(f1 - f0) + 1e-8;   // mfcc.py:151,156
+        out[(size_t)u * nc + threadIdx.x] = tot / (double)(f1 - f0);
     }
 }
 
-// cep[f,k] = sum_m (logmel[f,m] - mean[u,m]) C[k,m];  C = DCT-II ortho matrix (mfcc.py:151-152)
-__global__ void dct_kernel(const double* __restrict__ logmel, const double* __restrict__ mean,
-                           const int64_t* __restrict__ foff, int U, int64_t F, int n_mel,
-                           const double* __restrict__ C, double* __restrict__ cep) {
+// cep_raw[f,k] = sum_m logmel[f,m] C[k,m];  C = DCT-II ortho matrix (generic-FFT path; mfcc.py:152)
+__global__ void dct_kernel(const double* __restrict__ logmel, const int64_t* __restrict__ foff, int U, int64_t F,
+                           int n_mel, const double* __restrict__ C, double* __restrict__ cep) {
     extern __shared__ double row[];     // [rows][n_mel]
     const int rows = blockDim.x / n_mel;
     const int r = threadIdx.x / n_mel, k = threadIdx.x % n_mel;
     const int64_t f = (int64_t)blockIdx.x * rows + r;
     const bool ok = r < rows && f < F;
-    if (ok) {
-        const int u = find_utt(foff, U, f);
-        row[r * n_mel + k] = logmel[f * n_mel + k] - mean[(size_t)u * n_mel + k];
-    }
+    if (ok) row[r * n_mel + k] = logmel[f * n_mel + k];
     __syncthreads();
     if (ok) {
         double s = 0.0;
@@ -353,37 +371,39 @@ __global__ void dct_kernel(const double* __restrict__ logmel, const double* __re
     }
 }
 
-// features [F, 3*(nc+1)] and the returned cepstrum (cols 1..nc mean-normalised a second time)
-__global__ void feat_kernel(const double* __restrict__ cep, const double* __restrict__ mean2,
+// Returned cepstrum and features from cep_raw = DCT(log-mel) and its utterance column means Mk:
+//   first normalisation  (mfcc.py:151-152): cep[f,k] = cep_raw[f,k] - Mk - [k == 0] 1e-8 sqrt(n_mel)
+//       (DCT-II ortho of the constant 1e-8 is 1e-8 sqrt(n_mel) in bin 0 and zero elsewhere)
+//   second normalisation (mfcc.py:155-156), applied through a view so the RETURNED cepstrum has it
+//       too: columns 1..nc lose mean_f(cep[:,k]) + 1e-8, and mean_f(cep[:,k]) is zero by construction
+//   features: [cep[:,1..nc], log-energy], delta (row 0 = features[1]), delta-delta (mfcc.py:158-172)
+__global__ void feat_kernel(const double* __restrict__ cepraw, const double* __restrict__ M,
                             const double* __restrict__ energy, const int64_t* __restrict__ foff, int U, int64_t F,
                             int n_mel, int nc, double* __restrict__ cep_out, double* __restrict__ feat) {
     const int W = nc + 1;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= F * W) return;
-    const int64_t f = idx / W;
-    const int c = (int)(idx % W);
+    if (idx >= F * n_mel) return;
+    const int64_t f = idx / n_mel;
+    const int k = (int)(idx % n_mel);
     const int u = find_utt(foff, U, f);
     const int64_t f0 = foff[u];
-    const double* m2 = mean2 + (size_t)u * nc;
-    auto base = [&](int64_t ff) -> double {     // features[:, :13] of frame ff (mfcc.py:155-160)
-        return c < nc ? cep[ff * n_mel + 1 + c] - m2[c] : energy[ff];
+    const double* Mu = M + (size_t)u * n_mel;
+    const double shift0 = 1e-8 * sqrt((double)n_mel);
+    auto cepv = [&](int64_t ff, int kk) -> double {
+        double v = cepraw[ff * n_mel + kk] - Mu[kk];
+        if (kk == 0) v -= shift0;
+        if (kk >= 1 && kk <= nc) v -= 1e-8;
+        return v;
     };
-    auto delta = [&](int64_t ff) -> double {    // mfcc.py:162-166: row 0 is features[1]
-        return ff == f0 ? base(f0 + 1) : base(ff) - base(ff - 1);
-    };
-    const double v0 = base(f);
-    const double v1 = delta(f);
-    const double v2 = (f == f0) ? delta(f0 + 1) : delta(f) - delta(f - 1);      // mfcc.py:168-172
+    if (cep_out) cep_out[idx] = cepv(f, k);
+    if (k >= W) return;
+    const int c = k;                            // feature column
+    auto base = [&](int64_t ff) -> double { return c < nc ? cepv(ff, 1 + c) : energy[ff]; };
+    auto delta = [&](int64_t ff) -> double { return ff == f0 ? base(f0 + 1) : base(ff) - base(ff - 1); };
     double* out = feat + f * 3 * W;
-    out[c] = v0;
-    out[W + c] = v1;
-    out[2 * W + c] = v2;
-    if (cep_out && c < nc) cep_out[f * n_mel + 1 + c] = v0;
-}
-
-__global__ void copy_cep_kernel(const double* __restrict__ cep, int64_t total, double* __restrict__ out) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < total) out[i] = cep[i];
+    out[c] = base(f);
+    out[W + c] = delta(f);
+    out[2 * W + c] = (f == f0) ? delta(f0 + 1) : delta(f) - delta(f - 1);
 }
 
 // split_frames (utils.py:106-130)
@@ -518,11 +538,12 @@ int lnasr_mfcc(lnasr_ctx* ctx, const void* signal, int sample_kind, const int64_
     if (cepstrum_or_null) LN_TRY(stage_out(ctx, cepstrum_or_null, (size_t)F * n_mel * 8, ctx->ws_out2, &d_cep));
     LN_TRY(stage_out(ctx, features, (size_t)F * 3 * W * 8, ctx->ws_out3, &d_feat));
 
-    LN_LAUNCH(ctx, "mfcc_mel_range", mel_range_kernel, dim3((n_mel + 63) / 64), dim3(64), 0, (const double*)d_fb, n_mel,
+    LN_LAUNCH(ctx, "mfcc_mel_range", mel_range_kernel, dim3(n_mel), dim3(64), 0, (const double*)d_fb, n_mel,
               nbin, d_range);
     const size_t shm = (size_t)(2 * NFFT + nbin + 32) * 8;
     const int nt = NFFT / 2 < 256 ? (NFFT / 2 < 64 ? 64 : NFFT / 2) : 256;
-    if (NFFT == 512 && L <= 512 && n_mel <= 128 && !getenv("LNASR_NO_FFT512")) {
+    bool fused_dct = false;
+    if (NFFT == 512 && L <= 512 && n_mel <= 48 && !getenv("LNASR_NO_FFT512")) {
         // persistent waves (4 blocks of 4 waves per CU), each walking frames with a grid stride
         const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
         int64_t want = (F + 3) / 4;
@@ -531,11 +552,12 @@ int lnasr_mfcc(lnasr_ctx* ctx, const void* signal, int sample_kind, const int64_
         if (sample_kind == 1)
             LN_LAUNCH(ctx, "mfcc_frame512_i16", mfcc_frame512_kernel<int16_t>, dim3(grid), dim3(256), 0,
                       (const int16_t*)d_sig, d_soff, d_foff, U, F, L, S, n_mel, cfg->hpf_alpha, (const double*)d_win,
-                      (const double*)d_fb, d_range, d_tw, (double*)d_pow, logmel, energy);
+                      (const double*)d_fb, d_range, d_tw, d_C, (double*)d_pow, cep, energy);
         else
             LN_LAUNCH(ctx, "mfcc_frame512", mfcc_frame512_kernel<double>, dim3(grid), dim3(256), 0,
                       (const double*)d_sig, d_soff, d_foff, U, F, L, S, n_mel, cfg->hpf_alpha, (const double*)d_win,
-                      (const double*)d_fb, d_range, d_tw, (double*)d_pow, logmel, energy);
+                      (const double*)d_fb, d_range, d_tw, d_C, (double*)d_pow, cep, energy);
+        fused_dct = true;
     } else if (sample_kind == 1)
         LN_LAUNCH(ctx, "mfcc_frame_i16", mfcc_frame_kernel<int16_t>, dim3((unsigned)F), dim3(nt), shm,
                   (const int16_t*)d_sig, d_soff, d_foff, U, L, S, NFFT, log2n, n_mel, cfg->hpf_alpha,
@@ -545,21 +567,18 @@ int lnasr_mfcc(lnasr_ctx* ctx, const void* signal, int sample_kind, const int64_
                   (const double*)d_sig, d_soff, d_foff, U, L, S, NFFT, log2n, n_mel, cfg->hpf_alpha,
                   (const double*)d_win, (const double*)d_fb, d_range, d_tw, (double*)d_pow, logmel, energy);
     {
+        // cep_raw = DCT(log-mel) per frame; its per-utterance column means carry both of the reference's
+        // utterance-level normalisations (mfcc.py:151,156) because the DCT is linear
         int threads = 256 - 256 % n_mel;
         if (threads < n_mel) threads = n_mel;
-        LN_LAUNCH(ctx, "mfcc_col_mean", col_mean_kernel, dim3(U), dim3(threads), (size_t)threads * 8, logmel, d_foff,
-                  n_mel, 0, n_mel, mean1);
         const int rows = threads / n_mel;
-        LN_LAUNCH(ctx, "mfcc_dct", dct_kernel, dim3((unsigned)((F + rows - 1) / rows)), dim3(threads),
-                  (size_t)threads * 8, logmel, mean1, d_foff, U, F, n_mel, d_C, cep);
-        int t2 = 256 - 256 % nc;
-        LN_LAUNCH(ctx, "mfcc_col_mean", col_mean_kernel, dim3(U), dim3(t2), (size_t)t2 * 8, cep, d_foff, n_mel, 1, nc,
-                  mean2);
+        if (!fused_dct)
+            LN_LAUNCH(ctx, "mfcc_dct", dct_kernel, dim3((unsigned)((F + rows - 1) / rows)), dim3(threads),
+                      (size_t)threads * 8, logmel, d_foff, U, F, n_mel, d_C, cep);
+        LN_LAUNCH(ctx, "mfcc_col_mean", col_mean_kernel, dim3(U), dim3(threads), (size_t)threads * 8, cep, d_foff,
+                  n_mel, 0, n_mel, mean1);
     }
-    if (d_cep)
-        LN_LAUNCH(ctx, "mfcc_copy_cep", copy_cep_kernel, dim3((unsigned)(((size_t)F * n_mel + 255) / 256)), dim3(256),
-                  0, cep, (int64_t)F * n_mel, (double*)d_cep);
-    LN_LAUNCH(ctx, "mfcc_feat", feat_kernel, dim3((unsigned)(((size_t)F * W + 255) / 256)), dim3(256), 0, cep, mean2,
+    LN_LAUNCH(ctx, "mfcc_feat", feat_kernel, dim3((unsigned)(((size_t)F * n_mel + 255) / 256)), dim3(256), 0, cep, mean1,
               energy, d_foff, U, F, n_mel, nc, (double*)d_cep, (double*)d_feat);
     if (power_or_null) LN_TRY(finish_out(ctx, power_or_null, d_pow, (size_t)F * nbin * 8));
     if (cepstrum_or_null) LN_TRY(finish_out(ctx, cepstrum_or_null, d_cep, (size_t)F * n_mel * 8));
