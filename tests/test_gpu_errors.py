@@ -1,0 +1,63 @@
+"""GPU: error behaviour of the boundary -- bad arguments come back as LnasrError with the library's
+message (the reference raises ordinary numpy exceptions in the same situations), nothing crashes."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_argument_errors(synth):
+    from lnasr import _ffi
+    ctx = _ffi.Context(0)
+    try:
+        b = np.zeros((1, 4, 3))
+        with pytest.raises(_ffi.LnasrError, match="no HMM transition model"):
+            ctx.viterbi(b)
+        d = synth.synth_discrete(3, 4, 8, seed=1)
+        ctx.upload_hmm(d["A"], d["pi"])
+        with pytest.raises(_ffi.LnasrError, match="no GMM-HMM model"):
+            ctx.decode(np.zeros((1, 4, 2)))
+        with pytest.raises(_ffi.LnasrError, match="lens"):
+            ctx.viterbi(b, lens=np.array([9], dtype=np.int32))
+        with pytest.raises(_ffi.LnasrError, match="outside the symbol set"):
+            ctx.discrete_map_b(d["B"], np.array([[0, 1, 7]], dtype=np.int32))
+        with pytest.raises(ValueError):
+            ctx.upload_hmm(d["A"][:, :2], d["pi"])
+        mdl = synth.synth_model(4, 2, 5, seed=1)
+        with pytest.raises(ValueError):
+            ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"])      # diag flag missing
+        ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
+        with pytest.raises(ValueError, match="D="):
+            ctx.gmm_logprob(np.zeros((1, 3, 7)))
+        # empty batches are no-ops
+        assert ctx.decode(np.zeros((0, 5, 5))).shape == (0, 5)
+        # the context still works after errors
+        assert ctx.decode(synth.synth_obs(2, 6, 5, seed=3)).shape == (2, 6)
+        # singular covariance: det = 0 -> log det = -inf -> +inf density constant, as numpy would give inf/nan
+        var = mdl["var"].copy()
+        var[0, 0, 0] = 0.0
+        ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], var, diag=True)
+        out = ctx.gmm_logprob(synth.synth_obs(1, 3, 5, seed=3))
+        assert not np.isfinite(out[0, :, 0]).all()
+    finally:
+        ctx.close()
+
+
+def test_two_contexts_and_reupload(synth, oracle):
+    """Independent contexts; re-uploading a model of a different shape reuses the context."""
+    from lnasr import _ffi
+    a, b = _ffi.Context(0), _ffi.Context(0)
+    try:
+        m1 = synth.synth_model(6, 3, 4, seed=1)
+        m2 = synth.synth_model(128, 16, 39, seed=2)
+        a.upload_gmmhmm(m1["A"], m1["pi"], m1["w"], m1["mu"], m1["var"], diag=True)
+        b.upload_gmmhmm(m2["A"], m2["pi"], m2["w"], m2["mu"], m2["var"], diag=True)
+        o1, o2 = synth.synth_obs(2, 9, 4, seed=5), synth.synth_obs(2, 9, 39, seed=6)
+        p1, p2 = a.decode(o1), b.decode(o2)
+        assert np.array_equal(p1[0], oracle.decode_diag(o1[0], m1["A"], m1["pi"], m1["w"], m1["mu"], m1["var"]))
+        assert np.array_equal(p2[1], oracle.decode_diag(o2[1], m2["A"], m2["pi"], m2["w"], m2["mu"], m2["var"]))
+        a.upload_gmmhmm(m2["A"], m2["pi"], m2["w"], m2["mu"], m2["var"], diag=True)
+        assert np.array_equal(a.decode(o2), p2)
+    finally:
+        a.close()
+        b.close()
