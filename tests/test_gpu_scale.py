@@ -1,0 +1,72 @@
+"""GPU, BASELINE.json full sizes: size-independent properties of the decode path (determinism,
+path-score identity, spot checks against the oracle), and the section-8f 'next' rows
+(character-segmentation sized discrete HMM: n=4, m=65536, long T)."""
+import numpy as np
+import pytest
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def test_metric_config_full_size(synth, oracle):
+    """N=128, M=16, D=39, T=1000, U=1024 (one GPU's shard of config 4), inputs resident in HBM."""
+    from lnasr import _ffi
+    ctx = _ffi.default_ctx()
+    N, M, D, T, U = 128, 16, 39, 1000, 1024
+    mdl = synth.synth_model(N, M, D, seed=1)
+    obs = synth.synth_obs(U, T, D, seed=1000)
+    ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
+    d_obs = ctx.to_device(obs)
+    p1, s1 = ctx.decode(d_obs, want_score=True)
+    p2, s2 = ctx.decode(d_obs, want_score=True)
+    path, score = p1.to_host(), s1.to_host()
+    assert np.array_equal(path, p2.to_host()) and np.array_equal(score, s2.to_host())      # deterministic
+    assert path.max() < N
+    # path-score identity: the Viterbi score equals the score accumulated along the decoded path
+    b = ctx.gmm_logprob(d_obs).to_host()
+    uu = np.arange(U)[:, None]
+    tt = np.arange(T)[None, :]
+    emis = b[uu, tt, path]
+    trans = mdl["A"][path[:, :-1], path[:, 1:]]
+    along = mdl["pi"][path[:, 0]] + emis.sum(axis=1) + trans.sum(axis=1)
+    assert_close(along, score, 1e-11)
+    # optimality spot check: no single-state substitution improves the path score (local optimality)
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        u, t = int(rng.integers(U)), int(rng.integers(1, T - 1))
+        cur = path[u, t]
+        alt = int(rng.integers(N))
+        d_cur = mdl["A"][path[u, t - 1], cur] + b[u, t, cur] + mdl["A"][cur, path[u, t + 1]]
+        d_alt = mdl["A"][path[u, t - 1], alt] + b[u, t, alt] + mdl["A"][alt, path[u, t + 1]]
+        assert d_alt <= d_cur + 1e-9
+    # exact agreement with the oracle on a sample of utterances
+    for u in rng.choice(U, 6, replace=False):
+        ob, _ = oracle.gmm_map_b_diag(obs[u], mdl["w"], mdl["mu"], mdl["var"])
+        ref = oracle.viterbi(mdl["A"], mdl["pi"], ob)[2]
+        assert np.array_equal(path[u], ref), int(u)
+    # forward/backward at full size: sum_j exp(alpha+beta) is frame independent and equals the likelihood
+    d_b = ctx.to_device(b[:64])
+    alpha, ll = ctx.forward(d_b)
+    beta = ctx.backward(d_b)
+    tot = oracle.lse(alpha.to_host() + beta.to_host(), axis=2)
+    assert np.abs(tot - ll.to_host()[:, None]).max() < 1e-7
+
+
+def test_segmentation_sized_discrete_hmm(oracle):
+    """scripts/seg/seg.py shape: n = 4 (BMES), m = 65536 symbols, one long character sequence."""
+    from lnasr.hmm import HMM
+    rng = np.random.default_rng(4)
+    n, m, T = 4, 65536, 30000
+    a = 1.0 - rng.random((n, n))
+    bb = 1.0 - rng.random((n, m))
+    p = 1.0 - rng.random(n)
+    A, B, pi = np.log(a / a.sum(1, keepdims=True)), np.log(bb / bb.sum(1, keepdims=True)), np.log(p / p.sum())
+    obs = rng.integers(0, m, T).astype(np.int32)
+    h = HMM(n, m, A, B, pi)
+    path = h.decode(obs)
+    ref = oracle.viterbi(A, pi, oracle.map_b(B, obs))[2]
+    assert np.array_equal(path, ref)
+    ll = h.calc_prob(obs[:2000])
+    ref_ll = oracle.loglik(oracle.forward(A, pi, oracle.map_b(B, obs[:2000])))
+    assert abs(ll - ref_ll) < 1e-10 * abs(ref_ll)
