@@ -113,4 +113,70 @@ struct Lse {
     __device__ __forceinline__ double value() const { return (m == LN_NEG_INF) ? m : m + log(s); }
 };
 
+// exp(x) for x <= 0 (log-sum-exp terms after the max shift), ~1 ulp, 10 fp64 + 4 int instructions:
+//   x = k ln2/256 + r, |r| <= ln2/512   =>   exp(x) = 2^(k>>8) * 2^((k&255)/256) * (1 + r + r^2/2 + r^3/6 + r^4/24)
+// (remainder r^5/120 < 4e-17).  k comes out of the low mantissa bits of x*256/ln2 + 1.5*2^52; the
+// power of two is applied by adding to the exponent field of the table entry, which is safe
+// because x is clamped to >= -700 (e^-700 is 1e-304: no contribution to a sum whose largest term is 1).
+constexpr int kExpTab = 256;
+__device__ __forceinline__ double exp_nonpos(double x, const double* tab) {
+    constexpr double kInvStep = 369.32993046757463;          // 256 / ln 2
+    constexpr double kStepHi = 2.7076061740622863e-03;        // ln 2 / 256 (hi)
+    constexpr double kStepLo = 9.058776616587108e-20;         // ln 2 / 256 - hi
+    constexpr double kMagic = 6755399441055744.0;             // 1.5 * 2^52
+    x = vmax_f64(x, -700.0);
+    const double kp = fma(x, kInvStep, kMagic);
+    const int k = __double2loint(kp);
+    const double kd = kp - kMagic;
+    double r = fma(-kd, kStepHi, x);
+    r = fma(-kd, kStepLo, r);
+    double q = fma(r, 1.0 / 24.0, 1.0 / 6.0);
+    q = fma(q, r, 0.5);
+    const double p = fma(q, r * r, r);
+    const double t0 = tab[k & (kExpTab - 1)];
+    const int hi = __double2hiint(t0) + ((k >> 8) << 20);
+    const double t = __hiloint2double(hi, __double2loint(t0));
+    return fma(t, p, t);
+}
+
+// log(s) for the sum of a max-shifted log-sum-exp: 1 <= s <= 2^20.  s = 2^e m, m in [1,2);
+// c_j = 1 + (j + 1/2)/128 from the top seven mantissa bits; r = m/c_j - 1 (|r| <= 1/256, formed exactly
+// by an fma with the tabulated reciprocal); log s = e ln2 + log c_j + (r - r^2/2 + ... - r^6/6)
+// (remainder r^7/7 < 2e-18).  ltab[2j] = fl(1/c_j), ltab[2j+1] = -log(ltab[2j]).  ~10 fp64 + 6 integer
+// instructions against ~35 for the library log.
+constexpr int kLogTab = 128;
+__device__ __forceinline__ void log_table_init(double* ltab, int tid, int nt) {
+    for (int e = tid; e < kLogTab; e += nt) {
+        const double rc = 1.0 / (1.0 + ((double)e + 0.5) * (1.0 / kLogTab));
+        ltab[2 * e] = rc;
+        ltab[2 * e + 1] = -log(rc);
+    }
+}
+__device__ __forceinline__ double log_sum(double s, const double* ltab) {
+    constexpr double kLn2 = 0.69314718055994530942;
+    const int hi = __double2hiint(s);
+    const int e = (hi >> 20) - 1023;
+    const int j = (hi >> 13) & (kLogTab - 1);
+    const double m = __hiloint2double((hi & 0x000FFFFF) | 0x3FF00000, __double2loint(s));
+    const double r = fma(m, ltab[2 * j], -1.0);
+    double q = fma(r, -1.0 / 6.0, 0.2);
+    q = fma(q, r, -0.25);
+    q = fma(q, r, 1.0 / 3.0);
+    q = fma(q, r, -0.5);
+    q = fma(q, r, 1.0);
+    return fma((double)e, kLn2, fma(q, r, ltab[2 * j + 1]));
+}
+
+// exp(x) for any x: same scheme as exp_nonpos below 690, +inf above (callers treat an infinite term as
+// "this sum must be redone in the log domain", exactly what the library exp's overflow would trigger)
+__device__ __forceinline__ double exp_clamped(double x, const double* tab) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(690.0));
+    const double e = exp_nonpos(r, tab);
+    return x > 690.0 ? __builtin_huge_val() : e;
+}
+__device__ __forceinline__ void exp_table_init(double* etab, int tid, int nt) {
+    for (int e = tid; e < kExpTab; e += nt) etab[e] = exp2((double)e * (1.0 / kExpTab));
+}
+
 }  // namespace lnasr

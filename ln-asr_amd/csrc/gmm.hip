@@ -185,31 +185,7 @@ __global__ void pack_wfrag_kernel(const double* __restrict__ mu, const double* _
 // time is therefore MFMA cycles + epilogue VALU cycles, and the epilogue is written to use as
 // few vector instructions as possible.
 
-// exp(x) for x <= 0 (log-sum-exp terms after the max shift), ~1 ulp, 10 fp64 + 4 int instructions:
-//   x = k ln2/256 + r, |r| <= ln2/512   =>   exp(x) = 2^(k>>8) * 2^((k&255)/256) * (1 + r + r^2/2 + r^3/6 + r^4/24)
-// (remainder r^5/120 < 4e-17).  k comes out of the low mantissa bits of x*256/ln2 + 1.5*2^52; the
-// power of two is applied by adding to the exponent field of the table entry, which is safe
-// because x is clamped to >= -700 (e^-700 is 1e-304: no contribution to a sum whose largest term is 1).
-constexpr int kExpTab = 256;
-__device__ __forceinline__ double exp_nonpos(double x, const double* tab) {
-    constexpr double kInvStep = 369.32993046757463;          // 256 / ln 2
-    constexpr double kStepHi = 2.7076061740622863e-03;        // ln 2 / 256 (hi)
-    constexpr double kStepLo = 9.058776616587108e-20;         // ln 2 / 256 - hi
-    constexpr double kMagic = 6755399441055744.0;             // 1.5 * 2^52
-    x = vmax_f64(x, -700.0);
-    const double kp = fma(x, kInvStep, kMagic);
-    const int k = __double2loint(kp);
-    const double kd = kp - kMagic;
-    double r = fma(-kd, kStepHi, x);
-    r = fma(-kd, kStepLo, r);
-    double q = fma(r, 1.0 / 24.0, 1.0 / 6.0);
-    q = fma(q, r, 0.5);
-    const double p = fma(q, r * r, r);
-    const double t0 = tab[k & (kExpTab - 1)];
-    const int hi = __double2hiint(t0) + ((k >> 8) << 20);
-    const double t = __hiloint2double(hi, __double2loint(t0));
-    return fma(t, p, t);
-}
+// exp_nonpos / log_sum (devmath.h): table-driven exp and log, 10 fp64 instructions each.
 
 // ------------------------------------------------------------------------------------------
 // hot kernel: diagonal-covariance GMM bank on the fp64 matrix cores
@@ -234,9 +210,11 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 2))
     constexpr int OS = SPB + 1;                 // padded row stride of the staged outputs
     __shared__ double ob[2][TPS][16 * OS];
     __shared__ double etab[kExpTab];
+    __shared__ double ltab[2 * kLogTab];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     for (int e = tid; e < kExpTab; e += NT) etab[e] = exp2((double)e * (1.0 / kExpTab));
+    log_table_init(ltab, tid, NT);
     const long bid = blockIdx.x;
     const int xcd = (int)(bid & 7);
     const long i = bid >> 3;
@@ -384,7 +362,7 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
                 for (int r = 0; r < 4; ++r) s += exp_nonpos(acc[q][r] - mx, etab);
             // mx = -inf: every term is NaN -> clamped -> s = 0 -> log gives -inf; mx = +inf/NaN propagate
-            ob[cur][tt][fr * OS + 4 * w + g] = (mx == LN_NEG_INF) ? mx : mx + log(s);
+            ob[cur][tt][fr * OS + 4 * w + g] = (mx == LN_NEG_INF) ? mx : mx + log_sum(s, ltab);
 
         }
 

@@ -635,7 +635,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
     __shared__ double Ps[NW > 1 ? NW : 1][UB][NP];
     __shared__ double Ms[2][UB][CPT];     // per column-block max of prev
     __shared__ double Ss[2][UB];          // shift the e values of this buffer were computed with
+    __shared__ double etab[kExpTab];      // table-driven exp / log (devmath.h)
+    __shared__ double ltab[2 * kLogTab];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    exp_table_init(etab, threadIdx.x, 64 * NW);
+    log_table_init(ltab, threadIdx.x, 64 * NW);   // visible after the first __syncthreads below
     const int u0 = blockIdx.x * UB;
 
     double areg[CPT][RPT];
@@ -707,7 +711,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
 #pragma unroll
             for (int cc = 1; cc < CPT; ++cc) S = fmax(S, Ms[0][k][cc]);
             const double prev = Cs[0][k][j];
-            Es[0][k][j] = (S == LN_NEG_INF || prev == LN_NEG_INF) ? 0.0 : exp(prev - S);
+            Es[0][k][j] = (S == LN_NEG_INF || prev == LN_NEG_INF) ? 0.0 : exp_clamped(prev - S, etab);
             if (c == 0 && lane == 0) Ss[0][k] = S;
         }
     }
@@ -769,7 +773,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
                     const double Sc = Ss[cur][k];
                     double val;
                     if (sum >= kSafeSum && sum <= 1e290 && Sc != LN_NEG_INF) {
-                        val = Sc + log(sum);
+                        val = Sc + log_sum(sum, ltab);
                     } else {                       // exact log-domain column (rare)
                         const int jcl = j < N ? j : N - 1;
                         double mx = LN_NEG_INF;
@@ -796,7 +800,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
 #pragma unroll
                     for (int cc = 1; cc < CPT; ++cc) S = fmax(S, Ms[cur][k][cc]);
                     Cs[nxt][k][j] = prev;
-                    Es[nxt][k][j] = (S == LN_NEG_INF || prev == LN_NEG_INF) ? 0.0 : exp(prev - S);
+                    Es[nxt][k][j] = (S == LN_NEG_INF || prev == LN_NEG_INF) ? 0.0 : exp_clamped(prev - S, etab);
                     const double m = wave_max_dpp(prev);
                     if (lane == 0) Ms[nxt][k][c] = m;
                     if (c == 0 && lane == 0) Ss[nxt][k] = S;
