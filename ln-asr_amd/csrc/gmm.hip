@@ -209,11 +209,11 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 2))
     __shared__ double Fl[2][TPS][KP * FS];
     constexpr int OS = SPB + 1;                 // padded row stride of the staged outputs
     __shared__ double ob[2][TPS][16 * OS];
-    __shared__ double etab[kExpTab];
+    __shared__ double etab[kExpTabBig];
     __shared__ double ltab[2 * kLogTab];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    for (int e = tid; e < kExpTab; e += NT) etab[e] = exp2((double)e * (1.0 / kExpTab));
+    for (int e = tid; e < kExpTabBig; e += NT) etab[e] = exp2((double)e * (1.0 / kExpTabBig));
     log_table_init(ltab, tid, NT);
     const long bid = blockIdx.x;
     const int xcd = (int)(bid & 7);
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
             for (int q = 0; q < Q; ++q)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s += exp_nonpos(acc[q][r] - mx, etab);
+                for (int r = 0; r < 4; ++r) s += exp_nonpos_big(acc[q][r] - mx, etab);
             // mx = -inf: every term is NaN -> clamped -> s = 0 -> log gives -inf; mx = +inf/NaN propagate
             ob[cur][tt][fr * OS + 4 * w + g] = (mx == LN_NEG_INF) ? mx : mx + log_sum(s, ltab);
 
