@@ -1213,12 +1213,22 @@ int forward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
         return 0;
     }
     if (dtype == LNASR_F64 && N > 128 && N <= 1024 && !getenv("LNASR_NO_STREAM")) {
-        constexpr int UB = 4;
         const int NP = ((N + 63) / 64) * 64, RS = 1024 / NP, RPS = (N + RS - 1) / RS, NB = NP / 64;
-        const size_t shm = ((size_t)(4 + RS) * UB * NP + 2 * UB * NB + 2 * UB) * 8;
-        LN_LAUNCH(ctx, "forward_stream", (fwdbwd_stream<false, UB>), dim3((U + UB - 1) / UB), dim3(NP * RS), shm,
-                  (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
-                  (double*)alpha, loglik, U, T, N, NP, RS, RPS);
+        // few utterances: one per block keeps more CUs busy (the frame chain is the critical path);
+        // many: four per block share every read of exp(A)
+        if (U < 2 * ctx->prop.multiProcessorCount) {
+            constexpr int UB = 1;
+            const size_t shm = ((size_t)(4 + RS) * UB * NP + 2 * UB * NB + 2 * UB) * 8;
+            LN_LAUNCH(ctx, "forward_stream_u1", (fwdbwd_stream<false, UB>), dim3(U), dim3(NP * RS), shm, (const double*)b,
+                      md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens, (double*)alpha,
+                      loglik, U, T, N, NP, RS, RPS);
+        } else {
+            constexpr int UB = 4;
+            const size_t shm = ((size_t)(4 + RS) * UB * NP + 2 * UB * NB + 2 * UB) * 8;
+            LN_LAUNCH(ctx, "forward_stream", (fwdbwd_stream<false, UB>), dim3((U + UB - 1) / UB), dim3(NP * RS), shm,
+                      (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
+                      (double*)alpha, loglik, U, T, N, NP, RS, RPS);
+        }
         return 0;
     }
     int nt = ((N + 63) / 64) * 64;
@@ -1252,12 +1262,20 @@ int backward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* 
         return 0;
     }
     if (dtype == LNASR_F64 && N > 128 && N <= 1024 && !getenv("LNASR_NO_STREAM")) {
-        constexpr int UB = 4;
         const int NP = ((N + 63) / 64) * 64, RS = 1024 / NP, RPS = (N + RS - 1) / RS, NB = NP / 64;
-        const size_t shm = ((size_t)(4 + RS) * UB * NP + 2 * UB * NB + 2 * UB) * 8;
-        LN_LAUNCH(ctx, "backward_stream", (fwdbwd_stream<true, UB>), dim3((U + UB - 1) / UB), dim3(NP * RS), shm,
-                  (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
-                  (double*)nullptr, U, T, N, NP, RS, RPS);
+        if (U < 2 * ctx->prop.multiProcessorCount) {
+            constexpr int UB = 1;
+            const size_t shm = ((size_t)(4 + RS) * UB * NP + 2 * UB * NB + 2 * UB) * 8;
+            LN_LAUNCH(ctx, "backward_stream_u1", (fwdbwd_stream<true, UB>), dim3(U), dim3(NP * RS), shm, (const double*)b,
+                      expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta, (double*)nullptr, U,
+                      T, N, NP, RS, RPS);
+        } else {
+            constexpr int UB = 4;
+            const size_t shm = ((size_t)(4 + RS) * UB * NP + 2 * UB * NB + 2 * UB) * 8;
+            LN_LAUNCH(ctx, "backward_stream", (fwdbwd_stream<true, UB>), dim3((U + UB - 1) / UB), dim3(NP * RS), shm,
+                      (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
+                      (double*)nullptr, U, T, N, NP, RS, RPS);
+        }
         return 0;
     }
     int nt = ((N + 63) / 64) * 64;

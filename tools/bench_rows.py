@@ -96,3 +96,14 @@ if what & {"bw", "all"}:
     lib = _ffi.lib()
     timed("Baum-Welch statistics N=256 M=32", lambda: _ffi.check(lib.lnasr_bw_accumulate(ctx.handle, obs.ptr, U, T, None, stats.ptr)),
           U * T, "frames", reps=2)
+
+if what & {"full", "all"}:
+    # full-covariance bank (the reference's own M-step produces full Sigma): N=128, M=16, D=39
+    U, T, N, M, D = 16, 1000, 128, 16, 39
+    mdl = synth.synth_model(N, M, D, seed=1, full_cov=True)
+    ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["si"])
+    obs = ctx.to_device(synth.synth_obs(U, T, D, seed=1000))
+    b = ctx.empty((U, T, N), np.float64)
+    lib = _ffi.lib()
+    timed("gmm log-likelihood FULL cov N=128", lambda: _ffi.check(lib.lnasr_gmm_logprob(ctx.handle, obs.ptr, U, T, None, 0, b.ptr, None)),
+          U * T, "frames", reps=2, algo_flop=U * T * 2.0 * N * M * D * D)
