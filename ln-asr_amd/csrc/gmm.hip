@@ -16,6 +16,9 @@ namespace lnasr {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
+int pack_full_model(lnasr_ctx* ctx);                                                   // gmm_full.hip
+int emit_full_mfma_device(lnasr_ctx* ctx, const double* obs, long F, double* b, double* bm);
+
 // ------------------------------------------------------------------------------------------
 // model preparation
 // ------------------------------------------------------------------------------------------
@@ -722,6 +725,7 @@ static int model_upload_impl(lnasr_ctx* ctx, int N, int M, int D, const double* 
     md.D = D;
     md.diag = diag;
     md.wpack_Q = md.wpack_KS = 0;
+    md.wfull_Q = 0;
     if (diag) {
         LN_TRY(md.ivar.reserve(NMD * 8));
         LN_LAUNCH(ctx, "prep_diag", prep_diag_kernel, dim3((unsigned)((NM + 127) / 128)), dim3(128), 0,
@@ -762,6 +766,7 @@ static int model_upload_impl(lnasr_ctx* ctx, int N, int M, int D, const double* 
         size_t shmem = (size_t)D * 2 * D * 8;
         LN_LAUNCH(ctx, "lu_invert", lu_invert_kernel, dim3((unsigned)NM), dim3(64), shmem, md.sigma_raw.as<double>(),
                   md.prec.as<double>(), md.gconst.as<double>(), D);
+        LN_TRY(pack_full_model(ctx));
     }
     LN_HIP(hipStreamSynchronize(ctx->stream));
     md.has_gmm = true;
@@ -870,6 +875,10 @@ int emit_device(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, v
                       0, bdst, cells, md.wpack_virt, (double*)b);
         }
         return 0;
+    }
+    if (!md.diag && dtype == LNASR_F64) {
+        const int rc = emit_full_mfma_device(ctx, obs, F, (double*)b, (double*)bm);
+        if (rc != 0) return rc < 0 ? rc : 0;
     }
     const int fw = N >= 4 ? 1 : 4;
     const unsigned grid = (unsigned)((F + 64 * fw - 1) / (64 * fw));

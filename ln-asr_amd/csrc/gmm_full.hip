@@ -1,0 +1,332 @@
+// Full-covariance GMM bank on the fp64 matrix cores (gmm.py:59-68 inside gmmhmm.py:46-67).
+//
+// The reference's own M-step (gmmhmm.py:138-147) returns FULL covariance matrices, so every model
+// that went through GMMHMM.train() is scored here.  With P = Sigma^-1 (LU semantics, not
+// necessarily symmetric):
+//
+//   -1/2 (x-mu)^T P (x-mu) = sum_{d<=e} x_d x_e S[d,e] + sum_d x_d L[d] + K
+//       S[d,d] = -1/2 P[d,d],  S[d,e] = -1/2 (P[d,e] + P[e,d]) (d < e),
+//       L = 1/2 (P + P^T) mu,  K = -1/2 mu^T P mu  (+ log w - 1/2 (D ln 2pi + ln det Sigma))
+//
+// i.e. a GEMM  [frames x Kf] . [Kf x N*M]  with Kf = D(D+1)/2 + D + 1 quadratic features (820 at D = 39),
+// followed by the same in-lane M-way log-sum-exp as the diagonal kernel.  The coefficient matrix
+// (14 MB at the metric shape) cannot stay in registers: it is streamed from L2 in 80-feature chunks,
+// and every fragment load is reused for FT = 4 frame tiles (64 frames) per wave.  blockIdx is decoded
+// so that the blocks of one XCD work on the same state slab and its coefficients stay in that L2.
+#include "common.h"
+#include "devmath.h"
+
+namespace lnasr {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+constexpr int kFC = 80;          // features per chunk (20 MFMA k-steps)
+constexpr int kFKS = 20;
+
+// feature k -> (d, e): pairs d <= e row by row, then the D linear terms (e = 0xFF), then the constant
+// (d = e = 0xFF); anything beyond is padding (d = 0xFE).
+__global__ void pair_table_kernel(int D, int Kpad, int* __restrict__ tab) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= Kpad) return;
+    const int npair = D * (D + 1) / 2;
+    int d = 0xFE, e = 0xFE;
+    if (k < npair) {
+        int rem = k;
+        d = 0;
+        while (rem >= D - d) {
+            rem -= D - d;
+            ++d;
+        }
+        e = d + rem;
+    } else if (k < npair + D) {
+        d = k - npair;
+        e = 0xFF;
+    } else if (k == npair + D) {
+        d = 0xFF;
+        e = 0xFF;
+    }
+    tab[k] = d | (e << 8);
+}
+
+// wfull[(((sg*NCH + ch)*Q + q)*KS + ks)*64 + lane]: coefficient of component (state 4 sg + (row&3),
+// mixture 4 q + (row>>2)), row = lane & 15, feature k = 80 ch + 4 ks + (lane >> 4)
+__global__ void pack_wfull_kernel(const double* __restrict__ mu, const double* __restrict__ prec,
+                                  const double* __restrict__ gconst, const double* __restrict__ logw,
+                                  const int* __restrict__ pairtab, double* __restrict__ wfull, int N, int M, int D,
+                                  int Q, int NCH, int fold_w) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)(N / 4) * NCH * Q * kFKS * 64;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    size_t r1 = idx >> 6;
+    const int ks = (int)(r1 % kFKS);
+    r1 /= kFKS;
+    const int q = (int)(r1 % Q);
+    r1 /= Q;
+    const int ch = (int)(r1 % NCH);
+    const int sg = (int)(r1 / NCH);
+    const int row = lane & 15, k = kFC * ch + 4 * ks + (lane >> 4);
+    const int state = 4 * sg + (row & 3), mix = 4 * q + (row >> 2);
+    const size_t c = (size_t)state * M + mix;
+    const double* P = prec + c * D * D;
+    const double* m = mu + c * D;
+    const int code = pairtab[k], d = code & 0xFF, e = (code >> 8) & 0xFF;
+    double val = 0.0;
+    if (d < 0xFE && e < 0xFE) {
+        val = d == e ? -0.5 * P[(size_t)d * D + d] : -0.5 * (P[(size_t)d * D + e] + P[(size_t)e * D + d]);
+    } else if (d < 0xFE && e == 0xFF) {
+        double s = 0.0;
+        for (int j = 0; j < D; ++j) s += (P[(size_t)d * D + j] + P[(size_t)j * D + d]) * m[j];
+        val = 0.5 * s;
+    } else if (d == 0xFF) {
+        double s = 0.0;
+        for (int i = 0; i < D; ++i) {
+            double t = 0.0;
+            for (int j = 0; j < D; ++j) t += P[(size_t)i * D + j] * m[j];
+            s += m[i] * t;
+        }
+        val = (fold_w ? logw[c] : 0.0) + gconst[c] - 0.5 * s;
+    }
+    wfull[idx] = val;
+}
+
+template <int Q, bool WRITE_BM>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void emit_full_mfma(
+    const double* __restrict__ obs, const double* __restrict__ wfull, const int* __restrict__ pairtab,
+    const double* __restrict__ logw, double* __restrict__ b, double* __restrict__ bm, long F, int N, int D, int NG,
+    int GY, int NCH, long nsuper, int super_per_block, long nchunks) {
+    constexpr int NWV = 8, NT = 512, SPB = 32, FT = 4, FS = 17, OS = SPB + 1;
+    extern __shared__ double smem[];
+    double* xs = smem;                                   // [D][64] observations of the super-tile
+    double* Fl = xs + (size_t)D * 64;                    // [2][FT][kFC * FS] feature chunks (double buffered)
+    double* ob = Fl + 2 * FT * kFC * FS;                 // [FT][16 * OS] staged outputs
+    double* etab = ob + FT * 16 * OS;                    // [kExpTab]
+    double* ltab = etab + kExpTab;                       // [2 * kLogTab]
+    int* ptab = reinterpret_cast<int*>(ltab + 2 * kLogTab);   // [NCH * kFC]
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    exp_table_init(etab, tid, NT);
+    log_table_init(ltab, tid, NT);
+    for (int e = tid; e < NCH * kFC; e += NT) ptab[e] = pairtab[e];
+
+    // XCD-aware decode: every XCD serves one state slab (its coefficients stay in that XCD's L2)
+    const long bid = blockIdx.x;
+    const int xcd = (int)(bid & 7);
+    const long i = bid >> 3;
+    int y;
+    long chunk;
+    if (GY <= 8 && 8 % GY == 0) {
+        y = xcd % GY;
+        chunk = i * (8 / GY) + xcd / GY;
+    } else {
+        y = (int)(i % GY);
+        chunk = (i / GY) * 8 + xcd;
+    }
+    if (chunk >= nchunks) return;
+    const long sup0 = chunk * super_per_block;
+    long sup1 = sup0 + super_per_block;
+    if (sup1 > nsuper) sup1 = nsuper;
+    const int sg = NWV * y + w;
+    const bool active = sg < NG;
+    const int sgc = active ? sg : 0;
+    const int M = 4 * Q;
+    const int g = lane >> 4, fr = lane & 15;
+    const int my_state = 4 * sgc + g;
+    double lw[WRITE_BM ? Q * 4 : 1];
+    if (WRITE_BM) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lw[q * 4 + r] = logw[(size_t)my_state * M + 4 * q + r];
+    }
+    const double* wbase = wfull + (size_t)sgc * NCH * Q * kFKS * 64 + lane;
+    const long lim = F * (long)D;
+    __syncthreads();
+
+    for (long sup = sup0; sup < sup1; ++sup) {
+        // observations of the 64 frames -> LDS, d-major
+        const long fbase = sup * 64;
+        for (int e = tid; e < 64 * D; e += NT) {
+            const int f = e / D, d = e - f * D;
+            long ge = fbase * D + e;
+            ge = ge < lim ? ge : lim - 1;
+            xs[d * 64 + f] = obs[ge];
+        }
+        __syncthreads();
+        // feature chunk builder: wave w fills rows kk = w, w+8, ... of chunk `ch` into buffer `buf`
+        auto build = [&](int ch, int buf) {
+            double* Fb = Fl + (size_t)buf * FT * kFC * FS;
+#pragma unroll
+            for (int r = 0; r < kFC / NWV; ++r) {
+                const int kk = w + NWV * r;
+                const int code = ptab[ch * kFC + kk], d = code & 0xFF, e = (code >> 8) & 0xFF;
+                double val;
+                if (d < 0xFE && e < 0xFE) val = xs[d * 64 + lane] * xs[e * 64 + lane];
+                else if (d < 0xFE) val = xs[d * 64 + lane];
+                else val = d == 0xFF ? 1.0 : 0.0;
+                Fb[(lane >> 4) * (kFC * FS) + kk * FS + (lane & 15)] = val;
+            }
+        };
+        double4_t acc[FT][Q];
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+            for (int q = 0; q < Q; ++q) acc[ft][q] = double4_t{0.0, 0.0, 0.0, 0.0};
+
+        build(0, 0);
+        __syncthreads();
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int buf = ch & 1;
+            if (ch + 1 < NCH) build(ch + 1, buf ^ 1);
+            const double* Fb = Fl + (size_t)buf * FT * kFC * FS;
+            const double* wc = wbase + (size_t)ch * Q * kFKS * 64;
+            double wv[Q], wn[Q];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) wv[q] = wc[(size_t)(q * kFKS) * 64];
+#pragma unroll
+            for (int ks = 0; ks < kFKS; ++ks) {
+                if (ks + 1 < kFKS) {
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) wn[q] = wc[(size_t)(q * kFKS + ks + 1) * 64];
+                }
+#pragma unroll
+                for (int ft = 0; ft < FT; ++ft) {
+                    const double bf = Fb[ft * (kFC * FS) + (4 * ks + g) * FS + fr];
+#pragma unroll
+                    for (int q = 0; q < Q; ++q)
+                        acc[ft][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[q], bf, acc[ft][q], 0, 0, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < Q; ++q) wv[q] = wn[q];
+            }
+            __syncthreads();
+        }
+        // epilogue: in-lane M-way log-sum-exp per frame tile
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft) {
+            if (WRITE_BM) {
+                const long frame = fbase + ft * 16 + fr;
+                if (active && frame < F) {
+                    double* dst = bm + ((size_t)frame * N + my_state) * M;
+#pragma unroll
+                    for (int q = 0; q < Q; ++q)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) dst[4 * q + r] = acc[ft][q][r];
+                }
+#pragma unroll
+                for (int q = 0; q < Q; ++q)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[ft][q][r] += lw[q * 4 + r];
+            }
+            double mx = acc[ft][0][0];
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (q + r > 0) mx = vmax_f64(mx, acc[ft][q][r]);
+            double s = 0.0;
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s += exp_nonpos(acc[ft][q][r] - mx, etab);
+            ob[ft * 16 * OS + fr * OS + 4 * w + g] = (mx == LN_NEG_INF || mx != mx) ? mx : mx + log_sum(s, ltab);
+        }
+        __syncthreads();
+        for (int e = tid; e < FT * 16 * SPB; e += NT) {
+            const int ft = e / (16 * SPB), rem = e % (16 * SPB);
+            const int f = rem / SPB, st = rem % SPB;
+            const long frame = fbase + ft * 16 + f;
+            const int state = SPB * y + st;
+            if (frame < F && state < N) b[frame * N + state] = ob[ft * 16 * OS + f * OS + st];
+        }
+        // the next super-tile's xs / feature writes are fenced by the barrier at the top of the loop
+        __syncthreads();
+    }
+}
+
+int pack_full_model(lnasr_ctx* ctx) {
+    Model& md = ctx->model;
+    const int N = md.N, M = md.M, D = md.D;
+    md.wfull_Q = 0;
+    const int virt = (M > 16 && M % 16 == 0) ? M / 16 : 1;
+    const int Nv = N * virt, Mv = M / virt;
+    if (Nv % 4 != 0 || Mv % 4 != 0 || D > 64) return 0;
+    const int Q = Mv / 4;
+    if (!(Q == 1 || Q == 2 || Q == 4)) return 0;
+    const int K = D * (D + 1) / 2 + D + 1;
+    const int NCH = (K + kFC - 1) / kFC;
+    const size_t lds = ((size_t)D * 64 + 2 * 4 * kFC * 17 + 4 * 16 * 33 + kExpTab + 2 * kLogTab) * 8 + (size_t)NCH * kFC * 4;
+    if (lds > 160 * 1024) return 0;
+    LN_TRY(md.pairtab.reserve((size_t)NCH * kFC * 4));
+    LN_LAUNCH(ctx, "pair_table", pair_table_kernel, dim3((NCH * kFC + 255) / 256), dim3(256), 0, D, NCH * kFC,
+              md.pairtab.as<int>());
+    const size_t total = (size_t)(Nv / 4) * NCH * Q * kFKS * 64;
+    LN_TRY(md.wfull.reserve(total * 8));
+    LN_TRY(md.wfull_nw.reserve(total * 8));
+    for (int fold = 1; fold >= 0; --fold)
+        LN_LAUNCH(ctx, "pack_wfull", pack_wfull_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                  md.mu.as<double>(), md.prec.as<double>(), md.gconst.as<double>(), md.logw.as<double>(),
+                  md.pairtab.as<int>(), (fold ? md.wfull : md.wfull_nw).as<double>(), Nv, Mv, D, Q, NCH, fold);
+    md.wfull_Q = Q;
+    md.wfull_NCH = NCH;
+    md.wfull_virt = virt;
+    return 0;
+}
+
+template <int Q>
+static int launch_full(lnasr_ctx* ctx, const double* obs, long F, double* b, double* bm) {
+    Model& md = ctx->model;
+    const int N = md.N * md.wfull_virt, D = md.D, NCH = md.wfull_NCH;
+    const int GY = (N + 31) / 32;
+    const long nsuper = (F + 63) / 64;
+    const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+    long want_chunks = (long)cus / GY;
+    if (want_chunks < 8) want_chunks = 8;
+    want_chunks = (want_chunks / 8) * 8;
+    long spb = (nsuper + want_chunks - 1) / want_chunks;
+    if (spb < 1) spb = 1;
+    const long nchunks = (nsuper + spb - 1) / spb;
+    const long grid = (GY <= 8 && 8 % GY == 0) ? ((nchunks * GY + 7) / 8) * 8 : ((nchunks + 7) / 8) * 8 * GY;
+    const size_t shm = ((size_t)D * 64 + 2 * 4 * kFC * 17 + 4 * 16 * 33 + kExpTab + 2 * kLogTab) * 8 + (size_t)NCH * kFC * 4;
+    if (bm)
+        LN_LAUNCH(ctx, "emit_full_mfma_bm", (emit_full_mfma<Q, true>), dim3((unsigned)grid), dim3(512), shm, obs,
+                  md.wfull_nw.as<double>(), md.pairtab.as<int>(), md.logw.as<double>(), b, bm, F, N, D, N / 4, GY, NCH,
+                  nsuper, (int)spb, nchunks);
+    else
+        LN_LAUNCH(ctx, "emit_full_mfma", (emit_full_mfma<Q, false>), dim3((unsigned)grid), dim3(512), shm, obs,
+                  md.wfull.as<double>(), md.pairtab.as<int>(), md.logw.as<double>(), b, bm, F, N, D, N / 4, GY, NCH,
+                  nsuper, (int)spb, nchunks);
+    return 0;
+}
+
+__global__ void merge_virtual_full_kernel(const double* __restrict__ bv, size_t cells, int k, double* __restrict__ b) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= cells) return;
+    Lse acc;
+    for (int h = 0; h < k; ++h) acc.add(bv[idx * k + h]);
+    b[idx] = acc.value();
+}
+
+// returns 1 if the launch was issued, 0 if this model / dtype is not covered, < 0 on error
+int emit_full_mfma_device(lnasr_ctx* ctx, const double* obs, long F, double* b, double* bm) {
+    Model& md = ctx->model;
+    if (md.wfull_Q == 0 || getenv("LNASR_NO_MFMA")) return 0;
+    double* bdst = b;
+    if (md.wfull_virt > 1) {
+        LN_TRY(ctx->ws_misc2.reserve((size_t)F * md.N * md.wfull_virt * 8));
+        bdst = ctx->ws_misc2.as<double>();
+    }
+    int rc;
+    if (md.wfull_Q == 4) rc = launch_full<4>(ctx, obs, F, bdst, bm);
+    else if (md.wfull_Q == 2) rc = launch_full<2>(ctx, obs, F, bdst, bm);
+    else rc = launch_full<1>(ctx, obs, F, bdst, bm);
+    if (rc) return rc;
+    if (md.wfull_virt > 1) {
+        const size_t cells = (size_t)F * md.N;
+        LN_LAUNCH(ctx, "merge_virtual_states", merge_virtual_full_kernel, dim3((unsigned)((cells + 255) / 256)),
+                  dim3(256), 0, bdst, cells, md.wfull_virt, b);
+    }
+    return 1;
+}
+
+}  // namespace lnasr
