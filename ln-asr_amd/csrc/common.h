@@ -90,6 +90,7 @@ struct lnasr_ctx {
     lnasr::DevBuf ws_in, ws_in2, ws_in3, ws_in4, ws_in5;   // staged host inputs
     lnasr::DevBuf ws_out, ws_out2, ws_out3;                // staged outputs
     lnasr::DevBuf ws_b, ws_bm, ws_v, ws_alpha, ws_beta, ws_misc, ws_misc2, ws_lens, ws_stats;
+    lnasr::DevBuf ws_p, ws_q, ws_raw;                      // Baum-Welch statistics: xi factors, raw mixture moments
     // profiling
     bool prof_on = false;
     std::vector<std::string> prof_names;
@@ -126,6 +127,14 @@ int stage_in(lnasr_ctx* ctx, const void* p, size_t bytes, DevBuf& ws, const void
 // Prepare an output: returns device pointer to write; if host, `ws` is used and finish_out copies back.
 int stage_out(lnasr_ctx* ctx, void* p, size_t bytes, DevBuf& ws, void** out);
 int finish_out(lnasr_ctx* ctx, void* user, const void* dev, size_t bytes);
+
+// Baum-Welch statistics on the matrix cores (bwstats.hip)
+int xi_sum_device(lnasr_ctx* ctx, const double* alpha, const double* beta, const double* b, const double* loglik,
+                  const int32_t* d_lens, int U, int T, double* xi_sum);
+bool mix_stats_mfma_ok(const Model& md);
+int mix_stats_device(lnasr_ctx* ctx, const double* obs, const double* alpha, const double* beta, const double* b,
+                     const double* bm, const double* c1, const int32_t* d_lens, int U, int T, double* mix,
+                     double* mix_x, double* mix_xx);
 
 inline size_t dtype_size(int dtype) { return dtype == LNASR_F32 ? 4 : 8; }
 

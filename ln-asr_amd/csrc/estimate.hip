@@ -690,16 +690,24 @@ int lnasr_bw_accumulate(lnasr_ctx* ctx, const double* obs, int U, int T, const i
     LN_TRY(forward_device(ctx, b, U, T, d_lens, LNASR_F64, al, ll));
     LN_TRY(backward_device(ctx, b, U, T, d_lens, LNASR_F64, be));
     LN_REQUIRE(U <= 65535, "U=%d too large for one statistics launch", U);
-    const int tiles = (N + 15) / 16;
-    LN_LAUNCH(ctx, "acc_xi", acc_xi_kernel, dim3(tiles, tiles, U), dim3(256), 0, al, be, b, md.logA.as<double>(), ll,
-              d_lens, T, N, st + L.xi);
+    const bool mfma_stats = !getenv("LNASR_NO_MFMA_STATS");
+    if (mfma_stats) {
+        LN_TRY(xi_sum_device(ctx, al, be, b, ll, d_lens, U, T, st + L.xi));
+    } else {
+        const int tiles = (N + 15) / 16;
+        LN_LAUNCH(ctx, "acc_xi", acc_xi_kernel, dim3(tiles, tiles, U), dim3(256), 0, al, be, b, md.logA.as<double>(), ll,
+                  d_lens, T, N, st + L.xi);
+    }
     LN_LAUNCH(ctx, "rowsum", rowsum_kernel, dim3((N + 63) / 64), dim3(64), 0, st + L.xi, N, st + L.gsum);
     LN_LAUNCH(ctx, "acc_gamma0", acc_gamma0_kernel, dim3(U), dim3(64), 0, al, be, ll, d_lens, U, T, N, st + L.g0,
               st + L.ll, st + L.nutt, st + L.nfr);
     // frames past an utterance's length hold stale alpha/beta; ab_lse covers them but acc_mix skips them
     LN_LAUNCH(ctx, "ab_lse", ab_lse_kernel<double>, dim3((unsigned)(((size_t)U * T + 3) / 4)), dim3(256), 0, al, be,
               (long)U * T, N, c1);
-    if (md.diag) {
+    if (mix_stats_mfma_ok(md)) {
+        LN_TRY(mix_stats_device(ctx, (const double*)d_obs, al, be, b, bm, c1, d_lens, U, T, st + L.mix, st + L.mix_x,
+                                st + L.mix_xx));
+    } else if (md.diag) {
         const size_t shmem = (size_t)kMixCH * (M + D) * 8;
         LN_REQUIRE(shmem <= 160 * 1024, "M=%d, D=%d too large for the statistics kernel", M, D);
         LN_LAUNCH(ctx, "acc_mix_diag", acc_mix_diag_kernel, dim3(N, (T + kMixCH - 1) / kMixCH, U), dim3(256), shmem,

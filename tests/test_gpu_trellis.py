@@ -225,6 +225,60 @@ def test_bw_statistics(golden, synth, oracle, ctx):
         assert_close(m2[k], mo[k], 1e-9, 1e-12, msg=k)
 
 
+def _check_stats(st, ref, N, M, D, rtol=1e-9, atol=1e-12):
+    o = 0
+    for key, n in (("xi_sum", N * N), ("gamma_sum", N), ("gamma0", N), ("mix", N * M), ("mix_x", N * M * D),
+                   ("mix_xx", N * M * D)):
+        assert_close(st[o:o + n], np.asarray(ref[key]).ravel(), rtol, atol, msg=key)
+        o += n
+    assert abs(st[o] - ref["loglik"]) <= 1e-9 * abs(ref["loglik"])
+
+
+def test_bw_statistics_extreme_range(oracle, ctx):
+    """A frame whose xi needs more than e^690 of dynamic range (a state hopeless given the past but forced by
+    the future) cannot be factored into exp(alpha - c) * exp(beta + c); the statistics kernels must notice
+    and take those frames through the exact log-domain path instead of dropping the term."""
+    with np.errstate(divide="ignore"):
+        A = np.log(np.array([[0.5, 0.5], [0.0, 1.0]]))
+        pi = np.log(np.array([0.5, 0.5]))
+        w = np.log(np.ones((2, 1)))
+    mu = np.array([[[0.0]], [[40.0]]])
+    var = np.ones((2, 1, 1))
+    # o_0 = 40 makes state 0 e^-800 less likely than state 1, but o_1 = 0 can only come from state 0,
+    # and state 1 is absorbing: the path 0 -> 0 carries a third of the mass
+    obs = [np.array([[40.0], [0.0], [0.1], [39.5], [40.2]]), np.array([[0.3], [40.0], [39.0]])]
+    ctx.upload_gmmhmm(A, pi, w, mu, var, diag=True)
+    T = 5
+    batch = np.zeros((2, T, 1))
+    lens = np.array([5, 3], dtype=np.int32)
+    for u, o in enumerate(obs):
+        batch[u, :len(o)] = o
+    st = ctx.bw_accumulate(batch, lens=lens)
+    with np.errstate(divide="ignore", invalid="ignore", under="ignore"):
+        ref = oracle.bw_stats_diag(obs, A, pi, w, mu, var)
+    assert ref["xi_sum"][0, 0] > 0.3                      # the term in question is not negligible
+    _check_stats(st, ref, 2, 1, 1)
+
+
+def test_bw_statistics_wide(synth, oracle, ctx):
+    """Shapes that exercise every tile path of the matrix-core statistics kernels: N not a multiple of 8 or
+    16, M = 17..32 (two mixture tiles), D = 39 (five feature tiles), ragged lengths, -inf weights."""
+    for N, M, D, U, T, seed in ((19, 20, 39, 3, 70, 1), (130, 3, 5, 2, 40, 2), (8, 32, 13, 4, 33, 3)):
+        mdl = synth.synth_model(N, M, D, seed=seed)
+        w = mdl["w"].copy()
+        w[1, 0] = -np.inf                                   # a dead component
+        w[1] -= oracle.lse(w[1])
+        obs = synth.synth_obs(U, T, D, seed=60 + seed)
+        lens = np.array([T, T // 2, 1, T - 3][:U], dtype=np.int32)
+        ctx.upload_gmmhmm(mdl["A"], mdl["pi"], w, mdl["mu"], mdl["var"], diag=True)
+        st = ctx.bw_accumulate(obs, lens=lens)
+        with np.errstate(divide="ignore", invalid="ignore", under="ignore"):
+            ref = oracle.bw_stats_diag([obs[u, :lens[u]] for u in range(U)], mdl["A"], mdl["pi"], w, mdl["mu"],
+                                       mdl["var"])
+        _check_stats(st, ref, N, M, D, 1e-9, 1e-11)
+        assert st[N * N + 2 * N + M] == 0.0                 # mix[1, 0]: exact zero stays exact
+
+
 def test_forward_backward_large_n(synth, oracle, ctx):
     """N > 128 (streaming kernels): alpha / beta / loglik / posteriors against the oracle, ragged batch."""
     rng = np.random.default_rng(17)
