@@ -16,6 +16,12 @@ __device__ __forceinline__ void st(TS* p, size_t i, double v) { p[i] = (TS)v; }
 template <typename TS>
 __device__ __forceinline__ double rnd(double v) { return (double)(TS)v; }
 
+// Drain the vector-memory counter.  Put after loop-invariant operands have been loaded into registers and before
+// a loop that prefetches: otherwise the compiler's wait-count model carries the preamble's loads into the loop
+// as "possibly outstanding" and guards every use of those registers with s_waitcnt vmcnt(n), n counting down to
+// 0 -- which, the counter being in-order, stalls on the loop's OWN freshly issued prefetch.
+__device__ __forceinline__ void drain_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }   // vmcnt(0) only
+
 // one-instruction max: the library fmax first canonicalises operands the compiler cannot prove quiet
 // (MFMA results, LDS / global loads), which doubles the instruction count of max chains
 __device__ __forceinline__ double vmax_f64(double a, double b) {

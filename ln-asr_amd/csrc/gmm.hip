@@ -307,6 +307,7 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 2))
 
     load_stage(tile0);
     store_stage(0);
+    drain_vmem();                                        // wr[][] resident: no vmcnt guards inside the loop
     __syncthreads();
 
     int cur = 0;
@@ -420,8 +421,10 @@ __global__ __launch_bounds__(256) void emit_single_mfma(const double* __restrict
     constexpr int MAXLD = (16 * ((KP - 1) / 2) + 63) / 64;     // loads per lane for one 16-frame tile
     __shared__ double Fl[4][KP * FS];
     __shared__ double etab[kExpTab];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    __shared__ double ltab[2 * kLogTab];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int e = tid; e < kExpTab; e += 256) etab[e] = exp2((double)e * (1.0 / kExpTab));
+    log_table_init(ltab, tid, 256);
     double* Fw = &Fl[w][0];
     for (int e = lane; e < (KP - 2 * D) * 16; e += 64) {
         const int k = 2 * D + e / 16;
@@ -438,44 +441,54 @@ __global__ __launch_bounds__(256) void emit_single_mfma(const double* __restrict
     for (int r = 0; r < 4; ++r) lw[r] = (g + 4 * r < M) ? logw[g + 4 * r] : 0.0;
 
     const int EL = 16 * D;
-    const int nld = (EL + 63) / 64;
     const long lim = F * (long)D;
+    // straight-line staging: every lane issues all MAXLD loads (index clamped) and all LDS writes (lanes past
+    // the tile write the unused padding column 16) -- branches here would make the compiler drain the memory
+    // counter between consecutive loads
     int foff[MAXLD];
 #pragma unroll
     for (int r = 0; r < MAXLD; ++r) {
         const int e = lane + r * 64;
         const int f = e / D, d = e - f * D;
-        foff[r] = e < EL ? d * FS + f : -1;
+        foff[r] = e < EL ? d * FS + f : (lane & 15) * FS + 16;
     }
     double pre[MAXLD];
+    // buffer loads: the tile's base address and the bytes left in obs are wave-uniform (SGPRs), the lane offset
+    // is one 32-bit VGPR, and reads past the end of obs return 0 without any per-lane clamping
     auto load_tile = [&](long tile) {
-        const long base = tile * 16 * (long)D;
+        const long e0 = tile * 16 * (long)D;
+        long left = (lim - e0) * 8;
+        left = left < 0 ? 0 : (left > 0x7FFFFFFFL ? 0x7FFFFFFFL : left);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(obs + e0), 0, (int)left, 0x00020000);
 #pragma unroll
         for (int r = 0; r < MAXLD; ++r)
-            if (r < nld) {
-                long ge = base + lane + r * 64;
-                ge = ge < lim ? ge : lim - 1;
-                pre[r] = obs[ge];
-            }
+            pre[r] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, lane * 8 + r * 512, 0, 0));
     };
     const long wid = (long)blockIdx.x * 4 + w, nw = (long)gridDim.x * 4;
     long tile = wid;
-    if (tile < ntiles) load_tile(tile);
+    drain_vmem();                              // wr[] resident: no vmcnt guards inside the loop
+    load_tile(tile);
     for (; tile < ntiles; tile += nw) {
         const int xo = D * FS;
 #pragma unroll
-        for (int r = 0; r < MAXLD; ++r)
-            if (r < nld && foff[r] >= 0) {
-                const double x = pre[r];
-                Fw[foff[r]] = x * x;
-                Fw[foff[r] + xo] = x;
-            }
-        if (tile + nw < ntiles) load_tile(tile + nw);
+        for (int r = 0; r < MAXLD; ++r) {
+            const double x = pre[r];
+            Fw[foff[r]] = x * x;
+            Fw[foff[r] + xo] = x;
+        }
+        load_tile(tile + nw);
         __builtin_amdgcn_wave_barrier();       // wave-private tile: ordering within the wave is enough
         double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
+        // all B fragments are requested up front (the compiler would otherwise re-use one register pair and
+        // expose an LDS round trip in front of every second MFMA of the dependent chain)
+        double bf[KS];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wr[ks], Fw[(4 * ks + g) * FS + fr], acc, 0, 0, 0);
+        for (int ks = 0; ks < KS; ++ks) bf[ks] = Fw[(4 * ks + g) * FS + fr];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wr[ks], bf[ks], acc, 0, 0, 0);
+        }
         __builtin_amdgcn_wave_barrier();
         const long frame = tile * 16 + fr;
         if (WRITE_BM && frame < F) {
@@ -494,7 +507,7 @@ __global__ __launch_bounds__(256) void emit_single_mfma(const double* __restrict
         for (int r = 0; r < 4; ++r) sacc += exp_nonpos(c[r] - mx, etab);
         sacc += shfl_xor_f64(sacc, 16);
         sacc += shfl_xor_f64(sacc, 32);
-        if (g == 0 && frame < F) b[frame] = (mx == LN_NEG_INF) ? mx : mx + log(sacc);
+        if (g == 0 && frame < F) b[frame] = (mx == LN_NEG_INF) ? mx : mx + log_sum(sacc, ltab);
     }
 }
 
@@ -841,7 +854,8 @@ int emit_device(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, v
         const long ntiles = (F + 15) / 16;
         const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
         long grid = (ntiles + 3) / 4;
-        if (grid > (long)cus * 4) grid = (long)cus * 4;      // 16 waves per CU, grid-stride over tiles
+        // grid-stride over tiles; two 4-wave blocks per CU measured faster than three (LDS allows three) or four
+        if (grid > (long)cus * 2) grid = (long)cus * 2;
 #define LN_SCASE(ks)                                                                                              \
     if (md.wsingle_KS == ks) {                                                                                    \
         if (bm)                                                                                                   \

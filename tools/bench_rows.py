@@ -106,4 +106,4 @@ if what & {"full", "all"}:
     b = ctx.empty((U, T, N), np.float64)
     lib = _ffi.lib()
     timed("gmm log-likelihood FULL cov N=128", lambda: _ffi.check(lib.lnasr_gmm_logprob(ctx.handle, obs.ptr, U, T, None, 0, b.ptr, None)),
-          U * T, "frames", reps=2, algo_flop=U * T * 2.0 * N * M * D * D)
+          U * T, "frames", reps=2, algo_flop=U * T * 2.0 * N * M * (D * (D + 1) / 2 + D + 1))
