@@ -1,0 +1,18 @@
+#!/bin/bash
+# Runs on the GPU box (through gpurun): the driver-facing bench, then the rocprofv3 passes whose summaries
+# tools/prof_summary.py condenses into profiles/<tag>_*.  Counters are collected in their own passes.
+#   gpurun -- 'bash tools/profile_round.sh r01d'
+set -e
+tag=$1
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out
+mkdir -p $O
+cd /tmp
+export TMPDIR=/tmp
+python3 $R/bench.py --steps 20 --warmup 3 > $O/bench_$tag.json 2> $O/bench_$tag.err
+tail -c 600 $O/bench_$tag.json
+rm -rf $O/prof_${tag}_trace $O/prof_${tag}_fetch $O/prof_${tag}_write
+rocprofv3 --kernel-trace --stats -f csv -d $O/prof_${tag}_trace -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/prof_${tag}_trace.json 2> $O/prof_${tag}_trace.err
+rocprofv3 --pmc FETCH_SIZE -f csv -d $O/prof_${tag}_fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/prof_${tag}_fetch.err
+rocprofv3 --pmc WRITE_SIZE -f csv -d $O/prof_${tag}_write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/prof_${tag}_write.err
+echo done
