@@ -91,6 +91,11 @@ struct lnasr_ctx {
     lnasr::DevBuf ws_out, ws_out2, ws_out3;                // staged outputs
     lnasr::DevBuf ws_b, ws_bm, ws_v, ws_alpha, ws_beta, ws_misc, ws_misc2, ws_lens, ws_stats;
     lnasr::DevBuf ws_p, ws_q, ws_raw;                      // Baum-Welch statistics: xi factors, raw mixture moments
+    // MFCC constants (twiddles, DCT matrix), kept on the device between calls with the same fft_n / n_mel;
+    // the per-call frame offsets live here too so that the asynchronous upload never reads a dead host buffer
+    lnasr::DevBuf mfcc_const;
+    int mfcc_nfft = 0, mfcc_nmel = 0;
+    std::vector<int64_t> mfcc_foff;
     // profiling
     bool prof_on = false;
     std::vector<std::string> prof_names;

@@ -54,6 +54,42 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// wave64 max of a double through DPP (no LDS crossbar): quad_perm, half-mirror and mirror steps
+// leave every lane of a 16-lane row with the row's max; the four row results are then read as
+// scalars.  ctrl codes: quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_half_mirror = 0x141,
+// row_mirror = 0x140.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double x, int lane) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_max_dpp(double x) {
+    x = vmax_f64(x, dpp_f64<0xB1>(x));
+    x = vmax_f64(x, dpp_f64<0x4E>(x));
+    x = vmax_f64(x, dpp_f64<0x141>(x));
+    x = vmax_f64(x, dpp_f64<0x140>(x));
+    const double r0 = readlane_f64(x, 0), r1 = readlane_f64(x, 16), r2 = readlane_f64(x, 32),
+                 r3 = readlane_f64(x, 48);
+    return vmax_f64(vmax_f64(r0, r1), vmax_f64(r2, r3));
+}
+// same walk with additions (association: quads, rows of 16, then the four rows)
+__device__ __forceinline__ double wave_sum_dpp(double x) {
+    x += dpp_f64<0xB1>(x);
+    x += dpp_f64<0x4E>(x);
+    x += dpp_f64<0x141>(x);
+    x += dpp_f64<0x140>(x);
+    const double r0 = readlane_f64(x, 0), r1 = readlane_f64(x, 16), r2 = readlane_f64(x, 32),
+                 r3 = readlane_f64(x, 48);
+    return (r0 + r1) + (r2 + r3);
+}
+
 // (value, index) arg-max with numpy.argmax semantics: first index among equal maxima.
 __device__ __forceinline__ void argmax_combine(double& v, int& i, double ov, int oi) {
     if (ov > v || (ov == v && oi < i)) {

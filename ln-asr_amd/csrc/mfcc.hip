@@ -8,6 +8,8 @@
 //   dct_kernel          per frame: DCT-II of the mean-normalised log-mel row
 //   feat_kernel         per frame: second mean norm (applied to the returned cepstrum as well, as the
 //                       reference does through a view, mfcc.py:155-156), energy, delta, delta-delta
+#include <algorithm>
+
 #include "common.h"
 #include "devmath.h"
 
@@ -151,10 +153,67 @@ __device__ __forceinline__ void radix4(cplx v[4]) {
     v[3] = csub(t1, t3);
 }
 
+constexpr int kMfccWaves = 12;           // waves per block of the fft-512 frame kernel (they share ~35 KB of tables)
+
+template <typename T>
+__device__ __forceinline__ const T* uniform_ptr(const T* p) {
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (const T*)(((uint64_t)hi << 32) | lo);
+}
+
+// raw samples x[i-1], x[i], x[i+1] for the four point pairs of a lane
+struct RawFrame {
+    double xm[4], x0[4], x1[4];
+    int64_t base, n;
+};
+
+// Buffer loads: the frame's base address and the bytes left in the utterance are wave-uniform (SGPRs), one
+// VGPR holds the lane offset, the four pair offsets are immediates, and reads past the end of the utterance
+// return 0 without per-lane clamping.  x[i-1] uses a second descriptor starting one sample earlier (at the
+// utterance start, where there is no earlier sample, the first read goes out of range and returns 0).
 template <typename SAMPLE>
-__global__ __launch_bounds__(256) void mfcc_frame512_kernel(
+__device__ __forceinline__ void fetch_frame(const SAMPLE* __restrict__ x, int64_t n, int64_t base, int lane,
+                                            RawFrame& rw) {
+    constexpr int SZ = sizeof(SAMPLE);
+    rw.base = base;
+    rw.n = n;
+    int64_t left = (n - base) * SZ;
+    left = left < 0 ? 0 : (left > 0x7FFFFFF0L ? 0x7FFFFFF0L : left);
+    const int64_t back = base > 0 ? 1 : 0;
+    // everything in the descriptors is wave-uniform; say so, or the loads are wrapped in waterfall loops
+    const __amdgpu_buffer_rsrc_t ra =
+        __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(x + base), 0, __builtin_amdgcn_readfirstlane((int)left), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)uniform_ptr(x + base - back), 0, __builtin_amdgcn_readfirstlane((int)(left + back * SZ)), 0x00020000);
+    const int vo = lane * 2 * SZ;
+    // x[i-1]: at base == 0 descriptor rb starts at x[0] and the offsets move back by one sample; the one
+    // sample that does not exist (x[-1], never used: y[0] = x[0]) is clamped onto x[0] so no offset is negative
+    const int adj = back ? 0 : SZ;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        int vb = vo + (r * 128 * SZ - adj);
+        if (r == 0) vb = vb < 0 ? 0 : vb;
+        if constexpr (SZ == 8) {
+            typedef unsigned u4 __attribute__((ext_vector_type(4)));
+            const u4 q = __builtin_amdgcn_raw_buffer_load_b128(ra, vo + r * 128 * SZ, 0, 0);
+            rw.x0[r] = __hiloint2double((int)q[1], (int)q[0]);
+            rw.x1[r] = __hiloint2double((int)q[3], (int)q[2]);
+            rw.xm[r] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rb, vb, 0, 0));
+        } else {
+            // two 16-bit loads, not one dword: the range check is per load, and a dword holding the last sample
+            // of an odd-length utterance would be rejected whole
+            rw.x0[r] = (double)(short)__builtin_amdgcn_raw_buffer_load_b16(ra, vo + r * 128 * SZ, 0, 0);
+            rw.x1[r] = (double)(short)__builtin_amdgcn_raw_buffer_load_b16(ra, vo + r * 128 * SZ + SZ, 0, 0);
+            rw.xm[r] = (double)(short)__builtin_amdgcn_raw_buffer_load_b16(rb, vb, 0, 0);
+        }
+    }
+}
+
+template <typename SAMPLE>
+__global__ __launch_bounds__(64 * kMfccWaves) __attribute__((amdgpu_waves_per_eu(3, 3))) void mfcc_frame512_kernel(
     const SAMPLE* __restrict__ signal, const int64_t* __restrict__ soff, const int64_t* __restrict__ foff, int U,
-    int64_t F, int L, int S, int n_mel, double alpha, const double* __restrict__ window,
+    int64_t F, int L, int S, int n_mel, int n_out, double alpha, const double* __restrict__ window,
     const double* __restrict__ fbank, const int* __restrict__ mel_range, const double* __restrict__ tw512,
     const double* __restrict__ dctC, double* __restrict__ power_out, double* __restrict__ cepraw,
     double* __restrict__ energy) {
@@ -164,65 +223,88 @@ __global__ __launch_bounds__(256) void mfcc_frame512_kernel(
     __shared__ double taps[MAXTAP];                // non-zero filter taps, filter after filter
     __shared__ double Ct[MAXMEL * MAXMEL];         // DCT matrix, transposed: Ct[m][k] = C[k][m]
     __shared__ int tap_off[MAXMEL + 1];
-    __shared__ double bufs[4][2 * NC];             // per wave: FFT buffer (re, im interleaved), then power | log-mel
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    for (int e = tid; e < 2 * NC; e += 256) {
+    __shared__ int asg[4 * 64];                    // mel work split: per lane (filter, first tap, count, chain)
+    __shared__ int asg_cmax;
+    // per wave: FFT buffer (re, im interleaved; padding against bank conflicts was measured: no gain), then
+    // power | log-mel
+    __shared__ double bufs[kMfccWaves][2 * NC];
+    constexpr int NT = 64 * kMfccWaves;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int e = tid; e < 2 * NC; e += NT) {
         tws[e] = tw512[e];
         wins[e] = e < L ? window[e] : 0.0;
     }
-    for (int e = tid; e < n_mel * n_mel; e += 256) Ct[(e % n_mel) * n_mel + e / n_mel] = dctC[e];
+    for (int e = tid; e < n_mel * n_mel; e += NT) Ct[(e % n_mel) * n_mel + e / n_mel] = dctC[e];
     if (tid < n_mel) tap_off[tid + 1] = mel_range[2 * tid + 1] - mel_range[2 * tid];
     __syncthreads();
-    if (tid == 0) {                                // exclusive prefix of the tap counts, in LDS
-        int o = 0;
+    if (tid == 0) {
+        // exclusive prefix of the tap counts, then the lane assignment of the mel phase: a filter of cnt taps
+        // gets ceil(cnt / C) consecutive lanes (at most 3), C the smallest chunk for which 64 lanes suffice.
+        // C = 0 (keep one filter per lane) when that is impossible.
+        int o = 0, cmx = 0;
         for (int m = 0; m < n_mel; ++m) {
             const int c = tap_off[m + 1];
             tap_off[m] = o;
             o += c;
+            cmx = c > cmx ? c : cmx;
         }
         tap_off[n_mel] = o;
+        int C = (cmx + 2) / 3;
+        if (C < 1) C = 1;
+        for (;; ++C) {
+            int need = 0;
+            for (int m = 0; m < n_mel; ++m) {
+                const int c = tap_off[m + 1] - tap_off[m];
+                need += c > 0 ? (c + C - 1) / C : 1;
+            }
+            if (need <= 64) break;
+        }
+        int ln = 0;
+        for (int m = 0; m < n_mel; ++m) {
+            const int c = tap_off[m + 1] - tap_off[m];
+            const int parts = c > 0 ? (c + C - 1) / C : 1;
+            for (int q = 0; q < parts; ++q, ++ln) {
+                const int i0 = q * C, cnt = (c - i0) < C ? (c - i0) : C;
+                asg[4 * ln] = m;
+                asg[4 * ln + 1] = i0;
+                asg[4 * ln + 2] = cnt > 0 ? cnt : 0;
+                asg[4 * ln + 3] = (q == 0 ? 1 : 0) | ((q == 0 && parts > 1) ? 2 : 0) | ((q == 0 && parts > 2) ? 4 : 0);
+            }
+        }
+        for (; ln < 64; ++ln) asg[4 * ln] = -1, asg[4 * ln + 1] = 0, asg[4 * ln + 2] = 0, asg[4 * ln + 3] = 0;
+        asg_cmax = C;
     }
     __syncthreads();
     const bool taps_in_lds = tap_off[n_mel] <= MAXTAP;
     if (taps_in_lds)
-        for (int m = w; m < n_mel; m += 4) {
+        for (int m = w; m < n_mel; m += kMfccWaves) {
             const int lo = mel_range[2 * m], cnt = mel_range[2 * m + 1] - lo;
             for (int e = lane; e < cnt; e += 64) taps[tap_off[m] + e] = fbank[(size_t)m * NBIN + lo + e];
         }
     __syncthreads();                               // last block-level barrier: waves are independent from here
-    // raw samples of one frame, fetched one iteration ahead so that HBM latency hides behind the FFT
-    struct Raw {
-        double xm[4], x0[4], x1[4];
-        int64_t base, n;
-    };
-    const int64_t stride = (int64_t)gridDim.x * 4;
-    int64_t f = (int64_t)blockIdx.x * 4 + w;
+    // this lane's share of the mel phase (constant over frames)
+    const int my_m = asg[4 * lane], my_i0 = asg[4 * lane + 1], my_cnt = asg[4 * lane + 2], my_flags = asg[4 * lane + 3];
+    const int cmax = asg_cmax;
+    const int my_lo = my_m >= 0 ? mel_range[2 * my_m] + my_i0 : 0;
+    const double* my_tp = taps + (my_m >= 0 ? tap_off[my_m] + my_i0 : 0);
+    const double* my_fb = fbank + (size_t)(my_m >= 0 ? my_m : 0) * NBIN + my_lo;
+    // DCT split: n_out <= 16 outputs x 4 quarter-sums fill the wave; otherwise one output per lane
+    const bool dct_split = n_out * 4 <= 64;
+    const int dq = (n_mel + 3) / 4;
+
+    const int64_t stride = (int64_t)gridDim.x * kMfccWaves;
+    int64_t f = (int64_t)blockIdx.x * kMfccWaves + w;
     if (f >= F) return;
     int u = find_utt(foff, U, f);
-    auto fetch = [&](int64_t ff, Raw& rw) {
+    RawFrame cur;
+    auto fetch = [&](int64_t ff) {
         while (foff[u + 1] <= ff) ++u;             // frames visited by a wave are increasing
-        const SAMPLE* x = signal + soff[u];
-        rw.n = soff[u + 1] - soff[u];
-        rw.base = (ff - foff[u]) * S;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int64_t i0 = rw.base + 2 * (lane + 64 * r);
-            const int64_t last = rw.n - 1;
-            const int64_t im = i0 - 1 < 0 ? 0 : (i0 - 1 > last ? last : i0 - 1);
-            const int64_t ia = i0 > last ? last : i0, ib = i0 + 1 > last ? last : i0 + 1;
-            rw.xm[r] = sample_at(x, im);           // clamped addresses: loads are unconditional
-            rw.x0[r] = sample_at(x, ia);
-            rw.x1[r] = sample_at(x, ib);
-        }
+        fetch_frame(signal + soff[u], soff[u + 1] - soff[u], (ff - foff[u]) * S, lane, cur);
     };
-    Raw cur;
-    fetch(f, cur);
+    fetch(f);
     double* A = &bufs[w][0];
     double* lm = A + 320;                          // log-mel row: beyond the 257 power bins
     for (; f < F; f += stride) {
-    Raw nxt = cur;
-    if (f + stride < F) fetch(f + stride, nxt);
-
     // stage 0 (Ns = 1): v[r] = z[lane + 64 r] = (y[2n], y[2n+1]) * window, y = pre-emphasised signal
     cplx v[4];
 #pragma unroll
@@ -266,71 +348,108 @@ __global__ __launch_bounds__(256) void mfcc_frame512_kernel(
         const int j0 = (lane / Ns) * Ns * 4 + k;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            A[2 * (j0 + r * Ns)] = v[r].re;
-            A[2 * (j0 + r * Ns) + 1] = v[r].im;
+            const int dst = j0 + r * Ns;
+            A[2 * dst] = v[r].re;
+            A[2 * dst + 1] = v[r].im;
         }
         __builtin_amdgcn_wave_barrier();
     }
     // Z = A[0..255]; X[k] for k = 0..256; power |X|^2 / 512 (mfcc.py:141-142)
-    double pk[5];
+    double pk[4];
 #pragma unroll
-    for (int q = 0; q < 5; ++q) {
+    for (int q = 0; q < 4; ++q) {
         const int k = lane + 64 * q;
-        pk[q] = 0.0;
-        if (k < NBIN) {
-            const int ka = k & (NC - 1), kb = (NC - k) & (NC - 1);
-            const cplx zk = {A[2 * ka], A[2 * ka + 1]};
-            const cplx zc = {A[2 * kb], -A[2 * kb + 1]};
-            const cplx e = {0.5 * (zk.re + zc.re), 0.5 * (zk.im + zc.im)};
-            const cplx d = csub(zk, zc);
-            const cplx o = {0.5 * d.im, -0.5 * d.re};                // -(i/2) (zk - zc)
-            const cplx tw = k < NC ? cplx{tws[2 * k], tws[2 * k + 1]} : cplx{-1.0, 0.0};
-            const cplx xk = cadd(e, cmul(o, tw));
-            // |X|^2 directly (the reference squares np.abs: same value to an ulp, a fraction of the instructions)
-            pk[q] = (1.0 / 512.0) * fma(xk.re, xk.re, xk.im * xk.im);
-        }
+        const int kb = (NC - k) & (NC - 1);
+        const cplx zk = {A[2 * k], A[2 * k + 1]};
+        const cplx zc = {A[2 * kb], -A[2 * kb + 1]};
+        const cplx e = {0.5 * (zk.re + zc.re), 0.5 * (zk.im + zc.im)};
+        const cplx d = csub(zk, zc);
+        const cplx o = {0.5 * d.im, -0.5 * d.re};                    // -(i/2) (zk - zc)
+        const cplx tw = {tws[2 * k], tws[2 * k + 1]};
+        const cplx xk = cadd(e, cmul(o, tw));
+        // |X|^2 directly (the reference squares np.abs: same value to an ulp, a fraction of the instructions)
+        pk[q] = (1.0 / 512.0) * fma(xk.re, xk.re, xk.im * xk.im);
     }
+    // bin 256 (Nyquist): X = Re Z0 - Im Z0, the value the general expression gives with tw = -1
+    const double xn = A[0] - A[1];
     __builtin_amdgcn_wave_barrier();
     double* pw = A;                                // the FFT buffer is dead: reuse it for the power spectrum
     double esum = 0.0;
 #pragma unroll
-    for (int q = 0; q < 5; ++q) {
+    for (int q = 0; q < 4; ++q) {
         const int k = lane + 64 * q;
-        if (k < NBIN) {
-            pw[k] = pk[q];
-            esum += pk[q];
-            if (power_out) power_out[f * NBIN + k] = pk[q];
-        }
+        pw[k] = pk[q];
+        esum += pk[q];
+        if (power_out) power_out[f * NBIN + k] = pk[q];
     }
-    esum = wave_sum(esum);
+    if (lane == 0) {
+        const double pn = (1.0 / 512.0) * (xn * xn);
+        pw[NC] = pn;
+        esum += pn;
+        if (power_out) power_out[f * NBIN + NC] = pn;
+    }
+    esum = wave_sum_dpp(esum);
     if (lane == 0) energy[f] = log(esum);                               // mfcc.py:158-160
     __builtin_amdgcn_wave_barrier();
-    for (int m = lane; m < n_mel; m += 64) {
-        const int lo = mel_range[2 * m], hi = mel_range[2 * m + 1];
+    // Request the wave's next frame here, not right after stage 0: the FFT is the register-hungry phase, and
+    // values prefetched across it get spilled -- which forces the loads to complete on the spot.  The mel and
+    // DCT phases are long enough to cover the latency and need few registers.
+    if (f + stride < F) fetch(f + stride);
+    if (cmax > 0) {
+        // mel filter bank (mfcc.py:148): every lane sums its chunk of one filter's taps; a filter's two or
+        // three partial sums are added in the lane of its first chunk
         double s = 0.0;
+        const double* pp = pw + my_lo;
+        // branch-free: past the lane's count the index falls back to 0 and the tap to 0.0
         if (taps_in_lds) {
-            const double* tp = taps + tap_off[m] - lo;
 #pragma unroll 4
-            for (int k = lo; k < hi; ++k) s += pw[k] * tp[k];           // mfcc.py:148
+            for (int i = 0; i < cmax; ++i) {
+                const bool in = i < my_cnt;
+                const int ii = in ? i : 0;
+                s = fma(pp[ii], in ? my_tp[ii] : 0.0, s);
+            }
         } else {
-            const double* fb = fbank + (size_t)m * NBIN;
-            for (int k = lo; k < hi; ++k) s += pw[k] * fb[k];
+            for (int i = 0; i < cmax; ++i) {
+                const bool in = i < my_cnt;
+                const int ii = in ? i : 0;
+                s = fma(pp[ii], in ? my_fb[ii] : 0.0, s);
+            }
         }
-        if (s == 0.0) s = 2.220446049250313e-16;                         // mfcc.py:149
-        lm[m] = 20.0 * log10(s);                                         // mfcc.py:150
+        const double s1 = shfl_f64(s, (lane + 1) & 63), s2 = shfl_f64(s, (lane + 2) & 63);
+        if (my_flags & 2) s += s1;
+        if (my_flags & 4) s += s2;
+        if (my_flags & 1) {
+            if (s == 0.0) s = 2.220446049250313e-16;                     // mfcc.py:149
+            lm[my_m] = 20.0 * log10(s);                                  // mfcc.py:150
+        }
     }
     __builtin_amdgcn_wave_barrier();
     // DCT-II (ortho) of the RAW log-mel row.  The reference subtracts the utterance mean first
     // (mfcc.py:151-152); the DCT is linear, so that subtraction is applied to the transformed
     // row by feat_kernel and the frame kernel needs no utterance-level quantity.
-    for (int k = lane; k < n_mel; k += 64) {
+    if (dct_split) {
+        const int k = lane >> 2, part = lane & 3;
+        const int m0 = part * dq, m1 = (m0 + dq) < n_mel ? (m0 + dq) : n_mel;
         double s = 0.0;
-#pragma unroll 4
-        for (int m = 0; m < n_mel; ++m) s += lm[m] * Ct[m * n_mel + k];
-        cepraw[f * n_mel + k] = s;
+        if (k < n_out)
+            for (int m = m0; m < m1; ++m) s = fma(lm[m], Ct[m * n_mel + k], s);
+        s += dpp_f64<0xB1>(s);                     // quad_perm [1,0,3,2], then [2,3,0,1]: (q0 + q1) + (q2 + q3)
+        s += dpp_f64<0x4E>(s);
+        if (part == 0 && k < n_out) cepraw[f * n_mel + k] = s;
+    } else {
+        // same association as the split form (four quarter sums, pairwise) so both give identical bits
+        for (int k = lane; k < n_out; k += 64) {
+            double q[4];
+#pragma unroll
+            for (int part = 0; part < 4; ++part) {
+                const int m0 = part * dq, m1 = (m0 + dq) < n_mel ? (m0 + dq) : n_mel;
+                q[part] = 0.0;
+                for (int m = m0; m < m1; ++m) q[part] = fma(lm[m], Ct[m * n_mel + k], q[part]);
+            }
+            cepraw[f * n_mel + k] = (q[0] + q[1]) + (q[2] + q[3]);
+        }
     }
     __builtin_amdgcn_wave_barrier();               // the next frame overwrites this wave's buffer
-    cur = nxt;
     }
 }
 
@@ -378,15 +497,17 @@ __global__ void dct_kernel(const double* __restrict__ logmel, const int64_t* __r
 //       too: columns 1..nc lose mean_f(cep[:,k]) + 1e-8, and mean_f(cep[:,k]) is zero by construction
 //   features: [cep[:,1..nc], log-energy], delta (row 0 = features[1]), delta-delta (mfcc.py:158-172)
 __global__ void feat_kernel(const double* __restrict__ cepraw, const double* __restrict__ M,
-                            const double* __restrict__ energy, const int64_t* __restrict__ foff, int U, int64_t F,
-                            int n_mel, int nc, double* __restrict__ cep_out, double* __restrict__ feat) {
+                            const double* __restrict__ energy, const int64_t* __restrict__ foff, int n_mel, int nc,
+                            int ncols, double* __restrict__ cep_out, double* __restrict__ feat) {
+    // grid.y = utterance (no search for the frame's utterance); ncols = n_mel when the cepstrum is returned,
+    // nc + 1 (the feature columns) otherwise
     const int W = nc + 1;
+    const int u = blockIdx.y;
+    const int64_t f0 = foff[u], f1 = foff[u + 1];
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= F * n_mel) return;
-    const int64_t f = idx / n_mel;
-    const int k = (int)(idx % n_mel);
-    const int u = find_utt(foff, U, f);
-    const int64_t f0 = foff[u];
+    const int64_t f = f0 + idx / ncols;
+    const int k = (int)(idx % ncols);
+    if (f >= f1) return;
     const double* Mu = M + (size_t)u * n_mel;
     const double shift0 = 1e-8 * sqrt((double)n_mel);
     auto cepv = [&](int64_t ff, int kk) -> double {
@@ -395,7 +516,7 @@ __global__ void feat_kernel(const double* __restrict__ cepraw, const double* __r
         if (kk >= 1 && kk <= nc) v -= 1e-8;
         return v;
     };
-    if (cep_out) cep_out[idx] = cepv(f, k);
+    if (cep_out) cep_out[f * n_mel + k] = cepv(f, k);
     if (k >= W) return;
     const int c = k;                            // feature column
     auto base = [&](int64_t ff) -> double { return c < nc ? cepv(ff, 1 + c) : energy[ff]; };
@@ -485,7 +606,8 @@ int lnasr_mfcc(lnasr_ctx* ctx, const void* signal, int sample_kind, const int64_
     LN_REQUIRE(n_mel >= 1 && n_mel <= 256 && nc >= 1 && nc + 1 <= n_mel, "bad n_mel=%d / n_cep=%d", n_mel, nc);
     LN_REQUIRE(!is_device_ptr(offsets), "offsets must be a host array");
     const int nbin = NFFT / 2 + 1, W = nc + 1;
-    std::vector<int64_t> foff(U + 1, 0);
+    std::vector<int64_t>& foff = ctx->mfcc_foff;
+    foff.assign(U + 1, 0);
     for (int u = 0; u < U; ++u) {
         const int64_t n = offsets[u + 1] - offsets[u];
         LN_REQUIRE(n >= 1, "utterance %d is empty", u);
@@ -501,31 +623,41 @@ int lnasr_mfcc(lnasr_ctx* ctx, const void* signal, int sample_kind, const int64_
     LN_TRY(stage_in(ctx, signal, (size_t)NS * ssz, ctx->ws_in, &d_sig));
     LN_TRY(stage_in(ctx, window, (size_t)L * 8, ctx->ws_in2, &d_win));
     LN_TRY(stage_in(ctx, fbank, (size_t)n_mel * nbin * 8, ctx->ws_in3, &d_fb));
-    // constants: sample offsets, frame offsets, twiddles, DCT matrix
-    std::vector<double> tw(NFFT), C((size_t)n_mel * n_mel);
-    for (int k = 0; k < NFFT / 2; ++k) {
-        const double a = 2.0 * M_PI * (double)k / (double)NFFT;
-        tw[2 * k] = cos(a);
-        tw[2 * k + 1] = -sin(a);
-    }
-    for (int k = 0; k < n_mel; ++k)
-        for (int m = 0; m < n_mel; ++m) {
-            // scipy.fftpack.dct(type=2, norm='ortho'): y_k = f_k * 2 sum_m x_m cos(pi k (2m+1) / (2N)),
-            // f_0 = sqrt(1/(4N)), f_k = sqrt(1/(2N))
-            const double f = k == 0 ? sqrt(1.0 / (4.0 * n_mel)) : sqrt(1.0 / (2.0 * n_mel));
-            C[(size_t)k * n_mel + m] = 2.0 * f * cos(M_PI * (double)k * (2.0 * m + 1.0) / (2.0 * n_mel));
+    // constants that depend on (fft_n, n_mel) only: twiddles and the DCT matrix, built once and kept on the device
+    const size_t nC = (size_t)n_mel * n_mel;
+    if (ctx->mfcc_nfft != NFFT || ctx->mfcc_nmel != n_mel) {
+        std::vector<double> cst(NFFT + nC);
+        for (int k = 0; k < NFFT / 2; ++k) {
+            const double a = 2.0 * M_PI * (double)k / (double)NFFT;
+            cst[2 * k] = cos(a);
+            cst[2 * k + 1] = -sin(a);
         }
-    const size_t cbytes = (size_t)(2 * (U + 1)) * 8 + (size_t)NFFT * 8 + C.size() * 8 + (size_t)2 * n_mel * 4;
+        for (int k = 0; k < n_mel; ++k)
+            for (int m = 0; m < n_mel; ++m) {
+                // scipy.fftpack.dct(type=2, norm='ortho'): y_k = f_k * 2 sum_m x_m cos(pi k (2m+1) / (2N)),
+                // f_0 = sqrt(1/(4N)), f_k = sqrt(1/(2N))
+                const double f = k == 0 ? sqrt(1.0 / (4.0 * n_mel)) : sqrt(1.0 / (2.0 * n_mel));
+                cst[NFFT + (size_t)k * n_mel + m] = 2.0 * f * cos(M_PI * (double)k * (2.0 * m + 1.0) / (2.0 * n_mel));
+            }
+        LN_TRY(ctx->mfcc_const.reserve(cst.size() * 8));
+        LN_HIP(hipMemcpyAsync(ctx->mfcc_const.p, cst.data(), cst.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        LN_HIP(hipStreamSynchronize(ctx->stream));           // cst goes out of scope
+        ctx->mfcc_nfft = NFFT;
+        ctx->mfcc_nmel = n_mel;
+    }
+    double* d_tw = ctx->mfcc_const.as<double>();
+    double* d_C = d_tw + NFFT;
+    // per call: sample offsets, frame offsets, mel ranges
+    const size_t cbytes = (size_t)(2 * (U + 1)) * 8 + (size_t)2 * n_mel * 4;
     LN_TRY(ctx->ws_in4.reserve(cbytes));
     int64_t* d_soff = ctx->ws_in4.as<int64_t>();
     int64_t* d_foff = d_soff + (U + 1);
-    double* d_tw = reinterpret_cast<double*>(d_foff + (U + 1));
-    double* d_C = d_tw + NFFT;
-    int* d_range = reinterpret_cast<int*>(d_C + C.size());
+    int* d_range = reinterpret_cast<int*>(d_foff + (U + 1));
     LN_HIP(hipMemcpyAsync(d_soff, offsets, (size_t)(U + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     LN_HIP(hipMemcpyAsync(d_foff, foff.data(), (size_t)(U + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    LN_HIP(hipMemcpyAsync(d_tw, tw.data(), (size_t)NFFT * 8, hipMemcpyHostToDevice, ctx->stream));
-    LN_HIP(hipMemcpyAsync(d_C, C.data(), C.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    // `offsets` belongs to the caller and `foff` is rewritten by the next call: both uploads are over before any
+    // kernel is queued (the kernels themselves stay asynchronous, like every other entry point)
+    LN_HIP(hipStreamSynchronize(ctx->stream));
     // workspaces: logmel [F,n_mel], cep [F,n_mel], energy [F], mean1 [U,n_mel], mean2 [U,nc]
     LN_TRY(ctx->ws_misc.reserve(((size_t)F * n_mel * 2 + F + (size_t)U * n_mel + (size_t)U * nc) * 8));
     double* logmel = ctx->ws_misc.as<double>();
@@ -543,19 +675,29 @@ int lnasr_mfcc(lnasr_ctx* ctx, const void* signal, int sample_kind, const int64_
     const size_t shm = (size_t)(2 * NFFT + nbin + 32) * 8;
     const int nt = NFFT / 2 < 256 ? (NFFT / 2 < 64 ? 64 : NFFT / 2) : 256;
     bool fused_dct = false;
+    const int n_out = cepstrum_or_null ? n_mel : W;   // cepstral columns the frame kernel has to produce
     if (NFFT == 512 && L <= 512 && n_mel <= 48 && !getenv("LNASR_NO_FFT512")) {
-        // persistent waves (4 blocks of 4 waves per CU), each walking frames with a grid stride
+        // persistent waves, each walking frames with a grid stride
         const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
-        int64_t want = (F + 3) / 4;
-        if (want > (int64_t)cus * 4) want = (int64_t)cus * 4;
+        int64_t want = (F + kMfccWaves - 1) / kMfccWaves;
+        static int bpc_cache[2] = {0, 0};             // resident blocks per CU: the whole grid runs in one round
+        int& bpc = bpc_cache[sample_kind];
+        if (bpc == 0) {                               // (the occupancy query costs ~2 ms: once per process)
+            if (sample_kind == 1)
+                LN_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, mfcc_frame512_kernel<int16_t>, 64 * kMfccWaves, 0));
+            else
+                LN_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, mfcc_frame512_kernel<double>, 64 * kMfccWaves, 0));
+        }
+        if (bpc < 1) bpc = 1;
+        if (want > (int64_t)cus * bpc) want = (int64_t)cus * bpc;
         const unsigned grid = (unsigned)want;
         if (sample_kind == 1)
-            LN_LAUNCH(ctx, "mfcc_frame512_i16", mfcc_frame512_kernel<int16_t>, dim3(grid), dim3(256), 0,
-                      (const int16_t*)d_sig, d_soff, d_foff, U, F, L, S, n_mel, cfg->hpf_alpha, (const double*)d_win,
+            LN_LAUNCH(ctx, "mfcc_frame512_i16", mfcc_frame512_kernel<int16_t>, dim3(grid), dim3(64 * kMfccWaves), 0,
+                      (const int16_t*)d_sig, d_soff, d_foff, U, F, L, S, n_mel, n_out, cfg->hpf_alpha, (const double*)d_win,
                       (const double*)d_fb, d_range, d_tw, d_C, (double*)d_pow, cep, energy);
         else
-            LN_LAUNCH(ctx, "mfcc_frame512", mfcc_frame512_kernel<double>, dim3(grid), dim3(256), 0,
-                      (const double*)d_sig, d_soff, d_foff, U, F, L, S, n_mel, cfg->hpf_alpha, (const double*)d_win,
+            LN_LAUNCH(ctx, "mfcc_frame512", mfcc_frame512_kernel<double>, dim3(grid), dim3(64 * kMfccWaves), 0,
+                      (const double*)d_sig, d_soff, d_foff, U, F, L, S, n_mel, n_out, cfg->hpf_alpha, (const double*)d_win,
                       (const double*)d_fb, d_range, d_tw, d_C, (double*)d_pow, cep, energy);
         fused_dct = true;
     } else if (sample_kind == 1)
@@ -578,12 +720,17 @@ int lnasr_mfcc(lnasr_ctx* ctx, const void* signal, int sample_kind, const int64_
         LN_LAUNCH(ctx, "mfcc_col_mean", col_mean_kernel, dim3(U), dim3(threads), (size_t)threads * 8, cep, d_foff,
                   n_mel, 0, n_mel, mean1);
     }
-    LN_LAUNCH(ctx, "mfcc_feat", feat_kernel, dim3((unsigned)(((size_t)F * n_mel + 255) / 256)), dim3(256), 0, cep, mean1,
-              energy, d_foff, U, F, n_mel, nc, (double*)d_cep, (double*)d_feat);
+    {
+        int64_t maxnf = 0;
+        for (int u = 0; u < U; ++u) maxnf = std::max(maxnf, foff[u + 1] - foff[u]);
+        const int ncols = d_cep ? n_mel : W;
+        LN_REQUIRE(U <= 65535, "U=%d utterances is too many for one MFCC call", U);
+        LN_LAUNCH(ctx, "mfcc_feat", feat_kernel, dim3((unsigned)(((size_t)maxnf * ncols + 255) / 256), U), dim3(256), 0, cep,
+                  mean1, energy, d_foff, n_mel, nc, ncols, (double*)d_cep, (double*)d_feat);
+    }
     if (power_or_null) LN_TRY(finish_out(ctx, power_or_null, d_pow, (size_t)F * nbin * 8));
     if (cepstrum_or_null) LN_TRY(finish_out(ctx, cepstrum_or_null, d_cep, (size_t)F * n_mel * 8));
     LN_TRY(finish_out(ctx, features, d_feat, (size_t)F * 3 * W * 8));
-    LN_HIP(hipStreamSynchronize(ctx->stream));   // host-side constant vectors go out of scope
     return 0;
 }
 

@@ -474,9 +474,10 @@ class Context:
         check(lib().lnasr_split_frames(self.handle, _ptr(signal), len(signal), int(L), int(S), _ptr(out)))
         return out
 
-    def mfcc(self, signal, offsets, cfg, window, fbank, want_power=True, want_cepstrum=True):
+    def mfcc(self, signal, offsets, cfg, window, fbank, want_power=True, want_cepstrum=True, features_out=None):
         """signal: float64 or int16 samples (host or DeviceArray), utterances concatenated;
-        offsets int64 [U+1].  Returns (power|None, cepstrum|None, features, frame_offsets)."""
+        offsets int64 [U+1].  Returns (power|None, cepstrum|None, features, frame_offsets).
+        features_out: a DeviceArray [F, 3 (n_cep + 1)] to write into (saves a device allocation per call)."""
         if isinstance(signal, DeviceArray):
             kind = 1 if signal.dtype == np.int16 else 0
         else:
@@ -488,14 +489,21 @@ class Context:
                 kind = 0
         offsets = np.ascontiguousarray(offsets, dtype=np.int64)
         U = len(offsets) - 1
-        nfs = [num_frames(int(offsets[u + 1] - offsets[u]), cfg.frame_len, cfg.frame_step) for u in range(U)]
+        # int(np.ceil(np.abs(n - (L - S)) / S)) per utterance (utils.py:119), as lnasr_num_frames computes it
+        nfs = (np.abs(np.diff(offsets) - (cfg.frame_len - cfg.frame_step)) + cfg.frame_step - 1) // cfg.frame_step
         foff = np.concatenate([[0], np.cumsum(nfs)]).astype(np.int64)
         F = int(foff[-1])
         dev = isinstance(signal, DeviceArray)
         nbin = cfg.fft_n // 2 + 1
         power = self._out(dev, (F, nbin), np.float64) if want_power else None
         cep = self._out(dev, (F, cfg.n_mel), np.float64) if want_cepstrum else None
-        feat = self._out(dev, (F, 3 * (cfg.n_cep + 1)), np.float64)
+        if features_out is not None:
+            if not isinstance(features_out, DeviceArray) or features_out.shape != (F, 3 * (cfg.n_cep + 1)) \
+                    or features_out.dtype != np.float64:
+                raise ValueError("features_out must be a float64 DeviceArray of shape (%d, %d)" % (F, 3 * (cfg.n_cep + 1)))
+            feat = features_out
+        else:
+            feat = self._out(dev, (F, 3 * (cfg.n_cep + 1)), np.float64)
         window = np.ascontiguousarray(window, dtype=np.float64)
         fbank = np.ascontiguousarray(fbank, dtype=np.float64)
         check(lib().lnasr_mfcc(self.handle, _ptr(signal), kind, _ptr(offsets), U, C.byref(cfg), _ptr(window),

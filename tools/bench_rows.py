@@ -51,10 +51,11 @@ if what & {"mfcc", "all"}:
     cfg, win, bank = m._cfg()
     d_sig = ctx.to_device(batch)
     frames = U * 1000
-    timed("mfcc f64 samples (U=%d)" % U, lambda: ctx.mfcc(d_sig, offs, cfg, win, bank, False, False), frames, "frames",
+    fo = ctx.empty((frames, 39), np.float64)
+    timed("mfcc f64 samples (U=%d)" % U, lambda: ctx.mfcc(d_sig, offs, cfg, win, bank, False, False, fo), frames, "frames",
           algo_bytes=frames * 1592.0)
     d_i16 = ctx.to_device(np.clip(batch, -32768, 32767).astype(np.int16))
-    timed("mfcc int16 PCM (U=%d)" % U, lambda: ctx.mfcc(d_i16, offs, cfg, win, bank, False, False), frames, "frames",
+    timed("mfcc int16 PCM (U=%d)" % U, lambda: ctx.mfcc(d_i16, offs, cfg, win, bank, False, False, fo), frames, "frames",
           algo_bytes=frames * 632.0)
 
 if what & {"gmm", "all"}:
