@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 namespace lnasr {
 
 constexpr double kLog2Pi = 1.8378770664093454835606594728112;   // ln(2 pi)
@@ -88,6 +90,37 @@ __device__ __forceinline__ double wave_sum_dpp(double x) {
     const double r0 = readlane_f64(x, 0), r1 = readlane_f64(x, 16), r2 = readlane_f64(x, 32),
                  r3 = readlane_f64(x, 48);
     return (r0 + r1) + (r2 + r3);
+}
+
+// fp64 DPP exists on gfx950 for v_fmac_f64 / v_mov_b64 with row_newbcast only: lane NB of every
+// 16-lane row is broadcast to the whole row
+template <int NB>
+__device__ __forceinline__ void fmac_bcast(double& acc, double v, double a) {
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(v), "v"(a), "n"(NB));
+}
+template <int NB>
+__device__ __forceinline__ double mov_bcast(double v) {
+    double r;
+    asm("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(NB));
+    return r;
+}
+template <int I, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < E) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, E>(f);
+    }
+}
+
+// rare path (sum left the safe range): log-sum-exp of prev[i] + logA[i][j] in the log domain; kept out
+// of line so that its registers are not charged to the frame loop
+static __device__ __noinline__ double exact_column_lse(const double* prev, const double* Acol, int N) {
+    double mx = LN_NEG_INF;
+    for (int i = 0; i < N; ++i) mx = fmax(mx, prev[i] + Acol[(size_t)i * N]);
+    if (mx == LN_NEG_INF || mx != mx) return mx;
+    double s2 = 0.0;
+    for (int i = 0; i < N; ++i) s2 += exp(prev[i] + Acol[(size_t)i * N] - mx);
+    return mx + log(s2);
 }
 
 // (value, index) arg-max with numpy.argmax semantics: first index among equal maxima.

@@ -10,7 +10,6 @@
 // while the inner loop is one add + one max per (i, j).  The full bt matrix is produced by a
 // separate, fully parallel kernel only when the caller asks for it.
 #include "common.h"
-#include <type_traits>
 #include "devmath.h"
 
 namespace lnasr {
@@ -709,22 +708,27 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
             tn = tn < 0 ? 0 : (tn > T - 1 ? T - 1 : tn);
             if (jvalid[jj]) bnext[jj] = bp[jj][(size_t)tn * N];
         }
-        double er[UB][RPT];
+        // the wave's RPT e-values of an utterance sit in RPT/16 VGPR pairs, 16 per DPP row (lane l holds
+        // e[16 g + (l & 15)]); v_fmac_f64_dpp row_newbcast:n feeds value n to every lane, so a transition is
+        // ONE vector instruction and the LDS sees one read per utterance instead of one per row (the broadcast
+        // reads made this kernel LDS-bound: 64 of them per frame against 128 FMAs)
+        static_assert(RPT % 16 == 0, "row slices are whole DPP rows");
+        double ek[UB][RPT / 16];
 #pragma unroll
         for (int k = 0; k < UB; ++k)
 #pragma unroll
-            for (int r = 0; r < RPT; ++r) er[k][r] = Es[cur][k][w * RPT + r];
+            for (int g = 0; g < RPT / 16; ++g) ek[k][g] = Es[cur][k][w * RPT + 16 * g + (lane & 15)];
         double acc[UB][CPT];
 #pragma unroll
         for (int k = 0; k < UB; ++k)
 #pragma unroll
-            for (int c = 0; c < CPT; ++c) acc[k][c] = er[k][0] * areg[c][0];
-#pragma unroll
-        for (int r = 1; r < RPT; ++r)
+            for (int c = 0; c < CPT; ++c) acc[k][c] = 0.0;
+        static_for<0, RPT>([&](auto r) {
 #pragma unroll
             for (int k = 0; k < UB; ++k)
 #pragma unroll
-                for (int c = 0; c < CPT; ++c) acc[k][c] = fma(er[k][r], areg[c][r], acc[k][c]);
+                for (int c = 0; c < CPT; ++c) fmac_bcast<(r.value & 15)>(acc[k][c], ek[k][r.value >> 4], areg[c][r.value]);
+        });
         if (NW > 1) {
 #pragma unroll
             for (int k = 0; k < UB; ++k)
@@ -750,16 +754,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
                     if (sum >= kSafeSum && sum <= 1e290 && Sc != LN_NEG_INF) {
                         val = Sc + log_sum(sum, ltab);
                     } else {                       // exact log-domain column (rare)
-                        const int jcl = j < N ? j : N - 1;
-                        double mx = LN_NEG_INF;
-                        for (int i = 0; i < N; ++i) mx = fmax(mx, Cs[cur][k][i] + Alog[(size_t)i * N + jcl]);
-                        if (mx == LN_NEG_INF || mx != mx) {
-                            val = mx;
-                        } else {
-                            double s2 = 0.0;
-                            for (int i = 0; i < N; ++i) s2 += exp(Cs[cur][k][i] + Alog[(size_t)i * N + jcl] - mx);
-                            val = mx + log(s2);
-                        }
+                        val = exact_column_lse(&Cs[cur][k][0], Alog + (j < N ? j : N - 1), N);
                     }
                     const int t = frame_of(jj, step);
                     double prev;
@@ -1030,37 +1025,6 @@ __global__ __launch_bounds__(1024) void fwdbwd_stream(const double* __restrict__
 // N = 256, T = 2000, U = 64).  MODE 0: Viterbi, 1: forward, 2: backward (same arithmetic, shift rule and
 // exact fallback as the register-resident kernels).
 // ------------------------------------------------------------------------------------------
-
-// fp64 DPP exists on gfx950 for v_fmac_f64 / v_mov_b64 with row_newbcast only: lane NB of every
-// 16-lane row is broadcast to the whole row
-template <int NB>
-__device__ __forceinline__ void fmac_bcast(double& acc, double v, double a) {
-    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(v), "v"(a), "n"(NB));
-}
-template <int NB>
-__device__ __forceinline__ double mov_bcast(double v) {
-    double r;
-    asm("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(NB));
-    return r;
-}
-template <int I, int E, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < E) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, E>(f);
-    }
-}
-
-// rare path (sum left the safe range): log-sum-exp of prev[i] + logA[i][j] in the log domain; kept out
-// of line so that its registers are not charged to the frame loop
-__device__ __noinline__ double exact_column_lse(const double* prev, const double* Acol, int N) {
-    double mx = LN_NEG_INF;
-    for (int i = 0; i < N; ++i) mx = fmax(mx, prev[i] + Acol[(size_t)i * N]);
-    if (mx == LN_NEG_INF || mx != mx) return mx;
-    double s2 = 0.0;
-    for (int i = 0; i < N; ++i) s2 += exp(prev[i] + Acol[(size_t)i * N] - mx);
-    return mx + log(s2);
-}
 
 // LDS map of the on-chip kernel (doubles)
 constexpr int kT256FinReg = 32, kT256CmpReg = 52;                       // A rows held in registers per thread
@@ -1429,9 +1393,14 @@ int forward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
                       (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
                       (double*)alpha, loglik, U, T, N);
         else
-            LN_LAUNCH(ctx, "forward_reg_n128", (fwdbwd_reg<false, 2, 8, 16, 4, 2>), dim3((U + 3) / 4), dim3(512), 0,
-                      (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
-                      (double*)alpha, loglik, U, T, N);
+            if (U < 4 * ctx->prop.multiProcessorCount)      // few utterances: two per block keeps more CUs busy
+                LN_LAUNCH(ctx, "forward_reg_n128", (fwdbwd_reg<false, 2, 8, 16, 2, 4>), dim3((U + 1) / 2), dim3(512), 0,
+                          (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
+                          (double*)alpha, loglik, U, T, N);
+            else
+                LN_LAUNCH(ctx, "forward_reg_n128", (fwdbwd_reg<false, 2, 8, 16, 4, 2>), dim3((U + 3) / 4), dim3(512), 0,
+                          (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
+                          (double*)alpha, loglik, U, T, N);
         return 0;
     }
     if (dtype == LNASR_F64 && N > 128 && N <= 256 && !getenv("LNASR_NO_T256")) {
@@ -1484,9 +1453,14 @@ int backward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* 
                       (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
                       (double*)nullptr, U, T, N);
         else
-            LN_LAUNCH(ctx, "backward_reg_n128", (fwdbwd_reg<true, 2, 8, 16, 4, 2>), dim3((U + 3) / 4), dim3(512), 0,
-                      (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
-                      (double*)nullptr, U, T, N);
+            if (U < 4 * ctx->prop.multiProcessorCount)
+                LN_LAUNCH(ctx, "backward_reg_n128", (fwdbwd_reg<true, 2, 8, 16, 2, 4>), dim3((U + 1) / 2), dim3(512), 0,
+                          (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
+                          (double*)nullptr, U, T, N);
+            else
+                LN_LAUNCH(ctx, "backward_reg_n128", (fwdbwd_reg<true, 2, 8, 16, 4, 2>), dim3((U + 3) / 4), dim3(512), 0,
+                          (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
+                          (double*)nullptr, U, T, N);
         return 0;
     }
     if (dtype == LNASR_F64 && N > 128 && N <= 256 && !getenv("LNASR_NO_T256")) {
