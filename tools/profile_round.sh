@@ -15,4 +15,8 @@ rm -rf $O/prof_${tag}_trace $O/prof_${tag}_fetch $O/prof_${tag}_write
 rocprofv3 --kernel-trace --stats -f csv -d $O/prof_${tag}_trace -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/prof_${tag}_trace.json 2> $O/prof_${tag}_trace.err
 rocprofv3 --pmc FETCH_SIZE -f csv -d $O/prof_${tag}_fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/prof_${tag}_fetch.err
 rocprofv3 --pmc WRITE_SIZE -f csv -d $O/prof_${tag}_write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/prof_${tag}_write.err
-echo done
+
+# the other rows of SURVEY 8d (MFCC, single GMM, bank, forward / backward, Baum-Welch statistics, full covariance)
+rm -rf $O/prof_${tag}_rows
+rocprofv3 --kernel-trace --stats -f csv -d $O/prof_${tag}_rows -- python3 $R/tools/bench_rows.py all > $O/rows_${tag}.log 2> $O/prof_${tag}_rows.err
+echo rows done
