@@ -389,6 +389,230 @@ __global__ void mix_finish_kernel(const double* __restrict__ R, const double* __
     mix_xx[idx] = v > 0.0 ? v : 0.0;
 }
 
+// ------------------------------------------------------------------------------------------
+// Full covariance: the second moment of component (j,m) around its OLD mean (gmmhmm.py:138) is, with y = x - c
+// and delta = mu_old - c,   sum g (y - delta)(y - delta)^T = P - delta S1^T - S1 delta^T + delta delta^T Sg,
+// P[d,e] = sum g y_d y_e,  S1 = sum g y,  Sg = sum g  -- the K = D(D+1)/2 + D + 1 quadratic features of the
+// full-covariance emission kernel (same pair table, 80-column chunks).  Block = 8 states x one column chunk x
+// a contiguous frame range; the posteriors are recomputed per chunk (an exp per (frame, mixture): cheap next
+// to the 10 MFMAs it feeds), the chunk's feature rows y_a y_b are built once per 32 frames in LDS.
+// ------------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(512) void full_mfma_kernel(const double* __restrict__ obs, const double* __restrict__ alpha,
+                                                        const double* __restrict__ beta, const double* __restrict__ b,
+                                                        const double* __restrict__ bm, const double* __restrict__ c1,
+                                                        const double* __restrict__ logw, const double* __restrict__ centre,
+                                                        const int* __restrict__ pairtab, const int32_t* __restrict__ lens,
+                                                        long F, long FPB, int T, int N, int M, int D, int NCH,
+                                                        double* __restrict__ R) {
+    constexpr int CH = kMixFrames, CT = 5, NFP = 16 * CT, FST = NFP, YST = 42;
+    constexpr int OPT = (CH * 39 + 511) / 512;
+    __shared__ double feat[2][CH * FST];
+    __shared__ double yrow[2][CH * YST];             // y[0..D-1], then 1.0 at D and 0.0 at D+1
+    __shared__ double sab[2][CH * 8], sbb[2][CH * 8];
+    __shared__ double etab[kExpTab];
+    __shared__ double cen[40];
+    __shared__ int pa[NFP], pb[NFP];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l15 = lane & 15, kk = lane >> 4;
+    const int j = blockIdx.x * 8 + w, cc = blockIdx.y;
+    const bool active = j < N;
+    const int jc = active ? j : N - 1;
+    const long fb0 = (long)blockIdx.z * FPB;
+    long fb1 = fb0 + FPB;
+    if (fb1 > F) fb1 = F;
+    if (fb0 >= fb1) return;
+    exp_table_init(etab, tid, 512);
+    if (tid < D) cen[tid] = centre[tid];
+    if (tid < NFP) {
+        const int code = pairtab[cc * NFP + tid], d = code & 0xFF, e = (code >> 8) & 0xFF;
+        pa[tid] = d < D ? d : (d == 0xFF ? D : D + 1);
+        pb[tid] = e < D ? e : (e == 0xFF ? D : D + 1);
+    }
+    for (int e = tid; e < 2 * CH * 2; e += 512) {
+        const int bufi = e / (CH * 2), r = e % (CH * 2);
+        yrow[bufi][(r >> 1) * YST + D + (r & 1)] = (r & 1) ? 0.0 : 1.0;
+    }
+    double lw[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = 16 * mt + l15;
+        lw[mt] = m < M ? logw[(size_t)jc * M + m] : LN_NEG_INF;
+    }
+    double oreg[OPT], s_ab = 0.0, s_bb = 0.0;
+    auto stage_load = [&](long f0) {
+        const long nfr = (fb1 - f0) < CH ? (fb1 - f0) : CH;
+#pragma unroll
+        for (int r = 0; r < OPT; ++r) {
+            const int e = tid + r * 512;
+            oreg[r] = e < nfr * D ? obs[(size_t)f0 * D + e] : 0.0;
+        }
+        if (tid < CH * 8) {
+            const int fr = tid >> 3, js = blockIdx.x * 8 + (tid & 7);
+            const long f = f0 + fr;
+            s_ab = LN_NEG_INF;
+            s_bb = 0.0;
+            if (f < fb1 && js < N) {
+                const int u = (int)(f / T), t = (int)(f % T);
+                if (t < lens[u]) {
+                    const size_t fj = (size_t)f * N + js;
+                    s_ab = alpha[fj] + beta[fj] - c1[f];
+                    s_bb = b[fj];
+                }
+            }
+        }
+    };
+    auto stage_store = [&](int bufi) {
+#pragma unroll
+        for (int r = 0; r < OPT; ++r) {
+            const int e = tid + r * 512;
+            if (e < CH * D) {
+                const int fr = e / D, d = e % D;
+                yrow[bufi][fr * YST + d] = oreg[r] - cen[d];
+            }
+        }
+        if (tid < CH * 8) {
+            sab[bufi][tid] = s_ab;
+            sbb[bufi][tid] = s_bb;
+        }
+    };
+    auto build_feat = [&](int bufi) {
+        for (int e = tid; e < CH * NFP; e += 512) {
+            const int fr = e / NFP, col = e % NFP;
+            feat[bufi][fr * FST + col] = yrow[bufi][fr * YST + pa[col]] * yrow[bufi][fr * YST + pb[col]];
+        }
+    };
+
+    double4_t acc[MT][CT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[mt][ct] = double4_t{0.0, 0.0, 0.0, 0.0};
+    double ring[kMixRing][MT];
+    const double* bmj = bm + (size_t)jc * M + l15;
+    const size_t bstride = (size_t)N * M;
+    auto ring_load = [&](int slot, long f) {
+        const long fc = f < F ? f : F - 1;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) ring[slot][mt] = (16 * mt + l15 < M) ? bmj[(size_t)fc * bstride + 16 * mt] : 0.0;
+    };
+    __syncthreads();                       // cen, etab, pair table, constant columns
+    stage_load(fb0);
+    stage_store(0);
+#pragma unroll
+    for (int s = 0; s < kMixRing - 1; ++s) ring_load(s, fb0 + 4 * s + kk);
+    __syncthreads();
+    build_feat(0);
+    __syncthreads();
+
+    int cur = 0;
+    for (long f0 = fb0; f0 < fb1; f0 += CH, cur ^= 1) {
+        const bool has_next = f0 + CH < fb1;
+        if (has_next) stage_load(f0 + CH);
+        if (active) {
+#pragma unroll
+            for (int ks = 0; ks < CH / 4; ++ks) {
+                constexpr int RM = kMixRing;
+                ring_load((ks + RM - 1) % RM, f0 + 4 * (ks + RM - 1) + kk);
+                const int fk = 4 * ks + kk;
+                const double ab = sab[cur][fk * 8 + w], bb = sbb[cur][fk * 8 + w];
+                double g[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const double z = ab + ((lw[mt] + ring[ks % RM][mt]) - bb);
+                    const double ev = exp_nonpos(z, etab);
+                    g[mt] = (z >= -700.0) ? ev : 0.0;
+                }
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const double fv = feat[cur][fk * FST + 16 * ct + l15];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[mt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(g[mt], fv, acc[mt][ct], 0, 0, 0);
+                }
+            }
+        }
+        if (has_next) stage_store(cur ^ 1);
+        __syncthreads();
+        if (has_next) build_feat(cur ^ 1);
+        __syncthreads();
+    }
+    if (active) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = 16 * mt + kk + 4 * r;
+                    const double v = acc[mt][ct][r];
+                    if (v != 0.0) atomicAdd(&R[(((size_t)j * (16 * MT) + m) * NCH + cc) * NFP + 16 * ct + l15], v);
+                }
+    }
+}
+
+// raw sums -> mix, mix_x and the D x D second moment around the old mean
+__global__ void full_finish_kernel(const double* __restrict__ R, const double* __restrict__ mu,
+                                   const double* __restrict__ centre, int N, int M, int D, int MP, int KF,
+                                   double* __restrict__ mix, double* __restrict__ mix_x, double* __restrict__ mix_xx) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t DD = (size_t)D * D;
+    if (idx >= (size_t)N * M * DD) return;
+    const int e = (int)(idx % D), d = (int)((idx / D) % D);
+    const size_t c = idx / DD;
+    const int m = (int)(c % M), j = (int)(c / M);
+    const double* row = R + ((size_t)j * MP + m) * KF;
+    const int npair = D * (D + 1) / 2;
+    const int lo = d < e ? d : e, hi = d < e ? e : d;
+    const double P = row[lo * D - lo * (lo - 1) / 2 + (hi - lo)];
+    const double sd = row[npair + d], se = row[npair + e], sg = row[npair + D];
+    const double dd = mu[c * D + d] - centre[d], de = mu[c * D + e] - centre[e];
+    mix_xx[idx] = ((P - dd * se) - sd * de) + dd * de * sg;
+    if (e == 0) {
+        mix_x[c * D + d] = sd + centre[d] * sg;
+        if (d == 0) mix[c] = sg;
+    }
+}
+
+bool full_stats_mfma_ok(const Model& md) {
+    return !md.diag && md.wfull_Q > 0 && md.wfull_virt == 1 && md.M <= 32 && md.D <= 39 && !getenv("LNASR_NO_MFMA_STATS");
+}
+
+int full_stats_device(lnasr_ctx* ctx, const double* obs, const double* alpha, const double* beta, const double* b,
+                      const double* bm, const double* c1, const int32_t* d_lens, int U, int T, double* mix, double* mix_x,
+                      double* mix_xx) {
+    Model& md = ctx->model;
+    const int N = md.N, M = md.M, D = md.D, NCH = md.wfull_NCH;
+    const int MT = (M + 15) / 16, MP = 16 * MT, KF = NCH * 80;
+    const long F = (long)U * T;
+    const size_t nraw = (size_t)N * MP * KF;
+    LN_TRY(ctx->ws_raw.reserve((nraw + 64) * 8));
+    double* R = ctx->ws_raw.as<double>();
+    double* centre = R + nraw;
+    LN_HIP(hipMemsetAsync(R, 0, nraw * 8, ctx->stream));
+    LN_LAUNCH(ctx, "mix_centre", mix_centre_kernel, dim3(D), dim3(256), 0, md.mu.as<double>(), N * M, D, centre);
+    const int SG = (N + 7) / 8;
+    const long nchunk = (F + kMixFrames - 1) / kMixFrames;
+    long G = (2L * ctx->prop.multiProcessorCount + (long)SG * NCH - 1) / ((long)SG * NCH);
+    if (G > nchunk) G = nchunk;
+    if (G < 1) G = 1;
+    if (G > 65535) G = 65535;
+    const long FPB = ((nchunk + G - 1) / G) * kMixFrames;
+    G = (F + FPB - 1) / FPB;
+    const dim3 grid(SG, NCH, (unsigned)G);
+    const double* lw = md.logw.as<double>();
+    if (MT == 1)
+        LN_LAUNCH(ctx, "full_mfma", full_mfma_kernel<1>, grid, dim3(512), 0, obs, alpha, beta, b, bm, c1, lw,
+                  (const double*)centre, (const int*)md.pairtab.as<int>(), d_lens, F, FPB, T, N, M, D, NCH, R);
+    else
+        LN_LAUNCH(ctx, "full_mfma", full_mfma_kernel<2>, grid, dim3(512), 0, obs, alpha, beta, b, bm, c1, lw,
+                  (const double*)centre, (const int*)md.pairtab.as<int>(), d_lens, F, FPB, T, N, M, D, NCH, R);
+    const size_t nel = (size_t)N * M * D * D;
+    LN_LAUNCH(ctx, "full_finish", full_finish_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, (const double*)R,
+              md.mu.as<double>(), (const double*)centre, N, M, D, MP, KF, mix, mix_x, mix_xx);
+    return 0;
+}
+
 bool mix_stats_mfma_ok(const Model& md) {
     return md.diag && md.M <= 32 && md.D <= 39 && !getenv("LNASR_NO_MFMA_STATS");
 }

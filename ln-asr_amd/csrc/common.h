@@ -141,6 +141,11 @@ int mix_stats_device(lnasr_ctx* ctx, const double* obs, const double* alpha, con
                      const double* bm, const double* c1, const int32_t* d_lens, int U, int T, double* mix,
                      double* mix_x, double* mix_xx);
 
+bool full_stats_mfma_ok(const Model& md);
+int full_stats_device(lnasr_ctx* ctx, const double* obs, const double* alpha, const double* beta, const double* b,
+                      const double* bm, const double* c1, const int32_t* d_lens, int U, int T, double* mix,
+                      double* mix_x, double* mix_xx);
+
 inline size_t dtype_size(int dtype) { return dtype == LNASR_F32 ? 4 : 8; }
 
 }  // namespace lnasr

@@ -713,6 +713,9 @@ int lnasr_bw_accumulate(lnasr_ctx* ctx, const double* obs, int U, int T, const i
         LN_LAUNCH(ctx, "acc_mix_diag", acc_mix_diag_kernel, dim3(N, (T + kMixCH - 1) / kMixCH, U), dim3(256), shmem,
                   (const double*)d_obs, al, be, b, bm, c1, md.logw.as<double>(), md.mu.as<double>(), d_lens, T, N, M,
                   D, st + L.mix, st + L.mix_x, st + L.mix_xx);
+    } else if (full_stats_mfma_ok(md)) {
+        LN_TRY(full_stats_device(ctx, (const double*)d_obs, al, be, b, bm, c1, d_lens, U, T, st + L.mix, st + L.mix_x,
+                                 st + L.mix_xx));
     } else {
         const size_t shmem = ((size_t)T + 64 * (size_t)D) * 8;
         LN_REQUIRE(shmem <= 160 * 1024, "T=%d too long for the full-covariance statistics kernel", T);

@@ -2,6 +2,7 @@
 against golden vectors from the reference and against the CPU oracle."""
 import contextlib
 import io
+import os
 
 import numpy as np
 import pytest
@@ -277,6 +278,27 @@ def test_bw_statistics_wide(synth, oracle, ctx):
                                        mdl["var"])
         _check_stats(st, ref, N, M, D, 1e-9, 1e-11)
         assert st[N * N + 2 * N + M] == 0.0                 # mix[1, 0]: exact zero stays exact
+
+
+def test_bw_statistics_full_covariance_wide(synth, ctx):
+    """Full covariance with two mixture tiles (M = 20), N not a multiple of 8, ragged lengths: the matrix-core
+    statistics kernel against the scalar kernel that the golden vectors pin (LNASR_NO_MFMA_STATS)."""
+    N, M, D, U, T = 9, 20, 39, 3, 45
+    mdl = synth.synth_model(N, M, D, seed=12, full_cov=True)
+    obs = synth.synth_obs(U, T, D, seed=77)
+    lens = np.array([T, 17, T - 1], dtype=np.int32)
+    ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["si"])
+    assert not ctx.model_is_diag()
+    st = ctx.bw_accumulate(obs, lens=lens)
+    os.environ["LNASR_NO_MFMA_STATS"] = "1"
+    try:
+        ref = ctx.bw_accumulate(obs, lens=lens)
+    finally:
+        del os.environ["LNASR_NO_MFMA_STATS"]
+    assert st.shape == ref.shape == (N * N + 2 * N + N * M + N * M * D + N * M * D * D + 3,)
+    assert_close(st, ref, 1e-9, 1e-11)
+    si = ctx.bw_mstep(st)["si"]
+    assert np.allclose(si, np.swapaxes(si, -1, -2), rtol=0, atol=1e-12)      # symmetric second moments
 
 
 def test_forward_backward_large_n(synth, oracle, ctx):
