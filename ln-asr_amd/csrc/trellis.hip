@@ -393,14 +393,20 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
 // an LDS row read; arg-max = DPP wave max, then the first lane holding the max (ballot + ffs),
 // which is numpy.argmax's first-index rule because lane l holds states l and l+64.  Decoded
 // states are collected 64 frames at a time and written as one coalesced 256-byte row.
+template <int CPL, bool LDSAT>
 __global__ __launch_bounds__(256) void backtrace_lds_kernel(const double* __restrict__ v,
                                                            const double* __restrict__ AT,
                                                            const int32_t* __restrict__ lens,
                                                            uint32_t* __restrict__ path, double* __restrict__ best,
                                                            int U, int T, int N) {
-    extern __shared__ double ATs[];     // [N][N]: ATs[p*N + i] = A[i][p]
-    for (int e = threadIdx.x; e < N * N; e += blockDim.x) ATs[e] = AT[e];
-    __syncthreads();
+    // lane l holds states l, l+64, ... (CPL of them).  LDSAT: A^T [N][N] (ATs[p*N + i] = A[i][p]) lives in LDS
+    // (N <= 128); otherwise the one row a step needs is read from L2 (128 < N <= 256: 512 KB does not fit)
+    extern __shared__ double ATs[];
+    if (LDSAT) {
+        for (int e = threadIdx.x; e < N * N; e += blockDim.x) ATs[e] = AT[e];
+        __syncthreads();
+    }
+    const double* ATb = LDSAT ? ATs : AT;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int u = blockIdx.x * (blockDim.x >> 6) + w;
     if (u >= U) return;
@@ -408,46 +414,64 @@ __global__ __launch_bounds__(256) void backtrace_lds_kernel(const double* __rest
     if (L <= 0) return;
     const double* vu = v + (size_t)u * T * N;
     uint32_t* pu = path + (size_t)u * T;
-    const int j0 = lane, j1 = lane + 64;
-    const bool ok0 = j0 < N, ok1 = j1 < N;
-    const int jj0 = ok0 ? j0 : 0, jj1 = ok1 ? j1 : 0;        // clamped: every load is a valid address
-    auto pick = [&](double x0, double x1, double& mx) -> int {
-        mx = wave_max_dpp(vmax_f64(x0, x1));
-        const unsigned long long m0 = __ballot(x0 == mx), m1 = __ballot(x1 == mx);
-        return m0 ? (__ffsll((long long)m0) - 1) : (m1 ? 63 + __ffsll((long long)m1) : 0);
+    bool ok[CPL];
+    int jj[CPL];                                             // clamped: every load is a valid address
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        ok[c] = lane + 64 * c < N;
+        jj[c] = ok[c] ? lane + 64 * c : 0;
+    }
+    // first index among equal maxima (numpy.argmax): lowest column block first, lowest lane within it
+    auto pick = [&](const double (&x)[CPL], double& mx) -> int {
+        double m = x[0];
+#pragma unroll
+        for (int c = 1; c < CPL; ++c) m = vmax_f64(m, x[c]);
+        mx = wave_max_dpp(m);
+        int r = 0;
+        bool found = false;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const unsigned long long mk = __ballot(x[c] == mx);
+            if (!found && mk) {
+                r = 64 * c + __ffsll((long long)mk) - 1;
+                found = true;
+            }
+        }
+        return r;
     };
-    auto mask0 = [&](double x) { return ok0 ? x : LN_NEG_INF; };
-    auto mask1 = [&](double x) { return ok1 ? x : LN_NEG_INF; };
+    double x[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) x[c] = ok[c] ? vu[(size_t)(L - 1) * N + jj[c]] : LN_NEG_INF;
     double bestv;
-    int p = pick(mask0(vu[(size_t)(L - 1) * N + jj0]), mask1(vu[(size_t)(L - 1) * N + jj1]), bestv);
+    int p = pick(x, bestv);
     if (lane == 0 && best) best[u] = bestv;
     uint32_t mine = 0;
     if (lane == ((L - 1) & 63)) mine = (uint32_t)p;
     if (((L - 1) & 63) == 0) pu[L - 1] = (uint32_t)p;      // single-entry top block
     // v rows are streamed from HBM: keep PF frames in flight per wave (register ring) so that the
-    // dependent chain below only ever waits on LDS
-    constexpr int PF = 8;
-    double cur0[PF], cur1[PF], nxt0[PF], nxt1[PF];
-    auto load_rows = [&](int tstart, double* r0, double* r1) {     // frames tstart, tstart-1, ... (clamped at 0)
+    // dependent chain below only ever waits on the A^T row
+    constexpr int PF = CPL <= 2 ? 8 : 4;
+    double cur[PF][CPL], nxt[PF][CPL];
+    auto load_rows = [&](int tstart, double (&r)[PF][CPL]) {     // frames tstart, tstart-1, ... (clamped at 0)
 #pragma unroll
         for (int k = 0; k < PF; ++k) {
             const int tt = tstart - k > 0 ? tstart - k : 0;
-            r0[k] = vu[(size_t)tt * N + jj0];
-            r1[k] = vu[(size_t)tt * N + jj1];
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) r[k][c] = vu[(size_t)tt * N + jj[c]];
         }
     };
-    load_rows(L - 2 > 0 ? L - 2 : 0, cur0, cur1);
+    load_rows(L - 2 > 0 ? L - 2 : 0, cur);
     for (int tb = L - 2; tb >= 0; tb -= PF) {
-        load_rows(tb - PF > 0 ? tb - PF : 0, nxt0, nxt1);
+        load_rows(tb - PF > 0 ? tb - PF : 0, nxt);
 #pragma unroll
         for (int k = 0; k < PF; ++k) {
             const int t = tb - k;
             if (t >= 0) {                                   // wave-uniform
-                const double* col = ATs + p * N;
-                const double x0 = mask0(cur0[k] + col[jj0]);
-                const double x1 = mask1(cur1[k] + col[jj1]);
+                const double* col = ATb + (size_t)p * N;
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) x[c] = ok[c] ? cur[k][c] + col[jj[c]] : LN_NEG_INF;
                 double mx;
-                p = pick(x0, x1, mx);
+                p = pick(x, mx);
                 if (lane == (t & 63)) mine = (uint32_t)p;
                 if ((t & 63) == 0) {
                     // frames t .. min(t+63, L-1) are complete: lane l holds frame t + l
@@ -456,10 +480,9 @@ __global__ __launch_bounds__(256) void backtrace_lds_kernel(const double* __rest
             }
         }
 #pragma unroll
-        for (int k = 0; k < PF; ++k) {
-            cur0[k] = nxt0[k];
-            cur1[k] = nxt1[k];
-        }
+        for (int k = 0; k < PF; ++k)
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) cur[k][c] = nxt[k][c];
     }
 }
 
@@ -1370,8 +1393,14 @@ int backtrace_device(lnasr_ctx* ctx, const void* v, int U, int T, const int32_t*
     Model& md = ctx->model;
     const int wpb = 4;
     if (dtype == LNASR_F64 && md.N <= 128 && !getenv("LNASR_NO_LDSBT")) {
-        LN_LAUNCH(ctx, "backtrace_lds", backtrace_lds_kernel, dim3((U + wpb - 1) / wpb), dim3(64 * wpb),
+        LN_LAUNCH(ctx, "backtrace_lds", (backtrace_lds_kernel<2, true>), dim3((U + wpb - 1) / wpb), dim3(64 * wpb),
                   (size_t)md.N * md.N * 8, (const double*)v, md.logAT.as<double>(), d_lens, path, best, U, T, md.N);
+        return 0;
+    }
+    if (dtype == LNASR_F64 && md.N <= 256 && !getenv("LNASR_NO_LDSBT")) {
+        // one wave per block: with few utterances the waves should sit on different CUs
+        LN_LAUNCH(ctx, "backtrace_wave256", (backtrace_lds_kernel<4, false>), dim3(U), dim3(64), 0, (const double*)v,
+                  md.logAT.as<double>(), d_lens, path, best, U, T, md.N);
         return 0;
     }
     if (dtype == LNASR_F32)
