@@ -276,4 +276,13 @@ __device__ __forceinline__ void exp_table_init(double* etab, int tid, int nt) {
     for (int e = tid; e < kExpTab; e += nt) etab[e] = exp2((double)e * (1.0 / kExpTab));
 }
 
+// b[cell] = lse_h bv[cell*k + h]: M = 16*k mixtures are scored as k virtual 16-mixture states, then merged
+static __global__ void merge_virtual_kernel(const double* __restrict__ bv, size_t cells, int k, double* __restrict__ b) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= cells) return;
+    Lse acc;
+    for (int h = 0; h < k; ++h) acc.add(bv[idx * k + h]);
+    b[idx] = acc.value();
+}
+
 }  // namespace lnasr

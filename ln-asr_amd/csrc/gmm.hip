@@ -590,15 +590,6 @@ __global__ void emit_full_generic(const double* __restrict__ obs, const double* 
     }
 }
 
-// b[f,n] = lse_h b'[f, n*k + h]: merges the k virtual 16-mixture states of each state
-__global__ void merge_virtual_kernel(const double* __restrict__ bv, size_t cells, int k, double* __restrict__ b) {
-    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= cells) return;
-    Lse acc;
-    for (int h = 0; h < k; ++h) acc.add(bv[idx * k + h]);
-    b[idx] = acc.value();
-}
-
 // free functions of gmm.py --------------------------------------------------------------
 __global__ void gauss1d_kernel(const double* __restrict__ x, size_t L, double mu, double s2, int want_log,
                                double* __restrict__ out) {

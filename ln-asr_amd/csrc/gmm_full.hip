@@ -299,13 +299,6 @@ static int launch_full(lnasr_ctx* ctx, const double* obs, long F, double* b, dou
     return 0;
 }
 
-__global__ void merge_virtual_full_kernel(const double* __restrict__ bv, size_t cells, int k, double* __restrict__ b) {
-    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= cells) return;
-    Lse acc;
-    for (int h = 0; h < k; ++h) acc.add(bv[idx * k + h]);
-    b[idx] = acc.value();
-}
 
 // returns 1 if the launch was issued, 0 if this model / dtype is not covered, < 0 on error
 int emit_full_mfma_device(lnasr_ctx* ctx, const double* obs, long F, double* b, double* bm) {
@@ -323,7 +316,7 @@ int emit_full_mfma_device(lnasr_ctx* ctx, const double* obs, long F, double* b, 
     if (rc) return rc;
     if (md.wfull_virt > 1) {
         const size_t cells = (size_t)F * md.N;
-        LN_LAUNCH(ctx, "merge_virtual_states", merge_virtual_full_kernel, dim3((unsigned)((cells + 255) / 256)),
+        LN_LAUNCH(ctx, "merge_virtual_states", merge_virtual_kernel, dim3((unsigned)((cells + 255) / 256)),
                   dim3(256), 0, bdst, cells, md.wfull_virt, b);
     }
     return 1;
