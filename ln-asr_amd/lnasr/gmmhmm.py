@@ -30,12 +30,19 @@ class GMMHMM(HMM):
         self.min_std = 0.01
 
     # ------------------------------------------------------------------ plumbing
-    def _upload_gmm(self):
-        """All parameters -> device (per call on the reference API; see `upload()` for batches)."""
+    def _upload_gmm(self, force_full=False):
+        """All parameters -> device (per call on the reference API; unchanged parameters are recognised by their
+        hash and not sent again, see _ffi.Context.upload_gmmhmm)."""
         si = np.asarray(self.si, dtype=np.float64)
         mu = np.asarray(self.mu, dtype=np.float64)
+        if force_full and si.ndim == 3:
+            full = np.zeros(si.shape + (si.shape[-1],))
+            idx = np.arange(si.shape[-1])
+            full[..., idx, idx] = si
+            si = full
         self.ctx.upload_gmmhmm(np.asarray(self.A, dtype=np.float64), np.asarray(self.pi, dtype=np.float64),
-                               np.asarray(self.w, dtype=np.float64), mu, si, diag=(si.ndim == 3))
+                               np.asarray(self.w, dtype=np.float64), mu, si, diag=(si.ndim == 3 and not force_full),
+                               force_full=force_full)
 
     def upload(self):
         """Upload once before a series of *_batch calls (parameters must not change in between)."""
@@ -67,6 +74,49 @@ class GMMHMM(HMM):
         est = self.ctx.estimate_gmm(obs, bm, np.asarray(alpha, dtype=dt), np.asarray(beta, dtype=dt),
                                     np.asarray(xi, dtype=dt), np.asarray(gamma, dtype=dt), self.min_std)
         return est
+
+    # ------------------------------------------------------------------ training
+    _REF_STEPS = ("_map_b", "_forward", "_backward", "_baumwelch", "_estimate", "_updatemodel", "calc_prob")
+
+    def _fused_train_ok(self):
+        """The on-device E+M step computes exactly what `_map_b` .. `_estimate` compute (with one
+        utterance the accumulated statistics reduce to the reference's M-step), without moving xi [T,N,N] and
+        bm [N,M,T] through host memory.  It is only taken when none of those steps is overridden and the model is
+        float64; anything else walks the reference's sequence of calls (HMM.train)."""
+        if self.precision not in (np.double, np.float64):
+            return False
+        for name in self._REF_STEPS:
+            base = GMMHMM if name in GMMHMM.__dict__ else HMM
+            if getattr(type(self), name) is not getattr(base, name):
+                return False
+        return True
+
+    def train(self, obs, iters=1, eps=0.0001, verbose: bool = True):
+        """Baum-Welch on one sequence, stopping when |delta loglik| < eps  (hmm.py:285-313 with the
+        gmmhmm.py:69-156 M-step): same iterates, same printed line."""
+        if not self._fused_train_ok():
+            return super().train(obs, iters, eps, verbose)
+        obs = np.ascontiguousarray(obs, dtype=np.float64)
+        N, M, D = self.n, self.m, self.d
+        ll_at = N * N + 2 * N + N * M + N * M * D + N * M * D * D
+        for k in range(iters):
+            self._upload_gmm()
+            if self.ctx.model_is_diag():               # the reference's M-step returns a FULL Sigma even then
+                self._upload_gmm(force_full=True)
+            stats = self.ctx.bw_accumulate(obs[None])
+            model = self.ctx.bw_mstep(stats, self.min_std)
+            prob_old = self.precision(stats[ll_at])
+            self._updatemodel(model)
+            prob_new = self.calc_prob(obs)
+            prod_d = abs(prob_old - prob_new)
+            if verbose:
+                print("Iter: {:3},"
+                      " L(lambda|O) = {:.6e},"
+                      " L(lambda_new|O) = {:.6e},"
+                      " eps = {:.6f}"
+                      .format(k, prob_old, prob_new, prod_d))
+            if prod_d < eps:
+                break
 
     def _updatemodel(self, model):
         self.A = model["A"]

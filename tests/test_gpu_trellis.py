@@ -116,6 +116,33 @@ def test_gmmhmm_small_bw(golden, tag):
         assert np.array_equal(g2.A, g["A"]) and np.array_equal(g2.mu, g["mu"]) and np.array_equal(g2.si, g["si"])
 
 
+def test_train_fused_equals_stepwise(synth):
+    """GMMHMM.train takes the on-device E+M step when no step is overridden; a subclass that overrides one walks
+    the reference's call sequence instead.  Same iterates either way (and a diagonal start still yields the
+    reference's full Sigma)."""
+    from lnasr.gmmhmm import GMMHMM
+
+    class Stepwise(GMMHMM):
+        def _estimate(self, obs, alpha, beta, xi, gamma):
+            return super()._estimate(obs, alpha, beta, xi, gamma)
+
+    mdl = synth.synth_model(6, 3, 5, seed=21)                # si is diagonal here
+    obs = synth.synth_obs(1, 80, 5, seed=22)[0]
+    a = GMMHMM(6, 3, 5, mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["si"])
+    b = Stepwise(6, 3, 5, mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["si"])
+    assert a._fused_train_ok() and not b._fused_train_ok()
+    out_a, out_b = io.StringIO(), io.StringIO()
+    with contextlib.redirect_stdout(out_a):
+        a.train(obs, 3, 0.0, True)
+    with contextlib.redirect_stdout(out_b):
+        b.train(obs, 3, 0.0, True)
+    assert out_a.getvalue() == out_b.getvalue() and out_a.getvalue().count("Iter:") == 3
+    for k in ("A", "pi", "w", "mu", "si"):
+        assert_close(getattr(a, k), getattr(b, k), 1e-8, 1e-10, msg=k)
+    assert a.si.shape == (6, 3, 5, 5) and np.abs(a.si[0, 0] - np.diag(np.diag(a.si[0, 0]))).max() > 0
+    assert a.b.shape == (6, 80) and a.bm.shape == (6, 3, 80)
+
+
 @pytest.mark.parametrize("kind", ["diag", "full"])
 def test_gmmhmm_d39_bw(golden, kind):
     from lnasr.gmmhmm import GMMHMM
