@@ -84,6 +84,8 @@ struct ProfRec {
 struct lnasr_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;            // side stream: the backward pass runs beside the forward pass
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipDeviceProp_t prop;
     lnasr::Model model;
     // workspace

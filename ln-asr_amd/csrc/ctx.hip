@@ -179,6 +179,9 @@ int lnasr_ctx_create(int device_id, lnasr_ctx** out) {
         return fail(LNASR_E_NODEVICE, "device %d is %s; this library is built for gfx950 only", device_id, arch.c_str());
     }
     LN_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    LN_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    LN_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    LN_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     *out = ctx;
     return 0;
 }
@@ -198,6 +201,9 @@ void lnasr_ctx_destroy(lnasr_ctx* ctx) {
         (void)hipEventDestroy(r.e1);
     }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

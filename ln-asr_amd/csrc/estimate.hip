@@ -1,5 +1,7 @@
 // Log-sum-exp utility, Baum-Welch M-steps (hmm.py:202-225, gmmhmm.py:69-156) and the
 // multi-utterance sufficient-statistics path.
+#include <utility>
+
 #include "common.h"
 #include "devmath.h"
 
@@ -687,8 +689,17 @@ int lnasr_bw_accumulate(lnasr_ctx* ctx, const double* obs, int U, int T, const i
     double* al = ctx->ws_alpha.as<double>();
     double* be = ctx->ws_beta.as<double>();
     LN_TRY(emit_device(ctx, (const double*)d_obs, (long)U * T, LNASR_F64, b, bm));
+    // forward and backward only share their input: with few utterances per GPU (config 5: 64 blocks on 256 CUs)
+    // the backward pass runs on a side stream beside the forward pass
+    LN_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+    LN_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+    std::swap(ctx->stream, ctx->stream2);
+    const int rc_b = backward_device(ctx, b, U, T, d_lens, LNASR_F64, be);
+    std::swap(ctx->stream, ctx->stream2);
+    LN_TRY(rc_b);
+    LN_HIP(hipEventRecord(ctx->ev_join, ctx->stream2));
     LN_TRY(forward_device(ctx, b, U, T, d_lens, LNASR_F64, al, ll));
-    LN_TRY(backward_device(ctx, b, U, T, d_lens, LNASR_F64, be));
+    LN_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     LN_REQUIRE(U <= 65535, "U=%d too large for one statistics launch", U);
     const bool mfma_stats = !getenv("LNASR_NO_MFMA_STATS");
     if (mfma_stats) {
