@@ -210,13 +210,15 @@ int xi_sum_device(lnasr_ctx* ctx, const double* alpha, const double* beta, const
 }
 
 // ------------------------------------------------------------------------------------------
-// Mixture posteriors and moments (diagonal model).  Block = 8 waves = 8 consecutive states over a contiguous
+// Mixture posteriors and moments (diagonal model).  Block = kMixWaves waves = consecutive states over a contiguous
 // range of frames; the wave of state j turns bm[f,j,:] into posteriors g (the MFMA A operand, 16 mixtures x 4
 // frames per instruction) and multiplies them with the block's shared feature rows [x-c, (x-c)^2, 1] from LDS.
 // Raw sums go to R[(j, m), col]; mix_finish_kernel turns them into the reference's three accumulators.
 // ------------------------------------------------------------------------------------------
 constexpr int kMixFrames = 32;       // frames per staged chunk (8 MFMA k-steps)
 constexpr int kMixRing = 4;          // bm prefetch ring (k-steps)
+constexpr int kMixWaves = 8;         // waves (= states) per block; 4-wave blocks at 3 waves/SIMD were measured: slower (5.7 vs 4.1 ms)
+constexpr int kMixNT = 64 * kMixWaves;
 
 __global__ void mix_centre_kernel(const double* __restrict__ mu, int NM, int D, double* __restrict__ centre) {
     __shared__ double scratch[8];
@@ -228,31 +230,31 @@ __global__ void mix_centre_kernel(const double* __restrict__ mu, int NM, int D, 
 }
 
 template <int MT, int CT>
-__global__ __launch_bounds__(512) void mix_mfma_kernel(const double* __restrict__ obs, const double* __restrict__ alpha,
+__global__ __launch_bounds__(64 * kMixWaves) void mix_mfma_kernel(const double* __restrict__ obs, const double* __restrict__ alpha,
                                                        const double* __restrict__ beta, const double* __restrict__ b,
                                                        const double* __restrict__ bm, const double* __restrict__ c1,
                                                        const double* __restrict__ logw, const double* __restrict__ centre,
                                                        const int32_t* __restrict__ lens, long F, long FPB, int T, int N,
                                                        int M, int D, double* __restrict__ R) {
     constexpr int CH = kMixFrames, NFP = 16 * CT, FST = NFP + ((CT & 1) ? 0 : 16);
-    constexpr int OPT = (CH * 39 + 511) / 512;                       // obs doubles staged per thread (D <= 39)
+    constexpr int OPT = (CH * 39 + kMixNT - 1) / kMixNT;             // obs doubles staged per thread (D <= 39)
     __shared__ double feat[2][CH * FST];
-    __shared__ double sab[2][CH * 8], sbb[2][CH * 8];
+    __shared__ double sab[2][CH * kMixWaves], sbb[2][CH * kMixWaves];
     __shared__ double etab[kExpTab];
     __shared__ double cen[40];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l15 = lane & 15, kk = lane >> 4;
-    const int j = blockIdx.x * 8 + w;
+    const int j = blockIdx.x * kMixWaves + w;
     const bool active = j < N;
     const int jc = active ? j : N - 1;
     const long fb0 = (long)blockIdx.y * FPB;
     long fb1 = fb0 + FPB;
     if (fb1 > F) fb1 = F;
     if (fb0 >= fb1) return;
-    exp_table_init(etab, tid, 512);
+    exp_table_init(etab, tid, kMixNT);
     if (tid < D) cen[tid] = centre[tid];
     // constant feature columns: the ones column at 2D, zeros after it
-    for (int e = tid; e < 2 * CH * (FST - 2 * D); e += 512) {
+    for (int e = tid; e < 2 * CH * (FST - 2 * D); e += kMixNT) {
         const int bufi = e / (CH * (FST - 2 * D)), r = e % (CH * (FST - 2 * D));
         const int fr = r / (FST - 2 * D), col = 2 * D + r % (FST - 2 * D);
         feat[bufi][fr * FST + col] = (col == 2 * D) ? 1.0 : 0.0;
@@ -270,11 +272,11 @@ __global__ __launch_bounds__(512) void mix_mfma_kernel(const double* __restrict_
         const long nfr = (fb1 - f0) < CH ? (fb1 - f0) : CH;
 #pragma unroll
         for (int r = 0; r < OPT; ++r) {
-            const int e = tid + r * 512;
+            const int e = tid + r * kMixNT;
             oreg[r] = e < nfr * D ? obs[(size_t)f0 * D + e] : 0.0;
         }
-        if (tid < CH * 8) {
-            const int fr = tid >> 3, js = blockIdx.x * 8 + (tid & 7);
+        if (tid < CH * kMixWaves) {
+            const int fr = tid / kMixWaves, js = blockIdx.x * kMixWaves + (tid % kMixWaves);
             const long f = f0 + fr;
             s_ab = LN_NEG_INF;
             s_bb = 0.0;
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(512) void mix_mfma_kernel(const double* __restrict_
     auto stage_store = [&](int bufi) {
 #pragma unroll
         for (int r = 0; r < OPT; ++r) {
-            const int e = tid + r * 512;
+            const int e = tid + r * kMixNT;
             if (e < CH * D) {
                 const int fr = e / D, d = e % D;
                 const double x = oreg[r] - cen[d];
@@ -299,7 +301,7 @@ __global__ __launch_bounds__(512) void mix_mfma_kernel(const double* __restrict_
                 feat[bufi][fr * FST + D + d] = x * x;
             }
         }
-        if (tid < CH * 8) {
+        if (tid < CH * kMixWaves) {
             sab[bufi][tid] = s_ab;
             sbb[bufi][tid] = s_bb;
         }
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(512) void mix_mfma_kernel(const double* __restrict_
                 constexpr int RM = kMixRing;
                 ring_load((ks + RM - 1) % RM, f0 + 4 * (ks + RM - 1) + kk);
                 const int fk = 4 * ks + kk;
-                const double ab = sab[cur][fk * 8 + w], bb = sbb[cur][fk * 8 + w];
+                const double ab = sab[cur][fk * kMixWaves + w], bb = sbb[cur][fk * kMixWaves + w];
                 double g[MT];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
@@ -397,8 +399,10 @@ __global__ void mix_finish_kernel(const double* __restrict__ R, const double* __
 // a contiguous frame range; the posteriors are recomputed per chunk (an exp per (frame, mixture): cheap next
 // to the 10 MFMAs it feeds), the chunk's feature rows y_a y_b are built once per 32 frames in LDS.
 // ------------------------------------------------------------------------------------------
+constexpr int kFullWaves = 8, kFullNT = 64 * kFullWaves;   // the full-covariance kernel's LDS (69 KB) allows two blocks per CU
+
 template <int MT>
-__global__ __launch_bounds__(512) void full_mfma_kernel(const double* __restrict__ obs, const double* __restrict__ alpha,
+__global__ __launch_bounds__(64 * kFullWaves) void full_mfma_kernel(const double* __restrict__ obs, const double* __restrict__ alpha,
                                                         const double* __restrict__ beta, const double* __restrict__ b,
                                                         const double* __restrict__ bm, const double* __restrict__ c1,
                                                         const double* __restrict__ logw, const double* __restrict__ centre,
@@ -406,30 +410,30 @@ __global__ __launch_bounds__(512) void full_mfma_kernel(const double* __restrict
                                                         long F, long FPB, int T, int N, int M, int D, int NCH,
                                                         double* __restrict__ R) {
     constexpr int CH = kMixFrames, CT = 5, NFP = 16 * CT, FST = NFP, YST = 42;
-    constexpr int OPT = (CH * 39 + 511) / 512;
+    constexpr int OPT = (CH * 39 + kFullNT - 1) / kFullNT;
     __shared__ double feat[2][CH * FST];
     __shared__ double yrow[2][CH * YST];             // y[0..D-1], then 1.0 at D and 0.0 at D+1
-    __shared__ double sab[2][CH * 8], sbb[2][CH * 8];
+    __shared__ double sab[2][CH * kFullWaves], sbb[2][CH * kFullWaves];
     __shared__ double etab[kExpTab];
     __shared__ double cen[40];
     __shared__ int pa[NFP], pb[NFP];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l15 = lane & 15, kk = lane >> 4;
-    const int j = blockIdx.x * 8 + w, cc = blockIdx.y;
+    const int j = blockIdx.x * kFullWaves + w, cc = blockIdx.y;
     const bool active = j < N;
     const int jc = active ? j : N - 1;
     const long fb0 = (long)blockIdx.z * FPB;
     long fb1 = fb0 + FPB;
     if (fb1 > F) fb1 = F;
     if (fb0 >= fb1) return;
-    exp_table_init(etab, tid, 512);
+    exp_table_init(etab, tid, kFullNT);
     if (tid < D) cen[tid] = centre[tid];
     if (tid < NFP) {
         const int code = pairtab[cc * NFP + tid], d = code & 0xFF, e = (code >> 8) & 0xFF;
         pa[tid] = d < D ? d : (d == 0xFF ? D : D + 1);
         pb[tid] = e < D ? e : (e == 0xFF ? D : D + 1);
     }
-    for (int e = tid; e < 2 * CH * 2; e += 512) {
+    for (int e = tid; e < 2 * CH * 2; e += kFullNT) {
         const int bufi = e / (CH * 2), r = e % (CH * 2);
         yrow[bufi][(r >> 1) * YST + D + (r & 1)] = (r & 1) ? 0.0 : 1.0;
     }
@@ -444,11 +448,11 @@ __global__ __launch_bounds__(512) void full_mfma_kernel(const double* __restrict
         const long nfr = (fb1 - f0) < CH ? (fb1 - f0) : CH;
 #pragma unroll
         for (int r = 0; r < OPT; ++r) {
-            const int e = tid + r * 512;
+            const int e = tid + r * kFullNT;
             oreg[r] = e < nfr * D ? obs[(size_t)f0 * D + e] : 0.0;
         }
-        if (tid < CH * 8) {
-            const int fr = tid >> 3, js = blockIdx.x * 8 + (tid & 7);
+        if (tid < CH * kFullWaves) {
+            const int fr = tid / kFullWaves, js = blockIdx.x * kFullWaves + (tid % kFullWaves);
             const long f = f0 + fr;
             s_ab = LN_NEG_INF;
             s_bb = 0.0;
@@ -465,19 +469,19 @@ __global__ __launch_bounds__(512) void full_mfma_kernel(const double* __restrict
     auto stage_store = [&](int bufi) {
 #pragma unroll
         for (int r = 0; r < OPT; ++r) {
-            const int e = tid + r * 512;
+            const int e = tid + r * kFullNT;
             if (e < CH * D) {
                 const int fr = e / D, d = e % D;
                 yrow[bufi][fr * YST + d] = oreg[r] - cen[d];
             }
         }
-        if (tid < CH * 8) {
+        if (tid < CH * kFullWaves) {
             sab[bufi][tid] = s_ab;
             sbb[bufi][tid] = s_bb;
         }
     };
     auto build_feat = [&](int bufi) {
-        for (int e = tid; e < CH * NFP; e += 512) {
+        for (int e = tid; e < CH * NFP; e += kFullNT) {
             const int fr = e / NFP, col = e % NFP;
             feat[bufi][fr * FST + col] = yrow[bufi][fr * YST + pa[col]] * yrow[bufi][fr * YST + pb[col]];
         }
@@ -515,7 +519,7 @@ __global__ __launch_bounds__(512) void full_mfma_kernel(const double* __restrict
                 constexpr int RM = kMixRing;
                 ring_load((ks + RM - 1) % RM, f0 + 4 * (ks + RM - 1) + kk);
                 const int fk = 4 * ks + kk;
-                const double ab = sab[cur][fk * 8 + w], bb = sbb[cur][fk * 8 + w];
+                const double ab = sab[cur][fk * kFullWaves + w], bb = sbb[cur][fk * kFullWaves + w];
                 double g[MT];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
@@ -591,7 +595,7 @@ int full_stats_device(lnasr_ctx* ctx, const double* obs, const double* alpha, co
     double* centre = R + nraw;
     LN_HIP(hipMemsetAsync(R, 0, nraw * 8, ctx->stream));
     LN_LAUNCH(ctx, "mix_centre", mix_centre_kernel, dim3(D), dim3(256), 0, md.mu.as<double>(), N * M, D, centre);
-    const int SG = (N + 7) / 8;
+    const int SG = (N + kFullWaves - 1) / kFullWaves;
     const long nchunk = (F + kMixFrames - 1) / kMixFrames;
     long G = (2L * ctx->prop.multiProcessorCount + (long)SG * NCH - 1) / ((long)SG * NCH);
     if (G > nchunk) G = nchunk;
@@ -602,10 +606,10 @@ int full_stats_device(lnasr_ctx* ctx, const double* obs, const double* alpha, co
     const dim3 grid(SG, NCH, (unsigned)G);
     const double* lw = md.logw.as<double>();
     if (MT == 1)
-        LN_LAUNCH(ctx, "full_mfma", full_mfma_kernel<1>, grid, dim3(512), 0, obs, alpha, beta, b, bm, c1, lw,
+        LN_LAUNCH(ctx, "full_mfma", full_mfma_kernel<1>, grid, dim3(kFullNT), 0, obs, alpha, beta, b, bm, c1, lw,
                   (const double*)centre, (const int*)md.pairtab.as<int>(), d_lens, F, FPB, T, N, M, D, NCH, R);
     else
-        LN_LAUNCH(ctx, "full_mfma", full_mfma_kernel<2>, grid, dim3(512), 0, obs, alpha, beta, b, bm, c1, lw,
+        LN_LAUNCH(ctx, "full_mfma", full_mfma_kernel<2>, grid, dim3(kFullNT), 0, obs, alpha, beta, b, bm, c1, lw,
                   (const double*)centre, (const int*)md.pairtab.as<int>(), d_lens, F, FPB, T, N, M, D, NCH, R);
     const size_t nel = (size_t)N * M * D * D;
     LN_LAUNCH(ctx, "full_finish", full_finish_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, (const double*)R,
@@ -625,7 +629,7 @@ static int mix_launch(lnasr_ctx* ctx, int CT, dim3 grid, const double* obs, cons
     const double* lw = md.logw.as<double>();
 #define LN_MIX_CASE(ct)                                                                                              \
     case ct:                                                                                                         \
-        LN_LAUNCH(ctx, "mix_mfma", (mix_mfma_kernel<MT, ct>), grid, dim3(512), 0, obs, alpha, beta, b, bm, c1, lw, centre, \
+        LN_LAUNCH(ctx, "mix_mfma", (mix_mfma_kernel<MT, ct>), grid, dim3(kMixNT), 0, obs, alpha, beta, b, bm, c1, lw, centre, \
                   d_lens, F, FPB, T, md.N, md.M, md.D, R);                                                           \
         break;
     switch (CT) {
@@ -653,7 +657,7 @@ int mix_stats_device(lnasr_ctx* ctx, const double* obs, const double* alpha, con
     double* centre = R + nraw;
     LN_HIP(hipMemsetAsync(R, 0, nraw * 8, ctx->stream));
     LN_LAUNCH(ctx, "mix_centre", mix_centre_kernel, dim3(D), dim3(256), 0, md.mu.as<double>(), N * M, D, centre);
-    const int SG = (N + 7) / 8;
+    const int SG = (N + kMixWaves - 1) / kMixWaves;
     const long nchunk = (F + kMixFrames - 1) / kMixFrames;
     long G = (2L * ctx->prop.multiProcessorCount + SG - 1) / SG;
     if (G > nchunk) G = nchunk;
