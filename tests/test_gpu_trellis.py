@@ -291,7 +291,8 @@ def test_bw_statistics_extreme_range(oracle, ctx):
 def test_bw_statistics_wide(synth, oracle, ctx):
     """Shapes that exercise every tile path of the matrix-core statistics kernels: N not a multiple of 8 or
     16, M = 17..32 (two mixture tiles), D = 39 (five feature tiles), ragged lengths, -inf weights."""
-    for N, M, D, U, T, seed in ((19, 20, 39, 3, 70, 1), (130, 3, 5, 2, 40, 2), (8, 32, 13, 4, 33, 3)):
+    for N, M, D, U, T, seed in ((19, 20, 39, 3, 70, 1), (130, 3, 5, 2, 40, 2), (8, 32, 13, 4, 33, 3), (5, 2, 20, 2, 37, 4),
+                                (3, 17, 28, 1, 66, 5), (2, 2, 1, 2, 9, 6)):
         mdl = synth.synth_model(N, M, D, seed=seed)
         w = mdl["w"].copy()
         w[1, 0] = -np.inf                                   # a dead component
