@@ -65,8 +65,8 @@ struct Model {
     DevBuf sigma_raw;            // full upload staging [N,M,D,D]
     DevBuf wpack, wpack_nw;      // MFMA-packed coefficient fragments (diag): with / without log w folded in
     int wpack_Q = 0, wpack_KS = 0, wpack_NG = 0;
-    DevBuf wsingle;              // N = 1: coefficient fragments of the single mixture
-    int wsingle_KS = 0;
+    DevBuf wdirect;              // N = 1: coefficient fragments of the single mixture (gmm.hip: emit_single_direct)
+    int wdirect_KS = 0;
     DevBuf wfull, wfull_nw, pairtab;   // full covariance: quadratic-feature coefficients in MFMA fragment order
     int wfull_Q = 0, wfull_NCH = 0, wfull_virt = 1;
     int wpack_virt = 1;          // M = 16*virt mixtures are scored as `virt` virtual 16-mixture states, then merged

@@ -383,113 +383,98 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 2))
 // ------------------------------------------------------------------------------------------
 // single GMM (N = 1, M <= 16): HBM-bound row of the path (gmm.py:90-100 over a batch)
 // ------------------------------------------------------------------------------------------
-// 320 B of traffic per frame against 20 MFMAs: the kernel is laid out for bytes in flight, not
-// for FLOPs.  Every wave is independent (no block barriers): it owns a private LDS feature tile,
-// walks 16-frame tiles with the next tile's observations already in registers, runs the
-// 16-component x 16-frame MFMA chain and reduces the 16 mixtures across its four 16-lane rows.
-// wsingle[ks*64 + lane] = coefficient of component (lane & 15), k = 4*ks + (lane >> 4), log w excluded.
-__global__ void pack_single_kernel(const double* __restrict__ mu, const double* __restrict__ ivar,
-                                   const double* __restrict__ gconst, double* __restrict__ wsingle, int M, int D,
-                                   int KS) {
+// 320 B of traffic per frame against 20 MFMAs: the kernel is laid out for bytes in flight, not for FLOPs.
+// Every wave is independent (no block barriers) and walks 16-frame tiles with the next tile's observations
+// already requested; the 16-component x 16-frame MFMA chain is followed by a reduction of the 16 mixtures
+// across the wave's four 16-lane rows.
+//
+// No LDS staging.  With the features ordered as K = [x^2 block | x block], each block DP = 4*ceil((D+1)/4) wide
+// and the constant 1 sitting in the spare slot D of the x^2 block, the MFMA B operand of k-step ks is, for lane
+// (g = lane >> 4, frame fr = lane & 15), simply x[fr][4 j + g] (or its square, or 1): every lane loads its own
+// DP/4 values of its own frame straight from global memory (32-byte pieces of 16 rows per instruction: the ten
+// instructions of a tile hit the same 39 lines in L1), squares them in registers, and nothing goes through LDS.
+//   wdirect[ks*64 + lane]: component m = lane & 15, slot k = 4 ks + (lane >> 4)
+__global__ void pack_single_direct_kernel(const double* __restrict__ mu, const double* __restrict__ ivar,
+                                          const double* __restrict__ gconst, double* __restrict__ wdirect, int M, int D,
+                                          int KS) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= KS * 64) return;
+    const int DP = 2 * KS;
     const int lane = idx & 63, ks = idx >> 6;
     const int m = lane & 15, k = 4 * ks + (lane >> 4);
+    const int d = k < DP ? k : k - DP;
     double val = 0.0;
     if (m < M) {
-        if (k < D) {
-            val = -0.5 * ivar[(size_t)m * D + k];
-        } else if (k < 2 * D) {
-            val = mu[(size_t)m * D + k - D] * ivar[(size_t)m * D + k - D];
-        } else if (k == 2 * D) {
-            double sq = 0.0;
-            for (int d = 0; d < D; ++d) sq += mu[(size_t)m * D + d] * mu[(size_t)m * D + d] * ivar[(size_t)m * D + d];
-            val = gconst[m] - 0.5 * sq;
+        if (k < DP) {
+            if (d < D) {
+                val = -0.5 * ivar[(size_t)m * D + d];
+            } else if (d == D) {
+                double sq = 0.0;
+                for (int e = 0; e < D; ++e) sq += mu[(size_t)m * D + e] * mu[(size_t)m * D + e] * ivar[(size_t)m * D + e];
+                val = gconst[m] - 0.5 * sq;
+            }
+        } else if (d < D) {
+            val = mu[(size_t)m * D + d] * ivar[(size_t)m * D + d];
         }
-    } else if (k == 2 * D) {
+    } else if (k < DP && d == D) {
         val = LN_NEG_INF;                      // padding component: contributes exp(-inf) = 0
     }
-    wsingle[idx] = val;
+    wdirect[idx] = val;
 }
 
 template <int KS, bool WRITE_BM>
-__global__ __launch_bounds__(256) void emit_single_mfma(const double* __restrict__ obs,
-                                                        const double* __restrict__ wsingle,
-                                                        const double* __restrict__ logw, double* __restrict__ b,
-                                                        double* __restrict__ bm, long F, int M, int D, long ntiles) {
-    constexpr int KP = 4 * KS, FS = 17;
-    constexpr int MAXLD = (16 * ((KP - 1) / 2) + 63) / 64;     // loads per lane for one 16-frame tile
-    __shared__ double Fl[4][KP * FS];
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void emit_single_direct(const double* __restrict__ obs,
+                                                          const double* __restrict__ wdirect,
+                                                          const double* __restrict__ logw, double* __restrict__ b,
+                                                          double* __restrict__ bm, long F, int M, int D, long ntiles) {
+    constexpr int NL = KS / 2;                 // loads per lane and tile
     __shared__ double etab[kExpTab];
     __shared__ double ltab[2 * kLogTab];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int e = tid; e < kExpTab; e += 256) etab[e] = exp2((double)e * (1.0 / kExpTab));
     log_table_init(ltab, tid, 256);
-    double* Fw = &Fl[w][0];
-    for (int e = lane; e < (KP - 2 * D) * 16; e += 64) {
-        const int k = 2 * D + e / 16;
-        Fw[k * FS + (e % 16)] = (k == 2 * D) ? 1.0 : 0.0;
-    }
-    __syncthreads();                           // table ready; from here on waves never synchronise
-
+    __syncthreads();                           // tables ready; from here on waves never synchronise
     double wr[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) wr[ks] = wsingle[ks * 64 + lane];
+    for (int ks = 0; ks < KS; ++ks) wr[ks] = wdirect[ks * 64 + lane];
     const int g = lane >> 4, fr = lane & 15;
     double lw[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) lw[r] = (g + 4 * r < M) ? logw[g + 4 * r] : 0.0;
-
-    const int EL = 16 * D;
     const long lim = F * (long)D;
-    // straight-line staging: every lane issues all MAXLD loads (index clamped) and all LDS writes (lanes past
-    // the tile write the unused padding column 16) -- branches here would make the compiler drain the memory
-    // counter between consecutive loads
-    int foff[MAXLD];
+    // slot 4 j + g of this lane: a real dimension, the constant (== D), or padding (> D: coefficient 0; the value
+    // read there is the start of the next frame, or 0 past the end of obs)
+    bool is_one[NL];
 #pragma unroll
-    for (int r = 0; r < MAXLD; ++r) {
-        const int e = lane + r * 64;
-        const int f = e / D, d = e - f * D;
-        foff[r] = e < EL ? d * FS + f : (lane & 15) * FS + 16;
-    }
-    double pre[MAXLD];
-    // buffer loads: the tile's base address and the bytes left in obs are wave-uniform (SGPRs), the lane offset
-    // is one 32-bit VGPR, and reads past the end of obs return 0 without any per-lane clamping
+    for (int j = 0; j < NL; ++j) is_one[j] = (4 * j + g) == D;
+    double pre[NL];
     auto load_tile = [&](long tile) {
         const long e0 = tile * 16 * (long)D;
         long left = (lim - e0) * 8;
         left = left < 0 ? 0 : (left > 0x7FFFFFFFL ? 0x7FFFFFFFL : left);
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(obs + e0), 0, (int)left, 0x00020000);
+        const int vo = (fr * D + g) * 8;
 #pragma unroll
-        for (int r = 0; r < MAXLD; ++r)
-            pre[r] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, lane * 8 + r * 512, 0, 0));
+        for (int j = 0; j < NL; ++j)
+            pre[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, vo + 32 * j, 0, 0));
     };
     const long wid = (long)blockIdx.x * 4 + w, nw = (long)gridDim.x * 4;
     long tile = wid;
     drain_vmem();                              // wr[] resident: no vmcnt guards inside the loop
     load_tile(tile);
     for (; tile < ntiles; tile += nw) {
-        const int xo = D * FS;
+        double bx[NL], bq[NL];
 #pragma unroll
-        for (int r = 0; r < MAXLD; ++r) {
-            const double x = pre[r];
-            Fw[foff[r]] = x * x;
-            Fw[foff[r] + xo] = x;
+        for (int j = 0; j < NL; ++j) {
+            bx[j] = pre[j];
+            bq[j] = is_one[j] ? 1.0 : pre[j] * pre[j];
         }
         load_tile(tile + nw);
-        __builtin_amdgcn_wave_barrier();       // wave-private tile: ordering within the wave is enough
         double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
-        // all B fragments are requested up front (the compiler would otherwise re-use one register pair and
-        // expose an LDS round trip in front of every second MFMA of the dependent chain)
-        double bf[KS];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) bf[ks] = Fw[(4 * ks + g) * FS + fr];
-        __builtin_amdgcn_sched_barrier(0);
+        for (int j = 0; j < NL; ++j) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wr[j], bq[j], acc, 0, 0, 0);
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wr[ks], bf[ks], acc, 0, 0, 0);
-        }
-        __builtin_amdgcn_wave_barrier();
+        for (int j = 0; j < NL; ++j) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wr[NL + j], bx[j], acc, 0, 0, 0);
         const long frame = tile * 16 + fr;
         if (WRITE_BM && frame < F) {
 #pragma unroll
@@ -735,15 +720,15 @@ static int model_upload_impl(lnasr_ctx* ctx, int N, int M, int D, const double* 
         LN_LAUNCH(ctx, "prep_diag", prep_diag_kernel, dim3((unsigned)((NM + 127) / 128)), dim3(128), 0,
                   md.var.as<double>(), md.ivar.as<double>(), md.gconst.as<double>(), (int)NM, D);
         int Q = 0, KS = 0;
-        md.wsingle_KS = 0;
+        md.wdirect_KS = 0;
         if (N == 1 && M <= 16 && D <= 64) {
-            const int ks1 = (2 * D + 1 + 3) / 4;
-            if (ks1 == 20 || ks1 == 14 || ks1 == 7) {
-                LN_TRY(md.wsingle.reserve((size_t)ks1 * 64 * 8));
-                LN_LAUNCH(ctx, "pack_single", pack_single_kernel, dim3((ks1 * 64 + 255) / 256), dim3(256), 0,
-                          md.mu.as<double>(), md.ivar.as<double>(), md.gconst.as<double>(), md.wsingle.as<double>(), M,
-                          D, ks1);
-                md.wsingle_KS = ks1;
+            const int ksd = 2 * ((D + 1 + 3) / 4);           // LDS-free layout: K = 2 * 4 ceil((D+1)/4)
+            if (ksd == 20 || ksd == 14 || ksd == 8) {
+                LN_TRY(md.wdirect.reserve((size_t)ksd * 64 * 8));
+                LN_LAUNCH(ctx, "pack_single_direct", pack_single_direct_kernel, dim3((ksd * 64 + 255) / 256), dim3(256), 0,
+                          md.mu.as<double>(), md.ivar.as<double>(), md.gconst.as<double>(), md.wdirect.as<double>(), M,
+                          D, ksd);
+                md.wdirect_KS = ksd;
             }
         }
         // M = 16*k mixtures: score k virtual 16-mixture states per state ([N,M,D] is [N*k,16,D] in memory)
@@ -841,24 +826,24 @@ int emit_device(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, v
     if (!md.has_gmm) return fail(LNASR_E_NOMODEL, "no GMM-HMM model uploaded");
     if (F <= 0) return 0;
     const int N = md.N, M = md.M, D = md.D;
-    if (md.diag && dtype == LNASR_F64 && md.wsingle_KS > 0 && !getenv("LNASR_NO_MFMA")) {
+    if (md.diag && dtype == LNASR_F64 && md.wdirect_KS > 0 && !getenv("LNASR_NO_MFMA")) {
         const long ntiles = (F + 15) / 16;
         const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
         long grid = (ntiles + 3) / 4;
-        // grid-stride over tiles; two 4-wave blocks per CU measured faster than three (LDS allows three) or four
-        if (grid > (long)cus * 2) grid = (long)cus * 2;
-#define LN_SCASE(ks)                                                                                              \
-    if (md.wsingle_KS == ks) {                                                                                    \
+        // grid-stride over tiles, every wave resident: four 4-wave blocks per CU (128 VGPRs, 4 KB of LDS each)
+        if (grid > (long)cus * 4) grid = (long)cus * 4;
+#define LN_DCASE(ks)                                                                                              \
+    if (md.wdirect_KS == ks) {                                                                                    \
         if (bm)                                                                                                   \
-            LN_LAUNCH(ctx, "emit_single_mfma_bm", (emit_single_mfma<ks, true>), dim3((unsigned)grid), dim3(256), 0, obs, \
-                      md.wsingle.as<double>(), md.logw.as<double>(), (double*)b, (double*)bm, F, M, D, ntiles);   \
+            LN_LAUNCH(ctx, "emit_single_direct_bm", (emit_single_direct<ks, true>), dim3((unsigned)grid), dim3(256), 0, obs, \
+                      md.wdirect.as<double>(), md.logw.as<double>(), (double*)b, (double*)bm, F, M, D, ntiles);   \
         else                                                                                                      \
-            LN_LAUNCH(ctx, "emit_single_mfma", (emit_single_mfma<ks, false>), dim3((unsigned)grid), dim3(256), 0, obs, \
-                      md.wsingle.as<double>(), md.logw.as<double>(), (double*)b, (double*)bm, F, M, D, ntiles);   \
+            LN_LAUNCH(ctx, "emit_single_direct", (emit_single_direct<ks, false>), dim3((unsigned)grid), dim3(256), 0, obs, \
+                      md.wdirect.as<double>(), md.logw.as<double>(), (double*)b, (double*)bm, F, M, D, ntiles);   \
         return 0;                                                                                                 \
     }
-        LN_SCASE(20) LN_SCASE(14) LN_SCASE(7)
-#undef LN_SCASE
+        LN_DCASE(20) LN_DCASE(14) LN_DCASE(8)
+#undef LN_DCASE
     }
     if (md.diag && dtype == LNASR_F64 && md.wpack_Q > 0 && !getenv("LNASR_NO_MFMA")) {
         const int Q = md.wpack_Q, KS = md.wpack_KS;
