@@ -1,4 +1,6 @@
 // Runtime: context, device memory, staging, per-kernel HIP-event profiling, errors.
+#include <algorithm>
+
 #include "common.h"
 
 namespace lnasr {
@@ -85,6 +87,28 @@ int stage_out(lnasr_ctx* ctx, void* p, size_t bytes, DevBuf& ws, void** out) {
     }
     LN_TRY(ws.reserve(bytes));
     *out = ws.p;
+    return 0;
+}
+
+__global__ void widen_kernel(const float* __restrict__ s, double* __restrict__ d, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d[i] = (double)s[i];
+}
+__global__ void narrow_kernel(const double* __restrict__ s, float* __restrict__ d, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d[i] = (float)s[i];
+}
+bool f32_via_f64() { return !getenv("LNASR_F32_GENERIC"); }
+int widen_f32(lnasr_ctx* ctx, const void* src, size_t n, DevBuf& ws, double** out) {
+    LN_TRY(ws.reserve(n * 8));
+    *out = ws.as<double>();
+    if (n == 0) return 0;
+    const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 65535 * 4);
+    LN_LAUNCH(ctx, "widen_f32", widen_kernel, dim3(grid), dim3(256), 0, (const float*)src, *out, n);
+    return 0;
+}
+int narrow_f64(lnasr_ctx* ctx, const double* src, size_t n, void* dst) {
+    if (n == 0) return 0;
+    const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 65535 * 4);
+    LN_LAUNCH(ctx, "narrow_f64", narrow_kernel, dim3(grid), dim3(256), 0, src, (float*)dst, n);
     return 0;
 }
 
@@ -194,7 +218,7 @@ void lnasr_ctx_destroy(lnasr_ctx* ctx) {
     ctx->model.release();
     DevBuf* all[] = {&ctx->ws_in, &ctx->ws_in2, &ctx->ws_in3, &ctx->ws_in4, &ctx->ws_in5, &ctx->ws_out, &ctx->ws_out2,
                      &ctx->ws_out3, &ctx->ws_b, &ctx->ws_bm, &ctx->ws_v, &ctx->ws_alpha, &ctx->ws_beta,
-                     &ctx->ws_misc, &ctx->ws_misc2, &ctx->ws_lens, &ctx->ws_stats, &ctx->ws_p, &ctx->ws_q, &ctx->ws_raw, &ctx->mfcc_const};
+                     &ctx->ws_misc, &ctx->ws_misc2, &ctx->ws_lens, &ctx->ws_stats, &ctx->ws_p, &ctx->ws_q, &ctx->ws_raw, &ctx->ws_w1, &ctx->ws_w2, &ctx->ws_w3, &ctx->mfcc_const};
     for (DevBuf* b : all) b->release();
     for (auto& r : ctx->prof_recs) {
         (void)hipEventDestroy(r.e0);

@@ -826,6 +826,14 @@ int emit_device(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, v
     if (!md.has_gmm) return fail(LNASR_E_NOMODEL, "no GMM-HMM model uploaded");
     if (F <= 0) return 0;
     const int N = md.N, M = md.M, D = md.D;
+    if (dtype == LNASR_F32 && f32_via_f64()) {
+        const size_t cells = (size_t)F * N;
+        LN_TRY(ctx->ws_w1.reserve(cells * 8));
+        if (bm) LN_TRY(ctx->ws_w3.reserve(cells * M * 8));
+        LN_TRY(emit_device(ctx, obs, F, LNASR_F64, ctx->ws_w1.p, bm ? ctx->ws_w3.p : nullptr));
+        LN_TRY(narrow_f64(ctx, ctx->ws_w1.as<double>(), cells, b));
+        return bm ? narrow_f64(ctx, ctx->ws_w3.as<double>(), cells * M, bm) : 0;
+    }
     if (md.diag && dtype == LNASR_F64 && md.wdirect_KS > 0 && !getenv("LNASR_NO_MFMA")) {
         const long ntiles = (F + 15) / 16;
         const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;

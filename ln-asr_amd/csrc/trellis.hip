@@ -1416,6 +1416,17 @@ int forward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
                    double* loglik) {
     Model& md = ctx->model;
     const int N = md.N;
+    if (dtype == LNASR_F32 && f32_via_f64()) {
+        const size_t cells = (size_t)U * T * N;
+        double *b64, *a64 = nullptr;
+        LN_TRY(widen_f32(ctx, b, cells, ctx->ws_w1, &b64));
+        if (alpha) {
+            LN_TRY(ctx->ws_w2.reserve(cells * 8));
+            a64 = ctx->ws_w2.as<double>();
+        }
+        LN_TRY(forward_device(ctx, b64, U, T, d_lens, LNASR_F64, a64, loglik));
+        return alpha ? narrow_f64(ctx, a64, cells, alpha) : 0;
+    }
     if (dtype == LNASR_F64 && N <= 128 && !getenv("LNASR_NO_REGFWD")) {
         if (N <= 64)
             LN_LAUNCH(ctx, "forward_reg_n64", (fwdbwd_reg<false, 1, 2, 32, 2, 3>), dim3((U + 1) / 2), dim3(128), 0,
@@ -1475,6 +1486,14 @@ int forward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
 int backward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d_lens, int dtype, void* beta) {
     Model& md = ctx->model;
     const int N = md.N;
+    if (dtype == LNASR_F32 && f32_via_f64()) {
+        const size_t cells = (size_t)U * T * N;
+        double* b64;
+        LN_TRY(widen_f32(ctx, b, cells, ctx->ws_w1, &b64));
+        LN_TRY(ctx->ws_w2.reserve(cells * 8));
+        LN_TRY(backward_device(ctx, b64, U, T, d_lens, LNASR_F64, ctx->ws_w2.as<double>()));
+        return narrow_f64(ctx, ctx->ws_w2.as<double>(), cells, beta);
+    }
     const double* expAT = md.expAT.as<double>();
     if (dtype == LNASR_F64 && N <= 128 && !getenv("LNASR_NO_REGFWD")) {
         if (N <= 64)
@@ -1599,6 +1618,9 @@ int lnasr_viterbi(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* le
     LN_TRY(stage_out(ctx, v_or_null, cells * es, ctx->ws_v, &d_v));
     LN_TRY(stage_out(ctx, path, (size_t)U * T * 4, ctx->ws_out, &d_path));
     if (best_score_or_null) LN_TRY(stage_out(ctx, best_score_or_null, (size_t)U * 8, ctx->ws_out2, &d_best));
+    // float32 storage stays on the storage-templated kernels here: rounding v to f32 after every frame is what
+    // makes v, bt and path bit-identical to the reference run with precision=np.float32 (golden gmmhmm_small_f32);
+    // forward / backward / emission are tolerance-checked and take the widened f64 route (common.h)
     LN_TRY(viterbi_device(ctx, d_b, U, T, d_lens, dtype, d_v));
     LN_TRY(backtrace_device(ctx, d_v, U, T, d_lens, dtype, (uint32_t*)d_path, (double*)d_best));
     if (bt_or_null) {
