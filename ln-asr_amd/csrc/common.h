@@ -86,6 +86,7 @@ struct lnasr_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;            // side stream: the backward pass runs beside the forward pass
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    std::vector<hipEvent_t> copy_events;      // one per upload chunk of emit_batch
     hipDeviceProp_t prop;
     lnasr::Model model;
     // workspace
@@ -148,6 +149,11 @@ bool full_stats_mfma_ok(const Model& md);
 int full_stats_device(lnasr_ctx* ctx, const double* obs, const double* alpha, const double* beta, const double* b,
                       const double* bm, const double* c1, const int32_t* d_lens, int U, int T, double* mix,
                       double* mix_x, double* mix_xx);
+
+// Emission of a batch whose observations may still be in host memory: the upload is cut into chunks that a helper
+// thread pushes through the side stream while the emission kernel already runs on the chunks that have arrived
+// (device-resident observations: one plain launch).  b [U*T, N], bm [U*T, N, M] or null are device pointers.
+int emit_batch(lnasr_ctx* ctx, const double* obs, int U, int T, double* b, double* bm, const double** d_obs_out);
 
 // float32 storage (`precision=np.float32`): the tuned kernels are f64-only, so f32 inputs are widened, the f64
 // kernels run, and results are rounded to f32 on the way out (more accurate than rounding every stored

@@ -225,6 +225,7 @@ void lnasr_ctx_destroy(lnasr_ctx* ctx) {
         (void)hipEventDestroy(r.e1);
     }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    for (auto e : ctx->copy_events) (void)hipEventDestroy(e);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);

@@ -9,6 +9,10 @@
 //                         with the M-way log-sum-exp fused in-lane          (hot kernel)
 //   emit_diag_generic     any N/M/D, fp64 VALU, direct (x-mu)^2/var form
 //   emit_full_generic     full covariance: (x-mu)^T P (x-mu)
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+
 #include "common.h"
 #include "devmath.h"
 
@@ -902,6 +906,70 @@ int emit_device(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, v
                       (double*)b, (double*)bm, F, N, M, D, fw);
     }
     return 0;
+}
+
+int emit_batch(lnasr_ctx* ctx, const double* obs, int U, int T, double* b, double* bm, const double** d_obs_out) {
+    Model& md = ctx->model;
+    const size_t utt = (size_t)T * md.D;                       // doubles per utterance
+    constexpr int kMinChunk = 64, kMaxChunks = 8;
+    int nch = U / kMinChunk;
+    nch = nch > kMaxChunks ? kMaxChunks : nch;
+    if (is_device_ptr(obs) || nch < 2 || getenv("LNASR_NO_PIPELINE")) {
+        const void* d_obs;
+        LN_TRY(stage_in(ctx, obs, (size_t)U * utt * 8, ctx->ws_in, &d_obs));
+        if (d_obs_out) *d_obs_out = (const double*)d_obs;
+        return emit_device(ctx, (const double*)d_obs, (long)U * T, LNASR_F64, b, bm);
+    }
+    LN_TRY(ctx->ws_in.reserve((size_t)U * utt * 8));
+    double* d_obs = ctx->ws_in.as<double>();
+    if (d_obs_out) *d_obs_out = d_obs;
+    while ((int)ctx->copy_events.size() < nch) {
+        hipEvent_t e;
+        LN_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->copy_events.push_back(e);
+    }
+    // the side stream must not run ahead of work that still reads the staging buffer
+    LN_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+    LN_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+    std::mutex mu;
+    std::condition_variable cv;
+    int ready = 0;
+    hipError_t cerr = hipSuccess;
+    auto bounds = [&](int c) { return (int)((long)U * c / nch); };
+    std::thread copier([&] {
+        (void)hipSetDevice(ctx->device);
+        for (int c = 0; c < nch; ++c) {
+            const int u0 = bounds(c), u1 = bounds(c + 1);
+            hipError_t e = hipMemcpyAsync(d_obs + (size_t)u0 * utt, obs + (size_t)u0 * utt, (size_t)(u1 - u0) * utt * 8,
+                                          hipMemcpyHostToDevice, ctx->stream2);
+            if (e == hipSuccess) e = hipEventRecord(ctx->copy_events[c], ctx->stream2);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (e != hipSuccess) cerr = e;
+                ready = e == hipSuccess ? c + 1 : nch;
+            }
+            cv.notify_one();
+            if (e != hipSuccess) return;
+        }
+    });
+    int rc = 0;
+    for (int c = 0; c < nch && rc == 0; ++c) {
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return ready > c; });
+            if (cerr != hipSuccess) break;
+        }
+        const int u0 = bounds(c), u1 = bounds(c + 1);
+        if (hipStreamWaitEvent(ctx->stream, ctx->copy_events[c], 0) != hipSuccess) {
+            rc = fail(LNASR_E_HIP, "hipStreamWaitEvent failed in the upload pipeline");
+            break;
+        }
+        rc = emit_device(ctx, d_obs + (size_t)u0 * utt, (long)(u1 - u0) * T, LNASR_F64, b + (size_t)u0 * T * md.N,
+                         bm ? bm + (size_t)u0 * T * md.N * md.M : nullptr);
+    }
+    copier.join();
+    if (cerr != hipSuccess) return fail(LNASR_E_HIP, "upload pipeline: %s", hipGetErrorString(cerr));
+    return rc;
 }
 
 }  // namespace lnasr

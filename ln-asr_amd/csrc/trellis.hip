@@ -1652,14 +1652,12 @@ int lnasr_decode(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t*
     const size_t cells = (size_t)U * T * md.N;
     const int32_t* d_lens;
     LN_TRY(device_lens(ctx, lens, U, T, &d_lens));
-    const void* d_obs;
     void *d_path, *d_best = nullptr;
-    LN_TRY(stage_in(ctx, obs, (size_t)U * T * md.D * 8, ctx->ws_in, &d_obs));
     LN_TRY(ctx->ws_b.reserve(cells * 8));
     LN_TRY(ctx->ws_v.reserve(cells * 8));
     LN_TRY(stage_out(ctx, path, (size_t)U * T * 4, ctx->ws_out, &d_path));
     if (best_score_or_null) LN_TRY(stage_out(ctx, best_score_or_null, (size_t)U * 8, ctx->ws_out2, &d_best));
-    LN_TRY(emit_device(ctx, (const double*)d_obs, (long)U * T, LNASR_F64, ctx->ws_b.p, nullptr));
+    LN_TRY(emit_batch(ctx, obs, U, T, ctx->ws_b.as<double>(), nullptr, nullptr));
     LN_TRY(viterbi_device(ctx, ctx->ws_b.p, U, T, d_lens, LNASR_F64, ctx->ws_v.p));
     LN_TRY(backtrace_device(ctx, ctx->ws_v.p, U, T, d_lens, LNASR_F64, (uint32_t*)d_path, (double*)d_best));
     LN_TRY(finish_out(ctx, path, d_path, (size_t)U * T * 4));
@@ -1712,12 +1710,10 @@ int lnasr_calc_prob(lnasr_ctx* ctx, const double* obs, int U, int T, const int32
     const size_t cells = (size_t)U * T * md.N;
     const int32_t* d_lens;
     LN_TRY(device_lens(ctx, lens, U, T, &d_lens));
-    const void* d_obs;
     void* d_ll;
-    LN_TRY(stage_in(ctx, obs, (size_t)U * T * md.D * 8, ctx->ws_in, &d_obs));
     LN_TRY(ctx->ws_b.reserve(cells * 8));
     LN_TRY(stage_out(ctx, loglik, (size_t)U * 8, ctx->ws_out2, &d_ll));
-    LN_TRY(emit_device(ctx, (const double*)d_obs, (long)U * T, LNASR_F64, ctx->ws_b.p, nullptr));
+    LN_TRY(emit_batch(ctx, obs, U, T, ctx->ws_b.as<double>(), nullptr, nullptr));
     LN_TRY(forward_device(ctx, ctx->ws_b.p, U, T, d_lens, LNASR_F64, nullptr, (double*)d_ll));
     return finish_out(ctx, loglik, d_ll, (size_t)U * 8);
 }

@@ -1,6 +1,8 @@
 """GPU, BASELINE.json full sizes: size-independent properties of the decode path (determinism,
 path-score identity, spot checks against the oracle), and the section-8f 'next' rows
 (character-segmentation sized discrete HMM: n=4, m=65536, long T)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -70,3 +72,27 @@ def test_segmentation_sized_discrete_hmm(oracle):
     ll = h.calc_prob(obs[:2000])
     ref_ll = oracle.loglik(oracle.forward(A, pi, oracle.map_b(B, obs[:2000])))
     assert abs(ll - ref_ll) < 1e-10 * abs(ref_ll)
+
+
+def test_host_buffers_are_uploaded_in_a_pipeline(synth):
+    """Observations handed over as numpy arrays are uploaded in chunks from a helper thread while the emission
+    kernel already runs (>= 128 utterances); the result is the one a device-resident batch gives, ragged or not."""
+    from lnasr import _ffi
+    ctx = _ffi.default_ctx()
+    U, T, N, M, D = 333, 24, 16, 4, 39
+    mdl = synth.synth_model(N, M, D, seed=9)
+    obs = synth.synth_obs(U, T, D, seed=91)
+    lens = np.random.default_rng(5).integers(1, T + 1, U).astype(np.int32)
+    ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
+    dev = ctx.decode(ctx.to_device(obs), lens=lens).to_host()
+    piped = np.asarray(ctx.decode(obs, lens=lens))
+    ll_piped = np.asarray(ctx.calc_prob(obs, lens=lens))
+    os.environ["LNASR_NO_PIPELINE"] = "1"
+    try:
+        plain = np.asarray(ctx.decode(obs, lens=lens))
+        ll_plain = np.asarray(ctx.calc_prob(obs, lens=lens))
+    finally:
+        del os.environ["LNASR_NO_PIPELINE"]
+    for u in range(U):
+        assert np.array_equal(piped[u, :lens[u]], dev[u, :lens[u]]) and np.array_equal(plain[u, :lens[u]], dev[u, :lens[u]])
+    assert np.array_equal(ll_piped, ll_plain)
