@@ -670,9 +670,8 @@ int lnasr_bw_accumulate(lnasr_ctx* ctx, const double* obs, int U, int T, const i
     const StatsLayout L = stats_layout(N, M, D, md.diag);
     const int32_t* d_lens;
     LN_TRY(device_lens(ctx, lens, U, T, &d_lens));
-    const void* d_obs;
+    const double* d_obs;
     void* d_st;
-    LN_TRY(stage_in(ctx, obs, (size_t)U * T * D * 8, ctx->ws_in, &d_obs));
     LN_TRY(stage_out(ctx, stats, L.total * 8, ctx->ws_stats, &d_st));
     double* st = (double*)d_st;
     LN_HIP(hipMemsetAsync(st, 0, L.total * 8, ctx->stream));
@@ -688,7 +687,7 @@ int lnasr_bw_accumulate(lnasr_ctx* ctx, const double* obs, int U, int T, const i
     double* bm = ctx->ws_bm.as<double>();
     double* al = ctx->ws_alpha.as<double>();
     double* be = ctx->ws_beta.as<double>();
-    LN_TRY(emit_device(ctx, (const double*)d_obs, (long)U * T, LNASR_F64, b, bm));
+    LN_TRY(emit_batch(ctx, obs, U, T, b, bm, &d_obs));      // host observations: upload overlapped with the emission
     // forward and backward only share their input: with few utterances per GPU (config 5: 64 blocks on 256 CUs)
     // the backward pass runs on a side stream beside the forward pass
     LN_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
