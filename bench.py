@@ -179,7 +179,7 @@ def main():
             try:
                 ctx.comm_init(state["id"], rank, world)
                 buf = ctx.empty((world, U, T), np.uint32)
-                ctx.allgather_u32(d_path, out=buf)
+                ctx.allgather_paths(d_path, N_STATES, out=buf)
                 ctx.sync()
                 state["buf"] = buf
             except Exception as e:                                   # noqa: BLE001
@@ -204,7 +204,7 @@ def main():
         flag = torch.tensor([ok], dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 1:
-            gather = "rccl all-gather of u32 paths, %d B per GPU per step" % (U * T * 4)
+            gather = "rccl all-gather of the state paths (u8 on the wire, u32 in memory), %d B per GPU per step" % (U * T)
         else:
             gather = "FAILED to initialise RCCL; timed without the gather"
             d_all = None
@@ -212,7 +212,7 @@ def main():
     def step():
         ctx.decode(d_obs, path_out=d_path, score_out=d_score)
         if d_all is not None:
-            ctx.allgather_u32(d_path, out=d_all)
+            ctx.allgather_paths(d_path, N_STATES, out=d_all)
 
     for _ in range(args.warmup):
         step()

@@ -191,6 +191,9 @@ int lnasr_comm_init(lnasr_ctx* ctx, const void* id, int rank, int nranks);
 int lnasr_comm_destroy(lnasr_ctx* ctx);
 /* gather of decoded state paths: every rank contributes count u32, receives nranks*count */
 int lnasr_allgather_u32(lnasr_ctx* ctx, const uint32_t* local, size_t count, uint32_t* all);
+/* same gather for state paths of a model with n_states states: indices below 256 travel as bytes (a quarter
+ * of the xGMI traffic), the result is the u32 array lnasr_allgather_u32 would give */
+int lnasr_allgather_paths(lnasr_ctx* ctx, const uint32_t* local, size_t count, int n_states, uint32_t* all);
 /* sum all-reduce of packed Baum-Welch statistics, in place */
 int lnasr_allreduce_f64(lnasr_ctx* ctx, double* buf, size_t n);
 

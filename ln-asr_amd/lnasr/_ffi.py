@@ -79,6 +79,7 @@ SIGNATURES = {
     "lnasr_comm_init": [_vp, _vp, _i, _i],
     "lnasr_comm_destroy": [_vp],
     "lnasr_allgather_u32": [_vp, _vp, _sz, _vp],
+    "lnasr_allgather_paths": [_vp, _vp, _sz, _i, _vp],
     "lnasr_allreduce_f64": [_vp, _vp, _sz],
 }
 _RESTYPES = {"lnasr_last_error": C.c_char_p, "lnasr_ctx_destroy": None}
@@ -558,6 +559,15 @@ class Context:
         if out is None:
             out = self._out(isinstance(local, DeviceArray), (nr,) + tuple(local.shape), np.uint32)
         check(lib().lnasr_allgather_u32(self.handle, _ptr(local), n, _ptr(out)))
+        return out
+
+    def allgather_paths(self, local, n_states, out=None):
+        """allgather_u32 for decoded state paths: indices below 256 cross the links as bytes."""
+        local = _in(local, np.uint32)
+        n = int(np.prod(local.shape))
+        if out is None:
+            out = self._out(isinstance(local, DeviceArray), (self.nranks,) + tuple(local.shape), np.uint32)
+        check(lib().lnasr_allgather_paths(self.handle, _ptr(local), n, int(n_states), _ptr(out)))
         return out
 
     def allreduce_f64(self, buf):

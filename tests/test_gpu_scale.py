@@ -96,3 +96,25 @@ def test_host_buffers_are_uploaded_in_a_pipeline(synth):
     for u in range(U):
         assert np.array_equal(piped[u, :lens[u]], dev[u, :lens[u]]) and np.array_equal(plain[u, :lens[u]], dev[u, :lens[u]])
     assert np.array_equal(ll_piped, ll_plain)
+
+
+def test_rccl_single_rank_collectives():
+    """The two collectives on a 1-rank RCCL communicator (all a 1-GPU box can run): the path gather with and
+    without the byte packing gives back the input, the statistics all-reduce leaves a single contribution
+    unchanged."""
+    from lnasr import _ffi
+    ctx = _ffi.Context(0)
+    try:
+        ctx.comm_init(_ffi.comm_unique_id(), 0, 1)
+        rng = np.random.default_rng(3)
+        p = rng.integers(0, 128, (37, 40)).astype(np.uint32)          # 1480 entries: a multiple of 4
+        assert np.array_equal(np.asarray(ctx.allgather_u32(p))[0], p)
+        assert np.array_equal(np.asarray(ctx.allgather_paths(p, 128))[0], p)
+        assert np.array_equal(ctx.allgather_paths(ctx.to_device(p), 256).to_host()[0], p)
+        q = rng.integers(0, 1000, (3, 7)).astype(np.uint32)           # 21 entries, 1000 states: plain u32 route
+        assert np.array_equal(np.asarray(ctx.allgather_paths(q, 1000))[0], q)
+        assert np.array_equal(np.asarray(ctx.allgather_paths(q, 200))[0], q)
+        s = rng.standard_normal(1000)
+        assert np.array_equal(np.asarray(ctx.allreduce_f64(s.copy())), s)
+    finally:
+        ctx.comm_destroy()
