@@ -62,6 +62,7 @@ class GMMHMM(HMM):
         b, bm = self.ctx.gmm_logprob(obs[None], want_bm=True, precision=self.precision)
         self.b = b[0].T                              # [N,T]
         self.bm = bm[0].transpose(1, 2, 0)           # [N,M,T]
+        self._model_fresh = True                     # see HMM._remap_or_upload
 
     # ------------------------------------------------------------------ M-step
     def _estimate(self, obs: np.ndarray, alpha, beta, xi, gamma):

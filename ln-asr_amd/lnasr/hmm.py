@@ -41,6 +41,18 @@ class HMM:
         callers mutate A / pi in place between calls."""
         self.ctx.upload_hmm(np.asarray(self.A, dtype=np.float64), np.asarray(self.pi, dtype=np.float64))
 
+    def _remap_or_upload(self, obs, remap):
+        """Start of every trellis call: optionally recompute self.b, and make sure the device holds the current
+        parameters.  When `_map_b` has just uploaded (and hash-checked) the whole model inside this very call
+        (GMMHMM does), no user code ran in between and the second check is skipped."""
+        if remap:
+            self._model_fresh = False
+            self._map_b(obs)
+            if getattr(self, "_model_fresh", False):
+                self._model_fresh = False
+                return
+        self._upload()
+
     def _b_dev(self):
         """self.b [N,T] -> frame-major [1,T,N] of the storage dtype."""
         b = np.asarray(self.b)
@@ -57,32 +69,24 @@ class HMM:
     # ------------------------------------------------------------------ trellises
     def _forward(self, obs: np.ndarray, remap: bool = False) -> np.ndarray:
         """alpha [T,N]: alpha[t,j] = lse_i(alpha[t-1,i] + A[i,j]) + b[j,t]  (hmm.py:63-100)."""
-        if remap:
-            self._map_b(obs)
-        self._upload()
+        self._remap_or_upload(obs, remap)
         alpha, _ = self.ctx.forward(self._b_dev(), want_alpha=True, want_loglik=False)
         return alpha[0]
 
     def _backward(self, obs: np.ndarray, remap: bool = False) -> np.ndarray:
         """beta [T,N]: beta[t,i] = lse_j(beta[t+1,j] + A[i,j] + b[j,t+1])  (hmm.py:102-131)."""
-        if remap:
-            self._map_b(obs)
-        self._upload()
+        self._remap_or_upload(obs, remap)
         return self.ctx.backward(self._b_dev())[0]
 
     def _viterbi(self, obs: np.ndarray, remap: bool = False) -> Tuple[np.ndarray]:
         """(v [T,N], bt [T,N] uint32, path [T] uint32); ties -> first index  (hmm.py:133-172)."""
-        if remap:
-            self._map_b(obs)
-        self._upload()
+        self._remap_or_upload(obs, remap)
         r = self.ctx.viterbi(self._b_dev(), want_v=True, want_bt=True)
         return (r["v"][0], r["bt"][0], r["path"][0])
 
     def _baumwelch(self, obs: np.ndarray, alpha: np.ndarray, beta: np.ndarray, remap: bool = False) -> Tuple[np.ndarray]:
         """(xi [T,N,N], gamma [T,N]); the last frame is -inf  (hmm.py:174-200)."""
-        if remap:
-            self._map_b(obs)
-        self._upload()
+        self._remap_or_upload(obs, remap)
         b = self._b_dev()
         dt = b.dtype
         xi, gamma = self.ctx.baumwelch(b, np.asarray(alpha, dtype=dt)[None], np.asarray(beta, dtype=dt)[None])
@@ -127,8 +131,7 @@ class HMM:
     # ------------------------------------------------------------------ public API
     def calc_prob(self, obs: np.ndarray) -> float:
         """log P(O | model) = lse(alpha[T-1])  (hmm.py:268-274)."""
-        self._map_b(obs)
-        self._upload()
+        self._remap_or_upload(obs, True)
         _, ll = self.ctx.forward(self._b_dev(), want_alpha=False, want_loglik=True)
         return np.asarray(ll, dtype=self.precision)[0]
 
