@@ -70,6 +70,10 @@ struct Model {
     DevBuf wfull, wfull_nw, pairtab;   // full covariance: quadratic-feature coefficients in MFMA fragment order
     int wfull_Q = 0, wfull_NCH = 0, wfull_virt = 1;
     int wpack_virt = 1;          // M = 16*virt mixtures are scored as `virt` virtual 16-mixture states, then merged
+    // shapes the matrix-core bank kernel does not take directly (N not a multiple of 4, M not in {4, 8, 16, 16k}) are
+    // scored on a padded copy of the parameters (padding components have weight -inf) and compacted afterwards
+    DevBuf pad_mu, pad_ivar, pad_gconst, pad_logw;
+    int pad_N = 0, pad_M = 0;    // padded sizes, 0 = the model is used as it is
     DevBuf flags;                // small int scratch (diag detection)
     void release();
 };
@@ -95,6 +99,7 @@ struct lnasr_ctx {
     lnasr::DevBuf ws_b, ws_bm, ws_v, ws_alpha, ws_beta, ws_misc, ws_misc2, ws_lens, ws_stats;
     lnasr::DevBuf ws_p, ws_q, ws_raw;                      // Baum-Welch statistics: xi factors, raw mixture moments
     lnasr::DevBuf ws_w1, ws_w2, ws_w3;                     // float32 storage: widened inputs / outputs of the f64 kernels
+    lnasr::DevBuf ws_pad;                                  // bm of a padded model before compaction
     // MFCC constants (twiddles, DCT matrix), kept on the device between calls with the same fft_n / n_mel;
     // the per-call frame offsets live here too so that the asynchronous upload never reads a dead host buffer
     lnasr::DevBuf mfcc_const;

@@ -279,11 +279,20 @@ __device__ __forceinline__ void exp_table_init(double* etab, int tid, int nt) {
 }
 
 // b[cell] = lse_h bv[cell*k + h]: M = 16*k mixtures are scored as k virtual 16-mixture states, then merged
-static __global__ void merge_virtual_kernel(const double* __restrict__ bv, size_t cells, int k, double* __restrict__ b) {
+static __global__ void merge_virtual_kernel(const double* __restrict__ bv, size_t cells, int N, int Np, int k,
+                                            double* __restrict__ b) {
+    // bv [F, Np, k] (Np >= N: states padded to a multiple of four) -> b [F, N]
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= cells) return;
+    const size_t f = idx / N;
+    const int n = (int)(idx % N);
+    const double* src = bv + (f * Np + n) * k;
+    if (k == 1) {
+        b[idx] = src[0];
+        return;
+    }
     Lse acc;
-    for (int h = 0; h < k; ++h) acc.add(bv[idx * k + h]);
+    for (int h = 0; h < k; ++h) acc.add(src[h]);
     b[idx] = acc.value();
 }
 

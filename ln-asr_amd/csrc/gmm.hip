@@ -65,19 +65,27 @@ __device__ __forceinline__ double log_of_det(double logabs, int sign) {
 
 // one thread per component
 __global__ void prep_diag_kernel(const double* __restrict__ var, double* __restrict__ ivar,
-                                 double* __restrict__ gconst, int NM, int D) {
+                                 double* __restrict__ gconst, int NM, int D, int* __restrict__ degenerate) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= NM) return;
     double la = 0.0;
     int sign = 1;
+    bool bad = false;
     for (int d = 0; d < D; ++d) {
         double v = var[(size_t)c * D + d];
-        ivar[(size_t)c * D + d] = 1.0 / v;
+        const double iv = 1.0 / v;
+        ivar[(size_t)c * D + d] = iv;
         la += log(fabs(v));
         if (v < 0.0) sign = -sign;
         if (v == 0.0) sign = 0;
+        bad |= !(iv == iv) || iv == __builtin_huge_val() || iv == -__builtin_huge_val();
     }
-    gconst[c] = -0.5 * ((double)D * kLog2Pi + log_of_det(la, sign));
+    const double gc = -0.5 * ((double)D * kLog2Pi + log_of_det(la, sign));
+    gconst[c] = gc;
+    bad |= !(gc == gc) || gc == __builtin_huge_val() || gc == -__builtin_huge_val();
+    // a singular / non-finite variance: the expanded-quadratic (matrix-core) form would turn it into NaNs that the
+    // log-sum-exp ignores; such models stay on the direct-form kernels, which give the inf / nan numpy gives
+    if (bad) atomicOr(degenerate, 1);
 }
 
 // One block (64 threads) per component: Gauss-Jordan elimination with partial pivoting on
@@ -634,12 +642,42 @@ __global__ void mixture_combine_kernel(const double* __restrict__ comp, const do
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
+// padded copy of a diagonal model: [N,M] -> [Np,Mp]; padding components get weight -inf (and neutral parameters)
+__global__ void pad_model_kernel(const double* __restrict__ mu, const double* __restrict__ ivar,
+                                 const double* __restrict__ gconst, const double* __restrict__ logw, int N, int M, int D,
+                                 int Np, int Mp, double* __restrict__ mu_p, double* __restrict__ ivar_p,
+                                 double* __restrict__ gconst_p, double* __restrict__ logw_p) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)Np * Mp) return;
+    const int n = (int)(idx / Mp), m = (int)(idx % Mp);
+    const bool real = n < N && m < M;
+    const size_t c = (size_t)n * M + m;
+    gconst_p[idx] = real ? gconst[c] : 0.0;
+    logw_p[idx] = real ? logw[c] : LN_NEG_INF;
+    for (int d = 0; d < D; ++d) {
+        mu_p[idx * D + d] = real ? mu[c * D + d] : 0.0;
+        ivar_p[idx * D + d] = real ? ivar[c * D + d] : 0.0;
+    }
+}
+
+// bm of the padded model [F, Np, Mp] -> [F, N, M]
+__global__ void compact_bm_kernel(const double* __restrict__ src, size_t cells, int N, int M, int Np, int Mp,
+                                  double* __restrict__ dst) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= cells) return;
+    const int m = (int)(idx % M);
+    const size_t fn = idx / M;
+    const int n = (int)(fn % N);
+    const size_t f = fn / N;
+    dst[idx] = src[((f * Np + n) * Mp) + m];
+}
+
 static bool mfma_shape_supported(int N, int M, int D, int* Q, int* KS) {
     if (N % 4 != 0 || M % 4 != 0) return false;
     int q = M / 4, ks = (2 * D + 1 + 3) / 4;
     if (!(q == 1 || q == 2 || q == 4)) return false;
-    if (!(ks == 20 || ks == 14 || ks == 7)) return false;     // D in {39,38}, {27,26}, {13,12}
-    if (D > 64) return false;
+    ks = ks <= 7 ? 7 : (ks <= 14 ? 14 : (ks <= 20 ? 20 : 0));    // K rows past 2D+1 carry zero coefficients
+    if (ks == 0) return false;                                    // D <= 39
     *Q = q;
     *KS = ks;
     return true;
@@ -718,16 +756,23 @@ static int model_upload_impl(lnasr_ctx* ctx, int N, int M, int D, const double* 
     md.D = D;
     md.diag = diag;
     md.wpack_Q = md.wpack_KS = 0;
+    md.pad_N = md.pad_M = 0;
     md.wfull_Q = 0;
     if (diag) {
         LN_TRY(md.ivar.reserve(NMD * 8));
+        LN_TRY(md.flags.reserve(256));
+        LN_HIP(hipMemsetAsync(md.flags.p, 0, 4, ctx->stream));
         LN_LAUNCH(ctx, "prep_diag", prep_diag_kernel, dim3((unsigned)((NM + 127) / 128)), dim3(128), 0,
-                  md.var.as<double>(), md.ivar.as<double>(), md.gconst.as<double>(), (int)NM, D);
+                  md.var.as<double>(), md.ivar.as<double>(), md.gconst.as<double>(), (int)NM, D, md.flags.as<int>());
+        int degenerate = 0;
+        LN_HIP(hipMemcpyAsync(&degenerate, md.flags.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+        LN_HIP(hipStreamSynchronize(ctx->stream));
         int Q = 0, KS = 0;
         md.wdirect_KS = 0;
-        if (N == 1 && M <= 16 && D <= 64) {
-            const int ksd = 2 * ((D + 1 + 3) / 4);           // LDS-free layout: K = 2 * 4 ceil((D+1)/4)
-            if (ksd == 20 || ksd == 14 || ksd == 8) {
+        if (!degenerate && N == 1 && M <= 16 && D <= 64) {
+            int ksd = 2 * ((D + 1 + 3) / 4);                 // LDS-free layout: K = 2 * 4 ceil((D+1)/4)
+            ksd = ksd <= 8 ? 8 : (ksd <= 14 ? 14 : (ksd <= 20 ? 20 : 0));   // wider blocks: zero coefficients
+            if (ksd) {
                 LN_TRY(md.wdirect.reserve((size_t)ksd * 64 * 8));
                 LN_LAUNCH(ctx, "pack_single_direct", pack_single_direct_kernel, dim3((ksd * 64 + 255) / 256), dim3(256), 0,
                           md.mu.as<double>(), md.ivar.as<double>(), md.gconst.as<double>(), md.wdirect.as<double>(), M,
@@ -735,20 +780,41 @@ static int model_upload_impl(lnasr_ctx* ctx, int N, int M, int D, const double* 
                 md.wdirect_KS = ksd;
             }
         }
-        // M = 16*k mixtures: score k virtual 16-mixture states per state ([N,M,D] is [N*k,16,D] in memory)
-        const int virt = (M > 16 && M % 16 == 0) ? M / 16 : 1;
-        const int Nv = N * virt, Mv = M / virt;
+        // The bank kernel takes N a multiple of 4 and 4, 8 or 16 mixtures per (virtual) state; M = 16 k mixtures are
+        // scored as k virtual 16-mixture states per state ([N,M,D] is [N k,16,D] in memory).  Any other N / M is
+        // padded to the next such shape on a copy of the parameters.
+        const int Mp = M <= 4 ? 4 : (M <= 8 ? 8 : (M + 15) / 16 * 16);
+        const int Np = (N + 3) / 4 * 4;
+        const int virt = Mp > 16 ? Mp / 16 : 1;
+        const int Nv = Np * virt, Mv = Mp / virt;
         md.wpack_virt = 1;
-        if (mfma_shape_supported(Nv, Mv, D, &Q, &KS)) {
+        md.pad_N = md.pad_M = 0;
+        if (!degenerate && mfma_shape_supported(Nv, Mv, D, &Q, &KS) && ((Np == N && Mp == M) || !getenv("LNASR_NO_PAD"))) {
+            const double *mu_s = md.mu.as<double>(), *iv_s = md.ivar.as<double>(), *gc_s = md.gconst.as<double>(),
+                         *lw_s = md.logw.as<double>();
+            if (Np != N || Mp != M) {
+                const size_t NMp = (size_t)Np * Mp;
+                LN_TRY(md.pad_mu.reserve(NMp * D * 8));
+                LN_TRY(md.pad_ivar.reserve(NMp * D * 8));
+                LN_TRY(md.pad_gconst.reserve(NMp * 8));
+                LN_TRY(md.pad_logw.reserve(NMp * 8));
+                LN_LAUNCH(ctx, "pad_model", pad_model_kernel, dim3((unsigned)((NMp + 127) / 128)), dim3(128), 0, mu_s, iv_s,
+                          gc_s, lw_s, N, M, D, Np, Mp, md.pad_mu.as<double>(), md.pad_ivar.as<double>(),
+                          md.pad_gconst.as<double>(), md.pad_logw.as<double>());
+                mu_s = md.pad_mu.as<double>();
+                iv_s = md.pad_ivar.as<double>();
+                gc_s = md.pad_gconst.as<double>();
+                lw_s = md.pad_logw.as<double>();
+                md.pad_N = Np;
+                md.pad_M = Mp;
+            }
             size_t total = (size_t)(Nv / 4) * Q * KS * 64;
             LN_TRY(md.wpack.reserve(total * 8));
             LN_TRY(md.wpack_nw.reserve(total * 8));
-            LN_LAUNCH(ctx, "pack_wfrag", pack_wfrag_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                      md.mu.as<double>(), md.ivar.as<double>(), md.gconst.as<double>(), md.logw.as<double>(),
-                      md.wpack.as<double>(), Nv, Mv, D, Q, KS, 1);
-            LN_LAUNCH(ctx, "pack_wfrag", pack_wfrag_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                      md.mu.as<double>(), md.ivar.as<double>(), md.gconst.as<double>(), md.logw.as<double>(),
-                      md.wpack_nw.as<double>(), Nv, Mv, D, Q, KS, 0);
+            LN_LAUNCH(ctx, "pack_wfrag", pack_wfrag_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, mu_s, iv_s,
+                      gc_s, lw_s, md.wpack.as<double>(), Nv, Mv, D, Q, KS, 1);
+            LN_LAUNCH(ctx, "pack_wfrag", pack_wfrag_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, mu_s, iv_s,
+                      gc_s, lw_s, md.wpack_nw.as<double>(), Nv, Mv, D, Q, KS, 0);
             md.wpack_Q = Q;
             md.wpack_KS = KS;
             md.wpack_NG = Nv / 4;
@@ -769,7 +835,8 @@ static int model_upload_impl(lnasr_ctx* ctx, int N, int M, int D, const double* 
 template <int Q, int KS, int NWV, int TPS>
 static int launch_mfma_cfg(lnasr_ctx* ctx, const double* obs, long F, double* b, double* bm) {
     Model& md = ctx->model;
-    const int N = md.N * md.wpack_virt, D = md.D;      // (virtual) states scored by this launch
+    const int N = md.wpack_NG * 4, D = md.D;           // (virtual, padded) states scored by this launch
+    const double* lw = md.pad_N ? md.pad_logw.as<double>() : md.logw.as<double>();
     constexpr int SPB = 4 * NWV;
     const int GY = (N + SPB - 1) / SPB;
     const long ntiles = (F + 15) / 16;
@@ -786,11 +853,11 @@ static int launch_mfma_cfg(lnasr_ctx* ctx, const double* obs, long F, double* b,
     const long grid = ((nchunks + 7) / 8) * 8 * GY;
     if (bm) {
         LN_LAUNCH(ctx, "emit_diag_mfma_bm", (emit_diag_mfma<Q, KS, NWV, TPS, true>), dim3((unsigned)grid),
-                  dim3(64 * NWV), 0, obs, md.wpack_nw.as<double>(), md.logw.as<double>(), b, bm, F, N, D, md.wpack_NG, GY,
+                  dim3(64 * NWV), 0, obs, md.wpack_nw.as<double>(), lw, b, bm, F, N, D, md.wpack_NG, GY,
                   ntiles, (int)tpb, nchunks);
     } else {
         LN_LAUNCH(ctx, "emit_diag_mfma", (emit_diag_mfma<Q, KS, NWV, TPS, false>), dim3((unsigned)grid),
-                  dim3(64 * NWV), 0, obs, md.wpack.as<double>(), md.logw.as<double>(), b, bm, F, N, D, md.wpack_NG, GY,
+                  dim3(64 * NWV), 0, obs, md.wpack.as<double>(), lw, b, bm, F, N, D, md.wpack_NG, GY,
                   ntiles, (int)tpb, nchunks);
     }
     return 0;
@@ -859,22 +926,34 @@ int emit_device(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, v
     }
     if (md.diag && dtype == LNASR_F64 && md.wpack_Q > 0 && !getenv("LNASR_NO_MFMA")) {
         const int Q = md.wpack_Q, KS = md.wpack_KS;
+        const int Np = md.pad_N ? md.pad_N : N, Mp = md.pad_M ? md.pad_M : M, virt = md.wpack_virt;
+        const bool padded = md.pad_N != 0;
         double* bdst = (double*)b;
-        if (md.wpack_virt > 1) {
-            LN_TRY(ctx->ws_misc2.reserve((size_t)F * N * md.wpack_virt * 8));
+        double* bmdst = (double*)bm;
+        if (virt > 1 || padded) {
+            LN_TRY(ctx->ws_misc2.reserve((size_t)F * Np * virt * 8));
             bdst = ctx->ws_misc2.as<double>();
+        }
+        if (bm && padded) {
+            LN_TRY(ctx->ws_pad.reserve((size_t)F * Np * Mp * 8));
+            bmdst = ctx->ws_pad.as<double>();
         }
         int rc = LNASR_E_UNSUPPORTED;
 #define LN_CASE(q, ks) \
-    if (Q == q && KS == ks) rc = launch_mfma<q, ks>(ctx, obs, F, bdst, (double*)bm);
+    if (Q == q && KS == ks) rc = launch_mfma<q, ks>(ctx, obs, F, bdst, bmdst);
         LN_CASE(4, 20) LN_CASE(2, 20) LN_CASE(1, 20) LN_CASE(4, 14) LN_CASE(2, 14) LN_CASE(1, 14)
         LN_CASE(4, 7) LN_CASE(2, 7) LN_CASE(1, 7)
 #undef LN_CASE
         LN_TRY(rc);
-        if (md.wpack_virt > 1) {
+        if (virt > 1 || padded) {
             const size_t cells = (size_t)F * N;
             LN_LAUNCH(ctx, "merge_virtual_states", merge_virtual_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256),
-                      0, bdst, cells, md.wpack_virt, (double*)b);
+                      0, bdst, cells, N, Np, virt, (double*)b);
+        }
+        if (bm && padded) {
+            const size_t cells = (size_t)F * N * M;
+            LN_LAUNCH(ctx, "compact_bm", compact_bm_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0,
+                      (const double*)bmdst, cells, N, M, Np, Mp, (double*)bm);
         }
         return 0;
     }

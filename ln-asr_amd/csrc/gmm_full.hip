@@ -317,7 +317,7 @@ int emit_full_mfma_device(lnasr_ctx* ctx, const double* obs, long F, double* b, 
     if (md.wfull_virt > 1) {
         const size_t cells = (size_t)F * md.N;
         LN_LAUNCH(ctx, "merge_virtual_states", merge_virtual_kernel, dim3((unsigned)((cells + 255) / 256)),
-                  dim3(256), 0, bdst, cells, md.wfull_virt, b);
+                  dim3(256), 0, bdst, cells, md.N, md.N, md.wfull_virt, b);
     }
     return 1;
 }

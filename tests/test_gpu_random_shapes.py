@@ -1,0 +1,80 @@
+"""GPU parity over seeded random shapes: every dispatch branch (single mixture, matrix-core bank with and without
+virtual states, scalar kernels, on-chip / register / streaming trellises, statistics tile counts) meets shapes it was
+not hand-picked for.  Emission, forward and backward against the oracle to 1e-10; Viterbi on the GPU's own emissions
+bit-identical to the oracle's recursion on the same numbers; statistics to 1e-8."""
+import numpy as np
+import pytest
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from lnasr import _ffi
+    return _ffi.default_ctx()
+
+
+def _shape(seed):
+    rng = np.random.default_rng(1000 + seed)
+    N = int(rng.choice([1, 2, 3, 4, 5, 8, 12, 16, 31, 64, 65, 100, 128, 129, 160, 256, 257, 300]))
+    M = int(rng.choice([1, 2, 3, 4, 7, 8, 15, 16, 17, 32, 48]))
+    D = int(rng.choice([1, 2, 3, 5, 12, 13, 20, 26, 27, 38, 39, 40]))
+    # keep the oracle's work (N * M * T * D, and N^2 * T for the trellises) bounded
+    T = int(rng.integers(1, max(2, min(40, 400000 // (N * M * D) + 2, 3000000 // (N * N) + 2))))
+    U = int(rng.integers(1, 5))
+    return rng, N, M, D, T, U
+
+
+@pytest.mark.parametrize("seed", range(28))
+def test_random_shape(seed, synth, oracle, ctx):
+    rng, N, M, D, T, U = _shape(seed)
+    mdl = synth.synth_model(N, M, D, seed=seed + 7)
+    w = mdl["w"].copy()
+    A = mdl["A"].copy()
+    if seed % 3 == 0 and M > 1:                            # a dead component
+        w[0, M - 1] = -np.inf
+        w[0] -= oracle.lse(w[0])
+    if seed % 4 == 1 and N > 2:                            # a forbidden transition and an unreachable state
+        A[0, 1] = -np.inf
+        A[:, N - 1] = -np.inf
+        A -= oracle.lse(A, axis=1)[:, None]
+    obs = synth.synth_obs(U, T, D, seed=seed + 50)
+    lens = rng.integers(1, T + 1, U).astype(np.int32)
+    lens[0] = T
+    ctx.upload_gmmhmm(A, mdl["pi"], w, mdl["mu"], mdl["var"], diag=True)
+    tag = "seed=%d N=%d M=%d D=%d T=%d U=%d" % (seed, N, M, D, T, U)
+
+    b, bm = ctx.gmm_logprob(obs, want_bm=True)
+    r = ctx.viterbi(b, lens=lens)
+    alpha, ll = ctx.forward(b, lens=lens)
+    beta = ctx.backward(b, lens=lens)
+    path_fused = np.asarray(ctx.decode(obs, lens=lens))
+    for u in range(U):
+        L = int(lens[u])
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ob, obm = oracle.gmm_map_b_diag(obs[u, :L], w, mdl["mu"], mdl["var"])
+        assert_close(b[u, :L], ob.T, 1e-10, 1e-10, msg="b " + tag)
+        assert_close(bm[u, :L], np.transpose(obm, (2, 0, 1)), 1e-10, 1e-10, msg="bm " + tag)
+        gb = np.ascontiguousarray(b[u, :L].T)                 # the trellises are checked on the GPU's own b
+        v, bt, path = oracle.viterbi(A, mdl["pi"], gb)
+        assert np.array_equal(r["v"][u, :L], v), "v " + tag
+        assert np.array_equal(r["bt"][u, :L], bt) and np.array_equal(r["path"][u, :L], path), "path " + tag
+        assert np.array_equal(path_fused[u, :L], path), "decode " + tag
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ra, rb = oracle.forward(A, mdl["pi"], gb), oracle.backward(A, gb)
+        assert_close(alpha[u, :L], ra, 1e-10, 1e-10, msg="alpha " + tag)
+        assert_close(beta[u, :L], rb, 1e-10, 1e-10, msg="beta " + tag)
+        assert abs(ll[u] - oracle.loglik(ra)) <= 1e-10 * max(1.0, abs(ll[u])), "loglik " + tag
+
+    if N * N * T <= 400000 and N * M * D * T <= 200000:         # statistics: the oracle materialises xi [T,N,N]
+        st = ctx.bw_accumulate(obs, lens=lens)
+        with np.errstate(divide="ignore", invalid="ignore", under="ignore"):
+            ref = oracle.bw_stats_diag([obs[u, :lens[u]] for u in range(U)], A, mdl["pi"], w, mdl["mu"], mdl["var"])
+        o = 0
+        for key, n in (("xi_sum", N * N), ("gamma_sum", N), ("gamma0", N), ("mix", N * M), ("mix_x", N * M * D),
+                       ("mix_xx", N * M * D)):
+            assert_close(st[o:o + n], np.asarray(ref[key]).ravel(), 1e-8, 1e-10, msg=key + " " + tag)
+            o += n
+        assert abs(st[o] - ref["loglik"]) <= 1e-9 * max(1.0, abs(ref["loglik"]))
