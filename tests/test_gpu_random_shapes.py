@@ -78,3 +78,35 @@ def test_random_shape(seed, synth, oracle, ctx):
             assert_close(st[o:o + n], np.asarray(ref[key]).ravel(), 1e-8, 1e-10, msg=key + " " + tag)
             o += n
         assert abs(st[o] - ref["loglik"]) <= 1e-9 * max(1.0, abs(ref["loglik"]))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_shape_full_covariance(seed, synth, oracle, ctx):
+    """Full covariance: emission against the oracle's (x-mu)^T Sigma^-1 (x-mu) form, the matrix-core statistics
+    against the scalar statistics kernel."""
+    import os
+    rng = np.random.default_rng(2000 + seed)
+    N = int(rng.choice([1, 2, 3, 4, 5, 8, 9, 16, 20]))
+    M = int(rng.choice([1, 2, 3, 4, 5, 8, 16, 17]))
+    D = int(rng.choice([1, 2, 3, 5, 8, 13, 20, 39]))
+    T = int(rng.integers(2, max(3, min(24, 60000 // (N * M * D * D) + 3))))
+    U = int(rng.integers(1, 4))
+    mdl = synth.synth_model(N, M, D, seed=seed + 3, full_cov=True)
+    obs = synth.synth_obs(U, T, D, seed=seed + 70)
+    lens = rng.integers(2, T + 1, U).astype(np.int32)
+    lens[0] = T
+    tag = "seed=%d N=%d M=%d D=%d T=%d U=%d" % (seed, N, M, D, T, U)
+    ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["si"])
+    b, bm = ctx.gmm_logprob(obs, want_bm=True)
+    for u in range(U):
+        ob, obm = oracle.gmm_map_b(obs[u], mdl["w"], mdl["mu"], mdl["si"])
+        assert_close(b[u], ob.T, 1e-9, 1e-9, msg="b " + tag)
+        assert_close(bm[u], np.transpose(obm, (2, 0, 1)), 1e-9, 1e-9, msg="bm " + tag)
+    if D > 1 and not ctx.model_is_diag():
+        st = ctx.bw_accumulate(obs, lens=lens)
+        os.environ["LNASR_NO_MFMA_STATS"] = "1"
+        try:
+            ref = ctx.bw_accumulate(obs, lens=lens)
+        finally:
+            del os.environ["LNASR_NO_MFMA_STATS"]
+        assert_close(st, ref, 1e-8, 1e-10, msg="stats " + tag)
