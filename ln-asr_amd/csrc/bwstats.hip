@@ -579,7 +579,7 @@ __global__ void full_finish_kernel(const double* __restrict__ R, const double* _
 }
 
 bool full_stats_mfma_ok(const Model& md) {
-    return !md.diag && md.wfull_Q > 0 && md.wfull_virt == 1 && md.M <= 32 && md.D <= 39 && !getenv("LNASR_NO_MFMA_STATS");
+    return !md.diag && md.wfull_Q > 0 && md.M <= 32 && md.D <= 39 && !getenv("LNASR_NO_MFMA_STATS");
 }
 
 int full_stats_device(lnasr_ctx* ctx, const double* obs, const double* alpha, const double* beta, const double* b,

@@ -72,7 +72,7 @@ struct Model {
     int wpack_virt = 1;          // M = 16*virt mixtures are scored as `virt` virtual 16-mixture states, then merged
     // shapes the matrix-core bank kernel does not take directly (N not a multiple of 4, M not in {4, 8, 16, 16k}) are
     // scored on a padded copy of the parameters (padding components have weight -inf) and compacted afterwards
-    DevBuf pad_mu, pad_ivar, pad_gconst, pad_logw;
+    DevBuf pad_mu, pad_ivar, pad_gconst, pad_logw, pad_prec;
     int pad_N = 0, pad_M = 0;    // padded sizes, 0 = the model is used as it is
     DevBuf flags;                // small int scratch (diag detection)
     void release();

@@ -296,4 +296,16 @@ static __global__ void merge_virtual_kernel(const double* __restrict__ bv, size_
     b[idx] = acc.value();
 }
 
+// bm of the padded model [F, Np, Mp] -> [F, N, M]
+static __global__ void compact_bm_kernel(const double* __restrict__ src, size_t cells, int N, int M, int Np, int Mp,
+                                  double* __restrict__ dst) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= cells) return;
+    const int m = (int)(idx % M);
+    const size_t fn = idx / M;
+    const int n = (int)(fn % N);
+    const size_t f = fn / N;
+    dst[idx] = src[((f * Np + n) * Mp) + m];
+}
+
 }  // namespace lnasr

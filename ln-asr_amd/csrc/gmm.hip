@@ -660,18 +660,6 @@ __global__ void pad_model_kernel(const double* __restrict__ mu, const double* __
     }
 }
 
-// bm of the padded model [F, Np, Mp] -> [F, N, M]
-__global__ void compact_bm_kernel(const double* __restrict__ src, size_t cells, int N, int M, int Np, int Mp,
-                                  double* __restrict__ dst) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= cells) return;
-    const int m = (int)(idx % M);
-    const size_t fn = idx / M;
-    const int n = (int)(fn % N);
-    const size_t f = fn / N;
-    dst[idx] = src[((f * Np + n) * Mp) + m];
-}
-
 static bool mfma_shape_supported(int N, int M, int D, int* Q, int* KS) {
     if (N % 4 != 0 || M % 4 != 0) return false;
     int q = M / 4, ks = (2 * D + 1 + 3) / 4;

@@ -244,19 +244,60 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+// padded copy of a full-covariance model: [N,M] -> [Np,Mp]; padding components get weight -inf, zero precision
+__global__ void pad_full_model_kernel(const double* __restrict__ mu, const double* __restrict__ prec,
+                                      const double* __restrict__ gconst, const double* __restrict__ logw, int N, int M,
+                                      int D, int Np, int Mp, double* __restrict__ mu_p, double* __restrict__ prec_p,
+                                      double* __restrict__ gconst_p, double* __restrict__ logw_p) {
+    const size_t c = blockIdx.x;                       // padded component
+    if (c >= (size_t)Np * Mp) return;
+    const int n = (int)(c / Mp), m = (int)(c % Mp);
+    const bool real = n < N && m < M;
+    const size_t s = (size_t)n * M + m;
+    if (threadIdx.x == 0) {
+        gconst_p[c] = real ? gconst[s] : 0.0;
+        logw_p[c] = real ? logw[s] : LN_NEG_INF;
+    }
+    for (int d = threadIdx.x; d < D; d += blockDim.x) mu_p[c * D + d] = real ? mu[s * D + d] : 0.0;
+    for (int e = threadIdx.x; e < D * D; e += blockDim.x) prec_p[c * D * D + e] = real ? prec[s * D * D + e] : 0.0;
+}
+
 int pack_full_model(lnasr_ctx* ctx) {
     Model& md = ctx->model;
     const int N = md.N, M = md.M, D = md.D;
     md.wfull_Q = 0;
-    const int virt = (M > 16 && M % 16 == 0) ? M / 16 : 1;
-    const int Nv = N * virt, Mv = M / virt;
-    if (Nv % 4 != 0 || Mv % 4 != 0 || D > 64) return 0;
+    // same shape rules as the diagonal bank (gmm.hip): pad N to a multiple of 4 and M to 4, 8, 16 or 16 k
+    const int Mp = M <= 4 ? 4 : (M <= 8 ? 8 : (M + 15) / 16 * 16);
+    const int Np = (N + 3) / 4 * 4;
+    const int virt = Mp > 16 ? Mp / 16 : 1;
+    const int Nv = Np * virt, Mv = Mp / virt;
+    md.pad_N = md.pad_M = 0;
+    if (D > 64) return 0;
+    if ((Np != N || Mp != M) && getenv("LNASR_NO_PAD")) return 0;
     const int Q = Mv / 4;
     if (!(Q == 1 || Q == 2 || Q == 4)) return 0;
     const int K = D * (D + 1) / 2 + D + 1;
     const int NCH = (K + kFC - 1) / kFC;
     const size_t lds = ((size_t)D * 64 + 2 * 4 * kFC * 17 + 4 * 16 * 33 + kExpTab + 2 * kLogTab) * 8 + (size_t)NCH * kFC * 4;
     if (lds > 160 * 1024) return 0;
+    const double *mu_s = md.mu.as<double>(), *pr_s = md.prec.as<double>(), *gc_s = md.gconst.as<double>(),
+                 *lw_s = md.logw.as<double>();
+    if (Np != N || Mp != M) {
+        const size_t NMp = (size_t)Np * Mp;
+        LN_TRY(md.pad_mu.reserve(NMp * D * 8));
+        LN_TRY(md.pad_prec.reserve(NMp * D * D * 8));
+        LN_TRY(md.pad_gconst.reserve(NMp * 8));
+        LN_TRY(md.pad_logw.reserve(NMp * 8));
+        LN_LAUNCH(ctx, "pad_full_model", pad_full_model_kernel, dim3((unsigned)NMp), dim3(128), 0, mu_s, pr_s, gc_s, lw_s, N,
+                  M, D, Np, Mp, md.pad_mu.as<double>(), md.pad_prec.as<double>(), md.pad_gconst.as<double>(),
+                  md.pad_logw.as<double>());
+        mu_s = md.pad_mu.as<double>();
+        pr_s = md.pad_prec.as<double>();
+        gc_s = md.pad_gconst.as<double>();
+        lw_s = md.pad_logw.as<double>();
+        md.pad_N = Np;
+        md.pad_M = Mp;
+    }
     LN_TRY(md.pairtab.reserve((size_t)NCH * kFC * 4));
     LN_LAUNCH(ctx, "pair_table", pair_table_kernel, dim3((NCH * kFC + 255) / 256), dim3(256), 0, D, NCH * kFC,
               md.pairtab.as<int>());
@@ -264,9 +305,8 @@ int pack_full_model(lnasr_ctx* ctx) {
     LN_TRY(md.wfull.reserve(total * 8));
     LN_TRY(md.wfull_nw.reserve(total * 8));
     for (int fold = 1; fold >= 0; --fold)
-        LN_LAUNCH(ctx, "pack_wfull", pack_wfull_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                  md.mu.as<double>(), md.prec.as<double>(), md.gconst.as<double>(), md.logw.as<double>(),
-                  md.pairtab.as<int>(), (fold ? md.wfull : md.wfull_nw).as<double>(), Nv, Mv, D, Q, NCH, fold);
+        LN_LAUNCH(ctx, "pack_wfull", pack_wfull_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, mu_s, pr_s, gc_s,
+                  lw_s, md.pairtab.as<int>(), (fold ? md.wfull : md.wfull_nw).as<double>(), Nv, Mv, D, Q, NCH, fold);
     md.wfull_Q = Q;
     md.wfull_NCH = NCH;
     md.wfull_virt = virt;
@@ -276,7 +316,8 @@ int pack_full_model(lnasr_ctx* ctx) {
 template <int Q>
 static int launch_full(lnasr_ctx* ctx, const double* obs, long F, double* b, double* bm) {
     Model& md = ctx->model;
-    const int N = md.N * md.wfull_virt, D = md.D, NCH = md.wfull_NCH;
+    const int N = (md.pad_N ? md.pad_N : md.N) * md.wfull_virt, D = md.D, NCH = md.wfull_NCH;   // (virtual, padded) states
+    const double* lw = md.pad_N ? md.pad_logw.as<double>() : md.logw.as<double>();
     const int GY = (N + 31) / 32;
     const long nsuper = (F + 63) / 64;
     const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
@@ -290,11 +331,11 @@ static int launch_full(lnasr_ctx* ctx, const double* obs, long F, double* b, dou
     const size_t shm = ((size_t)D * 64 + 2 * 4 * kFC * 17 + 4 * 16 * 33 + kExpTab + 2 * kLogTab) * 8 + (size_t)NCH * kFC * 4;
     if (bm)
         LN_LAUNCH(ctx, "emit_full_mfma_bm", (emit_full_mfma<Q, true>), dim3((unsigned)grid), dim3(512), shm, obs,
-                  md.wfull_nw.as<double>(), md.pairtab.as<int>(), md.logw.as<double>(), b, bm, F, N, D, N / 4, GY, NCH,
+                  md.wfull_nw.as<double>(), md.pairtab.as<int>(), lw, b, bm, F, N, D, N / 4, GY, NCH,
                   nsuper, (int)spb, nchunks);
     else
         LN_LAUNCH(ctx, "emit_full_mfma", (emit_full_mfma<Q, false>), dim3((unsigned)grid), dim3(512), shm, obs,
-                  md.wfull.as<double>(), md.pairtab.as<int>(), md.logw.as<double>(), b, bm, F, N, D, N / 4, GY, NCH,
+                  md.wfull.as<double>(), md.pairtab.as<int>(), lw, b, bm, F, N, D, N / 4, GY, NCH,
                   nsuper, (int)spb, nchunks);
     return 0;
 }
@@ -304,20 +345,33 @@ static int launch_full(lnasr_ctx* ctx, const double* obs, long F, double* b, dou
 int emit_full_mfma_device(lnasr_ctx* ctx, const double* obs, long F, double* b, double* bm) {
     Model& md = ctx->model;
     if (md.wfull_Q == 0 || getenv("LNASR_NO_MFMA")) return 0;
+    const int N = md.N, M = md.M, virt = md.wfull_virt;
+    const int Np = md.pad_N ? md.pad_N : N, Mp = md.pad_M ? md.pad_M : M;
+    const bool padded = md.pad_N != 0;
     double* bdst = b;
-    if (md.wfull_virt > 1) {
-        LN_TRY(ctx->ws_misc2.reserve((size_t)F * md.N * md.wfull_virt * 8));
+    double* bmdst = bm;
+    if (virt > 1 || padded) {
+        LN_TRY(ctx->ws_misc2.reserve((size_t)F * Np * virt * 8));
         bdst = ctx->ws_misc2.as<double>();
     }
+    if (bm && padded) {
+        LN_TRY(ctx->ws_pad.reserve((size_t)F * Np * Mp * 8));
+        bmdst = ctx->ws_pad.as<double>();
+    }
     int rc;
-    if (md.wfull_Q == 4) rc = launch_full<4>(ctx, obs, F, bdst, bm);
-    else if (md.wfull_Q == 2) rc = launch_full<2>(ctx, obs, F, bdst, bm);
-    else rc = launch_full<1>(ctx, obs, F, bdst, bm);
+    if (md.wfull_Q == 4) rc = launch_full<4>(ctx, obs, F, bdst, bmdst);
+    else if (md.wfull_Q == 2) rc = launch_full<2>(ctx, obs, F, bdst, bmdst);
+    else rc = launch_full<1>(ctx, obs, F, bdst, bmdst);
     if (rc) return rc;
-    if (md.wfull_virt > 1) {
-        const size_t cells = (size_t)F * md.N;
+    if (virt > 1 || padded) {
+        const size_t cells = (size_t)F * N;
         LN_LAUNCH(ctx, "merge_virtual_states", merge_virtual_kernel, dim3((unsigned)((cells + 255) / 256)),
-                  dim3(256), 0, bdst, cells, md.N, md.N, md.wfull_virt, b);
+                  dim3(256), 0, bdst, cells, N, Np, virt, b);
+    }
+    if (bm && padded) {
+        const size_t cells = (size_t)F * N * M;
+        LN_LAUNCH(ctx, "compact_bm", compact_bm_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0,
+                  (const double*)bmdst, cells, N, M, Np, Mp, bm);
     }
     return 1;
 }
