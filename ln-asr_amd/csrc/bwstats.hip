@@ -235,7 +235,7 @@ __global__ __launch_bounds__(64 * kMixWaves) void mix_mfma_kernel(const double* 
                                                        const double* __restrict__ bm, const double* __restrict__ c1,
                                                        const double* __restrict__ logw, const double* __restrict__ centre,
                                                        const int32_t* __restrict__ lens, long F, long FPB, int T, int N,
-                                                       int M, int D, double* __restrict__ R) {
+                                                       int M, int D, int G, int MP, double* __restrict__ R) {
     constexpr int CH = kMixFrames, NFP = 16 * CT, FST = NFP + ((CT & 1) ? 0 : 16);
     constexpr int OPT = (CH * 39 + kMixNT - 1) / kMixNT;             // obs doubles staged per thread (D <= 39)
     __shared__ double feat[2][CH * FST];
@@ -244,7 +244,9 @@ __global__ __launch_bounds__(64 * kMixWaves) void mix_mfma_kernel(const double* 
     __shared__ double cen[40];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l15 = lane & 15, kk = lane >> 4;
-    const int j = blockIdx.x * kMixWaves + w;
+    // wave <-> (state j, group of 32 mixtures mg): M > 32 runs as G = ceil(M / 32) groups per state
+    const int jv = blockIdx.x * kMixWaves + w;
+    const int j = jv / G, mo = 32 * (jv % G);
     const bool active = j < N;
     const int jc = active ? j : N - 1;
     const long fb0 = (long)blockIdx.y * FPB;
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(64 * kMixWaves) void mix_mfma_kernel(const double* 
     double lw[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const int m = 16 * mt + l15;
+        const int m = mo + 16 * mt + l15;
         lw[mt] = m < M ? logw[(size_t)jc * M + m] : LN_NEG_INF;
     }
 
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(64 * kMixWaves) void mix_mfma_kernel(const double* 
             oreg[r] = e < nfr * D ? obs[(size_t)f0 * D + e] : 0.0;
         }
         if (tid < CH * kMixWaves) {
-            const int fr = tid / kMixWaves, js = blockIdx.x * kMixWaves + (tid % kMixWaves);
+            const int fr = tid / kMixWaves, js = (blockIdx.x * kMixWaves + (tid % kMixWaves)) / G;
             const long f = f0 + fr;
             s_ab = LN_NEG_INF;
             s_bb = 0.0;
@@ -315,12 +317,12 @@ __global__ __launch_bounds__(64 * kMixWaves) void mix_mfma_kernel(const double* 
 
     // bm prefetch ring: k-step s of the block covers frames fb0 + 4 s + kk
     double ring[kMixRing][MT];
-    const double* bmj = bm + (size_t)jc * M + l15;
+    const double* bmj = bm + (size_t)jc * M + mo + l15;
     const size_t bstride = (size_t)N * M;
     auto ring_load = [&](int slot, long f) {
         const long fc = f < F ? f : F - 1;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) ring[slot][mt] = (16 * mt + l15 < M) ? bmj[(size_t)fc * bstride + 16 * mt] : 0.0;
+        for (int mt = 0; mt < MT; ++mt) ring[slot][mt] = (mo + 16 * mt + l15 < M) ? bmj[(size_t)fc * bstride + 16 * mt] : 0.0;
     };
     __syncthreads();                       // cen, etab, constant columns
     stage_load(fb0);
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(64 * kMixWaves) void mix_mfma_kernel(const double* 
                 for (int r = 0; r < 4; ++r) {
                     const int m = 16 * mt + kk + 4 * r;
                     const double v = acc[mt][ct][r];
-                    if (v != 0.0) atomicAdd(&R[((size_t)j * (16 * MT) + m) * NFP + 16 * ct + l15], v);
+                    if (v != 0.0) atomicAdd(&R[((size_t)j * MP + mo + m) * NFP + 16 * ct + l15], v);
                 }
     }
 }
@@ -407,8 +409,8 @@ __global__ __launch_bounds__(64 * kFullWaves) void full_mfma_kernel(const double
                                                         const double* __restrict__ bm, const double* __restrict__ c1,
                                                         const double* __restrict__ logw, const double* __restrict__ centre,
                                                         const int* __restrict__ pairtab, const int32_t* __restrict__ lens,
-                                                        long F, long FPB, int T, int N, int M, int D, int NCH,
-                                                        double* __restrict__ R) {
+                                                        long F, long FPB, int T, int N, int M, int D, int NCH, int G,
+                                                        int MP, double* __restrict__ R) {
     constexpr int CH = kMixFrames, CT = 5, NFP = 16 * CT, FST = NFP, YST = 42;
     constexpr int OPT = (CH * 39 + kFullNT - 1) / kFullNT;
     __shared__ double feat[2][CH * FST];
@@ -419,7 +421,8 @@ __global__ __launch_bounds__(64 * kFullWaves) void full_mfma_kernel(const double
     __shared__ int pa[NFP], pb[NFP];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l15 = lane & 15, kk = lane >> 4;
-    const int j = blockIdx.x * kFullWaves + w, cc = blockIdx.y;
+    const int jv = blockIdx.x * kFullWaves + w, cc = blockIdx.y;
+    const int j = jv / G, mo = 32 * (jv % G);      // (state, group of 32 mixtures)
     const bool active = j < N;
     const int jc = active ? j : N - 1;
     const long fb0 = (long)blockIdx.z * FPB;
@@ -440,7 +443,7 @@ __global__ __launch_bounds__(64 * kFullWaves) void full_mfma_kernel(const double
     double lw[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const int m = 16 * mt + l15;
+        const int m = mo + 16 * mt + l15;
         lw[mt] = m < M ? logw[(size_t)jc * M + m] : LN_NEG_INF;
     }
     double oreg[OPT], s_ab = 0.0, s_bb = 0.0;
@@ -452,7 +455,7 @@ __global__ __launch_bounds__(64 * kFullWaves) void full_mfma_kernel(const double
             oreg[r] = e < nfr * D ? obs[(size_t)f0 * D + e] : 0.0;
         }
         if (tid < CH * kFullWaves) {
-            const int fr = tid / kFullWaves, js = blockIdx.x * kFullWaves + (tid % kFullWaves);
+            const int fr = tid / kFullWaves, js = (blockIdx.x * kFullWaves + (tid % kFullWaves)) / G;
             const long f = f0 + fr;
             s_ab = LN_NEG_INF;
             s_bb = 0.0;
@@ -493,12 +496,12 @@ __global__ __launch_bounds__(64 * kFullWaves) void full_mfma_kernel(const double
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) acc[mt][ct] = double4_t{0.0, 0.0, 0.0, 0.0};
     double ring[kMixRing][MT];
-    const double* bmj = bm + (size_t)jc * M + l15;
+    const double* bmj = bm + (size_t)jc * M + mo + l15;
     const size_t bstride = (size_t)N * M;
     auto ring_load = [&](int slot, long f) {
         const long fc = f < F ? f : F - 1;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) ring[slot][mt] = (16 * mt + l15 < M) ? bmj[(size_t)fc * bstride + 16 * mt] : 0.0;
+        for (int mt = 0; mt < MT; ++mt) ring[slot][mt] = (mo + 16 * mt + l15 < M) ? bmj[(size_t)fc * bstride + 16 * mt] : 0.0;
     };
     __syncthreads();                       // cen, etab, pair table, constant columns
     stage_load(fb0);
@@ -550,7 +553,7 @@ __global__ __launch_bounds__(64 * kFullWaves) void full_mfma_kernel(const double
                 for (int r = 0; r < 4; ++r) {
                     const int m = 16 * mt + kk + 4 * r;
                     const double v = acc[mt][ct][r];
-                    if (v != 0.0) atomicAdd(&R[(((size_t)j * (16 * MT) + m) * NCH + cc) * NFP + 16 * ct + l15], v);
+                    if (v != 0.0) atomicAdd(&R[(((size_t)j * MP + mo + m) * NCH + cc) * NFP + 16 * ct + l15], v);
                 }
     }
 }
@@ -579,7 +582,7 @@ __global__ void full_finish_kernel(const double* __restrict__ R, const double* _
 }
 
 bool full_stats_mfma_ok(const Model& md) {
-    return !md.diag && md.wfull_Q > 0 && md.M <= 32 && md.D <= 39 && !getenv("LNASR_NO_MFMA_STATS");
+    return !md.diag && md.wfull_Q > 0 && md.D <= 39 && !getenv("LNASR_NO_MFMA_STATS");
 }
 
 int full_stats_device(lnasr_ctx* ctx, const double* obs, const double* alpha, const double* beta, const double* b,
@@ -587,7 +590,7 @@ int full_stats_device(lnasr_ctx* ctx, const double* obs, const double* alpha, co
                       double* mix_xx) {
     Model& md = ctx->model;
     const int N = md.N, M = md.M, D = md.D, NCH = md.wfull_NCH;
-    const int MT = (M + 15) / 16, MP = 16 * MT, KF = NCH * 80;
+    const int MG = (M + 31) / 32, MT = MG > 1 ? 2 : (M + 15) / 16, MP = MG > 1 ? 32 * MG : 16 * MT, KF = NCH * 80;
     const long F = (long)U * T;
     const size_t nraw = (size_t)N * MP * KF;
     LN_TRY(ctx->ws_raw.reserve((nraw + 64) * 8));
@@ -595,7 +598,7 @@ int full_stats_device(lnasr_ctx* ctx, const double* obs, const double* alpha, co
     double* centre = R + nraw;
     LN_HIP(hipMemsetAsync(R, 0, nraw * 8, ctx->stream));
     LN_LAUNCH(ctx, "mix_centre", mix_centre_kernel, dim3(D), dim3(256), 0, md.mu.as<double>(), N * M, D, centre);
-    const int SG = (N + kFullWaves - 1) / kFullWaves;
+    const int SG = (N * MG + kFullWaves - 1) / kFullWaves;
     const long nchunk = (F + kMixFrames - 1) / kMixFrames;
     long G = (2L * ctx->prop.multiProcessorCount + (long)SG * NCH - 1) / ((long)SG * NCH);
     if (G > nchunk) G = nchunk;
@@ -607,10 +610,10 @@ int full_stats_device(lnasr_ctx* ctx, const double* obs, const double* alpha, co
     const double* lw = md.logw.as<double>();
     if (MT == 1)
         LN_LAUNCH(ctx, "full_mfma", full_mfma_kernel<1>, grid, dim3(kFullNT), 0, obs, alpha, beta, b, bm, c1, lw,
-                  (const double*)centre, (const int*)md.pairtab.as<int>(), d_lens, F, FPB, T, N, M, D, NCH, R);
+                  (const double*)centre, (const int*)md.pairtab.as<int>(), d_lens, F, FPB, T, N, M, D, NCH, MG, MP, R);
     else
         LN_LAUNCH(ctx, "full_mfma", full_mfma_kernel<2>, grid, dim3(kFullNT), 0, obs, alpha, beta, b, bm, c1, lw,
-                  (const double*)centre, (const int*)md.pairtab.as<int>(), d_lens, F, FPB, T, N, M, D, NCH, R);
+                  (const double*)centre, (const int*)md.pairtab.as<int>(), d_lens, F, FPB, T, N, M, D, NCH, MG, MP, R);
     const size_t nel = (size_t)N * M * D * D;
     LN_LAUNCH(ctx, "full_finish", full_finish_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, (const double*)R,
               md.mu.as<double>(), (const double*)centre, N, M, D, MP, KF, mix, mix_x, mix_xx);
@@ -618,19 +621,19 @@ int full_stats_device(lnasr_ctx* ctx, const double* obs, const double* alpha, co
 }
 
 bool mix_stats_mfma_ok(const Model& md) {
-    return md.diag && md.M <= 32 && md.D <= 39 && !getenv("LNASR_NO_MFMA_STATS");
+    return md.diag && md.D <= 39 && !getenv("LNASR_NO_MFMA_STATS");
 }
 
 template <int MT>
 static int mix_launch(lnasr_ctx* ctx, int CT, dim3 grid, const double* obs, const double* alpha, const double* beta,
                       const double* b, const double* bm, const double* c1, const double* centre, const int32_t* d_lens,
-                      long F, long FPB, int T, double* R) {
+                      long F, long FPB, int T, int G, int MP, double* R) {
     Model& md = ctx->model;
     const double* lw = md.logw.as<double>();
 #define LN_MIX_CASE(ct)                                                                                              \
     case ct:                                                                                                         \
         LN_LAUNCH(ctx, "mix_mfma", (mix_mfma_kernel<MT, ct>), grid, dim3(kMixNT), 0, obs, alpha, beta, b, bm, c1, lw, centre, \
-                  d_lens, F, FPB, T, md.N, md.M, md.D, R);                                                           \
+                  d_lens, F, FPB, T, md.N, md.M, md.D, G, MP, R);                                                    \
         break;
     switch (CT) {
         LN_MIX_CASE(1)
@@ -649,7 +652,9 @@ int mix_stats_device(lnasr_ctx* ctx, const double* obs, const double* alpha, con
                      double* mix_xx) {
     Model& md = ctx->model;
     const int N = md.N, M = md.M, D = md.D;
-    const int MT = (M + 15) / 16, CT = (2 * D + 1 + 15) / 16, MP = 16 * MT, NFP = 16 * CT;
+    // M > 32: MG groups of 32 mixtures per state, one wave each
+    const int MG = (M + 31) / 32, MT = MG > 1 ? 2 : (M + 15) / 16, CT = (2 * D + 1 + 15) / 16;
+    const int MP = MG > 1 ? 32 * MG : 16 * MT, NFP = 16 * CT;
     const long F = (long)U * T;
     const size_t nraw = (size_t)N * MP * NFP;
     LN_TRY(ctx->ws_raw.reserve((nraw + 64) * 8));
@@ -657,7 +662,7 @@ int mix_stats_device(lnasr_ctx* ctx, const double* obs, const double* alpha, con
     double* centre = R + nraw;
     LN_HIP(hipMemsetAsync(R, 0, nraw * 8, ctx->stream));
     LN_LAUNCH(ctx, "mix_centre", mix_centre_kernel, dim3(D), dim3(256), 0, md.mu.as<double>(), N * M, D, centre);
-    const int SG = (N + kMixWaves - 1) / kMixWaves;
+    const int SG = (N * MG + kMixWaves - 1) / kMixWaves;
     const long nchunk = (F + kMixFrames - 1) / kMixFrames;
     long G = (2L * ctx->prop.multiProcessorCount + SG - 1) / SG;
     if (G > nchunk) G = nchunk;
@@ -667,9 +672,9 @@ int mix_stats_device(lnasr_ctx* ctx, const double* obs, const double* alpha, con
     G = (F + FPB - 1) / FPB;
     const dim3 grid(SG, (unsigned)G);
     if (MT == 1)
-        LN_TRY(mix_launch<1>(ctx, CT, grid, obs, alpha, beta, b, bm, c1, centre, d_lens, F, FPB, T, R));
+        LN_TRY(mix_launch<1>(ctx, CT, grid, obs, alpha, beta, b, bm, c1, centre, d_lens, F, FPB, T, MG, MP, R));
     else
-        LN_TRY(mix_launch<2>(ctx, CT, grid, obs, alpha, beta, b, bm, c1, centre, d_lens, F, FPB, T, R));
+        LN_TRY(mix_launch<2>(ctx, CT, grid, obs, alpha, beta, b, bm, c1, centre, d_lens, F, FPB, T, MG, MP, R));
     const size_t nel = (size_t)N * M * D;
     LN_LAUNCH(ctx, "mix_finish", mix_finish_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, (const double*)R,
               md.mu.as<double>(), (const double*)centre, N, M, D, MP, NFP, mix, mix_x, mix_xx);

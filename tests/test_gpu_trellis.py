@@ -292,7 +292,8 @@ def test_bw_statistics_wide(synth, oracle, ctx):
     """Shapes that exercise every tile path of the matrix-core statistics kernels: N not a multiple of 8 or
     16, M = 17..32 (two mixture tiles), D = 39 (five feature tiles), ragged lengths, -inf weights."""
     for N, M, D, U, T, seed in ((19, 20, 39, 3, 70, 1), (130, 3, 5, 2, 40, 2), (8, 32, 13, 4, 33, 3), (5, 2, 20, 2, 37, 4),
-                                (3, 17, 28, 1, 66, 5), (2, 2, 1, 2, 9, 6)):
+                                (3, 17, 28, 1, 66, 5), (2, 2, 1, 2, 9, 6), (6, 48, 13, 2, 31, 7),
+                                (3, 70, 5, 2, 40, 8), (9, 33, 39, 1, 21, 9)):
         mdl = synth.synth_model(N, M, D, seed=seed)
         w = mdl["w"].copy()
         w[1, 0] = -np.inf                                   # a dead component
@@ -309,24 +310,25 @@ def test_bw_statistics_wide(synth, oracle, ctx):
 
 
 def test_bw_statistics_full_covariance_wide(synth, ctx):
-    """Full covariance with two mixture tiles (M = 20), N not a multiple of 8, ragged lengths: the matrix-core
-    statistics kernel against the scalar kernel that the golden vectors pin (LNASR_NO_MFMA_STATS)."""
-    N, M, D, U, T = 9, 20, 39, 3, 45
-    mdl = synth.synth_model(N, M, D, seed=12, full_cov=True)
-    obs = synth.synth_obs(U, T, D, seed=77)
-    lens = np.array([T, 17, T - 1], dtype=np.int32)
-    ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["si"])
-    assert not ctx.model_is_diag()
-    st = ctx.bw_accumulate(obs, lens=lens)
-    os.environ["LNASR_NO_MFMA_STATS"] = "1"
-    try:
-        ref = ctx.bw_accumulate(obs, lens=lens)
-    finally:
-        del os.environ["LNASR_NO_MFMA_STATS"]
-    assert st.shape == ref.shape == (N * N + 2 * N + N * M + N * M * D + N * M * D * D + 3,)
-    assert_close(st, ref, 1e-9, 1e-11)
-    si = ctx.bw_mstep(st)["si"]
-    assert np.allclose(si, np.swapaxes(si, -1, -2), rtol=0, atol=1e-12)      # symmetric second moments
+    """Full covariance with two mixture tiles (M = 20) and with more than 32 mixtures (groups of 32), N not a
+    multiple of 8, ragged lengths: the matrix-core statistics kernel against the scalar kernel that the golden
+    vectors pin (LNASR_NO_MFMA_STATS)."""
+    for N, M, D, U, T in ((9, 20, 39, 3, 45), (3, 40, 13, 2, 30)):
+        mdl = synth.synth_model(N, M, D, seed=12, full_cov=True)
+        obs = synth.synth_obs(U, T, D, seed=77)
+        lens = np.array([T, 17, T - 1][:U], dtype=np.int32)
+        ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["si"])
+        assert not ctx.model_is_diag()
+        st = ctx.bw_accumulate(obs, lens=lens)
+        os.environ["LNASR_NO_MFMA_STATS"] = "1"
+        try:
+            ref = ctx.bw_accumulate(obs, lens=lens)
+        finally:
+            del os.environ["LNASR_NO_MFMA_STATS"]
+        assert st.shape == ref.shape == (N * N + 2 * N + N * M + N * M * D + N * M * D * D + 3,)
+        assert_close(st, ref, 1e-9, 1e-11)
+        si = ctx.bw_mstep(st)["si"]
+        assert np.allclose(si, np.swapaxes(si, -1, -2), rtol=0, atol=1e-12)      # symmetric second moments
 
 
 def test_forward_backward_large_n(synth, oracle, ctx):
