@@ -427,21 +427,20 @@ __global__ __launch_bounds__(256) void backtrace_lds_kernel(const double* __rest
 #pragma unroll
         for (int c = 1; c < CPL; ++c) m = vmax_f64(m, x[c]);
         mx = wave_max_dpp(m);
-        int r = 0;
-        bool found = false;
+        int r = 0;                                            // scalar selects, highest block first: the lowest wins
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) {
+        for (int c = CPL - 1; c >= 0; --c) {
             const unsigned long long mk = __ballot(x[c] == mx);
-            if (!found && mk) {
-                r = 64 * c + __ffsll((long long)mk) - 1;
-                found = true;
-            }
+            r = mk ? 64 * c + __ffsll((long long)mk) - 1 : r;
         }
         return r;
     };
     double x[CPL];
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) x[c] = ok[c] ? vu[(size_t)(L - 1) * N + jj[c]] : LN_NEG_INF;
+    for (int c = 0; c < CPL; ++c) {
+        const double v0 = vu[(size_t)(L - 1) * N + jj[c]];
+        x[c] = ok[c] ? v0 : LN_NEG_INF;
+    }
     double bestv;
     int p = pick(x, bestv);
     if (lane == 0 && best) best[u] = bestv;
@@ -469,7 +468,10 @@ __global__ __launch_bounds__(256) void backtrace_lds_kernel(const double* __rest
             if (t >= 0) {                                   // wave-uniform
                 const double* col = ATb + (size_t)p * N;
 #pragma unroll
-                for (int c = 0; c < CPL; ++c) x[c] = ok[c] ? cur[k][c] + col[jj[c]] : LN_NEG_INF;
+                for (int c = 0; c < CPL; ++c) {
+                    const double sum = cur[k][c] + col[jj[c]];          // unconditional (clamped index), then a select
+                    x[c] = ok[c] ? sum : LN_NEG_INF;
+                }
                 double mx;
                 p = pick(x, mx);
                 if (lane == (t & 63)) mine = (uint32_t)p;
