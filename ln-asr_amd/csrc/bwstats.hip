@@ -317,12 +317,15 @@ __global__ __launch_bounds__(64 * kMixWaves) void mix_mfma_kernel(const double* 
 
     // bm prefetch ring: k-step s of the block covers frames fb0 + 4 s + kk
     double ring[kMixRing][MT];
-    const double* bmj = bm + (size_t)jc * M + mo + l15;
+    const double* bmj = bm + (size_t)jc * M + mo;
     const size_t bstride = (size_t)N * M;
+    int boff[MT];                          // lanes past the last mixture read mixture `mo` instead (their log w is -inf):
+#pragma unroll                             // an unconditional load, not a branch around one
+    for (int mt = 0; mt < MT; ++mt) boff[mt] = (mo + 16 * mt + l15 < M) ? 16 * mt + l15 : 0;
     auto ring_load = [&](int slot, long f) {
         const long fc = f < F ? f : F - 1;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) ring[slot][mt] = (mo + 16 * mt + l15 < M) ? bmj[(size_t)fc * bstride + 16 * mt] : 0.0;
+        for (int mt = 0; mt < MT; ++mt) ring[slot][mt] = bmj[(size_t)fc * bstride + boff[mt]];
     };
     __syncthreads();                       // cen, etab, constant columns
     stage_load(fb0);
@@ -496,12 +499,15 @@ __global__ __launch_bounds__(64 * kFullWaves) void full_mfma_kernel(const double
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) acc[mt][ct] = double4_t{0.0, 0.0, 0.0, 0.0};
     double ring[kMixRing][MT];
-    const double* bmj = bm + (size_t)jc * M + mo + l15;
+    const double* bmj = bm + (size_t)jc * M + mo;
     const size_t bstride = (size_t)N * M;
+    int boff[MT];                          // lanes past the last mixture read mixture `mo` instead (their log w is -inf):
+#pragma unroll                             // an unconditional load, not a branch around one
+    for (int mt = 0; mt < MT; ++mt) boff[mt] = (mo + 16 * mt + l15 < M) ? 16 * mt + l15 : 0;
     auto ring_load = [&](int slot, long f) {
         const long fc = f < F ? f : F - 1;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) ring[slot][mt] = (mo + 16 * mt + l15 < M) ? bmj[(size_t)fc * bstride + 16 * mt] : 0.0;
+        for (int mt = 0; mt < MT; ++mt) ring[slot][mt] = bmj[(size_t)fc * bstride + boff[mt]];
     };
     __syncthreads();                       // cen, etab, pair table, constant columns
     stage_load(fb0);
