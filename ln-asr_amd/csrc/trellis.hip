@@ -1043,6 +1043,307 @@ __global__ __launch_bounds__(1024) void fwdbwd_stream(const double* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------
+// N > 256, frame-parallel: beyond 256 states A (2 MB at N = 512) fits no CU, and a block that walks the frames of
+// its own utterances has to stream all of A from L2 on every frame -- with U/4 blocks doing that, the L2 is the
+// bound (42 us per frame at N = 512).  Here ONE launch advances ALL utterances by one frame: the (utterance,
+// column) outputs are tiled over the whole chip (128 columns x UT utterances x a slice of the rows per block), A
+// is read once per utterance tile instead of once per four utterances, and row slices meet in a floating-point
+// atomic max.  b[t,j] is added before the slices meet (rounding is monotonic: same bits as adding it after).
+// T launches per call; v has to be pre-filled with -inf (fill_f64_kernel).
+// ------------------------------------------------------------------------------------------
+template <int UT>
+__global__ __launch_bounds__(256) void viterbi_frame_kernel(const double* __restrict__ b, const double* __restrict__ A,
+                                                            const int32_t* __restrict__ lens, double* __restrict__ v,
+                                                            int U, int T, int N, int t, int RPS, int atomic) {
+    extern __shared__ double fsm[];
+    double* Vp = fsm;                                  // [UT][RPS]  v[t-1] of the slice rows
+    double* comb = fsm + (size_t)UT * RPS;             // [UT][128]  the four waves meet here (LDS atomic max)
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j0 = blockIdx.x * 128 + lane, j1 = j0 + 64;
+    const int u0 = blockIdx.y * UT;
+    const int r0 = blockIdx.z * RPS;
+    const int r1 = r0 + RPS < N ? r0 + RPS : N;
+    bool live[UT];
+    bool any_live = false;
+#pragma unroll
+    for (int k = 0; k < UT; ++k) {
+        live[k] = u0 + k < U && t < lens[u0 + k];
+        any_live |= live[k];
+    }
+    if (!any_live) return;                             // block-uniform
+    for (int e = tid; e < UT * RPS; e += 256) {
+        const int k = e / RPS, i = r0 + e % RPS;
+        const bool ok = u0 + k < U && t < lens[u0 + k] && i < N;
+        Vp[e] = ok ? v[((size_t)(u0 + k) * T + (t - 1)) * N + i] : LN_NEG_INF;
+    }
+    for (int e = tid; e < UT * 128; e += 256) comb[e] = LN_NEG_INF;
+    __syncthreads();
+    double acc[UT][2];
+#pragma unroll
+    for (int k = 0; k < UT; ++k) acc[k][0] = acc[k][1] = LN_NEG_INF;
+    const int jc0 = j0 < N ? j0 : N - 1, jc1 = j1 < N ? j1 : N - 1;     // clamped: loads are unconditional
+    // wave w walks a contiguous quarter of the slice two rows at a time: the two v values of an utterance come out
+    // of LDS in one 128-bit broadcast read, A two steps ahead in registers
+    const int RPW = RPS / 4;                            // RPS is a multiple of 8
+    const int w0 = r0 + w * RPW;
+    int w1 = w0 + RPW;
+    w1 = w1 < r1 ? w1 : r1;
+    constexpr int PF = 2;
+    double a0[PF][2], a1[PF][2];
+    auto loadA = [&](int i, int slot) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int ic = i + h;
+            ic = ic < N ? ic : N - 1;
+            a0[slot][h] = A[(size_t)ic * N + jc0];
+            a1[slot][h] = A[(size_t)ic * N + jc1];
+        }
+    };
+#pragma unroll
+    for (int p = 0; p < PF; ++p) loadA(w0 + 2 * p, p);
+    for (int i = w0; i < w1; i += 2 * PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const int ii = i + 2 * p;
+            const double x00 = a0[p][0], x01 = a0[p][1], x10 = a1[p][0], x11 = a1[p][1];
+            loadA(ii + 2 * PF, p);
+            if (ii < w1) {                             // wave-uniform; a row past the slice end holds -inf in Vp
+                const double* vp = Vp + (ii - r0);
+#pragma unroll
+                for (int k = 0; k < UT; ++k) {
+                    const double va = vp[k * RPS], vb = vp[k * RPS + 1];
+                    acc[k][0] = vmax_f64(acc[k][0], vmax_f64(va + x00, vb + x01));
+                    acc[k][1] = vmax_f64(acc[k][1], vmax_f64(va + x10, vb + x11));
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < UT; ++k) {
+        __hip_atomic_fetch_max(&comb[k * 128 + lane], acc[k][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_max(&comb[k * 128 + 64 + lane], acc[k][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+    for (int e = tid; e < UT * 128; e += 256) {
+        const int k = e >> 7, c = e & 127, j = blockIdx.x * 128 + c;
+        if (j < N && u0 + k < U && t < lens[u0 + k]) {
+            const double m = comb[e];
+            const size_t o = ((size_t)(u0 + k) * T + t) * N + j;
+            const double val = m + b[o];
+            if (atomic) atomicMax(&v[o], val);
+            else v[o] = val;
+        }
+    }
+}
+
+__global__ void viterbi_frame0_kernel(const double* __restrict__ b, const double* __restrict__ pi,
+                                      const int32_t* __restrict__ lens, double* __restrict__ v, int U, int T, int N) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)U * N) return;
+    const int u = (int)(idx / N), j = (int)(idx % N);
+    if (lens[u] > 0) v[(size_t)u * T * N + j] = pi[j] + b[(size_t)u * T * N + j];
+}
+
+__global__ void fill_value_kernel(double* __restrict__ p, size_t n, double value) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = value;
+}
+
+// Forward / backward for N > 256, one launch per step over the whole batch (same tiling as viterbi_frame_kernel,
+// rows not sliced across blocks so that every sum is added in a fixed order).  State between launches lives in
+// global memory: E[2][U][N] = exp(prev - shift), P[2][U][N] = prev (log domain, for the exact fallback) and a
+// ring M[4][U] of per-utterance maxima of prev (filled with a floating-point atomic max: order independent).
+// Step s of an utterance of length L is frame s (forward) or L-1-s (backward).  With h_s = M_{max(s-1,0)}:
+//     val = h_{s-1} + log(sum_i E_{s-1}[i] expA[i,j]),  prev_s = val + b,  E_s = exp(prev_s - h_s),  M_s = max_j prev_s
+// -- the lagged shift of the register-resident kernels, sums outside [1e-290, 1e290] redone exactly.
+template <int UT, bool BACKWARD>
+__global__ __launch_bounds__(256) void fwdbwd_frame_kernel(const double* __restrict__ b, const double* __restrict__ Aexp,
+                                                           const double* __restrict__ Alog,
+                                                           const int32_t* __restrict__ lens, double* __restrict__ out,
+                                                           double* __restrict__ E, double* __restrict__ P,
+                                                           double* __restrict__ Mring, int U, int T, int N, int s) {
+    extern __shared__ double fsm[];
+    double* Ep = fsm;                                   // [UT][NP]  e values of the previous step
+    const int NP = (N + 7) / 8 * 8;
+    double* part = fsm + (size_t)UT * NP;               // [4][UT][128]
+    __shared__ double etab[kExpTab];
+    __shared__ double ltab[2 * kLogTab];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j0 = blockIdx.x * 128 + lane, j1 = j0 + 64;
+    const int u0 = blockIdx.y * UT;
+    const int cur = (s - 1) & 1, nxt = s & 1;
+    bool any_live = false;
+#pragma unroll
+    for (int k = 0; k < UT; ++k) any_live |= u0 + k < U && s < lens[u0 + k];
+    // the ring slot of step s+1 is cleared by the first column tile (nobody reads or accumulates it during this launch)
+    if (blockIdx.x == 0 && tid < UT && u0 + tid < U) Mring[(size_t)((s + 1) & 3) * U + u0 + tid] = LN_NEG_INF;
+    if (!any_live) return;
+    exp_table_init(etab, tid, 256);
+    log_table_init(ltab, tid, 256);
+    for (int e = tid; e < UT * NP; e += 256) {
+        const int k = e / NP, i = e % NP;
+        const bool ok = u0 + k < U && s < lens[u0 + k] && i < N;
+        Ep[e] = ok ? E[((size_t)cur * U + u0 + k) * N + i] : 0.0;
+    }
+    __syncthreads();
+    double acc[UT][2];
+#pragma unroll
+    for (int k = 0; k < UT; ++k) acc[k][0] = acc[k][1] = 0.0;
+    const int jc0 = j0 < N ? j0 : N - 1, jc1 = j1 < N ? j1 : N - 1;
+    const int RPW = NP / 4;                              // a multiple of 2
+    const int w0 = w * RPW;
+    int w1 = w0 + RPW;
+    w1 = w1 < N ? w1 : N;
+    constexpr int PF = 2;
+    double a0[PF][2], a1[PF][2];
+    auto loadA = [&](int i, int slot) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int ic = i + h;
+            ic = ic < N ? ic : N - 1;
+            a0[slot][h] = Aexp[(size_t)ic * N + jc0];
+            a1[slot][h] = Aexp[(size_t)ic * N + jc1];
+        }
+    };
+#pragma unroll
+    for (int p = 0; p < PF; ++p) loadA(w0 + 2 * p, p);
+    for (int i = w0; i < w1; i += 2 * PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const int ii = i + 2 * p;
+            const double x00 = a0[p][0], x01 = a0[p][1], x10 = a1[p][0], x11 = a1[p][1];
+            loadA(ii + 2 * PF, p);
+            if (ii < w1) {                               // rows >= N carry e = 0 in Ep
+                const double* ep = Ep + ii;
+#pragma unroll
+                for (int k = 0; k < UT; ++k) {
+                    const double ea = ep[k * NP], eb = ep[k * NP + 1];
+                    acc[k][0] = fma(eb, x01, fma(ea, x00, acc[k][0]));
+                    acc[k][1] = fma(eb, x11, fma(ea, x10, acc[k][1]));
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < UT; ++k) {
+        part[(w * UT + k) * 128 + lane] = acc[k][0];
+        part[(w * UT + k) * 128 + 64 + lane] = acc[k][1];
+    }
+    __syncthreads();
+    for (int e = tid; e < UT * 128; e += 256) {          // a wave works on 64 columns of ONE utterance per round
+        const int k = e >> 7, c = e & 127, j = blockIdx.x * 128 + c, u = u0 + k;
+        const int L = u < U ? lens[u] : 0;
+        double prev = LN_NEG_INF;
+        if (j < N && s < L) {
+        const double sum = (part[(0 * UT + k) * 128 + c] + part[(1 * UT + k) * 128 + c]) +
+                           (part[(2 * UT + k) * 128 + c] + part[(3 * UT + k) * 128 + c]);
+        const double hprev = Mring[(size_t)((s >= 2 ? s - 2 : 0) & 3) * U + u];       // shift of E_{s-1}
+        const double hcur = Mring[(size_t)((s - 1) & 3) * U + u];                     // shift for E_s
+        double val;
+        if (sum >= kSafeSum && sum <= 1e290 && hprev != LN_NEG_INF) {
+            val = hprev + log_sum(sum, ltab);
+        } else {
+            val = exact_column_lse(P + ((size_t)cur * U + u) * N, Alog + j, N);
+        }
+        const int t = BACKWARD ? L - 1 - s : s;
+        const size_t o = ((size_t)u * T + t) * N + j;
+        if (BACKWARD) {
+            out[o] = val;
+            prev = val + b[o];
+        } else {
+            prev = val + b[o];
+            out[o] = prev;
+        }
+        P[((size_t)nxt * U + u) * N + j] = prev;
+        E[((size_t)nxt * U + u) * N + j] = (hcur == LN_NEG_INF || prev == LN_NEG_INF) ? 0.0 : exp_clamped(prev - hcur, etab);
+        }
+        // one atomic per wave, not per state: 512 atomics on one address per frame cost ~100 us
+        const double m = wave_max_dpp(prev);
+        if (lane == 0 && m != LN_NEG_INF) atomicMax(&Mring[(size_t)(s & 3) * U + u], m);
+    }
+}
+
+// step 0: prev_0 into out / P[0], its per-utterance maximum into M[0] (atomic max), M[1] cleared
+template <bool BACKWARD>
+__global__ void fwdbwd_frame0a_kernel(const double* __restrict__ b, const double* __restrict__ pi,
+                                      const int32_t* __restrict__ lens, double* __restrict__ out, double* __restrict__ P,
+                                      double* __restrict__ Mring, int U, int T, int N) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)U * N) return;
+    const int u = (int)(idx / N), j = (int)(idx % N);
+    const int L = lens[u];
+    double prev = LN_NEG_INF;
+    if (L > 0) {
+        const int t = BACKWARD ? L - 1 : 0;
+        const size_t o = ((size_t)u * T + t) * N + j;
+        if (BACKWARD) {
+            out[o] = 0.0;
+            prev = 0.0 + b[o];
+        } else {
+            prev = pi[j] + b[o];
+            out[o] = prev;
+        }
+        atomicMax(&Mring[u], prev);
+    }
+    P[idx] = prev;
+}
+__global__ void fwdbwd_frame0b_kernel(const double* __restrict__ P, const double* __restrict__ Mring,
+                                      double* __restrict__ E, int U, int N) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)U * N) return;
+    const double h = Mring[idx / N], prev = P[idx];
+    E[idx] = (h == LN_NEG_INF || prev == LN_NEG_INF) ? 0.0 : exp(prev - h);
+}
+// loglik[u] = lse_j alpha[len-1, j]  (hmm.py:274): one wave per utterance
+__global__ void final_loglik_kernel(const double* __restrict__ alpha, const int32_t* __restrict__ lens,
+                                    double* __restrict__ loglik, int U, int T, int N) {
+    const int lane = threadIdx.x & 63;
+    const int u = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (u >= U) return;
+    const int L = lens[u];
+    if (L <= 0) return;
+    const double* row = alpha + ((size_t)u * T + (L - 1)) * N;
+    double mx = LN_NEG_INF;
+    for (int j = lane; j < N; j += 64) mx = fmax(mx, row[j]);
+    mx = wave_max(mx);
+    double sacc = 0.0;
+    for (int j = lane; j < N; j += 64) sacc += (mx == LN_NEG_INF || row[j] == LN_NEG_INF) ? 0.0 : exp(row[j] - mx);
+    sacc = wave_sum(sacc);
+    if (lane == 0) loglik[u] = (mx == LN_NEG_INF) ? mx : mx + log(sacc);
+}
+
+template <bool BACKWARD>
+static int fwdbwd_frames(lnasr_ctx* ctx, const double* b, const double* Aexp, const double* Alog, int U, int T,
+                         const int32_t* d_lens, double* out, double* loglik) {
+    Model& md = ctx->model;
+    const int N = md.N;
+    constexpr int UT = 4;
+    const int NP = (N + 7) / 8 * 8;
+    const int ctiles = (N + 127) / 128, utiles = (U + UT - 1) / UT;
+    LN_REQUIRE(utiles <= 65535, "U=%d too large for the frame-parallel forward/backward", U);
+    const size_t shm = ((size_t)UT * NP + 4 * UT * 128) * 8;
+    LN_REQUIRE(shm + 4096 <= 160 * 1024, "N=%d too large for the frame-parallel forward/backward", N);
+    const size_t un = (size_t)U * N;
+    DevBuf& ws = BACKWARD ? ctx->ws_q : ctx->ws_p;     // the two directions may run side by side (bw_accumulate)
+    LN_TRY(ws.reserve((2 * un + 2 * un + 4 * (size_t)U) * 8));
+    double* E = ws.as<double>();
+    double* P = E + 2 * un;
+    double* Mring = P + 2 * un;
+    LN_LAUNCH(ctx, "fwdbwd_fill", fill_value_kernel, dim3((unsigned)((4 * (size_t)U + 255) / 256)), dim3(256), 0, Mring,
+              (size_t)4 * U, LN_NEG_INF);
+    LN_LAUNCH(ctx, BACKWARD ? "backward_frame0" : "forward_frame0", fwdbwd_frame0a_kernel<BACKWARD>,
+              dim3((unsigned)((un + 255) / 256)), dim3(256), 0, b, md.logpi.as<double>(), d_lens, out, P, Mring, U, T, N);
+    LN_LAUNCH(ctx, BACKWARD ? "backward_frame0" : "forward_frame0", fwdbwd_frame0b_kernel, dim3((unsigned)((un + 255) / 256)),
+              dim3(256), 0, (const double*)P, (const double*)Mring, E, U, N);
+    for (int s = 1; s < T; ++s)
+        LN_LAUNCH(ctx, BACKWARD ? "backward_frame" : "forward_frame", (fwdbwd_frame_kernel<UT, BACKWARD>),
+                  dim3(ctiles, utiles), dim3(256), shm, b, Aexp, Alog, d_lens, out, E, P, Mring, U, T, N, s);
+    if (!BACKWARD && loglik)
+        LN_LAUNCH(ctx, "forward_loglik", final_loglik_kernel, dim3((U + 3) / 4), dim3(256), 0, (const double*)out, d_lens,
+                  loglik, U, T, N);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // 128 < N <= 256: the transition matrix (512 KB at N = 256) is exactly the register file of one CU.
 // One 1024-thread block per utterance keeps it ON CHIP: thread (column jc, row slice rs) owns 64 rows
 // of its column, most of them in registers and the rest in LDS (136 KB for the block), so a frame costs
@@ -1334,6 +1635,10 @@ int device_lens(lnasr_ctx* ctx, const int32_t* lens, int U, int T, const int32_t
 }
 
 // v [U,T,N] must be device memory
+// N > 256: with few utterances the frame-parallel kernels (one launch per frame over the whole batch) beat the
+// per-utterance-block streaming kernels 3-16x; with ~1000 utterances the streaming kernels already fill the chip
+constexpr int kFrameParMaxU = 256;
+
 int viterbi_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d_lens, int dtype, void* v) {
     Model& md = ctx->model;
     const int N = md.N;
@@ -1368,6 +1673,33 @@ int viterbi_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
     if (dtype == LNASR_F64 && N > 128 && N <= 256 && !getenv("LNASR_NO_T256")) {
         LN_LAUNCH(ctx, "viterbi_onchip256", trellis256_kernel<0>, dim3(U), dim3(1024), trellis256_lds(), (const double*)b, A,
                   A, pi, d_lens, (double*)v, (double*)nullptr, U, T, N);
+        return 0;
+    }
+    if (dtype == LNASR_F64 && N > 256 && U <= kFrameParMaxU && !getenv("LNASR_NO_FRAMEPAR")) {
+        // one launch per frame over the whole batch (see viterbi_frame_kernel)
+        const int UT = U >= 256 ? 16 : 8;            // many utterances: fewer, larger tiles re-read A less often
+        const int ctiles = (N + 127) / 128, utiles = (U + UT - 1) / UT;
+        LN_REQUIRE(utiles <= 65535, "U=%d too large for the frame-parallel Viterbi", U);
+        int RS = (3 * ctx->prop.multiProcessorCount + ctiles * utiles - 1) / (ctiles * utiles);
+        if (RS > N / 64) RS = N / 64;
+        if (RS < 1) RS = 1;
+        int RPS = ((N + RS - 1) / RS + 7) / 8 * 8;
+        RS = (N + RPS - 1) / RPS;
+        const size_t cells = (size_t)U * T * N;
+        const size_t shm = ((size_t)UT * RPS + UT * 128) * 8;
+        LN_REQUIRE(shm <= 160 * 1024, "N=%d too large for the frame-parallel Viterbi", N);
+        if (RS > 1)
+            LN_LAUNCH(ctx, "viterbi_fill", fill_value_kernel, dim3(2048), dim3(256), 0, (double*)v, cells, LN_NEG_INF);
+        LN_LAUNCH(ctx, "viterbi_frame0", viterbi_frame0_kernel, dim3((unsigned)(((size_t)U * N + 255) / 256)), dim3(256), 0,
+                  (const double*)b, pi, d_lens, (double*)v, U, T, N);
+        for (int t = 1; t < T; ++t) {
+            if (UT == 16)
+                LN_LAUNCH(ctx, "viterbi_frame", (viterbi_frame_kernel<16>), dim3(ctiles, utiles, RS), dim3(256), shm,
+                          (const double*)b, A, d_lens, (double*)v, U, T, N, t, RPS, RS > 1 ? 1 : 0);
+            else
+                LN_LAUNCH(ctx, "viterbi_frame", (viterbi_frame_kernel<8>), dim3(ctiles, utiles, RS), dim3(256), shm,
+                          (const double*)b, A, d_lens, (double*)v, U, T, N, t, RPS, RS > 1 ? 1 : 0);
+        }
         return 0;
     }
     if (dtype == LNASR_F64 && N > 128 && N <= 1024 && !getenv("LNASR_NO_STREAM")) {
@@ -1451,6 +1783,15 @@ int forward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
                   N);
         return 0;
     }
+    if (dtype == LNASR_F64 && N > 256 && U <= kFrameParMaxU && !getenv("LNASR_NO_FRAMEPAR")) {
+        double* a = (double*)alpha;
+        if (!a) {                                         // log-likelihood only: alpha still has to exist somewhere
+            LN_TRY(ctx->ws_alpha.reserve((size_t)U * T * N * 8));
+            a = ctx->ws_alpha.as<double>();
+        }
+        return fwdbwd_frames<false>(ctx, (const double*)b, md.expA.as<double>(), md.logA.as<double>(), U, T, d_lens, a,
+                                    loglik);
+    }
     if (dtype == LNASR_F64 && N > 128 && N <= 1024 && !getenv("LNASR_NO_STREAM")) {
         const int NP = ((N + 63) / 64) * 64, RS = 1024 / NP, RPS = (N + RS - 1) / RS, NB = NP / 64;
         // few utterances: one per block keeps more CUs busy (the frame chain is the critical path);
@@ -1518,6 +1859,8 @@ int backward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* 
                   expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta, (double*)nullptr, U, T, N);
         return 0;
     }
+    if (dtype == LNASR_F64 && N > 256 && U <= kFrameParMaxU && !getenv("LNASR_NO_FRAMEPAR"))
+        return fwdbwd_frames<true>(ctx, (const double*)b, expAT, md.logAT.as<double>(), U, T, d_lens, (double*)beta, nullptr);
     if (dtype == LNASR_F64 && N > 128 && N <= 1024 && !getenv("LNASR_NO_STREAM")) {
         const int NP = ((N + 63) / 64) * 64, RS = 1024 / NP, RPS = (N + RS - 1) / RS, NB = NP / 64;
         if (U < 2 * ctx->prop.multiProcessorCount) {

@@ -309,6 +309,43 @@ def test_bw_statistics_wide(synth, oracle, ctx):
         assert st[N * N + 2 * N + M] == 0.0                 # mix[1, 0]: exact zero stays exact
 
 
+@pytest.mark.parametrize("route", ["frame-parallel", "streaming"])
+def test_trellises_beyond_256_states(route, synth, oracle, ctx):
+    """N > 256: the frame-parallel kernels (one launch per frame over the batch; the default for small batches) and
+    the per-utterance streaming kernels (large batches; forced here with LNASR_NO_FRAMEPAR) against the oracle."""
+    rng = np.random.default_rng(23)
+    if route == "streaming":
+        os.environ["LNASR_NO_FRAMEPAR"] = "1"
+    try:
+        for N in (257, 520):
+            d = synth.synth_discrete(N, 4, 8, seed=N)
+            A = d["A"].copy()
+            A[3, :] = -np.inf
+            A[3, 5] = 0.0
+            A[:, 7] = -np.inf
+            ctx.upload_hmm(A, d["pi"])
+            T = 11
+            b = np.ascontiguousarray(-30.0 * rng.random((4, T, N)))
+            lens = np.array([T, 1, 6, 2], dtype=np.int32)
+            alpha, ll = ctx.forward(b, lens=lens)
+            _, ll_only = ctx.forward(b, want_alpha=False, lens=lens)
+            beta = ctx.backward(b, lens=lens)
+            r = ctx.viterbi(b, lens=lens)
+            for u in range(4):
+                L = lens[u]
+                ob = np.ascontiguousarray(b[u, :L].T)
+                with np.errstate(invalid="ignore"):
+                    ra, rb = oracle.forward(A, d["pi"], ob), oracle.backward(A, ob)
+                assert_close(alpha[u, :L], ra, 1e-12, msg="alpha N=%d u=%d" % (N, u))
+                assert_close(beta[u, :L], rb, 1e-12, msg="beta N=%d u=%d" % (N, u))
+                assert abs(ll[u] - oracle.loglik(ra)) <= 1e-11 * abs(ll[u]) and ll_only[u] == ll[u]
+                v, bt, path = oracle.viterbi(A, d["pi"], ob)
+                assert np.array_equal(r["v"][u, :L], v) and np.array_equal(r["path"][u, :L], path)
+                assert np.array_equal(r["bt"][u, :L], bt)
+    finally:
+        os.environ.pop("LNASR_NO_FRAMEPAR", None)
+
+
 def test_bw_statistics_full_covariance_wide(synth, ctx):
     """Full covariance with two mixture tiles (M = 20) and with more than 32 mixtures (groups of 32), N not a
     multiple of 8, ragged lengths: the matrix-core statistics kernel against the scalar kernel that the golden
