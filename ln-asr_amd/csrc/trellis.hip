@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256) void backtrace_lds_kernel(const double* __rest
     if (((L - 1) & 63) == 0) pu[L - 1] = (uint32_t)p;      // single-entry top block
     // v rows are streamed from HBM: keep PF frames in flight per wave (register ring) so that the
     // dependent chain below only ever waits on the A^T row
-    constexpr int PF = CPL <= 2 ? 8 : 4;
+    constexpr int PF = CPL <= 2 ? 8 : (CPL <= 4 ? 4 : (CPL <= 8 ? 2 : 1));
     double cur[PF][CPL], nxt[PF][CPL];
     auto load_rows = [&](int tstart, double (&r)[PF][CPL]) {     // frames tstart, tstart-1, ... (clamped at 0)
 #pragma unroll
@@ -1731,10 +1731,17 @@ int backtrace_device(lnasr_ctx* ctx, const void* v, int U, int T, const int32_t*
                   (size_t)md.N * md.N * 8, (const double*)v, md.logAT.as<double>(), d_lens, path, best, U, T, md.N);
         return 0;
     }
-    if (dtype == LNASR_F64 && md.N <= 256 && !getenv("LNASR_NO_LDSBT")) {
-        // one wave per block: with few utterances the waves should sit on different CUs
-        LN_LAUNCH(ctx, "backtrace_wave256", (backtrace_lds_kernel<4, false>), dim3(U), dim3(64), 0, (const double*)v,
-                  md.logAT.as<double>(), d_lens, path, best, U, T, md.N);
+    if (dtype == LNASR_F64 && md.N <= 1024 && !getenv("LNASR_NO_LDSBT")) {
+        // one wave per block (with few utterances the waves should sit on different CUs), N / 64 states per lane
+        if (md.N <= 256)
+            LN_LAUNCH(ctx, "backtrace_wave256", (backtrace_lds_kernel<4, false>), dim3(U), dim3(64), 0, (const double*)v,
+                      md.logAT.as<double>(), d_lens, path, best, U, T, md.N);
+        else if (md.N <= 512)
+            LN_LAUNCH(ctx, "backtrace_wave512", (backtrace_lds_kernel<8, false>), dim3(U), dim3(64), 0, (const double*)v,
+                      md.logAT.as<double>(), d_lens, path, best, U, T, md.N);
+        else
+            LN_LAUNCH(ctx, "backtrace_wave1024", (backtrace_lds_kernel<16, false>), dim3(U), dim3(64), 0, (const double*)v,
+                      md.logAT.as<double>(), d_lens, path, best, U, T, md.N);
         return 0;
     }
     if (dtype == LNASR_F32)
