@@ -293,7 +293,7 @@ def test_bw_statistics_wide(synth, oracle, ctx):
     16, M = 17..32 (two mixture tiles), D = 39 (five feature tiles), ragged lengths, -inf weights."""
     for N, M, D, U, T, seed in ((19, 20, 39, 3, 70, 1), (130, 3, 5, 2, 40, 2), (8, 32, 13, 4, 33, 3), (5, 2, 20, 2, 37, 4),
                                 (3, 17, 28, 1, 66, 5), (2, 2, 1, 2, 9, 6), (6, 48, 13, 2, 31, 7),
-                                (3, 70, 5, 2, 40, 8), (9, 33, 39, 1, 21, 9)):
+                                (3, 70, 5, 2, 40, 8), (9, 33, 39, 1, 21, 9), (260, 2, 3, 2, 5, 10)):
         mdl = synth.synth_model(N, M, D, seed=seed)
         w = mdl["w"].copy()
         w[1, 0] = -np.inf                                   # a dead component
