@@ -664,8 +664,9 @@ static bool mfma_shape_supported(int N, int M, int D, int* Q, int* KS) {
     if (N % 4 != 0 || M % 4 != 0) return false;
     int q = M / 4, ks = (2 * D + 1 + 3) / 4;
     if (!(q == 1 || q == 2 || q == 4)) return false;
-    ks = ks <= 7 ? 7 : (ks <= 14 ? 14 : (ks <= 20 ? 20 : 0));    // K rows past 2D+1 carry zero coefficients
-    if (ks == 0) return false;                                    // D <= 39
+    ks = ks <= 7 ? 7 : (ks <= 14 ? 14 : (ks <= 20 ? 20 : (ks <= 32 ? 32 : 0)));   // K rows past 2D+1: zero coefficients
+    if (ks == 0) return false;                                    // D <= 63
+    if (ks == 32 && q > 2) return false;                          // 40 <= D <= 63: at most 8 mixtures per tile (registers)
     *Q = q;
     *KS = ks;
     return true;
@@ -771,9 +772,11 @@ static int model_upload_impl(lnasr_ctx* ctx, int N, int M, int D, const double* 
         // The bank kernel takes N a multiple of 4 and 4, 8 or 16 mixtures per (virtual) state; M = 16 k mixtures are
         // scored as k virtual 16-mixture states per state ([N,M,D] is [N k,16,D] in memory).  Any other N / M is
         // padded to the next such shape on a copy of the parameters.
-        const int Mp = M <= 4 ? 4 : (M <= 8 ? 8 : (M + 15) / 16 * 16);
+        // (40 <= D <= 63: 128 K rows leave registers for 8 mixtures per tile, so M > 8 runs as virtual 8-mixture states)
+        const int mtile = (2 * D + 1 + 3) / 4 > 20 ? 8 : 16;
+        const int Mp = M <= 4 ? 4 : (M <= 8 ? 8 : (M + mtile - 1) / mtile * mtile);
         const int Np = (N + 3) / 4 * 4;
-        const int virt = Mp > 16 ? Mp / 16 : 1;
+        const int virt = Mp > mtile ? Mp / mtile : 1;
         const int Nv = Np * virt, Mv = Mp / virt;
         md.wpack_virt = 1;
         md.pad_N = md.pad_M = 0;
@@ -930,7 +933,7 @@ int emit_device(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, v
 #define LN_CASE(q, ks) \
     if (Q == q && KS == ks) rc = launch_mfma<q, ks>(ctx, obs, F, bdst, bmdst);
         LN_CASE(4, 20) LN_CASE(2, 20) LN_CASE(1, 20) LN_CASE(4, 14) LN_CASE(2, 14) LN_CASE(1, 14)
-        LN_CASE(4, 7) LN_CASE(2, 7) LN_CASE(1, 7)
+        LN_CASE(4, 7) LN_CASE(2, 7) LN_CASE(1, 7) LN_CASE(2, 32) LN_CASE(1, 32)
 #undef LN_CASE
         LN_TRY(rc);
         if (virt > 1 || padded) {

@@ -20,7 +20,7 @@ def _shape(seed):
     rng = np.random.default_rng(1000 + seed)
     N = int(rng.choice([1, 2, 3, 4, 5, 8, 12, 16, 31, 64, 65, 100, 128, 129, 160, 256, 257, 300]))
     M = int(rng.choice([1, 2, 3, 4, 7, 8, 15, 16, 17, 32, 48]))
-    D = int(rng.choice([1, 2, 3, 5, 12, 13, 20, 26, 27, 38, 39, 40]))
+    D = int(rng.choice([1, 2, 3, 5, 12, 13, 20, 26, 27, 38, 39, 40, 50, 63, 64]))
     # keep the oracle's work (N * M * T * D, and N^2 * T for the trellises) bounded
     T = int(rng.integers(1, max(2, min(40, 400000 // (N * M * D) + 2, 3000000 // (N * N) + 2))))
     U = int(rng.integers(1, 5))
