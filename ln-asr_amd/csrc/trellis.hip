@@ -1051,37 +1051,42 @@ __global__ __launch_bounds__(1024) void fwdbwd_stream(const double* __restrict__
 // atomic max.  b[t,j] is added before the slices meet (rounding is monotonic: same bits as adding it after).
 // T launches per call; v has to be pre-filled with -inf (fill_f64_kernel).
 // ------------------------------------------------------------------------------------------
-template <int UT>
+template <int UT, int CPT>
 __global__ __launch_bounds__(256) void viterbi_frame_kernel(const double* __restrict__ b, const double* __restrict__ A,
                                                             const int32_t* __restrict__ lens, double* __restrict__ v,
                                                             int U, int T, int N, int t, int RPS, int atomic) {
+    // CPT columns per lane (tile = 64 CPT columns): every v value read from LDS serves CPT transitions, so the wider
+    // tile is the one for large batches, where the LDS broadcast reads are the bound
+    constexpr int TW = 64 * CPT;
     extern __shared__ double fsm[];
     double* Vp = fsm;                                  // [UT][RPS]  v[t-1] of the slice rows
-    double* comb = fsm + (size_t)UT * RPS;             // [UT][128]  the four waves meet here (LDS atomic max)
+    double* comb = fsm + (size_t)UT * RPS;             // [UT][TW]   the four waves meet here (LDS atomic max)
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j0 = blockIdx.x * 128 + lane, j1 = j0 + 64;
     const int u0 = blockIdx.y * UT;
     const int r0 = blockIdx.z * RPS;
     const int r1 = r0 + RPS < N ? r0 + RPS : N;
-    bool live[UT];
     bool any_live = false;
 #pragma unroll
-    for (int k = 0; k < UT; ++k) {
-        live[k] = u0 + k < U && t < lens[u0 + k];
-        any_live |= live[k];
-    }
+    for (int k = 0; k < UT; ++k) any_live |= u0 + k < U && t < lens[u0 + k];
     if (!any_live) return;                             // block-uniform
     for (int e = tid; e < UT * RPS; e += 256) {
         const int k = e / RPS, i = r0 + e % RPS;
         const bool ok = u0 + k < U && t < lens[u0 + k] && i < N;
         Vp[e] = ok ? v[((size_t)(u0 + k) * T + (t - 1)) * N + i] : LN_NEG_INF;
     }
-    for (int e = tid; e < UT * 128; e += 256) comb[e] = LN_NEG_INF;
+    for (int e = tid; e < UT * TW; e += 256) comb[e] = LN_NEG_INF;
     __syncthreads();
-    double acc[UT][2];
+    double acc[UT][CPT];
 #pragma unroll
-    for (int k = 0; k < UT; ++k) acc[k][0] = acc[k][1] = LN_NEG_INF;
-    const int jc0 = j0 < N ? j0 : N - 1, jc1 = j1 < N ? j1 : N - 1;     // clamped: loads are unconditional
+    for (int k = 0; k < UT; ++k)
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) acc[k][c] = LN_NEG_INF;
+    int jc[CPT];                                       // clamped: loads are unconditional
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+        const int j = blockIdx.x * TW + lane + 64 * c;
+        jc[c] = j < N ? j : N - 1;
+    }
     // wave w walks a contiguous quarter of the slice two rows at a time: the two v values of an utterance come out
     // of LDS in one 128-bit broadcast read, A two steps ahead in registers
     const int RPW = RPS / 4;                            // RPS is a multiple of 8
@@ -1089,14 +1094,14 @@ __global__ __launch_bounds__(256) void viterbi_frame_kernel(const double* __rest
     int w1 = w0 + RPW;
     w1 = w1 < r1 ? w1 : r1;
     constexpr int PF = 2;
-    double a0[PF][2], a1[PF][2];
+    double a[PF][2][CPT];
     auto loadA = [&](int i, int slot) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             int ic = i + h;
             ic = ic < N ? ic : N - 1;
-            a0[slot][h] = A[(size_t)ic * N + jc0];
-            a1[slot][h] = A[(size_t)ic * N + jc1];
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) a[slot][h][c] = A[(size_t)ic * N + jc[c]];
         }
     };
 #pragma unroll
@@ -1105,27 +1110,31 @@ __global__ __launch_bounds__(256) void viterbi_frame_kernel(const double* __rest
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
             const int ii = i + 2 * p;
-            const double x00 = a0[p][0], x01 = a0[p][1], x10 = a1[p][0], x11 = a1[p][1];
+            double x[2][CPT];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int c = 0; c < CPT; ++c) x[h][c] = a[p][h][c];
             loadA(ii + 2 * PF, p);
             if (ii < w1) {                             // wave-uniform; a row past the slice end holds -inf in Vp
                 const double* vp = Vp + (ii - r0);
 #pragma unroll
                 for (int k = 0; k < UT; ++k) {
                     const double va = vp[k * RPS], vb = vp[k * RPS + 1];
-                    acc[k][0] = vmax_f64(acc[k][0], vmax_f64(va + x00, vb + x01));
-                    acc[k][1] = vmax_f64(acc[k][1], vmax_f64(va + x10, vb + x11));
+#pragma unroll
+                    for (int c = 0; c < CPT; ++c) acc[k][c] = vmax_f64(acc[k][c], vmax_f64(va + x[0][c], vb + x[1][c]));
                 }
             }
         }
     }
 #pragma unroll
-    for (int k = 0; k < UT; ++k) {
-        __hip_atomic_fetch_max(&comb[k * 128 + lane], acc[k][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_max(&comb[k * 128 + 64 + lane], acc[k][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
+    for (int k = 0; k < UT; ++k)
+#pragma unroll
+        for (int c = 0; c < CPT; ++c)
+            __hip_atomic_fetch_max(&comb[k * TW + 64 * c + lane], acc[k][c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __syncthreads();
-    for (int e = tid; e < UT * 128; e += 256) {
-        const int k = e >> 7, c = e & 127, j = blockIdx.x * 128 + c;
+    for (int e = tid; e < UT * TW; e += 256) {
+        const int k = e / TW, c = e % TW, j = blockIdx.x * TW + c;
         if (j < N && u0 + k < U && t < lens[u0 + k]) {
             const double m = comb[e];
             const size_t o = ((size_t)(u0 + k) * T + t) * N + j;
@@ -1637,7 +1646,29 @@ int device_lens(lnasr_ctx* ctx, const int32_t* lens, int U, int T, const int32_t
 // v [U,T,N] must be device memory
 // N > 256: with few utterances the frame-parallel kernels (one launch per frame over the whole batch) beat the
 // per-utterance-block streaming kernels 3-16x; with ~1000 utterances the streaming kernels already fill the chip
-constexpr int kFrameParMaxU = 256;
+constexpr size_t kStreamLdsMax = 160 * 1024;     // dynamic LDS a streaming block may ask for
+// N > 256: frame-parallel kernels (one launch per frame over the whole batch) or per-utterance streaming kernels.
+// Measured on MI355X at T = 100 (tools/bign.py, ms, frame-parallel / streaming):
+//   Viterbi  N=320: U=64 1.2/2.1  U=512 2.2/2.2  U=1024 3.0/2.4    N=512: 1.1/4.5  3.0/4.6  4.2/5.1
+//            N=1024: 1.8/32  6.5/29  11.6/29
+//   forward  N=320: 1.8/1.5  2.2/2.0  2.8/2.2    N=512: 2.6/3.1  3.4/4.3  5.0/4.4    N=1024: 4.7/24  10.8/25  17/50
+// LNASR_FRAMEPAR_MAXU (developer/test switch) replaces the rule by "U <= value".
+static bool framepar_env(int U, bool* use) {
+    if (getenv("LNASR_NO_FRAMEPAR")) { *use = false; return true; }
+    const char* e = getenv("LNASR_FRAMEPAR_MAXU");
+    if (e) { *use = U <= atoi(e); return true; }
+    return false;
+}
+static bool viterbi_framepar(int N, int U) {
+    bool use;
+    if (framepar_env(U, &use)) return use;
+    return N > 384 || U <= 512;
+}
+static bool fwdbwd_framepar(int N, int U) {
+    bool use;
+    if (framepar_env(U, &use)) return use;
+    return N > 768 || (N > 384 && U <= 512);
+}
 
 int viterbi_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d_lens, int dtype, void* v) {
     Model& md = ctx->model;
@@ -1675,10 +1706,12 @@ int viterbi_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
                   A, pi, d_lens, (double*)v, (double*)nullptr, U, T, N);
         return 0;
     }
-    if (dtype == LNASR_F64 && N > 256 && U <= kFrameParMaxU && !getenv("LNASR_NO_FRAMEPAR")) {
+    if (dtype == LNASR_F64 && N > 256 && viterbi_framepar(N, U)) {
         // one launch per frame over the whole batch (see viterbi_frame_kernel)
-        const int UT = U >= 256 ? 16 : 8;            // many utterances: fewer, larger tiles re-read A less often
-        const int ctiles = (N + 127) / 128, utiles = (U + UT - 1) / UT;
+        constexpr int UT = 8;
+        const int CPT = U > 128 ? 4 : 2;             // wide tiles when the batch alone fills the chip
+        const int TW = 64 * CPT;
+        const int ctiles = (N + TW - 1) / TW, utiles = (U + UT - 1) / UT;
         LN_REQUIRE(utiles <= 65535, "U=%d too large for the frame-parallel Viterbi", U);
         int RS = (3 * ctx->prop.multiProcessorCount + ctiles * utiles - 1) / (ctiles * utiles);
         if (RS > N / 64) RS = N / 64;
@@ -1686,18 +1719,18 @@ int viterbi_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
         int RPS = ((N + RS - 1) / RS + 7) / 8 * 8;
         RS = (N + RPS - 1) / RPS;
         const size_t cells = (size_t)U * T * N;
-        const size_t shm = ((size_t)UT * RPS + UT * 128) * 8;
+        const size_t shm = ((size_t)UT * RPS + UT * TW) * 8;
         LN_REQUIRE(shm <= 160 * 1024, "N=%d too large for the frame-parallel Viterbi", N);
         if (RS > 1)
             LN_LAUNCH(ctx, "viterbi_fill", fill_value_kernel, dim3(2048), dim3(256), 0, (double*)v, cells, LN_NEG_INF);
         LN_LAUNCH(ctx, "viterbi_frame0", viterbi_frame0_kernel, dim3((unsigned)(((size_t)U * N + 255) / 256)), dim3(256), 0,
                   (const double*)b, pi, d_lens, (double*)v, U, T, N);
         for (int t = 1; t < T; ++t) {
-            if (UT == 16)
-                LN_LAUNCH(ctx, "viterbi_frame", (viterbi_frame_kernel<16>), dim3(ctiles, utiles, RS), dim3(256), shm,
+            if (CPT == 4)
+                LN_LAUNCH(ctx, "viterbi_frame", (viterbi_frame_kernel<UT, 4>), dim3(ctiles, utiles, RS), dim3(256), shm,
                           (const double*)b, A, d_lens, (double*)v, U, T, N, t, RPS, RS > 1 ? 1 : 0);
             else
-                LN_LAUNCH(ctx, "viterbi_frame", (viterbi_frame_kernel<8>), dim3(ctiles, utiles, RS), dim3(256), shm,
+                LN_LAUNCH(ctx, "viterbi_frame", (viterbi_frame_kernel<UT, 2>), dim3(ctiles, utiles, RS), dim3(256), shm,
                           (const double*)b, A, d_lens, (double*)v, U, T, N, t, RPS, RS > 1 ? 1 : 0);
         }
         return 0;
@@ -1790,7 +1823,7 @@ int forward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
                   N);
         return 0;
     }
-    if (dtype == LNASR_F64 && N > 256 && U <= kFrameParMaxU && !getenv("LNASR_NO_FRAMEPAR")) {
+    if (dtype == LNASR_F64 && N > 256 && fwdbwd_framepar(N, U)) {
         double* a = (double*)alpha;
         if (!a) {                                         // log-likelihood only: alpha still has to exist somewhere
             LN_TRY(ctx->ws_alpha.reserve((size_t)U * T * N * 8));
@@ -1809,6 +1842,12 @@ int forward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
             LN_LAUNCH(ctx, "forward_stream_u1", (fwdbwd_stream<false, UB>), dim3(U), dim3(NP * RS), shm, (const double*)b,
                       md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens, (double*)alpha,
                       loglik, U, T, N, NP, RS, RPS);
+        } else if (((size_t)(4 + RS) * 4 * NP + 8 * NB + 8) * 8 > kStreamLdsMax) {   // N > 960: four do not fit
+            constexpr int UB = 2;
+            const size_t shm = ((size_t)(4 + RS) * UB * NP + 2 * UB * NB + 2 * UB) * 8;
+            LN_LAUNCH(ctx, "forward_stream_u2", (fwdbwd_stream<false, UB>), dim3((U + UB - 1) / UB), dim3(NP * RS), shm,
+                      (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
+                      (double*)alpha, loglik, U, T, N, NP, RS, RPS);
         } else {
             constexpr int UB = 4;
             const size_t shm = ((size_t)(4 + RS) * UB * NP + 2 * UB * NB + 2 * UB) * 8;
@@ -1866,7 +1905,7 @@ int backward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* 
                   expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta, (double*)nullptr, U, T, N);
         return 0;
     }
-    if (dtype == LNASR_F64 && N > 256 && U <= kFrameParMaxU && !getenv("LNASR_NO_FRAMEPAR"))
+    if (dtype == LNASR_F64 && N > 256 && fwdbwd_framepar(N, U))
         return fwdbwd_frames<true>(ctx, (const double*)b, expAT, md.logAT.as<double>(), U, T, d_lens, (double*)beta, nullptr);
     if (dtype == LNASR_F64 && N > 128 && N <= 1024 && !getenv("LNASR_NO_STREAM")) {
         const int NP = ((N + 63) / 64) * 64, RS = 1024 / NP, RPS = (N + RS - 1) / RS, NB = NP / 64;
@@ -1876,6 +1915,12 @@ int backward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* 
             LN_LAUNCH(ctx, "backward_stream_u1", (fwdbwd_stream<true, UB>), dim3(U), dim3(NP * RS), shm, (const double*)b,
                       expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta, (double*)nullptr, U,
                       T, N, NP, RS, RPS);
+        } else if (((size_t)(4 + RS) * 4 * NP + 8 * NB + 8) * 8 > kStreamLdsMax) {
+            constexpr int UB = 2;
+            const size_t shm = ((size_t)(4 + RS) * UB * NP + 2 * UB * NB + 2 * UB) * 8;
+            LN_LAUNCH(ctx, "backward_stream_u2", (fwdbwd_stream<true, UB>), dim3((U + UB - 1) / UB), dim3(NP * RS), shm,
+                      (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
+                      (double*)nullptr, U, T, N, NP, RS, RPS);
         } else {
             constexpr int UB = 4;
             const size_t shm = ((size_t)(4 + RS) * UB * NP + 2 * UB * NB + 2 * UB) * 8;

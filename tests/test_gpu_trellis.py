@@ -346,6 +346,44 @@ def test_trellises_beyond_256_states(route, synth, oracle, ctx):
         os.environ.pop("LNASR_NO_FRAMEPAR", None)
 
 
+@pytest.mark.parametrize("N", [512, 1000, 1024])
+def test_trellises_beyond_256_states_large_batch(N, synth, oracle, ctx):
+    """N > 256 with a batch large enough for the blocked tiers (several utterances per streaming block -- two when
+    four do not fit the LDS, N > 960 -- and the wide-tile frame-parallel Viterbi): a sample of utterances against
+    the oracle, the rest against the same utterance decoded in a small batch."""
+    rng = np.random.default_rng(N)
+    d = synth.synth_discrete(N, 4, 8, seed=N)
+    ctx.upload_hmm(d["A"], d["pi"])
+    U, T = 600, 4
+    b = np.ascontiguousarray(-30.0 * rng.random((U, T, N)))
+    lens = rng.integers(1, T + 1, U).astype(np.int32)
+    lens[0] = T
+    for maxu in ("256", "4096"):                          # streaming, then frame-parallel for this batch
+        os.environ["LNASR_FRAMEPAR_MAXU"] = maxu
+        try:
+            alpha, ll = ctx.forward(b, lens=lens)
+            beta = ctx.backward(b, lens=lens)
+            r = ctx.viterbi(b, lens=lens, want_bt=False)
+        finally:
+            os.environ.pop("LNASR_FRAMEPAR_MAXU", None)
+        for u in (0, 1, 2, 3, 298, 597, 598, 599):
+            L = lens[u]
+            ob = np.ascontiguousarray(b[u, :L].T)
+            ra, rb = oracle.forward(d["A"], d["pi"], ob), oracle.backward(d["A"], ob)
+            assert_close(alpha[u, :L], ra, 1e-12, msg="alpha N=%d u=%d" % (N, u))
+            assert_close(beta[u, :L], rb, 1e-12, msg="beta N=%d u=%d" % (N, u))
+            assert abs(ll[u] - oracle.loglik(ra)) <= 1e-11 * abs(ll[u])
+            v, _, path = oracle.viterbi(d["A"], d["pi"], ob)
+            assert np.array_equal(r["v"][u, :L], v) and np.array_equal(r["path"][u, :L], path)
+        sub = slice(100, 104)                              # small batch: the per-utterance tier
+        a2, ll2 = ctx.forward(b[sub], lens=lens[sub])
+        r2 = ctx.viterbi(b[sub], lens=lens[sub], want_bt=False)
+        for k, u in enumerate(range(100, 104)):
+            L = lens[u]
+            assert_close(alpha[u, :L], a2[k, :L], 1e-12, msg="alpha vs small batch u=%d" % u)
+            assert np.array_equal(r["v"][u, :L], r2["v"][k, :L]) and np.array_equal(r["path"][u, :L], r2["path"][k, :L])
+
+
 def test_bw_statistics_full_covariance_wide(synth, ctx):
     """Full covariance with two mixture tiles (M = 20) and with more than 32 mixtures (groups of 32), N not a
     multiple of 8, ragged lengths: the matrix-core statistics kernel against the scalar kernel that the golden
