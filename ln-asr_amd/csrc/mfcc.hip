@@ -131,6 +131,153 @@ __global__ void mfcc_frame_kernel(const SAMPLE* __restrict__ signal, const int64
     }
 }
 
+// A lane's constant share of the mel and DCT phases of the fft-512 kernels
+struct Mel512Lane {
+    int m, cnt, flags, cmax, n_mel, n_out, dq;
+    const double* tp;          // its taps in the LDS
+    const double* fb;          // ... in global memory (filter banks too dense for the LDS table)
+    const double* Ct;          // DCT matrix, transposed, in the LDS
+    int lo;
+    bool taps_in_lds, dct_split;
+};
+
+// Block-level tables (three block barriers; waves are independent afterwards): DCT matrix transposed, the
+// non-zero filter taps packed filter after filter, and the lane assignment of the mel phase -- a filter of
+// cnt taps gets ceil(cnt / C) consecutive lanes (at most 3), C the smallest chunk for which 64 lanes suffice.
+__device__ __forceinline__ void mel_plan_setup(int n_mel, int n_out, const int* __restrict__ mel_range,
+                                               const double* __restrict__ fbank, const double* __restrict__ dctC,
+                                               double* taps, double* Ct, int* tap_off, int* asg, int* asg_cmax, int tid,
+                                               int NT, int lane, int w, int nwaves) {
+    constexpr int NBIN = 257, MAXTAP = 1024;
+    for (int e = tid; e < n_mel * n_mel; e += NT) Ct[(e % n_mel) * n_mel + e / n_mel] = dctC[e];
+    if (tid < n_mel) tap_off[tid + 1] = mel_range[2 * tid + 1] - mel_range[2 * tid];
+    __syncthreads();
+    if (tid == 0) {
+        int o = 0, cmx = 0;
+        for (int m = 0; m < n_mel; ++m) {
+            const int c = tap_off[m + 1];
+            tap_off[m] = o;
+            o += c;
+            cmx = c > cmx ? c : cmx;
+        }
+        tap_off[n_mel] = o;
+        int C = (cmx + 2) / 3;
+        if (C < 1) C = 1;
+        for (;; ++C) {
+            int need = 0;
+            for (int m = 0; m < n_mel; ++m) {
+                const int c = tap_off[m + 1] - tap_off[m];
+                need += c > 0 ? (c + C - 1) / C : 1;
+            }
+            if (need <= 64) break;
+        }
+        int ln = 0;
+        for (int m = 0; m < n_mel; ++m) {
+            const int c = tap_off[m + 1] - tap_off[m];
+            const int parts = c > 0 ? (c + C - 1) / C : 1;
+            for (int q = 0; q < parts; ++q, ++ln) {
+                const int i0 = q * C, cnt = (c - i0) < C ? (c - i0) : C;
+                asg[4 * ln] = m;
+                asg[4 * ln + 1] = i0;
+                asg[4 * ln + 2] = cnt > 0 ? cnt : 0;
+                asg[4 * ln + 3] = (q == 0 ? 1 : 0) | ((q == 0 && parts > 1) ? 2 : 0) | ((q == 0 && parts > 2) ? 4 : 0);
+            }
+        }
+        for (; ln < 64; ++ln) asg[4 * ln] = -1, asg[4 * ln + 1] = 0, asg[4 * ln + 2] = 0, asg[4 * ln + 3] = 0;
+        *asg_cmax = C;
+    }
+    __syncthreads();
+    if (tap_off[n_mel] <= MAXTAP)
+        for (int m = w; m < n_mel; m += nwaves) {
+            const int lo = mel_range[2 * m], cnt = mel_range[2 * m + 1] - lo;
+            for (int e = lane; e < cnt; e += 64) taps[tap_off[m] + e] = fbank[(size_t)m * NBIN + lo + e];
+        }
+    __syncthreads();
+}
+
+__device__ __forceinline__ Mel512Lane mel_plan_lane(int n_mel, int n_out, const int* __restrict__ mel_range,
+                                                    const double* __restrict__ fbank, const double* taps,
+                                                    const double* Ct, const int* tap_off, const int* asg, int cmax,
+                                                    int lane) {
+    constexpr int NBIN = 257, MAXTAP = 1024;
+    Mel512Lane ml;
+    ml.m = asg[4 * lane];
+    const int i0 = asg[4 * lane + 1];
+    ml.cnt = asg[4 * lane + 2];
+    ml.flags = asg[4 * lane + 3];
+    ml.cmax = cmax;
+    ml.n_mel = n_mel;
+    ml.n_out = n_out;
+    ml.dq = (n_mel + 3) / 4;
+    ml.lo = ml.m >= 0 ? mel_range[2 * ml.m] + i0 : 0;
+    ml.tp = taps + (ml.m >= 0 ? tap_off[ml.m] + i0 : 0);
+    ml.fb = fbank + (size_t)(ml.m >= 0 ? ml.m : 0) * NBIN + ml.lo;
+    ml.Ct = Ct;
+    ml.taps_in_lds = tap_off[n_mel] <= MAXTAP;
+    ml.dct_split = n_out * 4 <= 64;            // n_out <= 16 outputs x 4 quarter-sums fill the wave
+    return ml;
+}
+
+// power spectrum pw [257] (LDS) -> log-mel row lm (LDS) -> DCT-II row in global memory.  The reference
+// subtracts the utterance mean before the DCT (mfcc.py:151-152); the DCT is linear, so that subtraction is
+// applied to the transformed row by feat_kernel and nothing here needs an utterance-level quantity.
+__device__ __forceinline__ void mel_dct_frame(const Mel512Lane& ml, const double* pw, double* lm, int lane,
+                                              double* __restrict__ cep_row) {
+    {
+        // mel filter bank (mfcc.py:148): every lane sums its chunk of one filter's taps; a filter's two or
+        // three partial sums are added in the lane of its first chunk
+        double s = 0.0;
+        const double* pp = pw + ml.lo;
+        // branch-free: past the lane's count the index falls back to 0 and the tap to 0.0
+        if (ml.taps_in_lds) {
+#pragma unroll 4
+            for (int i = 0; i < ml.cmax; ++i) {
+                const bool in = i < ml.cnt;
+                const int ii = in ? i : 0;
+                s = fma(pp[ii], in ? ml.tp[ii] : 0.0, s);
+            }
+        } else {
+            for (int i = 0; i < ml.cmax; ++i) {
+                const bool in = i < ml.cnt;
+                const int ii = in ? i : 0;
+                s = fma(pp[ii], in ? ml.fb[ii] : 0.0, s);
+            }
+        }
+        const double s1 = shfl_f64(s, (lane + 1) & 63), s2 = shfl_f64(s, (lane + 2) & 63);
+        if (ml.flags & 2) s += s1;
+        if (ml.flags & 4) s += s2;
+        if (ml.flags & 1) {
+            if (s == 0.0) s = 2.220446049250313e-16;                     // mfcc.py:149
+            lm[ml.m] = 20.0 * log10(s);                                  // mfcc.py:150
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int n_mel = ml.n_mel, dq = ml.dq;
+    if (ml.dct_split) {
+        const int k = lane >> 2, part = lane & 3;
+        const int m0 = part * dq, m1 = (m0 + dq) < n_mel ? (m0 + dq) : n_mel;
+        double s = 0.0;
+        if (k < ml.n_out)
+            for (int m = m0; m < m1; ++m) s = fma(lm[m], ml.Ct[m * n_mel + k], s);
+        s += dpp_f64<0xB1>(s);                     // quad_perm [1,0,3,2], then [2,3,0,1]: (q0 + q1) + (q2 + q3)
+        s += dpp_f64<0x4E>(s);
+        if (part == 0 && k < ml.n_out) cep_row[k] = s;
+    } else {
+        // same association as the split form (four quarter sums, pairwise) so both give identical bits
+        for (int k = lane; k < ml.n_out; k += 64) {
+            double q[4];
+#pragma unroll
+            for (int part = 0; part < 4; ++part) {
+                const int m0 = part * dq, m1 = (m0 + dq) < n_mel ? (m0 + dq) : n_mel;
+                q[part] = 0.0;
+                for (int m = m0; m < m1; ++m) q[part] = fma(lm[m], ml.Ct[m * n_mel + k], q[part]);
+            }
+            cep_row[k] = (q[0] + q[1]) + (q[2] + q[3]);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 // fft_n = 512 fast path: ONE WAVE PER FRAME, no block-level barriers.
 //   real 512-point FFT = 256-point complex FFT of z[n] = y[2n] + i y[2n+1] (Stockham radix-4, four
 //   stages, one radix-4 butterfly per lane per stage, ping-pong buffers in the wave's private LDS
@@ -453,6 +600,430 @@ __global__ __launch_bounds__(64 * kMfccWaves) __attribute__((amdgpu_waves_per_eu
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// fft_n = 512, FOUR FRAMES PER WAVE: the 256-point complex FFT as 16 x 16 with both 16-point transforms in
+// registers.  A 16-lane row owns one frame.
+//   pass 1  lane (row, n1) holds z[n1 + 16 n2], n2 = 0..15 (16 strided loads), transforms over n2 -> Y[n1][k2],
+//           multiplies by W256^(n1 k2);
+//   exchange (the only trip of the transform through the LDS, real parts then imaginary parts so a wave needs
+//           8 bytes per point): lane (row, k2) collects Y[n1][k2], n1 = 0..15;
+//   pass 2  transforms over n1 -> Z[16 k1 + k2], k1 = 0..15, in registers.
+// Real-input split: X[k] and X[256-k] come from the same pair (Z[k], Z[256-k]):
+//     s = Z[k] + conj Z[256-k],  t = -i (Z[k] - conj Z[256-k]) W512^k,  |X[k]|^2 = |s + t|^2 / 4,
+//     |X[256-k]|^2 = |s - t|^2 / 4
+// and Z[256-k] sits in lane 16 - k2 of the same row (register 15 - k1), so every lane handles its k1 < 8 and
+// fetches eight values from its mirror lane.  Lane 0 is its own mirror (k = 16 k1 <-> 16 (16 - k1)) and also
+// owns k = 0 / 256.
+// Against the radix-4 kernel above: one LDS round trip of the data instead of four, the split at half the
+// arithmetic, and 16 independent butterflies per lane to hide latencies behind.
+constexpr int kX4Waves = 8;
+constexpr int kX4FS = 308;             // doubles per frame in a wave's LDS slice: 16 x 17 exchange tile, later
+                                       // 257 power bins, log-mel row at 260
+
+__device__ __forceinline__ void fft16(cplx v[16]) {
+    // index n = a + 4 a', output k = b + 4 c:  W16^(nk) = W4^(a'b) W16^(ab) W4^(ac)
+    constexpr double C1 = 0.92387953251128674, S1 = 0.38268343236508977, R = 0.70710678118654752;
+    cplx u[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        cplx t[4] = {v[a], v[a + 4], v[a + 8], v[a + 12]};
+        radix4(t);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) u[a][b] = t[b];
+    }
+    auto w2 = [&](cplx z) -> cplx { return {R * (z.re + z.im), R * (z.im - z.re)}; };       // * W16^2
+    auto w6 = [&](cplx z) -> cplx { return {R * (z.im - z.re), -R * (z.re + z.im)}; };      // * W16^6
+    u[1][1] = cmul(u[1][1], {C1, -S1});
+    u[1][2] = w2(u[1][2]);
+    u[1][3] = cmul(u[1][3], {S1, -C1});
+    u[2][1] = w2(u[2][1]);
+    u[2][2] = mul_neg_i(u[2][2]);
+    u[2][3] = w6(u[2][3]);
+    u[3][1] = cmul(u[3][1], {S1, -C1});
+    u[3][2] = w6(u[3][2]);
+    u[3][3] = cmul(u[3][3], {-C1, S1});
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        cplx t[4] = {u[0][b], u[1][b], u[2][b], u[3][b]};
+        radix4(t);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[b + 4 * c] = t[c];
+    }
+}
+
+// One row's raw samples through buffer loads (frames at the edges of an utterance).  Called with only that
+// row's lanes active: base, n and the utterance pointer are the same in all of them, so the descriptors are
+// uniform.  Same descriptors as fetch_frame: reads beyond the utterance return 0.
+template <typename SAMPLE>
+__device__ __noinline__ void fetch_row(const SAMPLE* __restrict__ x, int64_t n, int64_t base, int n1, double alpha,
+                                       cplx v[16]) {
+    constexpr int SZ = sizeof(SAMPLE);
+    int64_t left = (n - base) * SZ;
+    left = left < 0 ? 0 : (left > 0x7FFFFFF0L ? 0x7FFFFFF0L : left);
+    const int64_t back = base > 0 ? 1 : 0;
+    const __amdgpu_buffer_rsrc_t ra =
+        __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(x + base), 0, __builtin_amdgcn_readfirstlane((int)left), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)uniform_ptr(x + base - back), 0, __builtin_amdgcn_readfirstlane((int)(left + back * SZ)), 0x00020000);
+    const int vo = n1 * 2 * SZ;
+    const int adj = back ? 0 : SZ;                 // see fetch_frame
+#pragma unroll
+    for (int n2 = 0; n2 < 16; ++n2) {
+        int vb = vo + (n2 * 32 * SZ - adj);
+        if (n2 == 0) vb = vb < 0 ? 0 : vb;
+        double x0, x1, xm;
+        if constexpr (SZ == 8) {
+            typedef unsigned u4 __attribute__((ext_vector_type(4)));
+            const u4 q = __builtin_amdgcn_raw_buffer_load_b128(ra, vo + n2 * 32 * SZ, 0, 0);
+            x0 = __hiloint2double((int)q[1], (int)q[0]);
+            x1 = __hiloint2double((int)q[3], (int)q[2]);
+            xm = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rb, vb, 0, 0));
+        } else {
+            x0 = (double)(short)__builtin_amdgcn_raw_buffer_load_b16(ra, vo + n2 * 32 * SZ, 0, 0);
+            x1 = (double)(short)__builtin_amdgcn_raw_buffer_load_b16(ra, vo + n2 * 32 * SZ + SZ, 0, 0);
+            xm = (double)(short)__builtin_amdgcn_raw_buffer_load_b16(rb, vb, 0, 0);
+        }
+        const int64_t i0 = base + 2 * (n1 + 16 * n2);
+        double a = i0 == 0 ? x0 : __dsub_rn(x0, __dmul_rn(alpha, xm));   // y[0] = x[0] (mfcc.py:63)
+        double c = __dsub_rn(x1, __dmul_rn(alpha, x0));
+        if (i0 >= n) a = 0.0;                                             // utils.py:121-125
+        if (i0 + 1 >= n) c = 0.0;
+        v[n2] = {a, c};
+    }
+}
+
+// log(x) for the mel and energy sums: the table-driven log of devmath.h (a dozen instructions, error below
+// 2e-16 of the result) for normal x; the library log for the rest (0 -> -inf, denormals)
+__device__ __forceinline__ double log_fast(double x, const double* ltab) {
+    if (__builtin_expect(!(x >= 1e-300 && x <= 1e300), 0)) return log(x);
+    return log_sum(x, ltab);
+}
+
+// mel -> log -> DCT of the four frames of a wave's slice in one walk: a lane keeps its filter chunk (and its
+// DCT output) for all four, so taps and DCT coefficients are read once and the four chains overlap; taps are
+// taken four at a time with every load ahead of the first product.  Per frame the sums run in the order of
+// mel_dct_frame.
+__device__ __forceinline__ void mel_dct_frames4(const Mel512Lane& ml, double* slice, const double* ltab, int lane,
+                                                double* __restrict__ cep_rows, int nlive) {
+    constexpr int FS = kX4FS;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    const double* pp = slice + ml.lo;
+    const double* tp = ml.taps_in_lds ? ml.tp : ml.fb;
+    for (int i = 0; i < ml.cmax; i += 4) {
+        double tap[4], pv[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool in = i + q < ml.cnt;         // past the lane's count: index 0, tap 0.0 (adds nothing)
+            const int ii = in ? i + q : 0;
+            const double t = tp[ii];
+            tap[q] = in ? t : 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pv[r][q] = pp[r * FS + ii];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[r] = fma(pv[r][q], tap[q], s[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const double s1 = shfl_f64(s[r], (lane + 1) & 63), s2 = shfl_f64(s[r], (lane + 2) & 63);
+        if (ml.flags & 2) s[r] += s1;
+        if (ml.flags & 4) s[r] += s2;
+    }
+    if (ml.flags & 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double x = s[r];
+            if (x == 0.0) x = 2.220446049250313e-16;                                  // mfcc.py:149
+            slice[r * FS + 260 + ml.m] = (20.0 / 2.302585092994045684) * log_fast(x, ltab);   // 20 log10: mfcc.py:150
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int n_mel = ml.n_mel, dq = ml.dq;
+    const double* lm = slice + 260;
+    if (ml.dct_split) {
+        const int k = lane >> 2, part = lane & 3;
+        const int m0 = part * dq, m1 = (m0 + dq) < n_mel ? (m0 + dq) : n_mel;
+        const int kc = k < ml.n_out ? k : 0;
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int mb = m0; mb < m0 + dq; mb += 4) {
+            double c[4], x[4][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool in = mb + q < m1;
+                const int m = in ? mb + q : 0;
+                const double cc = ml.Ct[m * n_mel + kc];
+                c[q] = in ? cc : 0.0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[r][q] = lm[r * FS + m];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = fma(x[r][q], c[q], acc[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            acc[r] += dpp_f64<0xB1>(acc[r]);       // (q0 + q1) + (q2 + q3)
+            acc[r] += dpp_f64<0x4E>(acc[r]);
+            if (part == 0 && k < ml.n_out && r < nlive) cep_rows[(size_t)r * n_mel + k] = acc[r];
+        }
+    } else {
+        for (int k = lane; k < ml.n_out; k += 64) {
+            double q[4][4];
+#pragma unroll
+            for (int part = 0; part < 4; ++part) {
+                const int m0 = part * dq, m1 = (m0 + dq) < n_mel ? (m0 + dq) : n_mel;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) q[r][part] = 0.0;
+                for (int m = m0; m < m1; ++m) {
+                    const double c = ml.Ct[m * n_mel + k];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) q[r][part] = fma(lm[r * FS + m], c, q[r][part]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (r < nlive) cep_rows[(size_t)r * n_mel + k] = (q[r][0] + q[r][1]) + (q[r][2] + q[r][3]);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// raw samples of a lane for one group, as loaded: pairs (x[2n], x[2n+1]), n = n1 + 16 n2, and the one sample
+// before the frame.  x[2n-1] is the neighbour lane's x[2(n-1)+1] and is fetched with a row rotate.
+template <typename SAMPLE>
+struct RawRow;
+template <>
+struct RawRow<double> {
+    double x0[16], x1[16], prev;
+};
+template <>
+struct RawRow<int16_t> {
+    int q[16];                 // x[2n] | x[2n+1] << 16
+    int prev;
+};
+typedef int __attribute__((aligned(2))) int_a2;                 // a sample pair starts on any even byte
+struct __attribute__((aligned(8))) double_pair {
+    double a, b;
+};
+
+__device__ __forceinline__ void load_row(const double* p, RawRow<double>& rw) {
+#pragma unroll
+    for (int n2 = 0; n2 < 16; ++n2) {
+        const double_pair d = *reinterpret_cast<const double_pair*>(p + 32 * n2);
+        rw.x0[n2] = d.a;
+        rw.x1[n2] = d.b;
+    }
+}
+__device__ __forceinline__ void load_row(const int16_t* p, RawRow<int16_t>& rw) {
+#pragma unroll
+    for (int n2 = 0; n2 < 16; ++n2) rw.q[n2] = *reinterpret_cast<const int_a2*>(p + 32 * n2);
+}
+
+// y[2n], y[2n+1] of an interior frame: y[i] = x[i] - alpha x[i-1], multiply and subtract rounded separately
+// (mfcc.py:63)
+__device__ __forceinline__ void preemph_row(const RawRow<double>& rw, int n1, double alpha, cplx v[16]) {
+    double t[16];
+#pragma unroll
+    for (int n2 = 0; n2 < 16; ++n2) t[n2] = dpp_f64<0x121>(rw.x1[n2]);      // row_ror:1: lane l <- lane l - 1 (mod 16)
+#pragma unroll
+    for (int n2 = 0; n2 < 16; ++n2) {
+        // lane 0 received lane 15's pair n2, which precedes its own pair n2 + 1
+        const double wrap = n2 == 0 ? rw.prev : t[n2 - 1];
+        const double xm = n1 == 0 ? wrap : t[n2];
+        v[n2] = {__dsub_rn(rw.x0[n2], __dmul_rn(alpha, xm)), __dsub_rn(rw.x1[n2], __dmul_rn(alpha, rw.x0[n2]))};
+    }
+}
+__device__ __forceinline__ void preemph_row(const RawRow<int16_t>& rw, int n1, double alpha, cplx v[16]) {
+    int t[16];
+#pragma unroll
+    for (int n2 = 0; n2 < 16; ++n2) t[n2] = __builtin_amdgcn_update_dpp(rw.q[n2], rw.q[n2], 0x121, 0xf, 0xf, false);
+#pragma unroll
+    for (int n2 = 0; n2 < 16; ++n2) {
+        const int wrap = n2 == 0 ? rw.prev : (t[n2 - 1] >> 16);
+        const double xm = (double)(n1 == 0 ? wrap : (t[n2] >> 16));
+        const double x0 = (double)(short)(rw.q[n2] & 0xffff), x1 = (double)(rw.q[n2] >> 16);
+        v[n2] = {__dsub_rn(x0, __dmul_rn(alpha, xm)), __dsub_rn(x1, __dmul_rn(alpha, x0))};
+    }
+}
+
+template <typename SAMPLE, bool POWER>
+__global__ __launch_bounds__(64 * kX4Waves) void mfcc_frame512x4_kernel(
+    const SAMPLE* __restrict__ signal, const int64_t* __restrict__ soff, const int64_t* __restrict__ foff, int U,
+    int64_t F, int L, int S, int n_mel, int n_out, double alpha, const double* __restrict__ window,
+    const double* __restrict__ fbank, const int* __restrict__ mel_range, const double* __restrict__ tw512,
+    const double* __restrict__ dctC, double* __restrict__ power_out, double* __restrict__ cepraw,
+    double* __restrict__ energy) {
+    constexpr int NC = 256, NBIN = 257, MAXTAP = 1024, MAXMEL = 48, FS = kX4FS;
+    __shared__ double tws[2 * NC];                 // tw512
+    __shared__ double wins[2 * NC];                // window, zero beyond L
+    __shared__ double T16[2 * 256];                // W256^(n1 k2) at [k2][n1]
+    __shared__ double ltab[2 * kLogTab];           // table-driven log (devmath.h)
+    __shared__ double taps[MAXTAP];
+    __shared__ double Ct[MAXMEL * MAXMEL];
+    __shared__ int tap_off[MAXMEL + 1];
+    __shared__ int asg[4 * 64];
+    __shared__ int asg_cmax;
+    __shared__ double bufs[kX4Waves][4 * FS];
+    constexpr int NT = 64 * kX4Waves;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int e = tid; e < 2 * NC; e += NT) {
+        tws[e] = tw512[e];
+        wins[e] = e < L ? window[e] : 0.0;
+    }
+    for (int e = tid; e < 256; e += NT) {
+        const int m2 = 2 * (e & 15) * (e >> 4);    // W256^m = tw512[2m], tw512[i + 256] = -tw512[i]; 2m <= 450
+        const int idx = m2 & (NC - 1);
+        const double sg = m2 >= NC ? -1.0 : 1.0;
+        T16[2 * e] = sg * tw512[2 * idx];
+        T16[2 * e + 1] = sg * tw512[2 * idx + 1];
+    }
+    log_table_init(ltab, tid, NT);
+    mel_plan_setup(n_mel, n_out, mel_range, fbank, dctC, taps, Ct, tap_off, asg, &asg_cmax, tid, NT, lane, w, kX4Waves);
+    const Mel512Lane ml = mel_plan_lane(n_mel, n_out, mel_range, fbank, taps, Ct, tap_off, asg, asg_cmax, lane);
+
+    const int row = lane >> 4, n1 = lane & 15;     // pass 1: (frame row, n1); pass 2 and after: k2 = n1
+    // a wave walks a contiguous range of groups: its rows change utterance rarely and the 240 samples that
+    // successive frames share are still in the L1 when the next group asks for them
+    const int64_t G = (F + 3) / 4, nwv = (int64_t)gridDim.x * kX4Waves, per = (G + nwv - 1) / nwv;
+    double* slice = &bufs[w][0];
+    double* X = slice + row * FS;
+    int64_t g = ((int64_t)blockIdx.x * kX4Waves + w) * per;
+    const int64_t gend = g + per < G ? g + per : G;
+    if (g >= gend) return;
+    // The utterance of this row's frame: frames visited by a row only increase, so the bounds of the current
+    // utterance stay in registers and memory is touched again only when a row crosses into the next one.
+    int u;
+    int64_t fbeg, fend, so, n;
+    auto locate = [&](int64_t fc, bool first) {
+        if (first) u = find_utt(foff, U, fc);
+        else
+            while (foff[u + 1] <= fc) ++u;
+        fbeg = foff[u];
+        fend = foff[u + 1];
+        so = soff[u];
+        n = soff[u + 1] - so;
+    };
+    // state of the group about to be transformed
+    bool live, inner;                              // inner: all four frames lie wholly inside their utterances
+    int64_t f, base;
+    const SAMPLE* xu;
+    auto place = [&](int64_t gg, bool first) {
+        f = 4 * gg + row;
+        live = f < F;
+        const int64_t fc = live ? f : F - 1;       // a row past the end recomputes the last frame and stores nothing
+        if (first || fc >= fend) locate(fc, first);
+        base = (fc - fbeg) * S;
+        xu = signal + so;
+        inner = __all(base >= 1 && base + 2 * NC <= n);
+    };
+    RawRow<SAMPLE> rw;
+    auto request = [&]() {                         // plain loads at constant offsets from one pointer
+        const SAMPLE* p = xu + base + 2 * n1;
+        load_row(p, rw);
+        rw.prev = (decltype(rw.prev))xu[base - 1];
+    };
+    place(g, true);
+    if (inner) request();
+    for (;;) {
+        cplx v[16];
+        if (inner) {
+            preemph_row(rw, n1, alpha, v);
+        } else {
+            cplx vs[16];                           // through the stack (out-of-line call): v itself stays in registers
+#pragma unroll 1
+            for (int r = 0; r < 4; ++r)
+                if (row == r) fetch_row(xu, n, base, n1, alpha, vs);
+#pragma unroll
+            for (int n2 = 0; n2 < 16; ++n2) v[n2] = vs[n2];
+        }
+        const int64_t fcur = f;
+        const bool lcur = live;
+        const int64_t gcur = g;
+        ++g;
+        const bool more = g < gend;
+        if (more) place(g, false);                 // the next group's whereabouts, ahead of its loads
+#pragma unroll
+        for (int n2 = 0; n2 < 16; ++n2) {
+            const int k0 = 2 * (n1 + 16 * n2);
+            v[n2].re *= wins[k0];
+            v[n2].im *= wins[k0 + 1];
+        }
+        fft16(v);                                  // over n2
+#pragma unroll
+        for (int k2 = 1; k2 < 16; ++k2) {
+            const cplx tw = {T16[2 * (16 * k2 + n1)], T16[2 * (16 * k2 + n1) + 1]};
+            v[k2] = cmul(v[k2], tw);
+        }
+        // exchange: tile [k2][n1] with rows of 17 (both sides free of bank conflicts)
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) X[k2 * 17 + n1] = v[k2].re;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j].re = X[n1 * 17 + j];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) X[k2 * 17 + n1] = v[k2].im;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j].im = X[n1 * 17 + j];
+        __builtin_amdgcn_wave_barrier();
+        fft16(v);                                  // over n1: v[k1] = Z[16 k1 + k2]
+        // mirror lane's upper half
+        const int k2 = n1;
+        const int msrc = (lane & 48) | ((16 - k2) & 15);
+        cplx mz[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mz[j] = {shfl_f64(v[15 - j].re, msrc), shfl_f64(v[15 - j].im, msrc)};
+        const bool lane0 = k2 == 0;
+        double esum = 0.0;
+        double* prow = POWER && lcur ? power_out + fcur * NBIN : nullptr;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const cplx mine = lane0 ? v[j + 1] : v[j];
+            const int k = lane0 ? 16 * (j + 1) : 16 * j + k2;
+            const cplx tw = {tws[2 * k], tws[2 * k + 1]};
+            const cplx sm = {mine.re + mz[j].re, mine.im - mz[j].im};
+            const cplx d = {mine.re - mz[j].re, mine.im + mz[j].im};
+            const cplx t = cmul({d.im, -d.re}, tw);
+            const double ar = sm.re + t.re, ai = sm.im + t.im, br = sm.re - t.re, bi = sm.im - t.im;
+            // |X|^2 / 512 (mfcc.py:141-142; the reference squares np.abs: same value to an ulp)
+            const double pa = (1.0 / 2048.0) * fma(ar, ar, ai * ai), pb = (1.0 / 2048.0) * fma(br, br, bi * bi);
+            X[NC - k] = pb;                        // k = 128 (lane 0, j = 7) is its own mirror: pa is the one kept
+            X[k] = pa;
+            esum += (lane0 && j == 7) ? pa : pa + pb;
+            if (POWER && prow) {
+                prow[NC - k] = pb;
+                prow[k] = pa;
+            }
+        }
+        if (lane0) {                               // k = 0 and the Nyquist bin from Z[0]
+            const double sp = v[0].re + v[0].im, sq = v[0].re - v[0].im;
+            const double p0 = (1.0 / 512.0) * (sp * sp), pn = (1.0 / 512.0) * (sq * sq);
+            X[0] = p0;
+            X[NC] = pn;
+            esum += p0 + pn;
+            if (POWER && prow) {
+                prow[0] = p0;
+                prow[NC] = pn;
+            }
+        }
+        esum += dpp_f64<0xB1>(esum);               // sum over the row
+        esum += dpp_f64<0x4E>(esum);
+        esum += dpp_f64<0x141>(esum);
+        esum += dpp_f64<0x140>(esum);
+        if (n1 == 0 && lcur) energy[fcur] = log_fast(esum, ltab);            // mfcc.py:158-160
+        __builtin_amdgcn_wave_barrier();
+        // the next group's samples travel while the mel / DCT phase (few registers) runs
+        if (more && inner) request();
+        const int64_t left = F - 4 * gcur;
+        mel_dct_frames4(ml, slice, ltab, lane, cepraw + 4 * gcur * n_mel, left < 4 ? (int)left : 4);
+        if (!more) break;
+    }
+}
+
 // mean over the frames of each utterance of columns [c0, c0+nc) of X [F, ld]
 __global__ void col_mean_kernel(const double* __restrict__ X, const int64_t* __restrict__ foff, int ld, int c0,
                                 int nc, double* __restrict__ out) {
@@ -676,7 +1247,24 @@ int lnasr_mfcc(lnasr_ctx* ctx, const void* signal, int sample_kind, const int64_
     const int nt = NFFT / 2 < 256 ? (NFFT / 2 < 64 ? 64 : NFFT / 2) : 256;
     bool fused_dct = false;
     const int n_out = cepstrum_or_null ? n_mel : W;   // cepstral columns the frame kernel has to produce
-    if (NFFT == 512 && L <= 512 && n_mel <= 48 && !getenv("LNASR_NO_FFT512")) {
+    if (NFFT == 512 && L <= 512 && n_mel <= 48 && !getenv("LNASR_NO_FFT512") && !getenv("LNASR_NO_FFT512X4")) {
+        // four frames per wave, persistent waves walking groups of four frames with a grid stride; the LDS
+        // (tables + a slice per wave) allows one block per CU
+        const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+        int64_t want = ((F + 3) / 4 + kX4Waves - 1) / kX4Waves;
+        if (want > cus) want = cus;
+        const unsigned grid = (unsigned)want;
+#define LN_X4(name, SAMPLE, POWER)                                                                                   \
+    LN_LAUNCH(ctx, name, (mfcc_frame512x4_kernel<SAMPLE, POWER>), dim3(grid), dim3(64 * kX4Waves), 0,                \
+              (const SAMPLE*)d_sig, d_soff, d_foff, U, F, L, S, n_mel, n_out, cfg->hpf_alpha, (const double*)d_win,  \
+              (const double*)d_fb, d_range, d_tw, d_C, (double*)d_pow, cep, energy)
+        if (sample_kind == 1 && d_pow) LN_X4("mfcc_frame512x4_i16", int16_t, true);
+        else if (sample_kind == 1) LN_X4("mfcc_frame512x4_i16", int16_t, false);
+        else if (d_pow) LN_X4("mfcc_frame512x4", double, true);
+        else LN_X4("mfcc_frame512x4", double, false);
+#undef LN_X4
+        fused_dct = true;
+    } else if (NFFT == 512 && L <= 512 && n_mel <= 48 && !getenv("LNASR_NO_FFT512")) {
         // persistent waves, each walking frames with a grid stride
         const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
         int64_t want = (F + kMfccWaves - 1) / kMfccWaves;
