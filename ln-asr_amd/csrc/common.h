@@ -105,6 +105,9 @@ struct lnasr_ctx {
     lnasr::DevBuf mfcc_const;
     int mfcc_nfft = 0, mfcc_nmel = 0;
     std::vector<int64_t> mfcc_foff;
+    int64_t* mfcc_meta = nullptr;                          // pinned: sample offsets [U+1] then frame offsets [U+1] of the call
+    size_t mfcc_meta_cap = 0;                              // ... in elements
+    hipEvent_t mfcc_meta_ev = nullptr;                     // the upload that last read mfcc_meta
     // profiling
     bool prof_on = false;
     std::vector<std::string> prof_names;

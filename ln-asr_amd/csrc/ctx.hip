@@ -226,6 +226,8 @@ void lnasr_ctx_destroy(lnasr_ctx* ctx) {
     }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     for (auto e : ctx->copy_events) (void)hipEventDestroy(e);
+    if (ctx->mfcc_meta_ev) (void)hipEventDestroy(ctx->mfcc_meta_ev);
+    if (ctx->mfcc_meta) (void)hipHostFree(ctx->mfcc_meta);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);

@@ -582,7 +582,7 @@ __global__ __launch_bounds__(64 * kMfccWaves) __attribute__((amdgpu_waves_per_eu
             for (int m = m0; m < m1; ++m) s = fma(lm[m], Ct[m * n_mel + k], s);
         s += dpp_f64<0xB1>(s);                     // quad_perm [1,0,3,2], then [2,3,0,1]: (q0 + q1) + (q2 + q3)
         s += dpp_f64<0x4E>(s);
-        if (part == 0 && k < n_out) cepraw[f * n_mel + k] = s;
+        if (part == 0 && k < n_out) cepraw[f * n_out + k] = s;
     } else {
         // same association as the split form (four quarter sums, pairwise) so both give identical bits
         for (int k = lane; k < n_out; k += 64) {
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(64 * kMfccWaves) __attribute__((amdgpu_waves_per_eu
                 q[part] = 0.0;
                 for (int m = m0; m < m1; ++m) q[part] = fma(lm[m], Ct[m * n_mel + k], q[part]);
             }
-            cepraw[f * n_mel + k] = (q[0] + q[1]) + (q[2] + q[3]);
+            cepraw[f * n_out + k] = (q[0] + q[1]) + (q[2] + q[3]);
         }
     }
     __builtin_amdgcn_wave_barrier();               // the next frame overwrites this wave's buffer
@@ -767,7 +767,7 @@ __device__ __forceinline__ void mel_dct_frames4(const Mel512Lane& ml, double* sl
         for (int r = 0; r < 4; ++r) {
             acc[r] += dpp_f64<0xB1>(acc[r]);       // (q0 + q1) + (q2 + q3)
             acc[r] += dpp_f64<0x4E>(acc[r]);
-            if (part == 0 && k < ml.n_out && r < nlive) cep_rows[(size_t)r * n_mel + k] = acc[r];
+            if (part == 0 && k < ml.n_out && r < nlive) cep_rows[(size_t)r * ml.n_out + k] = acc[r];
         }
     } else {
         for (int k = lane; k < ml.n_out; k += 64) {
@@ -785,7 +785,7 @@ __device__ __forceinline__ void mel_dct_frames4(const Mel512Lane& ml, double* sl
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (r < nlive) cep_rows[(size_t)r * n_mel + k] = (q[r][0] + q[r][1]) + (q[r][2] + q[r][3]);
+                if (r < nlive) cep_rows[(size_t)r * ml.n_out + k] = (q[r][0] + q[r][1]) + (q[r][2] + q[r][3]);
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -1019,28 +1019,33 @@ __global__ __launch_bounds__(64 * kX4Waves) void mfcc_frame512x4_kernel(
         // the next group's samples travel while the mel / DCT phase (few registers) runs
         if (more && inner) request();
         const int64_t left = F - 4 * gcur;
-        mel_dct_frames4(ml, slice, ltab, lane, cepraw + 4 * gcur * n_mel, left < 4 ? (int)left : 4);
+        mel_dct_frames4(ml, slice, ltab, lane, cepraw + 4 * gcur * n_out, left < 4 ? (int)left : 4);
         if (!more) break;
     }
 }
 
-// mean over the frames of each utterance of columns [c0, c0+nc) of X [F, ld]
-__global__ void col_mean_kernel(const double* __restrict__ X, const int64_t* __restrict__ foff, int ld, int c0,
-                                int nc, double* __restrict__ out) {
+// Column sums over the frames of each utterance of the first nc columns of X [F, ld].  grid = (U, P): an
+// utterance's frames are cut into P contiguous parts (a function of its own frame count only, so a batch and a
+// single utterance add in the same order); feat_kernel adds the P partial sums in part order.  (No "last block
+// finishes" here: a device-scope fence writes back the whole L2 on this multi-die part.)
+constexpr int kMeanParts = 8;
+__global__ void col_sum_kernel(const double* __restrict__ X, const int64_t* __restrict__ foff, int ld, int nc,
+                               double* __restrict__ partial) {
     extern __shared__ double sm[];      // [slices][nc]
-    const int u = blockIdx.x;
-    const int64_t f0 = foff[u], f1 = foff[u + 1];
+    const int u = blockIdx.x, p = blockIdx.y, P = gridDim.y;
+    const int64_t f0 = foff[u], f1 = foff[u + 1], chunk = (f1 - f0 + P - 1) / P;
+    const int64_t a = f0 + p * chunk, b = a + chunk < f1 ? a + chunk : f1;
     const int slices = blockDim.x / nc;
     const int c = threadIdx.x % nc, sl = threadIdx.x / nc;
     double s = 0.0;
     if (sl < slices)
-        for (int64_t f = f0 + sl; f < f1; f += slices) s += X[f * ld + c0 + c];
+        for (int64_t f = a + sl; f < b; f += slices) s += X[f * ld + c];
     if (sl < slices) sm[sl * nc + c] = s;
     __syncthreads();
     if (threadIdx.x < nc) {
         double tot = 0.0;
         for (int k = 0; k < slices; ++k) tot += sm[k * nc + threadIdx.x];
-        out[(size_t)u * nc + threadIdx.x] = tot / (double)(f1 - f0);
+        partial[((size_t)u * P + p) * nc + threadIdx.x] = tot;
     }
 }
 
@@ -1069,20 +1074,29 @@ __global__ void dct_kernel(const double* __restrict__ logmel, const int64_t* __r
 //   features: [cep[:,1..nc], log-energy], delta (row 0 = features[1]), delta-delta (mfcc.py:158-172)
 __global__ void feat_kernel(const double* __restrict__ cepraw, const double* __restrict__ M,
                             const double* __restrict__ energy, const int64_t* __restrict__ foff, int n_mel, int nc,
-                            int ncols, double* __restrict__ cep_out, double* __restrict__ feat) {
+                            int ncols, int ld, double* __restrict__ cep_out, double* __restrict__ feat) {
     // grid.y = utterance (no search for the frame's utterance); ncols = n_mel when the cepstrum is returned,
     // nc + 1 (the feature columns) otherwise
     const int W = nc + 1;
     const int u = blockIdx.y;
     const int64_t f0 = foff[u], f1 = foff[u + 1];
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t f = f0 + idx / ncols;
-    const int k = (int)(idx % ncols);
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;      // < 2^32: checked by the host
+    const unsigned fi = idx / (unsigned)ncols;
+    const int64_t f = f0 + fi;
+    const int k = (int)(idx - fi * (unsigned)ncols);
     if (f >= f1) return;
-    const double* Mu = M + (size_t)u * n_mel;
+    // utterance mean of column kk: the kMeanParts partial sums of col_sum_kernel, in part order
+    const double* Pu = M + (size_t)u * kMeanParts * ncols;
+    auto mean_of = [&](int kk) -> double {
+        double tot = 0.0;
+#pragma unroll
+        for (int q = 0; q < kMeanParts; ++q) tot += Pu[q * ncols + kk];
+        return tot / (double)(f1 - f0);
+    };
+    const double mean_k = mean_of(k), mean_c = k < W && k < nc ? mean_of(1 + k) : 0.0;
     const double shift0 = 1e-8 * sqrt((double)n_mel);
-    auto cepv = [&](int64_t ff, int kk) -> double {
-        double v = cepraw[ff * n_mel + kk] - Mu[kk];
+    auto cepv = [&](int64_t ff, int kk) -> double {      // kk is k or 1 + k
+        double v = cepraw[ff * ld + kk] - (kk == k ? mean_k : mean_c);
         if (kk == 0) v -= shift0;
         if (kk >= 1 && kk <= nc) v -= 1e-8;
         return v;
@@ -1224,18 +1238,28 @@ int lnasr_mfcc(lnasr_ctx* ctx, const void* signal, int sample_kind, const int64_
     int64_t* d_soff = ctx->ws_in4.as<int64_t>();
     int64_t* d_foff = d_soff + (U + 1);
     int* d_range = reinterpret_cast<int*>(d_foff + (U + 1));
-    LN_HIP(hipMemcpyAsync(d_soff, offsets, (size_t)(U + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    LN_HIP(hipMemcpyAsync(d_foff, foff.data(), (size_t)(U + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    // `offsets` belongs to the caller and `foff` is rewritten by the next call: both uploads are over before any
-    // kernel is queued (the kernels themselves stay asynchronous, like every other entry point)
-    LN_HIP(hipStreamSynchronize(ctx->stream));
-    // workspaces: logmel [F,n_mel], cep [F,n_mel], energy [F], mean1 [U,n_mel], mean2 [U,nc]
-    LN_TRY(ctx->ws_misc.reserve(((size_t)F * n_mel * 2 + F + (size_t)U * n_mel + (size_t)U * nc) * 8));
+    // Both offset arrays go up from a pinned buffer of the context, so the call does not wait for the copy: the
+    // event tells the next call when the buffer may be rewritten (normally long before it asks).
+    const size_t nmeta = (size_t)2 * (U + 1);
+    if (ctx->mfcc_meta_ev) LN_HIP(hipEventSynchronize(ctx->mfcc_meta_ev));
+    else LN_HIP(hipEventCreateWithFlags(&ctx->mfcc_meta_ev, hipEventDisableTiming));
+    if (ctx->mfcc_meta_cap < nmeta) {
+        if (ctx->mfcc_meta) LN_HIP(hipHostFree(ctx->mfcc_meta));
+        ctx->mfcc_meta = nullptr;
+        ctx->mfcc_meta_cap = 0;
+        LN_HIP(hipHostMalloc((void**)&ctx->mfcc_meta, nmeta * 2 * 8, hipHostMallocDefault));
+        ctx->mfcc_meta_cap = nmeta * 2;
+    }
+    memcpy(ctx->mfcc_meta, offsets, (size_t)(U + 1) * 8);
+    memcpy(ctx->mfcc_meta + (U + 1), foff.data(), (size_t)(U + 1) * 8);
+    LN_HIP(hipMemcpyAsync(d_soff, ctx->mfcc_meta, nmeta * 8, hipMemcpyHostToDevice, ctx->stream));   // d_foff follows d_soff
+    LN_HIP(hipEventRecord(ctx->mfcc_meta_ev, ctx->stream));
+    // workspaces: logmel [F,n_mel], cep [F,n_mel], energy [F], partial column sums [U,kMeanParts,ncols]
+    LN_TRY(ctx->ws_misc.reserve(((size_t)F * n_mel * 2 + F + (size_t)U * n_mel * kMeanParts) * 8));
     double* logmel = ctx->ws_misc.as<double>();
     double* cep = logmel + (size_t)F * n_mel;
     double* energy = cep + (size_t)F * n_mel;
-    double* mean1 = energy + F;
-    double* mean2 = mean1 + (size_t)U * n_mel;
+    double* mean_part = energy + F;                                     // [U, kMeanParts, ncols]
     void *d_pow = nullptr, *d_cep = nullptr, *d_feat;
     if (power_or_null) LN_TRY(stage_out(ctx, power_or_null, (size_t)F * nbin * 8, ctx->ws_out, &d_pow));
     if (cepstrum_or_null) LN_TRY(stage_out(ctx, cepstrum_or_null, (size_t)F * n_mel * 8, ctx->ws_out2, &d_cep));
@@ -1305,16 +1329,23 @@ int lnasr_mfcc(lnasr_ctx* ctx, const void* signal, int sample_kind, const int64_
         if (!fused_dct)
             LN_LAUNCH(ctx, "mfcc_dct", dct_kernel, dim3((unsigned)((F + rows - 1) / rows)), dim3(threads),
                       (size_t)threads * 8, logmel, d_foff, U, F, n_mel, d_C, cep);
-        LN_LAUNCH(ctx, "mfcc_col_mean", col_mean_kernel, dim3(U), dim3(threads), (size_t)threads * 8, cep, d_foff,
-                  n_mel, 0, n_mel, mean1);
+    }
+    // the fused kernels write rows of n_out columns (the ones in use), the DCT kernel rows of n_mel
+    const int ncols = n_out, ldc = fused_dct ? n_out : n_mel;
+    LN_REQUIRE(U <= 65535, "U=%d utterances is too many for one MFCC call", U);
+    {
+        int threads = 256 - 256 % ncols;
+        if (threads < ncols) threads = ncols;
+        LN_LAUNCH(ctx, "mfcc_col_sum", col_sum_kernel, dim3(U, kMeanParts), dim3(threads), (size_t)threads * 8, cep, d_foff,
+                  ldc, ncols, mean_part);
     }
     {
         int64_t maxnf = 0;
         for (int u = 0; u < U; ++u) maxnf = std::max(maxnf, foff[u + 1] - foff[u]);
-        const int ncols = d_cep ? n_mel : W;
-        LN_REQUIRE(U <= 65535, "U=%d utterances is too many for one MFCC call", U);
+        LN_REQUIRE((size_t)maxnf * ncols + 256 < 0xFFFFFFFFull, "utterance of %lld frames is too long for one MFCC call",
+                   (long long)maxnf);
         LN_LAUNCH(ctx, "mfcc_feat", feat_kernel, dim3((unsigned)(((size_t)maxnf * ncols + 255) / 256), U), dim3(256), 0, cep,
-                  mean1, energy, d_foff, n_mel, nc, ncols, (double*)d_cep, (double*)d_feat);
+                  mean_part, energy, d_foff, n_mel, nc, ncols, ldc, (double*)d_cep, (double*)d_feat);
     }
     if (power_or_null) LN_TRY(finish_out(ctx, power_or_null, d_pow, (size_t)F * nbin * 8));
     if (cepstrum_or_null) LN_TRY(finish_out(ctx, cepstrum_or_null, d_cep, (size_t)F * n_mel * 8));

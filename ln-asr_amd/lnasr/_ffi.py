@@ -536,8 +536,20 @@ class Context:
             feat = features_out
         else:
             feat = self._out(dev, (F, 3 * (cfg.n_cep + 1)), np.float64)
-        window = np.ascontiguousarray(window, dtype=np.float64)
-        fbank = np.ascontiguousarray(fbank, dtype=np.float64)
+        if not isinstance(window, DeviceArray) and not isinstance(fbank, DeviceArray):
+            # host tables: kept on the device between calls while their bytes stay the same (the reference
+            # rebuilds the filter bank on every call, mfcc.py:78-106; the upload need not follow suit)
+            window = np.ascontiguousarray(window, dtype=np.float64)
+            fbank = np.ascontiguousarray(fbank, dtype=np.float64)
+            fp = self._fingerprint("mfcc-tables", (window, fbank))
+            cached = getattr(self, "_mfcc_tables", None)
+            if fp is not None and cached is not None and cached[0] == fp:
+                window, fbank = cached[1], cached[2]
+            elif fp is not None:
+                self._mfcc_tables = (fp, self.to_device(window), self.to_device(fbank))
+                window, fbank = self._mfcc_tables[1], self._mfcc_tables[2]
+        else:
+            window, fbank = _in(window, np.float64), _in(fbank, np.float64)
         check(lib().lnasr_mfcc(self.handle, _ptr(signal), kind, _ptr(offsets), U, C.byref(cfg), _ptr(window),
                                _ptr(fbank), _ptr(power), _ptr(cep), _ptr(feat)))
         return power, cep, feat, foff
