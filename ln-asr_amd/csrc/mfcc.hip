@@ -3,11 +3,12 @@
 // norm -> log-energy -> delta / delta-delta.  fp64 throughout, utterances batched by offsets.
 //
 // Kernels
-//   mfcc_frame_kernel   one block per frame: samples -> power [nbin], log-mel [n_mel], log-energy
-//   col_mean_kernel     per-utterance column means (the reference's two utterance-level means)
-//   dct_kernel          per frame: DCT-II of the mean-normalised log-mel row
-//   feat_kernel         per frame: second mean norm (applied to the returned cepstrum as well, as the
-//                       reference does through a view, mfcc.py:155-156), energy, delta, delta-delta
+//   mfcc_frame512x4_kernel  fft_n = 512: four frames per wave, samples -> power [257], DCT of the log-mel row, log-energy
+//   mfcc_frame_kernel       any other fft_n: one block per frame (radix-2), samples -> power, log-mel, log-energy
+//   dct_kernel              (generic path) per frame: DCT-II of the log-mel row
+//   col_sum_kernel          per-utterance column sums (both of the reference's utterance-level means)
+//   feat_kernel             per frame: the mean subtractions (the second one applied to the returned cepstrum as
+//                           well, as the reference does through a view, mfcc.py:155-156), energy, delta, delta-delta
 #include <algorithm>
 
 #include "common.h"
@@ -218,70 +219,10 @@ __device__ __forceinline__ Mel512Lane mel_plan_lane(int n_mel, int n_out, const 
     return ml;
 }
 
-// power spectrum pw [257] (LDS) -> log-mel row lm (LDS) -> DCT-II row in global memory.  The reference
-// subtracts the utterance mean before the DCT (mfcc.py:151-152); the DCT is linear, so that subtraction is
-// applied to the transformed row by feat_kernel and nothing here needs an utterance-level quantity.
-__device__ __forceinline__ void mel_dct_frame(const Mel512Lane& ml, const double* pw, double* lm, int lane,
-                                              double* __restrict__ cep_row) {
-    {
-        // mel filter bank (mfcc.py:148): every lane sums its chunk of one filter's taps; a filter's two or
-        // three partial sums are added in the lane of its first chunk
-        double s = 0.0;
-        const double* pp = pw + ml.lo;
-        // branch-free: past the lane's count the index falls back to 0 and the tap to 0.0
-        if (ml.taps_in_lds) {
-#pragma unroll 4
-            for (int i = 0; i < ml.cmax; ++i) {
-                const bool in = i < ml.cnt;
-                const int ii = in ? i : 0;
-                s = fma(pp[ii], in ? ml.tp[ii] : 0.0, s);
-            }
-        } else {
-            for (int i = 0; i < ml.cmax; ++i) {
-                const bool in = i < ml.cnt;
-                const int ii = in ? i : 0;
-                s = fma(pp[ii], in ? ml.fb[ii] : 0.0, s);
-            }
-        }
-        const double s1 = shfl_f64(s, (lane + 1) & 63), s2 = shfl_f64(s, (lane + 2) & 63);
-        if (ml.flags & 2) s += s1;
-        if (ml.flags & 4) s += s2;
-        if (ml.flags & 1) {
-            if (s == 0.0) s = 2.220446049250313e-16;                     // mfcc.py:149
-            lm[ml.m] = 20.0 * log10(s);                                  // mfcc.py:150
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    const int n_mel = ml.n_mel, dq = ml.dq;
-    if (ml.dct_split) {
-        const int k = lane >> 2, part = lane & 3;
-        const int m0 = part * dq, m1 = (m0 + dq) < n_mel ? (m0 + dq) : n_mel;
-        double s = 0.0;
-        if (k < ml.n_out)
-            for (int m = m0; m < m1; ++m) s = fma(lm[m], ml.Ct[m * n_mel + k], s);
-        s += dpp_f64<0xB1>(s);                     // quad_perm [1,0,3,2], then [2,3,0,1]: (q0 + q1) + (q2 + q3)
-        s += dpp_f64<0x4E>(s);
-        if (part == 0 && k < ml.n_out) cep_row[k] = s;
-    } else {
-        // same association as the split form (four quarter sums, pairwise) so both give identical bits
-        for (int k = lane; k < ml.n_out; k += 64) {
-            double q[4];
-#pragma unroll
-            for (int part = 0; part < 4; ++part) {
-                const int m0 = part * dq, m1 = (m0 + dq) < n_mel ? (m0 + dq) : n_mel;
-                q[part] = 0.0;
-                for (int m = m0; m < m1; ++m) q[part] = fma(lm[m], ml.Ct[m * n_mel + k], q[part]);
-            }
-            cep_row[k] = (q[0] + q[1]) + (q[2] + q[3]);
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-}
+// (The mel -> log -> DCT phase itself is mel_dct_frames4 below.  The reference subtracts the utterance mean before
+// the DCT (mfcc.py:151-152); the DCT is linear, so that subtraction is applied to the transformed row by
+// feat_kernel and nothing in the frame kernel needs an utterance-level quantity.)
 
-// fft_n = 512 fast path: ONE WAVE PER FRAME, no block-level barriers.
-//   real 512-point FFT = 256-point complex FFT of z[n] = y[2n] + i y[2n+1] (Stockham radix-4, four
-//   stages, one radix-4 butterfly per lane per stage, ping-pong buffers in the wave's private LDS
-//   slice) followed by the even/odd split  X[k] = E[k] + W512^k O[k].
 // tw512[k] = (cos, -sin)(2 pi k / 512), k < 256; the 256-point twiddles are tw512[2m].
 struct cplx {
     double re, im;
@@ -300,304 +241,11 @@ __device__ __forceinline__ void radix4(cplx v[4]) {
     v[3] = csub(t1, t3);
 }
 
-constexpr int kMfccWaves = 12;           // waves per block of the fft-512 frame kernel (they share ~35 KB of tables)
-
 template <typename T>
 __device__ __forceinline__ const T* uniform_ptr(const T* p) {
     const uint64_t v = (uint64_t)p;
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
     return (const T*)(((uint64_t)hi << 32) | lo);
-}
-
-// raw samples x[i-1], x[i], x[i+1] for the four point pairs of a lane
-struct RawFrame {
-    double xm[4], x0[4], x1[4];
-    int64_t base, n;
-};
-
-// Buffer loads: the frame's base address and the bytes left in the utterance are wave-uniform (SGPRs), one
-// VGPR holds the lane offset, the four pair offsets are immediates, and reads past the end of the utterance
-// return 0 without per-lane clamping.  x[i-1] uses a second descriptor starting one sample earlier (at the
-// utterance start, where there is no earlier sample, the first read goes out of range and returns 0).
-template <typename SAMPLE>
-__device__ __forceinline__ void fetch_frame(const SAMPLE* __restrict__ x, int64_t n, int64_t base, int lane,
-                                            RawFrame& rw) {
-    constexpr int SZ = sizeof(SAMPLE);
-    rw.base = base;
-    rw.n = n;
-    int64_t left = (n - base) * SZ;
-    left = left < 0 ? 0 : (left > 0x7FFFFFF0L ? 0x7FFFFFF0L : left);
-    const int64_t back = base > 0 ? 1 : 0;
-    // everything in the descriptors is wave-uniform; say so, or the loads are wrapped in waterfall loops
-    const __amdgpu_buffer_rsrc_t ra =
-        __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(x + base), 0, __builtin_amdgcn_readfirstlane((int)left), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)uniform_ptr(x + base - back), 0, __builtin_amdgcn_readfirstlane((int)(left + back * SZ)), 0x00020000);
-    const int vo = lane * 2 * SZ;
-    // x[i-1]: at base == 0 descriptor rb starts at x[0] and the offsets move back by one sample; the one
-    // sample that does not exist (x[-1], never used: y[0] = x[0]) is clamped onto x[0] so no offset is negative
-    const int adj = back ? 0 : SZ;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        int vb = vo + (r * 128 * SZ - adj);
-        if (r == 0) vb = vb < 0 ? 0 : vb;
-        if constexpr (SZ == 8) {
-            typedef unsigned u4 __attribute__((ext_vector_type(4)));
-            const u4 q = __builtin_amdgcn_raw_buffer_load_b128(ra, vo + r * 128 * SZ, 0, 0);
-            rw.x0[r] = __hiloint2double((int)q[1], (int)q[0]);
-            rw.x1[r] = __hiloint2double((int)q[3], (int)q[2]);
-            rw.xm[r] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rb, vb, 0, 0));
-        } else {
-            // two 16-bit loads, not one dword: the range check is per load, and a dword holding the last sample
-            // of an odd-length utterance would be rejected whole
-            rw.x0[r] = (double)(short)__builtin_amdgcn_raw_buffer_load_b16(ra, vo + r * 128 * SZ, 0, 0);
-            rw.x1[r] = (double)(short)__builtin_amdgcn_raw_buffer_load_b16(ra, vo + r * 128 * SZ + SZ, 0, 0);
-            rw.xm[r] = (double)(short)__builtin_amdgcn_raw_buffer_load_b16(rb, vb, 0, 0);
-        }
-    }
-}
-
-template <typename SAMPLE>
-__global__ __launch_bounds__(64 * kMfccWaves) __attribute__((amdgpu_waves_per_eu(3, 3))) void mfcc_frame512_kernel(
-    const SAMPLE* __restrict__ signal, const int64_t* __restrict__ soff, const int64_t* __restrict__ foff, int U,
-    int64_t F, int L, int S, int n_mel, int n_out, double alpha, const double* __restrict__ window,
-    const double* __restrict__ fbank, const int* __restrict__ mel_range, const double* __restrict__ tw512,
-    const double* __restrict__ dctC, double* __restrict__ power_out, double* __restrict__ cepraw,
-    double* __restrict__ energy) {
-    constexpr int NC = 256, NBIN = 257, MAXTAP = 1024, MAXMEL = 48;
-    __shared__ double tws[2 * NC];                 // tw512, shared by the block
-    __shared__ double wins[2 * NC];                // window (L <= 512)
-    __shared__ double taps[MAXTAP];                // non-zero filter taps, filter after filter
-    __shared__ double Ct[MAXMEL * MAXMEL];         // DCT matrix, transposed: Ct[m][k] = C[k][m]
-    __shared__ int tap_off[MAXMEL + 1];
-    __shared__ int asg[4 * 64];                    // mel work split: per lane (filter, first tap, count, chain)
-    __shared__ int asg_cmax;
-    // per wave: FFT buffer (re, im interleaved; padding against bank conflicts was measured: no gain), then
-    // power | log-mel
-    __shared__ double bufs[kMfccWaves][2 * NC];
-    constexpr int NT = 64 * kMfccWaves;
-    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int e = tid; e < 2 * NC; e += NT) {
-        tws[e] = tw512[e];
-        wins[e] = e < L ? window[e] : 0.0;
-    }
-    for (int e = tid; e < n_mel * n_mel; e += NT) Ct[(e % n_mel) * n_mel + e / n_mel] = dctC[e];
-    if (tid < n_mel) tap_off[tid + 1] = mel_range[2 * tid + 1] - mel_range[2 * tid];
-    __syncthreads();
-    if (tid == 0) {
-        // exclusive prefix of the tap counts, then the lane assignment of the mel phase: a filter of cnt taps
-        // gets ceil(cnt / C) consecutive lanes (at most 3), C the smallest chunk for which 64 lanes suffice.
-        // C = 0 (keep one filter per lane) when that is impossible.
-        int o = 0, cmx = 0;
-        for (int m = 0; m < n_mel; ++m) {
-            const int c = tap_off[m + 1];
-            tap_off[m] = o;
-            o += c;
-            cmx = c > cmx ? c : cmx;
-        }
-        tap_off[n_mel] = o;
-        int C = (cmx + 2) / 3;
-        if (C < 1) C = 1;
-        for (;; ++C) {
-            int need = 0;
-            for (int m = 0; m < n_mel; ++m) {
-                const int c = tap_off[m + 1] - tap_off[m];
-                need += c > 0 ? (c + C - 1) / C : 1;
-            }
-            if (need <= 64) break;
-        }
-        int ln = 0;
-        for (int m = 0; m < n_mel; ++m) {
-            const int c = tap_off[m + 1] - tap_off[m];
-            const int parts = c > 0 ? (c + C - 1) / C : 1;
-            for (int q = 0; q < parts; ++q, ++ln) {
-                const int i0 = q * C, cnt = (c - i0) < C ? (c - i0) : C;
-                asg[4 * ln] = m;
-                asg[4 * ln + 1] = i0;
-                asg[4 * ln + 2] = cnt > 0 ? cnt : 0;
-                asg[4 * ln + 3] = (q == 0 ? 1 : 0) | ((q == 0 && parts > 1) ? 2 : 0) | ((q == 0 && parts > 2) ? 4 : 0);
-            }
-        }
-        for (; ln < 64; ++ln) asg[4 * ln] = -1, asg[4 * ln + 1] = 0, asg[4 * ln + 2] = 0, asg[4 * ln + 3] = 0;
-        asg_cmax = C;
-    }
-    __syncthreads();
-    const bool taps_in_lds = tap_off[n_mel] <= MAXTAP;
-    if (taps_in_lds)
-        for (int m = w; m < n_mel; m += kMfccWaves) {
-            const int lo = mel_range[2 * m], cnt = mel_range[2 * m + 1] - lo;
-            for (int e = lane; e < cnt; e += 64) taps[tap_off[m] + e] = fbank[(size_t)m * NBIN + lo + e];
-        }
-    __syncthreads();                               // last block-level barrier: waves are independent from here
-    // this lane's share of the mel phase (constant over frames)
-    const int my_m = asg[4 * lane], my_i0 = asg[4 * lane + 1], my_cnt = asg[4 * lane + 2], my_flags = asg[4 * lane + 3];
-    const int cmax = asg_cmax;
-    const int my_lo = my_m >= 0 ? mel_range[2 * my_m] + my_i0 : 0;
-    const double* my_tp = taps + (my_m >= 0 ? tap_off[my_m] + my_i0 : 0);
-    const double* my_fb = fbank + (size_t)(my_m >= 0 ? my_m : 0) * NBIN + my_lo;
-    // DCT split: n_out <= 16 outputs x 4 quarter-sums fill the wave; otherwise one output per lane
-    const bool dct_split = n_out * 4 <= 64;
-    const int dq = (n_mel + 3) / 4;
-
-    const int64_t stride = (int64_t)gridDim.x * kMfccWaves;
-    int64_t f = (int64_t)blockIdx.x * kMfccWaves + w;
-    if (f >= F) return;
-    int u = find_utt(foff, U, f);
-    RawFrame cur;
-    auto fetch = [&](int64_t ff) {
-        while (foff[u + 1] <= ff) ++u;             // frames visited by a wave are increasing
-        fetch_frame(signal + soff[u], soff[u + 1] - soff[u], (ff - foff[u]) * S, lane, cur);
-    };
-    fetch(f);
-    double* A = &bufs[w][0];
-    double* lm = A + 320;                          // log-mel row: beyond the 257 power bins
-    for (; f < F; f += stride) {
-    // stage 0 (Ns = 1): v[r] = z[lane + 64 r] = (y[2n], y[2n+1]) * window, y = pre-emphasised signal
-    cplx v[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int k0 = 2 * (lane + 64 * r);
-        const int64_t i0 = cur.base + k0;
-        // y[i] = x[i] - alpha x[i-1] (mfcc.py:63), y[0] = x[0]; zero beyond the utterance (utils.py:121-125)
-        double a = i0 == 0 ? cur.x0[r] : __dsub_rn(cur.x0[r], __dmul_rn(alpha, cur.xm[r]));
-        double c = __dsub_rn(cur.x1[r], __dmul_rn(alpha, cur.x0[r]));
-        if (i0 >= cur.n) a = 0.0;
-        if (i0 + 1 >= cur.n) c = 0.0;
-        v[r] = {a * wins[k0], c * wins[k0 + 1]};   // wins is zero beyond the frame length
-    }
-    radix4(v);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        A[2 * (4 * lane + r)] = v[r].re;
-        A[2 * (4 * lane + r) + 1] = v[r].im;
-    }
-    __builtin_amdgcn_wave_barrier();
-    // stages Ns = 4, 16, 64: all reads of a stage happen before its writes, so one buffer is enough
-#pragma unroll
-    for (int Ns = 4; Ns < NC; Ns *= 4) {
-        const int k = lane & (Ns - 1);
-        const int step = NC / (Ns * 4);            // twiddle index stride in units of 2 pi / 256
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int src = lane + 64 * r;
-            cplx z = {A[2 * src], A[2 * src + 1]};
-            if (r > 0) {
-                const int m2 = 2 * k * r * step;   // W256^m = tw512[2m]; the table holds half a turn:
-                const int idx = m2 & (NC - 1);     // tw512[i + 256] = -tw512[i]
-                const double sg = m2 >= NC ? -1.0 : 1.0;
-                const cplx tw = {sg * tws[2 * idx], sg * tws[2 * idx + 1]};
-                z = cmul(z, tw);
-            }
-            v[r] = z;
-        }
-        radix4(v);
-        __builtin_amdgcn_wave_barrier();
-        const int j0 = (lane / Ns) * Ns * 4 + k;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int dst = j0 + r * Ns;
-            A[2 * dst] = v[r].re;
-            A[2 * dst + 1] = v[r].im;
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    // Z = A[0..255]; X[k] for k = 0..256; power |X|^2 / 512 (mfcc.py:141-142)
-    double pk[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int k = lane + 64 * q;
-        const int kb = (NC - k) & (NC - 1);
-        const cplx zk = {A[2 * k], A[2 * k + 1]};
-        const cplx zc = {A[2 * kb], -A[2 * kb + 1]};
-        const cplx e = {0.5 * (zk.re + zc.re), 0.5 * (zk.im + zc.im)};
-        const cplx d = csub(zk, zc);
-        const cplx o = {0.5 * d.im, -0.5 * d.re};                    // -(i/2) (zk - zc)
-        const cplx tw = {tws[2 * k], tws[2 * k + 1]};
-        const cplx xk = cadd(e, cmul(o, tw));
-        // |X|^2 directly (the reference squares np.abs: same value to an ulp, a fraction of the instructions)
-        pk[q] = (1.0 / 512.0) * fma(xk.re, xk.re, xk.im * xk.im);
-    }
-    // bin 256 (Nyquist): X = Re Z0 - Im Z0, the value the general expression gives with tw = -1
-    const double xn = A[0] - A[1];
-    __builtin_amdgcn_wave_barrier();
-    double* pw = A;                                // the FFT buffer is dead: reuse it for the power spectrum
-    double esum = 0.0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int k = lane + 64 * q;
-        pw[k] = pk[q];
-        esum += pk[q];
-        if (power_out) power_out[f * NBIN + k] = pk[q];
-    }
-    if (lane == 0) {
-        const double pn = (1.0 / 512.0) * (xn * xn);
-        pw[NC] = pn;
-        esum += pn;
-        if (power_out) power_out[f * NBIN + NC] = pn;
-    }
-    esum = wave_sum_dpp(esum);
-    if (lane == 0) energy[f] = log(esum);                               // mfcc.py:158-160
-    __builtin_amdgcn_wave_barrier();
-    // Request the wave's next frame here, not right after stage 0: the FFT is the register-hungry phase, and
-    // values prefetched across it get spilled -- which forces the loads to complete on the spot.  The mel and
-    // DCT phases are long enough to cover the latency and need few registers.
-    if (f + stride < F) fetch(f + stride);
-    if (cmax > 0) {
-        // mel filter bank (mfcc.py:148): every lane sums its chunk of one filter's taps; a filter's two or
-        // three partial sums are added in the lane of its first chunk
-        double s = 0.0;
-        const double* pp = pw + my_lo;
-        // branch-free: past the lane's count the index falls back to 0 and the tap to 0.0
-        if (taps_in_lds) {
-#pragma unroll 4
-            for (int i = 0; i < cmax; ++i) {
-                const bool in = i < my_cnt;
-                const int ii = in ? i : 0;
-                s = fma(pp[ii], in ? my_tp[ii] : 0.0, s);
-            }
-        } else {
-            for (int i = 0; i < cmax; ++i) {
-                const bool in = i < my_cnt;
-                const int ii = in ? i : 0;
-                s = fma(pp[ii], in ? my_fb[ii] : 0.0, s);
-            }
-        }
-        const double s1 = shfl_f64(s, (lane + 1) & 63), s2 = shfl_f64(s, (lane + 2) & 63);
-        if (my_flags & 2) s += s1;
-        if (my_flags & 4) s += s2;
-        if (my_flags & 1) {
-            if (s == 0.0) s = 2.220446049250313e-16;                     // mfcc.py:149
-            lm[my_m] = 20.0 * log10(s);                                  // mfcc.py:150
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    // DCT-II (ortho) of the RAW log-mel row.  The reference subtracts the utterance mean first
-    // (mfcc.py:151-152); the DCT is linear, so that subtraction is applied to the transformed
-    // row by feat_kernel and the frame kernel needs no utterance-level quantity.
-    if (dct_split) {
-        const int k = lane >> 2, part = lane & 3;
-        const int m0 = part * dq, m1 = (m0 + dq) < n_mel ? (m0 + dq) : n_mel;
-        double s = 0.0;
-        if (k < n_out)
-            for (int m = m0; m < m1; ++m) s = fma(lm[m], Ct[m * n_mel + k], s);
-        s += dpp_f64<0xB1>(s);                     // quad_perm [1,0,3,2], then [2,3,0,1]: (q0 + q1) + (q2 + q3)
-        s += dpp_f64<0x4E>(s);
-        if (part == 0 && k < n_out) cepraw[f * n_out + k] = s;
-    } else {
-        // same association as the split form (four quarter sums, pairwise) so both give identical bits
-        for (int k = lane; k < n_out; k += 64) {
-            double q[4];
-#pragma unroll
-            for (int part = 0; part < 4; ++part) {
-                const int m0 = part * dq, m1 = (m0 + dq) < n_mel ? (m0 + dq) : n_mel;
-                q[part] = 0.0;
-                for (int m = m0; m < m1; ++m) q[part] = fma(lm[m], Ct[m * n_mel + k], q[part]);
-            }
-            cepraw[f * n_out + k] = (q[0] + q[1]) + (q[2] + q[3]);
-        }
-    }
-    __builtin_amdgcn_wave_barrier();               // the next frame overwrites this wave's buffer
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -614,8 +262,9 @@ __global__ __launch_bounds__(64 * kMfccWaves) __attribute__((amdgpu_waves_per_eu
 // and Z[256-k] sits in lane 16 - k2 of the same row (register 15 - k1), so every lane handles its k1 < 8 and
 // fetches eight values from its mirror lane.  Lane 0 is its own mirror (k = 16 k1 <-> 16 (16 - k1)) and also
 // owns k = 0 / 256.
-// Against the radix-4 kernel above: one LDS round trip of the data instead of four, the split at half the
-// arithmetic, and 16 independent butterflies per lane to hide latencies behind.
+// Against a one-frame-per-wave radix-4 Stockham (the first version of this kernel, 0.60 ms per 256k frames against
+// 0.35): one LDS round trip of the data instead of four, the split at half the arithmetic, and 16 independent
+// butterflies per lane to hide latencies behind.
 constexpr int kX4Waves = 8;
 constexpr int kX4FS = 308;             // doubles per frame in a wave's LDS slice: 16 x 17 exchange tile, later
                                        // 257 power bins, log-mel row at 260
@@ -653,7 +302,11 @@ __device__ __forceinline__ void fft16(cplx v[16]) {
 
 // One row's raw samples through buffer loads (frames at the edges of an utterance).  Called with only that
 // row's lanes active: base, n and the utterance pointer are the same in all of them, so the descriptors are
-// uniform.  Same descriptors as fetch_frame: reads beyond the utterance return 0.
+// uniform (say so with readfirstlane, or the loads are wrapped in waterfall loops) and reads beyond the utterance
+// return 0 without per-lane clamping.  x[i-1] uses a second descriptor starting one sample earlier; at the
+// utterance start, where there is no earlier sample, that descriptor starts at x[0] and the offsets move back
+// by one sample -- the one sample that does not exist (x[-1], never used: y[0] = x[0]) is clamped onto x[0] so
+// no offset is negative.
 template <typename SAMPLE>
 __device__ __noinline__ void fetch_row(const SAMPLE* __restrict__ x, int64_t n, int64_t base, int n1, double alpha,
                                        cplx v[16]) {
@@ -666,7 +319,7 @@ __device__ __noinline__ void fetch_row(const SAMPLE* __restrict__ x, int64_t n, 
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
         (void*)uniform_ptr(x + base - back), 0, __builtin_amdgcn_readfirstlane((int)(left + back * SZ)), 0x00020000);
     const int vo = n1 * 2 * SZ;
-    const int adj = back ? 0 : SZ;                 // see fetch_frame
+    const int adj = back ? 0 : SZ;
 #pragma unroll
     for (int n2 = 0; n2 < 16; ++n2) {
         int vb = vo + (n2 * 32 * SZ - adj);
@@ -701,8 +354,7 @@ __device__ __forceinline__ double log_fast(double x, const double* ltab) {
 
 // mel -> log -> DCT of the four frames of a wave's slice in one walk: a lane keeps its filter chunk (and its
 // DCT output) for all four, so taps and DCT coefficients are read once and the four chains overlap; taps are
-// taken four at a time with every load ahead of the first product.  Per frame the sums run in the order of
-// mel_dct_frame.
+// taken four at a time with every load ahead of the first product.
 __device__ __forceinline__ void mel_dct_frames4(const Mel512Lane& ml, double* slice, const double* ltab, int lane,
                                                 double* __restrict__ cep_rows, int nlive) {
     constexpr int FS = kX4FS;
@@ -1080,23 +732,24 @@ __global__ void feat_kernel(const double* __restrict__ cepraw, const double* __r
     const int W = nc + 1;
     const int u = blockIdx.y;
     const int64_t f0 = foff[u], f1 = foff[u + 1];
+    // utterance means of the columns in use: the kMeanParts partial sums of col_sum_kernel, in part order
+    __shared__ double mean_s[256];
+    const double* Pu = M + (size_t)u * kMeanParts * ncols;
+    for (int kk = threadIdx.x; kk < ncols; kk += blockDim.x) {
+        double tot = 0.0;
+#pragma unroll
+        for (int q = 0; q < kMeanParts; ++q) tot += Pu[q * ncols + kk];
+        mean_s[kk] = tot / (double)(f1 - f0);
+    }
+    __syncthreads();
     const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;      // < 2^32: checked by the host
     const unsigned fi = idx / (unsigned)ncols;
     const int64_t f = f0 + fi;
     const int k = (int)(idx - fi * (unsigned)ncols);
     if (f >= f1) return;
-    // utterance mean of column kk: the kMeanParts partial sums of col_sum_kernel, in part order
-    const double* Pu = M + (size_t)u * kMeanParts * ncols;
-    auto mean_of = [&](int kk) -> double {
-        double tot = 0.0;
-#pragma unroll
-        for (int q = 0; q < kMeanParts; ++q) tot += Pu[q * ncols + kk];
-        return tot / (double)(f1 - f0);
-    };
-    const double mean_k = mean_of(k), mean_c = k < W && k < nc ? mean_of(1 + k) : 0.0;
     const double shift0 = 1e-8 * sqrt((double)n_mel);
-    auto cepv = [&](int64_t ff, int kk) -> double {      // kk is k or 1 + k
-        double v = cepraw[ff * ld + kk] - (kk == k ? mean_k : mean_c);
+    auto cepv = [&](int64_t ff, int kk) -> double {
+        double v = cepraw[ff * ld + kk] - mean_s[kk];
         if (kk == 0) v -= shift0;
         if (kk >= 1 && kk <= nc) v -= 1e-8;
         return v;
@@ -1271,7 +924,7 @@ int lnasr_mfcc(lnasr_ctx* ctx, const void* signal, int sample_kind, const int64_
     const int nt = NFFT / 2 < 256 ? (NFFT / 2 < 64 ? 64 : NFFT / 2) : 256;
     bool fused_dct = false;
     const int n_out = cepstrum_or_null ? n_mel : W;   // cepstral columns the frame kernel has to produce
-    if (NFFT == 512 && L <= 512 && n_mel <= 48 && !getenv("LNASR_NO_FFT512") && !getenv("LNASR_NO_FFT512X4")) {
+    if (NFFT == 512 && L <= 512 && n_mel <= 48 && !getenv("LNASR_NO_FFT512")) {
         // four frames per wave, persistent waves walking groups of four frames with a grid stride; the LDS
         // (tables + a slice per wave) allows one block per CU
         const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
@@ -1287,30 +940,6 @@ int lnasr_mfcc(lnasr_ctx* ctx, const void* signal, int sample_kind, const int64_
         else if (d_pow) LN_X4("mfcc_frame512x4", double, true);
         else LN_X4("mfcc_frame512x4", double, false);
 #undef LN_X4
-        fused_dct = true;
-    } else if (NFFT == 512 && L <= 512 && n_mel <= 48 && !getenv("LNASR_NO_FFT512")) {
-        // persistent waves, each walking frames with a grid stride
-        const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
-        int64_t want = (F + kMfccWaves - 1) / kMfccWaves;
-        static int bpc_cache[2] = {0, 0};             // resident blocks per CU: the whole grid runs in one round
-        int& bpc = bpc_cache[sample_kind];
-        if (bpc == 0) {                               // (the occupancy query costs ~2 ms: once per process)
-            if (sample_kind == 1)
-                LN_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, mfcc_frame512_kernel<int16_t>, 64 * kMfccWaves, 0));
-            else
-                LN_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, mfcc_frame512_kernel<double>, 64 * kMfccWaves, 0));
-        }
-        if (bpc < 1) bpc = 1;
-        if (want > (int64_t)cus * bpc) want = (int64_t)cus * bpc;
-        const unsigned grid = (unsigned)want;
-        if (sample_kind == 1)
-            LN_LAUNCH(ctx, "mfcc_frame512_i16", mfcc_frame512_kernel<int16_t>, dim3(grid), dim3(64 * kMfccWaves), 0,
-                      (const int16_t*)d_sig, d_soff, d_foff, U, F, L, S, n_mel, n_out, cfg->hpf_alpha, (const double*)d_win,
-                      (const double*)d_fb, d_range, d_tw, d_C, (double*)d_pow, cep, energy);
-        else
-            LN_LAUNCH(ctx, "mfcc_frame512", mfcc_frame512_kernel<double>, dim3(grid), dim3(64 * kMfccWaves), 0,
-                      (const double*)d_sig, d_soff, d_foff, U, F, L, S, n_mel, n_out, cfg->hpf_alpha, (const double*)d_win,
-                      (const double*)d_fb, d_range, d_tw, d_C, (double*)d_pow, cep, energy);
         fused_dct = true;
     } else if (sample_kind == 1)
         LN_LAUNCH(ctx, "mfcc_frame_i16", mfcc_frame_kernel<int16_t>, dim3((unsigned)F), dim3(nt), shm,

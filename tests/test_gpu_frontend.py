@@ -126,3 +126,25 @@ def test_recognizer_wiring(tmp_path, synth):
     pcm = np.clip(synth.synth_signal(8000, seed=1) * 5, -32768, 32767).astype(np.int16)
     states = rec.recognize(pcm)
     assert states.dtype == np.uint32 and states.shape == (49,) and states.max() < 4
+
+
+def test_mfcc_ragged_edges(oracle):
+    """Utterance lengths around every boundary of the four-frames-per-wave kernel: frames that start beyond the
+    samples (n < L - S), a last frame cut anywhere, frame counts that are not multiples of four, odd sample offsets
+    in the int16 batch (pairs of samples are loaded as one unaligned dword), groups of four frames that straddle
+    utterances.  Batch == single utterance bit for bit; both against the oracle."""
+    from lnasr.mfcc import MFCC
+    rng = np.random.default_rng(5)
+    lens = [10, 79, 401, 560, 561, 562, 721, 1000, 1001, 3333, 7777, 512, 513, 672, 673, 2 * 160 + 241, 4001]
+    sigs16 = [rng.integers(-3000, 3000, n).astype(np.int16) for n in lens]
+    sigs16[3][:] = 0                                               # an all-zero utterance: eps and -inf paths
+    for sigs in (sigs16, [s.astype(np.float64) * 1.000244140625 for s in sigs16]):
+        feat, foff = MFCC().calc_mfcc_batch(sigs)
+        for u, x in enumerate(sigs):
+            p, c, fu = MFCC().calc_mfcc(x)
+            assert np.array_equal(feat[foff[u]:foff[u + 1]], fu, equal_nan=True), "batch vs single, utterance %d (n=%d)" % (u, len(x))
+            with np.errstate(divide="ignore", invalid="ignore"):
+                op, oc, of = oracle.mfcc(np.asarray(x, dtype=np.float64))
+            assert_close(p, op, 1e-9, 1e-6, msg="power n=%d" % len(x))
+            assert_close(c, oc, 1e-9, 1e-9, msg="cepstrum n=%d" % len(x))
+            assert_close(fu, of, 1e-9, 1e-9, msg="features n=%d" % len(x))
