@@ -9,6 +9,13 @@ from conftest import assert_close
 
 pytestmark = pytest.mark.gpu
 
+# LNASR_TEST_SEEDS="a:b" widens (or moves) the seed range of both sweeps for a soak run; the default is what the
+# suite runs every time
+import os
+_lo, _hi = (int(x) for x in os.environ.get("LNASR_TEST_SEEDS", "0:28").split(":"))
+_SEEDS_DIAG = range(_lo, _hi)
+_SEEDS_FULL = range(_lo, _lo + max(1, (_hi - _lo) * 12 // 28))
+
 
 @pytest.fixture(scope="module")
 def ctx():
@@ -27,7 +34,7 @@ def _shape(seed):
     return rng, N, M, D, T, U
 
 
-@pytest.mark.parametrize("seed", range(28))
+@pytest.mark.parametrize("seed", _SEEDS_DIAG)
 def test_random_shape(seed, synth, oracle, ctx):
     rng, N, M, D, T, U = _shape(seed)
     mdl = synth.synth_model(N, M, D, seed=seed + 7)
@@ -80,7 +87,7 @@ def test_random_shape(seed, synth, oracle, ctx):
         assert abs(st[o] - ref["loglik"]) <= 1e-9 * max(1.0, abs(ref["loglik"]))
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", _SEEDS_FULL)
 def test_random_shape_full_covariance(seed, synth, oracle, ctx):
     """Full covariance: emission against the oracle's (x-mu)^T Sigma^-1 (x-mu) form, the matrix-core statistics
     against the scalar statistics kernel."""
