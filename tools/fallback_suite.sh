@@ -1,0 +1,16 @@
+#!/bin/bash
+# Runs on the GPU box: the whole GPU suite once per group of fallback switches, so that every layer
+# under the tuned kernels is itself shown parity-green.   gpurun -- 'bash tools/fallback_suite.sh'
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R
+rc=0
+run() {
+    echo "== $*"
+    env "$@" timeout -k 10 600 python -m pytest tests -q -m gpu -x 2>&1 | tail -3
+    [ ${PIPESTATUS[0]} -eq 0 ] || rc=1
+}
+run LNASR_NO_PAD=1
+run LNASR_NO_MFMA=1 LNASR_NO_MFMA_STATS=1
+run LNASR_NO_REGVIT=1 LNASR_NO_REGFWD=1 LNASR_NO_T256=1 LNASR_NO_LDSBT=1 LNASR_VIT=a
+run LNASR_NO_STREAM=1 LNASR_NO_FRAMEPAR=1 LNASR_NO_T256=1 LNASR_F32_GENERIC=1 LNASR_NO_FFT512=1 LNASR_NO_PIPELINE=1
+exit $rc
