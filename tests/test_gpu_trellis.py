@@ -384,6 +384,50 @@ def test_trellises_beyond_256_states_large_batch(N, synth, oracle, ctx):
             assert np.array_equal(r["v"][u, :L], r2["v"][k, :L]) and np.array_equal(r["path"][u, :L], r2["path"][k, :L])
 
 
+@pytest.mark.parametrize("N", [65, 100, 128])
+def test_forward_backward_column_owned_kernel(N, synth, oracle, ctx):
+    """64 < N <= 128 with a batch that fills the chip four utterances per block (U >= 4 x CUs): the column-owned
+    forward / backward kernel (row-group sums exchanged with permlane swaps) against the oracle on a sample of
+    utterances and against the row-sliced kernel (LNASR_NO_COLFWD) on all of them; ragged lengths, a forbidden
+    transition, an unreachable state, an utterance whose likelihood underflows the linear domain (exact fallback)."""
+    rng = np.random.default_rng(N)
+    d = synth.synth_discrete(N, 4, 8, seed=N)
+    A = d["A"].copy()
+    A[3, :] = -np.inf
+    A[3, 5] = 0.0
+    A[:, 7] = -np.inf
+    ctx.upload_hmm(A, d["pi"])
+    U, T = 4 * ctx.device_info()["cu_count"] + 6, 7
+    b = np.ascontiguousarray(-30.0 * rng.random((U, T, N)))
+    b[5, 3] -= 2000.0                                      # a frame far below the shift: column sums underflow
+    b[6, 2, : N // 2] = -np.inf
+    lens = rng.integers(1, T + 1, U).astype(np.int32)
+    lens[:8] = T
+    alpha, ll = ctx.forward(b, lens=lens)
+    _, ll_only = ctx.forward(b, want_alpha=False, lens=lens)
+    beta = ctx.backward(b, lens=lens)
+    os.environ["LNASR_NO_COLFWD"] = "1"
+    try:
+        alpha2, ll2 = ctx.forward(b, lens=lens)
+        beta2 = ctx.backward(b, lens=lens)
+    finally:
+        del os.environ["LNASR_NO_COLFWD"]
+    assert np.array_equal(ll_only, ll)
+    for u in range(U):
+        L = lens[u]
+        assert_close(alpha[u, :L], alpha2[u, :L], 1e-12, msg="alpha vs row-sliced kernel u=%d" % u)
+        assert_close(beta[u, :L], beta2[u, :L], 1e-12, msg="beta vs row-sliced kernel u=%d" % u)
+    assert_close(ll, ll2, 1e-12)
+    for u in (0, 1, 2, 3, 4, 5, 6, 7, U // 2, U - 3, U - 2, U - 1):
+        L = lens[u]
+        ob = np.ascontiguousarray(b[u, :L].T)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            ra, rb = oracle.forward(A, d["pi"], ob), oracle.backward(A, ob)
+        assert_close(alpha[u, :L], ra, 1e-12, msg="alpha N=%d u=%d" % (N, u))
+        assert_close(beta[u, :L], rb, 1e-12, msg="beta N=%d u=%d" % (N, u))
+        assert abs(ll[u] - oracle.loglik(ra)) <= 1e-11 * abs(ll[u])
+
+
 def test_bw_statistics_full_covariance_wide(synth, ctx):
     """Full covariance with two mixture tiles (M = 20) and with more than 32 mixtures (groups of 32), N not a
     multiple of 8, ragged lengths: the matrix-core statistics kernel against the scalar kernel that the golden
