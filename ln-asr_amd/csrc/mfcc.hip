@@ -963,8 +963,9 @@ int lnasr_mfcc(lnasr_ctx* ctx, const void* signal, int sample_kind, const int64_
     const int ncols = n_out, ldc = fused_dct ? n_out : n_mel;
     LN_REQUIRE(U <= 65535, "U=%d utterances is too many for one MFCC call", U);
     {
-        int threads = 256 - 256 % ncols;
-        if (threads < ncols) threads = ncols;
+        // four row slices whatever the column count: the order of the sums (and so every bit of the features) does
+        // not depend on whether the cepstrum was asked for
+        const int threads = 4 * ncols;
         LN_LAUNCH(ctx, "mfcc_col_sum", col_sum_kernel, dim3(U, kMeanParts), dim3(threads), (size_t)threads * 8, cep, d_foff,
                   ldc, ncols, mean_part);
     }

@@ -142,13 +142,27 @@ class DeviceArray:
         check(lib().lnasr_memcpy_h2d(ctx.handle, d.ptr, arr.ctypes.data, d.nbytes))
         return d
 
+    def view(self, shape):
+        """The same device memory under another shape (same element count); the view keeps its parent alive and
+        does not own the allocation.  Lets a batch stay in HBM between entry points, e.g. MFCC features [F, D] ->
+        decode input [U, T, D]."""
+        shape = tuple(int(s) for s in shape)
+        if int(np.prod(shape, dtype=np.int64)) * self.dtype.itemsize != self.nbytes:
+            raise ValueError("view of %s as %s changes the size" % (self.shape, shape))
+        v = DeviceArray.__new__(DeviceArray)
+        v.ctx, v.shape, v.dtype, v.nbytes, v.ptr = self.ctx, shape, self.dtype, self.nbytes, self.ptr
+        v._parent = self
+        return v
+
     def to_host(self):
         out = np.empty(self.shape, dtype=self.dtype)
         check(lib().lnasr_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, self.nbytes))
         return out
 
     def free(self):
-        if self.ptr and self.ctx.handle:
+        if getattr(self, "_parent", None) is not None:      # a view: the parent owns the memory
+            self._parent = None
+        elif self.ptr and self.ctx.handle:
             lib().lnasr_dev_free(self.ctx.handle, self.ptr)
         self.ptr = None
 

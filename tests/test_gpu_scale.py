@@ -118,3 +118,28 @@ def test_rccl_single_rank_collectives():
         assert np.array_equal(np.asarray(ctx.allreduce_f64(s.copy())), s)
     finally:
         ctx.comm_destroy()
+
+
+def test_pcm_to_paths_on_device(synth):
+    """int16 PCM -> MFCC -> decode with the features never leaving the device (DeviceArray.view) gives the paths of
+    the host round trip (Recognizer-style: calc_mfcc to numpy, then decode)."""
+    from lnasr import _ffi
+    from lnasr.mfcc import MFCC
+    ctx = _ffi.default_ctx()
+    U, n, N, M, D = 6, 16240, 12, 3, 39                     # 100 frames per utterance
+    rng = np.random.default_rng(3)
+    pcm = rng.integers(-4000, 4000, U * n).astype(np.int16)
+    offs = (np.arange(U + 1) * n).astype(np.int64)
+    mdl = synth.synth_model(N, M, D, seed=2)
+    ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
+    m = MFCC()
+    cfg, win, bank = m._cfg()
+    _, _, feat, foff = ctx.mfcc(ctx.to_device(pcm), offs, cfg, win, bank, False, False)
+    T = int(foff[1])
+    assert np.all(np.diff(foff) == T)
+    path_dev = np.asarray(ctx.decode(feat.view((U, T, D))).to_host())
+    host_feat = np.stack([m.calc_mfcc(pcm[offs[u]:offs[u + 1]])[2] for u in range(U)])
+    assert np.array_equal(feat.to_host().reshape(U, T, D), host_feat)
+    assert np.array_equal(path_dev, np.asarray(ctx.decode(host_feat)))
+    with pytest.raises(ValueError):
+        feat.view((U, T, D + 1))

@@ -2,7 +2,7 @@
 """Per-row measurements of the other BASELINE.json configs on one GPU (development / DESIGN.md numbers;
 the driver-facing benchmark is bench.py).  Inputs resident in HBM, HIP-event kernel times.
 
-    python tools/bench_rows.py [mfcc] [gmm] [fwd] [bw] [all]
+    python tools/bench_rows.py [mfcc] [e2e] [gmm] [fwd] [bw] [all]
 """
 import os
 import sys
@@ -57,6 +57,26 @@ if what & {"mfcc", "all"}:
     d_i16 = ctx.to_device(np.clip(batch, -32768, 32767).astype(np.int16))
     timed("mfcc int16 PCM (U=%d)" % U, lambda: ctx.mfcc(d_i16, offs, cfg, win, bank, False, False, fo), frames, "frames",
           algo_bytes=frames * 632.0)
+
+if what & {"e2e", "all"}:
+    # PCM -> state paths: int16 samples resident in HBM -> MFCC (D=39) -> emission -> Viterbi -> backtrace,
+    # features and trellis never leave the device; 1024 utterances x 1000 frames, N=128, M=16
+    U, n, N, M, D = 1024, 160240, 128, 16, 39
+    sig = np.clip(synth.synth_signal(n, seed=7), -32768, 32767).astype(np.int16)
+    d_pcm = ctx.to_device(np.tile(sig, U))
+    offs = (np.arange(U + 1) * n).astype(np.int64)
+    cfg, win, bank = MFCC()._cfg()
+    mdl = synth.synth_model(N, M, D, seed=1)
+    ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
+    feat = ctx.empty((U * 1000, D), np.float64)
+    path = ctx.empty((U, 1000), np.uint32)
+
+    def e2e():
+        ctx.mfcc(d_pcm, offs, cfg, win, bank, False, False, feat)
+        ctx.decode(feat.view((U, 1000, D)), path_out=path)
+
+    timed("int16 PCM -> MFCC -> decode (U=%d)" % U, e2e, U * 1000, "frames", algo_bytes=U * 1000 * (632.0 + 4))
+    del d_pcm, feat, path
 
 if what & {"gmm", "all"}:
     # config 3: T=1000, M=16, D=39, U=1024; single GMM (N=1) and the 128-state bank
