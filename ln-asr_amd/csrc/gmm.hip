@@ -251,15 +251,15 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) wr[q][ks] = wpack[(((size_t)sgc * Q + q) * KS + ks) * 64 + lane];
 
-    double lw[WRITE_BM ? Q * 4 : 1];
+    // log weights of the lane's state (bm path: the coefficients carry none).  In the LDS, not in registers: with
+    // Q = 4, KS = 20 the 32 VGPRs they took made the kernel spill, and a scratch reload waits on vmcnt -- which counts
+    // in issue order, so every reload inside the MFMA chain also waited for all the bm stores before it (the write
+    // stream ran in series with the arithmetic: 4.57 ms at config 5)
+    __shared__ double lws[WRITE_BM ? SPB * 4 * Q : 1];
     const int g = lane >> 4, fr = lane & 15;
     const int my_state = 4 * sgc + g;
-    if (WRITE_BM) {
-#pragma unroll
-        for (int q = 0; q < Q; ++q)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) lw[q * 4 + r] = logw[(size_t)my_state * M + 4 * q + r];
-    }
+    const double* lw = lws + (WRITE_BM ? (4 * w + g) * 4 * Q : 0);
+    if (WRITE_BM && fr < 4 * Q) lws[(4 * w + g) * 4 * Q + fr] = logw[(size_t)my_state * M + fr];
 
     // constant rows of F (k >= 2D): 1 for k == 2D, 0 above
     {
@@ -354,11 +354,11 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 2))
             if (WRITE_BM) {     // coefficients carry no log w here: bm is the raw component log-density
                 const long frame = (tile + tt) * 16 + fr;
                 if (active && tile + tt < tile1 && frame < F) {
-                    double* dst = bm + ((size_t)frame * N + my_state) * M;
+                    // a lane owns the 4 Q mixtures of its (frame, state): 32-byte vector stores (M is a multiple of 4 on
+                    // this path and bm is 256-byte aligned) instead of one 8-byte request per value
+                    double4_t* dst = reinterpret_cast<double4_t*>(bm + ((size_t)frame * N + my_state) * M);
 #pragma unroll
-                    for (int q = 0; q < Q; ++q)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) dst[4 * q + r] = acc[q][r];
+                    for (int q = 0; q < Q; ++q) dst[q] = acc[q];
                 }
 #pragma unroll
                 for (int q = 0; q < Q; ++q)
@@ -382,6 +382,11 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 2))
 
         }
 
+        // With bm stores in flight the prefetched features are consumed as late as possible: vmcnt counts in issue
+        // order, so a wait for those loads hoisted into the next MFMA chain (where the scheduler likes to put it) also
+        // waits for the bm stores issued before them.  (Consuming them right after the MFMA chain, ahead of this
+        // tile's stores, was measured too: slower -- the previous tile's stores are still in flight there.)
+        if (WRITE_BM) __builtin_amdgcn_sched_barrier(0);
         if (has_next) store_stage(cur ^ 1);
         __syncthreads();
     }
