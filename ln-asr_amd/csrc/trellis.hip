@@ -273,10 +273,13 @@ __global__ void backtrace_kernel(const TS* __restrict__ v, const double* __restr
 // (rounding is monotonic, so max_i((v_i + A_ij) + b_j) == max_i(v_i + A_ij) + b_j bit for bit) and
 // the slices are merged with LDS floating-point atomic max into a triple-buffered v row: one
 // barrier per frame, no partial-maximum round trip.
-template <int CPT, int NW, int RPT, int UB, int WPE>
+// TS = storage type of b and v.  float: the arithmetic stays fp64 and every v is rounded to float where the
+// reference's float32 array rounds it (hmm.py:165 with precision=np.float32) -- each row-slice maximum right
+// before the slices meet, which equals rounding their maximum (rounding is monotonic).
+template <int CPT, int NW, int RPT, int UB, int WPE, typename TS = double>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void viterbi_reg1b(
-    const double* __restrict__ b, const double* __restrict__ A, const double* __restrict__ pi,
-    const int32_t* __restrict__ lens, double* __restrict__ v, int U, int T, int N) {
+    const TS* __restrict__ b, const double* __restrict__ A, const double* __restrict__ pi,
+    const int32_t* __restrict__ lens, TS* __restrict__ v, int U, int T, int N) {
     constexpr int NP = 64 * CPT;
     __shared__ double Vs[3][UB][NP];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -302,8 +305,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
             double val = LN_NEG_INF;
             if (j < N && len[k] > 0) {
                 size_t o = ((size_t)(u0 + k) * T) * N + j;
-                val = pi[j] + b[o];
-                v[o] = val;
+                val = rnd<TS>(pi[j] + ld(b, o));
+                st(v, o, val);
             }
             Vs[0][k][j] = val;
             Vs[1][k][j] = LN_NEG_INF;
@@ -312,7 +315,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
     }
     // emission streams of this wave's columns (every wave needs b for all UB*CPT column blocks):
     // one per-lane pointer per column block, utterance/frame offsets stay scalar
-    const double* pl[CPT];
+    const TS* pl[CPT];
     size_t uoff[UB];
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
 #pragma unroll
     for (int k = 0; k < UB; ++k)
 #pragma unroll
-        for (int c = 0; c < CPT; ++c) bnext[k][c] = pl[c][(uoff[k] + (T > 1 ? 1 : 0)) * N];
+        for (int c = 0; c < CPT; ++c) bnext[k][c] = ld(pl[c], (uoff[k] + (T > 1 ? 1 : 0)) * N);
     // store duty: (utterance, column block) q = w + jj*NW written to global one frame late
     constexpr int NJOB = CPT * UB;
     __syncthreads();
@@ -340,12 +343,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
 #pragma unroll
             for (int c = 0; c < CPT; ++c) {
                 bcur[k][c] = bnext[k][c];
-                bnext[k][c] = pl[c][(uoff[k] + tn) * N];
+                bnext[k][c] = ld(pl[c], (uoff[k] + tn) * N);
             }
         // v[t-1] of the columns this wave stores to global (complete since the last barrier)
         if (t > 1 && w < NJOB) {
             const int k = w / CPT, c = w % CPT, j = lane + 64 * c;
-            if (j < N && t - 1 < len[k]) v[((size_t)(u0 + k) * T + (t - 1)) * N + j] = Vs[cur][k][j];
+            if (j < N && t - 1 < len[k]) st(v, ((size_t)(u0 + k) * T + (t - 1)) * N + j, Vs[cur][k][j]);
         }
         // reset the buffer that frame t+1 will accumulate into
         if (w == NW - 1) {
@@ -377,7 +380,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
         for (int k = 0; k < UB; ++k)
 #pragma unroll
             for (int c = 0; c < CPT; ++c)
-                __hip_atomic_fetch_max(&Vs[nxt][k][lane + 64 * c], acc[k][c] + bcur[k][c], __ATOMIC_RELAXED,
+                __hip_atomic_fetch_max(&Vs[nxt][k][lane + 64 * c], rnd<TS>(acc[k][c] + bcur[k][c]), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
         __syncthreads();
         cur = nxt;
@@ -385,7 +388,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
     // last frame
     if (maxlen > 1 && w < NJOB) {
         const int k = w / CPT, c = w % CPT, j = lane + 64 * c;
-        if (j < N && maxlen - 1 < len[k]) v[((size_t)(u0 + k) * T + (maxlen - 1)) * N + j] = Vs[cur][k][j];
+        if (j < N && maxlen - 1 < len[k]) st(v, ((size_t)(u0 + k) * T + (maxlen - 1)) * N + j, Vs[cur][k][j]);
     }
 }
 
@@ -393,8 +396,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
 // an LDS row read; arg-max = DPP wave max, then the first lane holding the max (ballot + ffs),
 // which is numpy.argmax's first-index rule because lane l holds states l and l+64.  Decoded
 // states are collected 64 frames at a time and written as one coalesced 256-byte row.
-template <int CPL, bool LDSAT>
-__global__ __launch_bounds__(256) void backtrace_lds_kernel(const double* __restrict__ v,
+template <int CPL, bool LDSAT, typename TS = double>
+__global__ __launch_bounds__(256) void backtrace_lds_kernel(const TS* __restrict__ v,
                                                            const double* __restrict__ AT,
                                                            const int32_t* __restrict__ lens,
                                                            uint32_t* __restrict__ path, double* __restrict__ best,
@@ -412,7 +415,7 @@ __global__ __launch_bounds__(256) void backtrace_lds_kernel(const double* __rest
     if (u >= U) return;
     const int L = lens[u];
     if (L <= 0) return;
-    const double* vu = v + (size_t)u * T * N;
+    const TS* vu = v + (size_t)u * T * N;
     uint32_t* pu = path + (size_t)u * T;
     bool ok[CPL];
     int jj[CPL];                                             // clamped: every load is a valid address
@@ -438,7 +441,7 @@ __global__ __launch_bounds__(256) void backtrace_lds_kernel(const double* __rest
     double x[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
-        const double v0 = vu[(size_t)(L - 1) * N + jj[c]];
+        const double v0 = ld(vu, (size_t)(L - 1) * N + jj[c]);
         x[c] = ok[c] ? v0 : LN_NEG_INF;
     }
     double bestv;
@@ -456,7 +459,7 @@ __global__ __launch_bounds__(256) void backtrace_lds_kernel(const double* __rest
         for (int k = 0; k < PF; ++k) {
             const int tt = tstart - k > 0 ? tstart - k : 0;
 #pragma unroll
-            for (int c = 0; c < CPL; ++c) r[k][c] = vu[(size_t)tt * N + jj[c]];
+            for (int c = 0; c < CPL; ++c) r[k][c] = ld(vu, (size_t)tt * N + jj[c]);
         }
     };
     load_rows(L - 2 > 0 ? L - 2 : 0, cur);
@@ -1883,6 +1886,16 @@ int viterbi_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
         }
 #undef LN_VIT
     }
+    if (dtype == LNASR_F32 && N <= 128 && !getenv("LNASR_NO_REGVIT") && !getenv("LNASR_F32_GENERIC")) {
+        // precision=np.float32: the same register-resident kernel, fp64 arithmetic, float storage and rounding
+        if (U < 512)
+            LN_LAUNCH(ctx, "viterbi_reg1b_n128_u1_f32", (viterbi_reg1b<2, 8, 16, 1, 4, float>), dim3(U), dim3(512), 0,
+                      (const float*)b, A, pi, d_lens, (float*)v, U, T, N);
+        else
+            LN_LAUNCH(ctx, "viterbi_reg1b_n128_f32", (viterbi_reg1b<2, 8, 16, 2, 4, float>), dim3((U + 1) / 2), dim3(512), 0,
+                      (const float*)b, A, pi, d_lens, (float*)v, U, T, N);
+        return 0;
+    }
     constexpr int UB = 4;
     if (dtype == LNASR_F64 && N > 128 && N <= 256 && !getenv("LNASR_NO_T256")) {
         LN_LAUNCH(ctx, "viterbi_onchip256", trellis256_kernel<0>, dim3(U), dim3(1024), trellis256_lds(), (const double*)b, A,
@@ -1958,6 +1971,11 @@ int backtrace_device(lnasr_ctx* ctx, const void* v, int U, int T, const int32_t*
         else
             LN_LAUNCH(ctx, "backtrace_wave1024", (backtrace_lds_kernel<16, false>), dim3(U), dim3(64), 0, (const double*)v,
                       md.logAT.as<double>(), d_lens, path, best, U, T, md.N);
+        return 0;
+    }
+    if (dtype == LNASR_F32 && md.N <= 128 && !getenv("LNASR_NO_LDSBT") && !getenv("LNASR_F32_GENERIC")) {
+        LN_LAUNCH(ctx, "backtrace_lds_f32", (backtrace_lds_kernel<2, true, float>), dim3((U + wpb - 1) / wpb), dim3(64 * wpb),
+                  (size_t)md.N * md.N * 8, (const float*)v, md.logAT.as<double>(), d_lens, path, best, U, T, md.N);
         return 0;
     }
     if (dtype == LNASR_F32)

@@ -203,3 +203,34 @@ def test_single_gmm_batch(synth, oracle, ctx):
             si[:, np.arange(39), np.arange(39)] = mdl["var"][0]
             ref = oracle.gaussian_mixture_log(mdl["w"][0], obs[u], mdl["mu"][0], si)
             assert_close(b[u, :, 0], ref, 1e-12)
+
+
+@pytest.mark.parametrize("N,U", [(128, 5), (100, 3), (37, 4), (128, 520)])
+def test_viterbi_float32_register_kernels(N, U, synth, ctx):
+    """precision=np.float32: the register-resident Viterbi and the LDS backtrace with float storage (fp64 arithmetic,
+    v rounded to float where the reference's float32 array rounds it) against the storage-templated generic kernels
+    that the float32 golden pins (LNASR_F32_GENERIC), bit for bit; ragged lengths, a forbidden transition."""
+    import os
+    rng = np.random.default_rng(N + U)
+    d = synth.synth_discrete(N, 4, 8, seed=N)
+    A = d["A"].copy()
+    if N > 4:
+        A[3, :] = -np.inf
+        A[3, 2] = 0.0
+    ctx.upload_hmm(A, d["pi"])
+    T = 9 if U > 100 else 40
+    b = np.ascontiguousarray((-30.0 * rng.random((U, T, N))).astype(np.float32))
+    lens = rng.integers(1, T + 1, U).astype(np.int32)
+    lens[0] = T
+    r = ctx.viterbi(b, lens=lens, want_score=True)
+    os.environ["LNASR_F32_GENERIC"] = "1"
+    try:
+        ref = ctx.viterbi(b, lens=lens, want_score=True)
+    finally:
+        del os.environ["LNASR_F32_GENERIC"]
+    assert r["v"].dtype == np.float32
+    for u in range(U):
+        L = lens[u]
+        assert np.array_equal(r["v"][u, :L], ref["v"][u, :L]), "v u=%d" % u
+        assert np.array_equal(r["bt"][u, :L], ref["bt"][u, :L]) and np.array_equal(r["path"][u, :L], ref["path"][u, :L])
+    assert np.array_equal(r["score"], ref["score"])
