@@ -55,6 +55,26 @@ def has_gpu():
     return os.path.exists("/dev/kfd") and os.access("/dev/kfd", os.R_OK | os.W_OK)
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def env_switch(**kv):
+    """Set environment switches for the block and put back what was there before (the fallback-suite runs set
+    some of them for the whole process: a test must not clear those)."""
+    import os
+    before = {k: os.environ.get(k) for k in kv}
+    os.environ.update({k: str(v) for k, v in kv.items()})
+    try:
+        yield
+    finally:
+        for k, v in before.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def assert_close(a, b, rtol=1e-10, atol=0.0, msg=""):
     """allclose that treats equal infinities (and NaN==NaN) as equal."""
     a = np.asarray(a, dtype=np.float64)

@@ -3,7 +3,7 @@ C-ABI, against the golden vectors from the reference and against the CPU oracle.
 import numpy as np
 import pytest
 
-from conftest import assert_close
+from conftest import assert_close, env_switch
 
 pytestmark = pytest.mark.gpu
 
@@ -107,16 +107,11 @@ def test_metric_slice(golden, synth, oracle, ctx):
     ov, obt, opath = oracle.viterbi(mdl["A"], mdl["pi"], np.ascontiguousarray(b[0].T))
     assert np.array_equal(r["v"][0], ov) and np.array_equal(r["bt"][0], obt) and np.array_equal(r["path"][0], opath)
     # generic kernels give the same answers as the MFMA / register-resident ones
-    import os
-    os.environ["LNASR_NO_MFMA"] = "1"
-    os.environ["LNASR_NO_REGVIT"] = "1"
-    try:
+    with env_switch(LNASR_NO_MFMA=1, LNASR_NO_REGVIT=1):
         b2 = ctx.gmm_logprob(obs[:1])
         assert_close(b2[0], b[0], 1e-13)
         r2 = ctx.viterbi(b[:1], want_v=True, want_bt=False)
         assert np.array_equal(r2["v"][0], r["v"][0]) and np.array_equal(r2["path"][0], r["path"][0])
-    finally:
-        del os.environ["LNASR_NO_MFMA"], os.environ["LNASR_NO_REGVIT"]
 
 
 def test_batch_ragged_and_device_resident(synth, oracle, ctx):
@@ -178,12 +173,8 @@ def test_mfma_virtual_states(synth, oracle, ctx):
             with np.errstate(divide="ignore"):
                 ob, obm = oracle.gmm_map_b_diag(obs[u], mdl["w"], mdl["mu"], mdl["var"])
             assert_close(b[u].T, ob, 1e-12), assert_close(bm[u].transpose(1, 2, 0), obm, 1e-12)
-        import os
-        os.environ["LNASR_NO_MFMA"] = "1"
-        try:
+        with env_switch(LNASR_NO_MFMA=1):
             b2 = ctx.gmm_logprob(obs)
-        finally:
-            del os.environ["LNASR_NO_MFMA"]
         assert_close(b2, b, 1e-13)
 
 
@@ -210,7 +201,6 @@ def test_viterbi_float32_register_kernels(N, U, synth, ctx):
     """precision=np.float32: the register-resident Viterbi and the LDS backtrace with float storage (fp64 arithmetic,
     v rounded to float where the reference's float32 array rounds it) against the storage-templated generic kernels
     that the float32 golden pins (LNASR_F32_GENERIC), bit for bit; ragged lengths, a forbidden transition."""
-    import os
     rng = np.random.default_rng(N + U)
     d = synth.synth_discrete(N, 4, 8, seed=N)
     A = d["A"].copy()
@@ -223,11 +213,8 @@ def test_viterbi_float32_register_kernels(N, U, synth, ctx):
     lens = rng.integers(1, T + 1, U).astype(np.int32)
     lens[0] = T
     r = ctx.viterbi(b, lens=lens, want_score=True)
-    os.environ["LNASR_F32_GENERIC"] = "1"
-    try:
+    with env_switch(LNASR_F32_GENERIC=1):
         ref = ctx.viterbi(b, lens=lens, want_score=True)
-    finally:
-        del os.environ["LNASR_F32_GENERIC"]
     assert r["v"].dtype == np.float32
     for u in range(U):
         L = lens[u]

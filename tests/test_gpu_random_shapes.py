@@ -5,7 +5,7 @@ bit-identical to the oracle's recursion on the same numbers; statistics to 1e-8.
 import numpy as np
 import pytest
 
-from conftest import assert_close
+from conftest import assert_close, env_switch
 
 pytestmark = pytest.mark.gpu
 
@@ -111,9 +111,6 @@ def test_random_shape_full_covariance(seed, synth, oracle, ctx):
         assert_close(bm[u], np.transpose(obm, (2, 0, 1)), 1e-9, 1e-9, msg="bm " + tag)
     if D > 1 and not ctx.model_is_diag():
         st = ctx.bw_accumulate(obs, lens=lens)
-        os.environ["LNASR_NO_MFMA_STATS"] = "1"
-        try:
+        with env_switch(LNASR_NO_MFMA_STATS=1):
             ref = ctx.bw_accumulate(obs, lens=lens)
-        finally:
-            del os.environ["LNASR_NO_MFMA_STATS"]
         assert_close(st, ref, 1e-8, 1e-10, msg="stats " + tag)

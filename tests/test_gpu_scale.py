@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import assert_close
+from conftest import assert_close, env_switch
 
 pytestmark = pytest.mark.gpu
 
@@ -87,12 +87,9 @@ def test_host_buffers_are_uploaded_in_a_pipeline(synth):
     dev = ctx.decode(ctx.to_device(obs), lens=lens).to_host()
     piped = np.asarray(ctx.decode(obs, lens=lens))
     ll_piped = np.asarray(ctx.calc_prob(obs, lens=lens))
-    os.environ["LNASR_NO_PIPELINE"] = "1"
-    try:
+    with env_switch(LNASR_NO_PIPELINE=1):
         plain = np.asarray(ctx.decode(obs, lens=lens))
         ll_plain = np.asarray(ctx.calc_prob(obs, lens=lens))
-    finally:
-        del os.environ["LNASR_NO_PIPELINE"]
     for u in range(U):
         assert np.array_equal(piped[u, :lens[u]], dev[u, :lens[u]]) and np.array_equal(plain[u, :lens[u]], dev[u, :lens[u]])
     assert np.array_equal(ll_piped, ll_plain)

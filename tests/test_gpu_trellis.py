@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import assert_close
+from conftest import assert_close, env_switch
 
 pytestmark = pytest.mark.gpu
 
@@ -314,9 +314,7 @@ def test_trellises_beyond_256_states(route, synth, oracle, ctx):
     """N > 256: the frame-parallel kernels (one launch per frame over the batch; the default for small batches) and
     the per-utterance streaming kernels (large batches; forced here with LNASR_NO_FRAMEPAR) against the oracle."""
     rng = np.random.default_rng(23)
-    if route == "streaming":
-        os.environ["LNASR_NO_FRAMEPAR"] = "1"
-    try:
+    with env_switch(**({"LNASR_NO_FRAMEPAR": 1} if route == "streaming" else {})):
         for N in (257, 520):
             d = synth.synth_discrete(N, 4, 8, seed=N)
             A = d["A"].copy()
@@ -342,8 +340,6 @@ def test_trellises_beyond_256_states(route, synth, oracle, ctx):
                 v, bt, path = oracle.viterbi(A, d["pi"], ob)
                 assert np.array_equal(r["v"][u, :L], v) and np.array_equal(r["path"][u, :L], path)
                 assert np.array_equal(r["bt"][u, :L], bt)
-    finally:
-        os.environ.pop("LNASR_NO_FRAMEPAR", None)
 
 
 @pytest.mark.parametrize("N", [512, 1000, 1024])
@@ -359,13 +355,10 @@ def test_trellises_beyond_256_states_large_batch(N, synth, oracle, ctx):
     lens = rng.integers(1, T + 1, U).astype(np.int32)
     lens[0] = T
     for maxu in ("256", "4096"):                          # streaming, then frame-parallel for this batch
-        os.environ["LNASR_FRAMEPAR_MAXU"] = maxu
-        try:
+        with env_switch(LNASR_FRAMEPAR_MAXU=maxu):
             alpha, ll = ctx.forward(b, lens=lens)
             beta = ctx.backward(b, lens=lens)
             r = ctx.viterbi(b, lens=lens, want_bt=False)
-        finally:
-            os.environ.pop("LNASR_FRAMEPAR_MAXU", None)
         for u in (0, 1, 2, 3, 298, 597, 598, 599):
             L = lens[u]
             ob = np.ascontiguousarray(b[u, :L].T)
@@ -406,12 +399,9 @@ def test_forward_backward_column_owned_kernel(N, synth, oracle, ctx):
     alpha, ll = ctx.forward(b, lens=lens)
     _, ll_only = ctx.forward(b, want_alpha=False, lens=lens)
     beta = ctx.backward(b, lens=lens)
-    os.environ["LNASR_NO_COLFWD"] = "1"
-    try:
+    with env_switch(LNASR_NO_COLFWD=1):
         alpha2, ll2 = ctx.forward(b, lens=lens)
         beta2 = ctx.backward(b, lens=lens)
-    finally:
-        del os.environ["LNASR_NO_COLFWD"]
     assert np.array_equal(ll_only, ll)
     for u in range(U):
         L = lens[u]
@@ -439,11 +429,8 @@ def test_bw_statistics_full_covariance_wide(synth, ctx):
         ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["si"])
         assert not ctx.model_is_diag()
         st = ctx.bw_accumulate(obs, lens=lens)
-        os.environ["LNASR_NO_MFMA_STATS"] = "1"
-        try:
+        with env_switch(LNASR_NO_MFMA_STATS=1):
             ref = ctx.bw_accumulate(obs, lens=lens)
-        finally:
-            del os.environ["LNASR_NO_MFMA_STATS"]
         assert st.shape == ref.shape == (N * N + 2 * N + N * M + N * M * D + N * M * D * D + 3,)
         assert_close(st, ref, 1e-9, 1e-11)
         si = ctx.bw_mstep(st)["si"]
