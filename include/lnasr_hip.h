@@ -184,6 +184,13 @@ int lnasr_mfcc(lnasr_ctx* ctx, const void* signal, int sample_kind, const int64_
                const lnasr_mfcc_cfg* cfg, const double* window, const double* fbank,
                double* power_or_null, double* cepstrum_or_null, double* features);
 
+/* Ragged -> rectangular: rows row_offsets[u] .. row_offsets[u+1] of packed [sumNf, W] (e.g. the features of
+ * lnasr_mfcc) become rows 0 .. of padded[u] in padded [U, pad_rows, W]; the remaining rows are zero.  This is
+ * the layout lnasr_decode / lnasr_calc_prob / lnasr_bw_accumulate take together with lens[u] = row count
+ * (variable-length utterances batched by an offsets array).  row_offsets is a host array. */
+int lnasr_pad_rows(lnasr_ctx* ctx, const double* packed, const int64_t* row_offsets, int U, int W, int64_t pad_rows,
+                   double* padded);
+
 /* ---- multi-GPU (one process per GPU, RCCL over xGMI) --------------------------------- */
 #define LNASR_UNIQUE_ID_BYTES 128
 int lnasr_comm_unique_id(void* id_out /* LNASR_UNIQUE_ID_BYTES */);

@@ -781,6 +781,19 @@ __global__ void preemph_kernel(const double* __restrict__ x, int64_t n, double a
     if (i < n) y[i] = preemph(x, n, i, a);
 }
 
+// rows of utterance u (foff[u] .. foff[u+1]) of a packed [F, W] block -> rows u * pad .. of a [U, pad, W] block;
+// the padding rows are zero
+__global__ void pad_rows_kernel(const double* __restrict__ src, const int64_t* __restrict__ foff, int W, int64_t pad,
+                                double* __restrict__ dst) {
+    const int u = blockIdx.y;
+    const int64_t f0 = foff[u], nf = foff[u + 1] - f0;
+    const int64_t n = pad * W;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / W;
+        dst[(size_t)u * n + e] = r < nf ? src[(size_t)f0 * W + e] : 0.0;
+    }
+}
+
 static int64_t num_frames_host(int64_t n, int L, int S) {
     // int(np.ceil(np.abs(n - (L - S)) / S))  (utils.py:119)
     int64_t a = n - (int64_t)(L - S);
@@ -981,6 +994,30 @@ int lnasr_mfcc(lnasr_ctx* ctx, const void* signal, int sample_kind, const int64_
     if (cepstrum_or_null) LN_TRY(finish_out(ctx, cepstrum_or_null, d_cep, (size_t)F * n_mel * 8));
     LN_TRY(finish_out(ctx, features, d_feat, (size_t)F * 3 * W * 8));
     return 0;
+}
+
+int lnasr_pad_rows(lnasr_ctx* ctx, const double* packed, const int64_t* row_offsets, int U, int W, int64_t pad_rows,
+                   double* padded) {
+    LN_REQUIRE(ctx && packed && row_offsets && padded, "null argument");
+    LN_REQUIRE(U >= 1 && U <= 65535 && W >= 1 && pad_rows >= 1, "bad U=%d / W=%d / pad_rows=%lld", U, W, (long long)pad_rows);
+    LN_REQUIRE(!is_device_ptr(row_offsets), "row_offsets must be a host array");
+    LN_REQUIRE(row_offsets[0] == 0, "row_offsets[0] must be 0");
+    for (int u = 0; u < U; ++u) {
+        const int64_t nf = row_offsets[u + 1] - row_offsets[u];
+        LN_REQUIRE(nf >= 0 && nf <= pad_rows, "utterance %d has %lld rows, pad_rows is %lld", u, (long long)nf, (long long)pad_rows);
+    }
+    const int64_t F = row_offsets[U];
+    const void* d_src;
+    void* d_dst;
+    LN_TRY(stage_in(ctx, packed, (size_t)F * W * 8, ctx->ws_in, &d_src));
+    LN_TRY(stage_out(ctx, padded, (size_t)U * pad_rows * W * 8, ctx->ws_out, &d_dst));
+    LN_TRY(ctx->ws_in4.reserve((size_t)(U + 1) * 8));
+    LN_HIP(hipMemcpyAsync(ctx->ws_in4.p, row_offsets, (size_t)(U + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    LN_HIP(hipStreamSynchronize(ctx->stream));           // row_offsets belongs to the caller
+    const unsigned gx = (unsigned)std::min<int64_t>((pad_rows * W + 255) / 256, 1024);
+    LN_LAUNCH(ctx, "pad_rows", pad_rows_kernel, dim3(gx, U), dim3(256), 0, (const double*)d_src, ctx->ws_in4.as<int64_t>(), W,
+              pad_rows, (double*)d_dst);
+    return finish_out(ctx, padded, d_dst, (size_t)U * pad_rows * W * 8);
 }
 
 }  // extern "C"

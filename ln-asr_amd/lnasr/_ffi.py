@@ -75,6 +75,7 @@ SIGNATURES = {
     "lnasr_preemphasis": [_vp, _vp, _i64, _dbl, _vp],
     "lnasr_split_frames": [_vp, _vp, _i64, _i, _i, _vp],
     "lnasr_mfcc": [_vp, _vp, _i, _vp, _i, _P(MfccCfgStruct), _vp, _vp, _vp, _vp, _vp],
+    "lnasr_pad_rows": [_vp, _vp, _vp, _i, _i, _i64, _vp],
     "lnasr_comm_unique_id": [_vp],
     "lnasr_comm_init": [_vp, _vp, _i, _i],
     "lnasr_comm_destroy": [_vp],
@@ -567,6 +568,19 @@ class Context:
         check(lib().lnasr_mfcc(self.handle, _ptr(signal), kind, _ptr(offsets), U, C.byref(cfg), _ptr(window),
                                _ptr(fbank), _ptr(power), _ptr(cep), _ptr(feat)))
         return power, cep, feat, foff
+
+    def pad_rows(self, packed, row_offsets, pad_rows=None):
+        """packed [F, W] (host or DeviceArray) + row offsets [U+1] -> ([U, pad_rows, W], lens [U] int32): the
+        rectangular batch decode / calc_prob / bw_accumulate take.  pad_rows defaults to the longest utterance."""
+        packed = _in(packed, np.float64)
+        row_offsets = np.ascontiguousarray(row_offsets, dtype=np.int64)
+        U, W = len(row_offsets) - 1, int(packed.shape[-1])
+        lens = np.diff(row_offsets).astype(np.int32)
+        if pad_rows is None:
+            pad_rows = int(lens.max())
+        out = self._out(isinstance(packed, DeviceArray), (U, int(pad_rows), W), np.float64)
+        check(lib().lnasr_pad_rows(self.handle, _ptr(packed), _ptr(row_offsets), U, W, int(pad_rows), _ptr(out)))
+        return out, lens
 
     # -- multi-GPU ---------------------------------------------------------------------------------
     def comm_init(self, unique_id, rank, nranks):

@@ -140,3 +140,34 @@ def test_pcm_to_paths_on_device(synth):
     assert np.array_equal(path_dev, np.asarray(ctx.decode(host_feat)))
     with pytest.raises(ValueError):
         feat.view((U, T, D + 1))
+
+
+def test_ragged_pcm_to_paths_on_device(synth):
+    """Variable-length utterances batched by offsets: int16 PCM -> MFCC (packed [F, 39]) -> pad_rows ->
+    decode with lens, all on the device, equals decoding every utterance on its own."""
+    from lnasr import _ffi
+    from lnasr.mfcc import MFCC
+    ctx = _ffi.default_ctx()
+    N, M, D = 12, 3, 39
+    rng = np.random.default_rng(4)
+    ns = [16240, 4000, 700, 9999, 16241, 2500]
+    pcm = [rng.integers(-4000, 4000, n).astype(np.int16) for n in ns]
+    offs = np.concatenate([[0], np.cumsum(ns)]).astype(np.int64)
+    mdl = synth.synth_model(N, M, D, seed=2)
+    ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
+    m = MFCC()
+    cfg, win, bank = m._cfg()
+    _, _, feat, foff = ctx.mfcc(ctx.to_device(np.concatenate(pcm)), offs, cfg, win, bank, False, False)
+    padded, lens = ctx.pad_rows(feat, foff)
+    assert padded.shape == (len(ns), int(np.diff(foff).max()), D) and np.array_equal(lens, np.diff(foff))
+    paths = ctx.decode(padded, lens=lens).to_host()
+    host = padded.to_host()
+    for u, x in enumerate(pcm):
+        fu = m.calc_mfcc(x)[2]
+        assert np.array_equal(host[u, :lens[u]], fu) and not host[u, lens[u]:].any()
+        assert np.array_equal(paths[u, :lens[u]], np.asarray(ctx.decode(fu[None]))[0])
+    # host arrays take the same route; a pad shorter than an utterance is refused
+    p2, _ = ctx.pad_rows(feat.to_host(), foff, pad_rows=int(lens.max()) + 3)
+    assert p2.shape[1] == lens.max() + 3 and np.array_equal(p2[:, :lens.max()], host)
+    with pytest.raises(_ffi.LnasrError):
+        ctx.pad_rows(feat, foff, pad_rows=int(lens.max()) - 1)
