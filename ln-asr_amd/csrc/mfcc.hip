@@ -360,23 +360,26 @@ __device__ __forceinline__ void mel_dct_frames4(const Mel512Lane& ml, double* sl
     constexpr int FS = kX4FS;
     double s[4] = {0.0, 0.0, 0.0, 0.0};
     const double* pp = slice + ml.lo;
-    const double* tp = ml.taps_in_lds ? ml.tp : ml.fb;
-    for (int i = 0; i < ml.cmax; i += 4) {
-        double tap[4], pv[4][4];
+    auto mel = [&](const double* tp) {             // called once per source so that each keeps its address space
+        for (int i = 0; i < ml.cmax; i += 4) {
+            double tap[4], pv[4][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const bool in = i + q < ml.cnt;         // past the lane's count: index 0, tap 0.0 (adds nothing)
-            const int ii = in ? i + q : 0;
-            const double t = tp[ii];
-            tap[q] = in ? t : 0.0;
+            for (int q = 0; q < 4; ++q) {
+                const bool in = i + q < ml.cnt;     // past the lane's count: index 0, tap 0.0 (adds nothing)
+                const int ii = in ? i + q : 0;
+                const double t = tp[ii];
+                tap[q] = in ? t : 0.0;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) pv[r][q] = pp[r * FS + ii];
+                for (int r = 0; r < 4; ++r) pv[r][q] = pp[r * FS + ii];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[r] = fma(pv[r][q], tap[q], s[r]);
         }
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s[r] = fma(pv[r][q], tap[q], s[r]);
-    }
+    };
+    if (ml.taps_in_lds) mel(ml.tp);                // taps in the LDS table
+    else mel(ml.fb);                               // filter bank too dense for it: from global memory
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const double s1 = shfl_f64(s[r], (lane + 1) & 63), s2 = shfl_f64(s[r], (lane + 2) & 63);
