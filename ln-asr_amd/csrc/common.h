@@ -100,6 +100,9 @@ struct lnasr_ctx {
     lnasr::DevBuf ws_p, ws_q, ws_raw;                      // Baum-Welch statistics: xi factors, raw mixture moments
     lnasr::DevBuf ws_w1, ws_w2, ws_w3;                     // float32 storage: widened inputs / outputs of the f64 kernels
     lnasr::DevBuf ws_pad;                                  // bm of a padded model before compaction
+    lnasr::DevBuf ws_bp;                                   // byte back-pointers of the tiny-model Viterbi (N <= 16)
+    const void* bp_v = nullptr;                            // the v array ws_bp belongs to (set by viterbi_device,
+    int bp_U = 0, bp_T = 0, bp_nmax = 0;                   //   consumed by backtrace_device)
     // MFCC constants (twiddles, DCT matrix), kept on the device between calls with the same fft_n / n_mel;
     // the per-call frame offsets live here too so that the asynchronous upload never reads a dead host buffer
     lnasr::DevBuf mfcc_const;

@@ -392,6 +392,166 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Tiny models (N <= 16): the character-segmentation HMM of scripts/seg/seg.py (n = 4, one sequence of tens of
+// thousands of symbols) and the toy models of the reference's tests.  One WAVE per utterance, no LDS, no barrier:
+// lane j holds v[t-1, j]; v[t-1, i] reaches the others as a scalar (v_readlane), the column A[:, j] sits in
+// registers, and the winning i is kept as a byte -- with N this small the back-pointers cost N bytes per frame and
+// turn the backtrace into a chain of scalar table look-ups instead of an arg-max over a re-added column.
+// Same additions and the same first-index tie rule as every other kernel here: bit-identical v, bt, path.
+//   bp [U][T][NMAX] bytes: bp[u, t, j] = argmax_i(v[t-1, i] + A[i, j]),  bp[u, 0, :] = 0
+// ------------------------------------------------------------------------------------------
+template <typename TS, int NMAX>
+__global__ __launch_bounds__(256) void viterbi_tiny_kernel(const TS* __restrict__ b, const double* __restrict__ A,
+                                                           const double* __restrict__ pi, const int32_t* __restrict__ lens,
+                                                           TS* __restrict__ v, uint8_t* __restrict__ bp, int U, int T, int N) {
+    // Global memory is touched 64 frames at a time (emissions in, v and back-pointers out, all through the wave's
+    // LDS slice): with a load or a store in every frame the recursion ran at the latency of the memory counter
+    // (vmcnt is in order: the wait for an emission also waited for the store of the frame before), 275 ns a frame.
+    constexpr int C = 64;
+    __shared__ double bch[4][C * NMAX];                   // emissions of the chunk, [frame][state] with stride N
+    __shared__ double vch[4][C * NMAX];                   // v of the chunk, same layout
+    __shared__ uint8_t bpch[4][C * NMAX];                 // back-pointers, stride NMAX
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int u = blockIdx.x * (blockDim.x >> 6) + w;
+    if (u >= U) return;
+    const int L = lens[u];
+    if (L <= 0) return;
+    const bool act = lane < N;
+    const int j = act ? lane : N - 1;
+    double a[NMAX];                                       // A[i, j]; rows beyond N never win
+#pragma unroll
+    for (int i = 0; i < NMAX; ++i) a[i] = i < N ? A[(size_t)i * N + j] : LN_NEG_INF;
+    const TS* bu = b + (size_t)u * T * N;
+    TS* vu = v + (size_t)u * T * N;
+    uint8_t* bpu = bp + (size_t)u * T * NMAX;
+    double* bc = bch[w];
+    double* vc = vch[w];
+    uint8_t* pc = bpch[w];
+    constexpr int EPL = (C * NMAX + 63) / 64;             // chunk elements per lane (at most)
+    double stage[EPL];
+    auto fetch = [&](int t0) {                            // emissions of frames t0 .. t0 + C - 1 (clamped) -> registers
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int idx = lane + 64 * e;
+            const size_t g = (size_t)t0 * N + idx;
+            stage[e] = (idx < C * N && g < (size_t)L * N) ? ld(bu, g) : 0.0;
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int idx = lane + 64 * e;
+            if (idx < C * N) bc[idx] = stage[e];
+        }
+    };
+    fetch(0);
+    stash();
+    __builtin_amdgcn_wave_barrier();
+    double vcur = 0.0;
+    for (int t0 = 0; t0 < L; t0 += C) {
+        const int nfr = L - t0 < C ? L - t0 : C;
+        if (t0 + C < L) fetch(t0 + C);                    // next chunk's emissions travel during this one
+        double bnx = bc[j];
+        for (int k = 0; k < nfr; ++k) {
+            const double bt_ = bnx;
+            bnx = bc[(k + 1 < C ? k + 1 : k) * N + j];    // the next frame's emission is read a frame ahead
+            int bi = 0;
+            if (t0 + k == 0) {
+                vcur = rnd<TS>(pi[j] + bt_);
+            } else {
+                // v[t-1, i] comes from lane i of the DPP row (the utterance sits in lanes 0..N-1 of row 0); the NMAX
+                // candidates meet in a tree whose upper operand wins only when strictly greater: the first index
+                // among equal maxima (numpy.argmax), log2(NMAX) dependent steps instead of NMAX
+                double cnd[NMAX];
+                int idx[NMAX];
+                static_for<0, NMAX>([&](auto I) {
+                    constexpr int i = decltype(I)::value;
+                    cnd[i] = mov_bcast<i>(vcur) + a[i];
+                    idx[i] = i;
+                });
+#pragma unroll
+                for (int wd = NMAX / 2; wd >= 1; wd /= 2)
+#pragma unroll
+                    for (int i = 0; i < wd; ++i) {
+                        const bool win = cnd[2 * i + 1] > cnd[2 * i];
+                        cnd[i] = win ? cnd[2 * i + 1] : cnd[2 * i];
+                        idx[i] = win ? idx[2 * i + 1] : idx[2 * i];
+                    }
+                bi = idx[0];
+                vcur = rnd<TS>(cnd[0] + bt_);
+            }
+            if (act) vc[k * N + j] = vcur;
+            if (lane < NMAX) pc[k * NMAX + lane] = (uint8_t)bi;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // the chunk's v and back-pointers leave in whole rows
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int idx = lane + 64 * e;
+            if (idx < nfr * N) st(vu, (size_t)t0 * N + idx, vc[idx]);
+        }
+        {
+            const uint32_t* pw = reinterpret_cast<const uint32_t*>(pc);
+            uint32_t* gw = reinterpret_cast<uint32_t*>(bpu + (size_t)t0 * NMAX);
+#pragma unroll
+            for (int e = 0; e < (C * NMAX / 4 + 63) / 64; ++e) {
+                const int idx = lane + 64 * e;
+                if (idx < nfr * NMAX / 4) gw[idx] = pw[idx];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (t0 + C < L) stash();
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <typename TS, int NMAX>
+__global__ __launch_bounds__(256) void backtrace_tiny_kernel(const TS* __restrict__ v, const uint8_t* __restrict__ bp,
+                                                             const int32_t* __restrict__ lens, uint32_t* __restrict__ path,
+                                                             double* __restrict__ best, int U, int T, int N) {
+    const int lane = threadIdx.x & 63;
+    const int u = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (u >= U) return;
+    const int L = lens[u];
+    if (L <= 0) return;
+    // last frame: first index among equal maxima
+    const double x = lane < N ? ld(v, ((size_t)u * T + (L - 1)) * N + lane) : LN_NEG_INF;
+    const double mx = wave_max_dpp(x);
+    const unsigned long long mk = __ballot(x == mx);
+    int p = __builtin_amdgcn_readfirstlane(mk ? __ffsll((long long)mk) - 1 : 0);
+    if (lane == 0 && best) best[u] = mx;
+    uint32_t* pu = path + (size_t)u * T;
+    const uint32_t* rows = reinterpret_cast<const uint32_t*>(bp + (size_t)u * T * NMAX);   // NMAX / 4 words per frame
+    constexpr int WPR = NMAX / 4;
+    uint32_t mine = 0;
+    if (lane == ((L - 1) & 63)) mine = (uint32_t)p;
+    if (((L - 1) & 63) == 0) pu[L - 1] = (uint32_t)p;
+    // frames are walked 64 at a time: lane l holds the back-pointer row of frame tb - l; path[t - 1] = row(t)[p]
+    for (int tb = L - 1; tb >= 1; tb -= 64) {
+        uint32_t w[WPR];
+        const int tl = tb - lane > 0 ? tb - lane : 0;
+#pragma unroll
+        for (int q = 0; q < WPR; ++q) w[q] = rows[(size_t)tl * WPR + q];
+#pragma unroll 8
+        for (int k = 0; k < 64; ++k) {
+            const int t = tb - k;
+            if (t >= 1) {                                 // wave-uniform
+                uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)w[0], k);
+#pragma unroll
+                for (int q = 1; q < WPR; ++q) {
+                    const uint32_t wq = (uint32_t)__builtin_amdgcn_readlane((int)w[q], k);
+                    word = (p >> 2) == q ? wq : word;
+                }
+                p = (int)((word >> (8 * (p & 3))) & 0xffu);
+                const int tp = t - 1;
+                if (lane == (tp & 63)) mine = (uint32_t)p;
+                if ((tp & 63) == 0 && tp + lane < L) pu[tp + lane] = mine;      // frames tp .. tp + 63 are complete
+            }
+        }
+    }
+}
+
 // Backtrace for N <= 128 (fp64): A^T lives in LDS so the only dependent memory access per step is
 // an LDS row read; arg-max = DPP wave max, then the first lane holding the max (ballot + ffs),
 // which is numpy.argmax's first-index rule because lane l holds states l and l+64.  Decoded
@@ -1861,6 +2021,32 @@ int viterbi_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
     const int N = md.N;
     const double* A = md.logA.as<double>();
     const double* pi = md.logpi.as<double>();
+    ctx->bp_v = nullptr;
+    if (N <= 16 && !getenv("LNASR_NO_TINYVIT")) {
+        // one wave per utterance, byte back-pointers for the backtrace (viterbi_tiny_kernel)
+        const int nmax = N <= 4 ? 4 : (N <= 8 ? 8 : 16);
+        LN_TRY(ctx->ws_bp.reserve((size_t)U * T * nmax));
+        uint8_t* bp = ctx->ws_bp.as<uint8_t>();
+        const dim3 grid((U + 3) / 4), block(256);
+#define LN_TINY(TS, NM)                                                                                          \
+    LN_LAUNCH(ctx, "viterbi_tiny", (viterbi_tiny_kernel<TS, NM>), grid, block, 0, (const TS*)b, A, pi, d_lens, (TS*)v, bp, \
+              U, T, N)
+        if (dtype == LNASR_F32) {
+            if (nmax == 4) LN_TINY(float, 4);
+            else if (nmax == 8) LN_TINY(float, 8);
+            else LN_TINY(float, 16);
+        } else {
+            if (nmax == 4) LN_TINY(double, 4);
+            else if (nmax == 8) LN_TINY(double, 8);
+            else LN_TINY(double, 16);
+        }
+#undef LN_TINY
+        ctx->bp_v = v;
+        ctx->bp_U = U;
+        ctx->bp_T = T;
+        ctx->bp_nmax = nmax;
+        return 0;
+    }
     if (dtype == LNASR_F64 && !getenv("LNASR_NO_REGVIT")) {
         const char* var = getenv("LNASR_VIT");
         const char vsel = var ? var[0] : 'e';
@@ -1955,6 +2141,27 @@ int backtrace_device(lnasr_ctx* ctx, const void* v, int U, int T, const int32_t*
                      double* best) {
     Model& md = ctx->model;
     const int wpb = 4;
+    if (ctx->bp_v == v && ctx->bp_U == U && ctx->bp_T == T && v != nullptr) {
+        // v came from viterbi_tiny_kernel: its byte back-pointers are in ws_bp
+        const uint8_t* bp = ctx->ws_bp.as<uint8_t>();
+        const int nmax = ctx->bp_nmax;
+        ctx->bp_v = nullptr;
+        const dim3 grid((U + wpb - 1) / wpb), block(64 * wpb);
+#define LN_TINY(TS, NM)                                                                                        \
+    LN_LAUNCH(ctx, "backtrace_tiny", (backtrace_tiny_kernel<TS, NM>), grid, block, 0, (const TS*)v, bp, d_lens, path, best, \
+              U, T, md.N)
+        if (dtype == LNASR_F32) {
+            if (nmax == 4) LN_TINY(float, 4);
+            else if (nmax == 8) LN_TINY(float, 8);
+            else LN_TINY(float, 16);
+        } else {
+            if (nmax == 4) LN_TINY(double, 4);
+            else if (nmax == 8) LN_TINY(double, 8);
+            else LN_TINY(double, 16);
+        }
+#undef LN_TINY
+        return 0;
+    }
     if (dtype == LNASR_F64 && md.N <= 128 && !getenv("LNASR_NO_LDSBT")) {
         LN_LAUNCH(ctx, "backtrace_lds", (backtrace_lds_kernel<2, true>), dim3((U + wpb - 1) / wpb), dim3(64 * wpb),
                   (size_t)md.N * md.N * 8, (const double*)v, md.logAT.as<double>(), d_lens, path, best, U, T, md.N);
