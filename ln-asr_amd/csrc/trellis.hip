@@ -533,21 +533,23 @@ __global__ __launch_bounds__(256) void backtrace_tiny_kernel(const TS* __restric
         const int tl = tb - lane > 0 ? tb - lane : 0;
 #pragma unroll
         for (int q = 0; q < WPR; ++q) w[q] = rows[(size_t)tl * WPR + q];
-#pragma unroll 8
-        for (int k = 0; k < 64; ++k) {
-            const int t = tb - k;
-            if (t >= 1) {                                 // wave-uniform
-                uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)w[0], k);
+        auto step = [&](int k) {
+            uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)w[0], k);
 #pragma unroll
-                for (int q = 1; q < WPR; ++q) {
-                    const uint32_t wq = (uint32_t)__builtin_amdgcn_readlane((int)w[q], k);
-                    word = (p >> 2) == q ? wq : word;
-                }
-                p = (int)((word >> (8 * (p & 3))) & 0xffu);
-                const int tp = t - 1;
-                if (lane == (tp & 63)) mine = (uint32_t)p;
-                if ((tp & 63) == 0 && tp + lane < L) pu[tp + lane] = mine;      // frames tp .. tp + 63 are complete
+            for (int q = 1; q < WPR; ++q) {
+                const uint32_t wq = (uint32_t)__builtin_amdgcn_readlane((int)w[q], k);
+                word = (p >> 2) == q ? wq : word;
             }
+            p = (int)((word >> (8 * (p & 3))) & 0xffu);
+            const int tp = tb - k - 1;
+            if (lane == (tp & 63)) mine = (uint32_t)p;
+            if ((tp & 63) == 0 && tp + lane < L) pu[tp + lane] = mine;          // frames tp .. tp + 63 are complete
+        };
+        if (tb >= 64) {                                   // a whole chunk: 64 steps, lanes known at compile time
+#pragma unroll
+            for (int k = 0; k < 64; ++k) step(k);
+        } else {
+            for (int k = 0; k < tb; ++k) step(k);         // frames tb .. 1
         }
     }
 }
