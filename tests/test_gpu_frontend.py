@@ -148,3 +148,30 @@ def test_mfcc_ragged_edges(oracle):
             assert_close(p, op, 1e-9, 1e-6, msg="power n=%d" % len(x))
             assert_close(c, oc, 1e-9, 1e-9, msg="cepstrum n=%d" % len(x))
             assert_close(fu, of, 1e-9, 1e-9, msg="features n=%d" % len(x))
+
+
+@pytest.mark.parametrize("kw", [
+    dict(frame_T=32e-3, frame_stride=8e-3, mfbank_num=26, cepstrum_num=12),      # L = 512 = fft_N, S = 128
+    dict(frame_T=20e-3, frame_stride=5e-3, mfbank_num=48, cepstrum_num=20),      # 48 filters, 21 feature columns
+    dict(frame_T=25e-3, frame_stride=10e-3, mfbank_num=40, cepstrum_num=39, hpf_alpha=0.9),   # n_cep = n_mel - 1
+    dict(fs=8000, frame_T=50e-3, frame_stride=12.5e-3, mfbank_num=23, cepstrum_num=10),       # 8 kHz, L = 400, S = 100
+])
+def test_mfcc_fft512_other_parameters(kw, oracle):
+    """The four-frames-per-wave fft-512 kernel away from the reference's defaults: frame length equal to the FFT
+    size, other hops, filter counts up to the table limit (48), more than 16 feature columns (the unsplit DCT),
+    another pre-emphasis; single utterance (power and cepstrum returned) and a ragged int16 batch, against the oracle."""
+    from lnasr.mfcc import MFCC
+    rng = np.random.default_rng(11)
+    m = MFCC(**kw)
+    ocfg = oracle.MfccCfg(**kw)
+    assert m.fft_N == 512
+    sigs = [rng.integers(-3000, 3000, n).astype(np.int16) for n in (5000, 1777, 12345)]
+    feat, foff = m.calc_mfcc_batch(sigs)
+    for u, x in enumerate(sigs):
+        p, c, fu = m.calc_mfcc(x)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            op, oc, of = oracle.mfcc(x.astype(np.float64), ocfg)
+        assert_close(p, op, 1e-9, 1e-6, msg="power %d" % u)
+        assert_close(c, oc, 1e-9, 1e-9, msg="cepstrum %d" % u)
+        assert_close(fu, of, 1e-9, 1e-9, msg="features %d" % u)
+        assert np.array_equal(feat[foff[u]:foff[u + 1]], fu, equal_nan=True)
