@@ -221,3 +221,31 @@ def test_viterbi_float32_register_kernels(N, U, synth, ctx):
         assert np.array_equal(r["v"][u, :L], ref["v"][u, :L]), "v u=%d" % u
         assert np.array_equal(r["bt"][u, :L], ref["bt"][u, :L]) and np.array_equal(r["path"][u, :L], ref["path"][u, :L])
     assert np.array_equal(r["score"], ref["score"])
+
+
+@pytest.mark.parametrize("N", [1, 3, 4, 7, 8, 13, 16])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_viterbi_tiny_models_chunk_boundaries(N, dtype, synth, oracle, ctx):
+    """N <= 16 (one-wave kernels, byte back-pointers, 64-frame chunks): utterance lengths on and around the chunk
+    boundaries, ties (the first index wins), a forbidden transition; v / bt / path against the oracle bit for bit
+    (float32: the oracle run on float32 emissions with float32 v, as the reference does)."""
+    rng = np.random.default_rng(100 + N)
+    d = synth.synth_discrete(N, 4, 8, seed=N)
+    A = d["A"].copy()
+    if N > 2:
+        A[1, :] = -np.inf
+        A[1, 0] = 0.0
+    ctx.upload_hmm(A, d["pi"])
+    lens = np.array([200, 1, 63, 64, 65, 127, 128, 129, 192, 193], dtype=np.int32)
+    U, T = len(lens), int(lens.max())
+    b = np.round(-8.0 * rng.random((U, T, N)), 1).astype(dtype)          # coarse values: plenty of exact ties
+    r = ctx.viterbi(b, lens=lens, want_score=True)
+    assert r["v"].dtype == dtype
+    for u in range(U):
+        L = lens[u]
+        ob = np.ascontiguousarray(b[u, :L].T)
+        v, bt, path = oracle.viterbi(A, d["pi"], ob, precision=dtype)
+        assert np.array_equal(r["v"][u, :L], v), "v N=%d u=%d" % (N, u)
+        assert np.array_equal(r["bt"][u, :L], bt), "bt N=%d u=%d" % (N, u)
+        assert np.array_equal(r["path"][u, :L], path), "path N=%d u=%d" % (N, u)
+        assert r["score"][u] == v[-1].max()
