@@ -2,7 +2,7 @@
 """Per-row measurements of the other BASELINE.json configs on one GPU (development / DESIGN.md numbers;
 the driver-facing benchmark is bench.py).  Inputs resident in HBM, HIP-event kernel times.
 
-    python tools/bench_rows.py [mfcc] [e2e] [gmm] [fwd] [bw] [all]
+    python tools/bench_rows.py [mfcc] [e2e] [seg] [gmm] [fwd] [bw] [all]
 """
 import os
 import sys
@@ -77,6 +77,15 @@ if what & {"e2e", "all"}:
 
     timed("int16 PCM -> MFCC -> decode (U=%d)" % U, e2e, U * 1000, "frames", algo_bytes=U * 1000 * (632.0 + 4))
     del d_pcm, feat, path
+
+if what & {"seg", "all"}:
+    # scripts/seg/seg.py shape: BMES segmentation HMM, n = 4 states, m = 65536 symbols, one long
+    # sequence through the reference-shaped API (host arrays in, host path out)
+    from lnasr.hmm import HMM
+    n, m, T = 4, 65536, 30000
+    d = synth.synth_discrete(n, m, T, seed=3)
+    h = HMM(n, m, d["A"], d["B"], d["pi"])
+    timed("HMM.decode n=4 m=65536 T=%d" % T, lambda: h.decode(d["obs"]), T, "frames")
 
 if what & {"gmm", "all"}:
     # config 3: T=1000, M=16, D=39, U=1024; single GMM (N=1) and the 128-state bank
