@@ -410,8 +410,9 @@ __global__ __launch_bounds__(256) void viterbi_tiny_kernel(const TS* __restrict_
     // (vmcnt is in order: the wait for an emission also waited for the store of the frame before), 275 ns a frame.
     constexpr int C = 64;
     __shared__ double bch[4][C * NMAX];                   // emissions of the chunk, [frame][state] with stride N
-    __shared__ double vch[4][C * NMAX];                   // v of the chunk, same layout
-    __shared__ uint8_t bpch[4][C * NMAX];                 // back-pointers, stride NMAX
+    __shared__ double vch[4][C * NMAX + 1];               // v of the chunk, same layout (+ a slot for idle lanes)
+    __shared__ uint8_t bpch[4][C * NMAX + 4];             // back-pointers, stride NMAX (+ a slot for idle lanes)
+    constexpr int VDUMP = C * NMAX, PDUMP = C * NMAX;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int u = blockIdx.x * (blockDim.x >> 6) + w;
     if (u >= U) return;
@@ -448,41 +449,43 @@ __global__ __launch_bounds__(256) void viterbi_tiny_kernel(const TS* __restrict_
     fetch(0);
     stash();
     __builtin_amdgcn_wave_barrier();
-    double vcur = 0.0;
+    // lanes with nothing to write aim at a spare slot behind the chunk instead of branching around the store: the
+    // frame loop below is one straight block (a lone wave pays dearly for every taken branch)
+    double vcur = rnd<TS>(pi[j] + bc[j]);                 // frame 0
     for (int t0 = 0; t0 < L; t0 += C) {
         const int nfr = L - t0 < C ? L - t0 : C;
         if (t0 + C < L) fetch(t0 + C);                    // next chunk's emissions travel during this one
-        double bnx = bc[j];
-        for (int k = 0; k < nfr; ++k) {
+        int k0 = 0;
+        if (t0 == 0) {
+            if (act) vc[j] = vcur;
+            if (lane < NMAX) pc[lane] = 0;
+            k0 = 1;
+        }
+        double bnx = bc[(k0 < C ? k0 : 0) * N + j];
+        for (int k = k0; k < nfr; ++k) {
             const double bt_ = bnx;
             bnx = bc[(k + 1 < C ? k + 1 : k) * N + j];    // the next frame's emission is read a frame ahead
-            int bi = 0;
-            if (t0 + k == 0) {
-                vcur = rnd<TS>(pi[j] + bt_);
-            } else {
-                // v[t-1, i] comes from lane i of the DPP row (the utterance sits in lanes 0..N-1 of row 0); the NMAX
-                // candidates meet in a tree whose upper operand wins only when strictly greater: the first index
-                // among equal maxima (numpy.argmax), log2(NMAX) dependent steps instead of NMAX
-                double cnd[NMAX];
-                int idx[NMAX];
-                static_for<0, NMAX>([&](auto I) {
-                    constexpr int i = decltype(I)::value;
-                    cnd[i] = mov_bcast<i>(vcur) + a[i];
-                    idx[i] = i;
-                });
+            // v[t-1, i] comes from lane i of the DPP row (the utterance sits in lanes 0..N-1 of row 0); the NMAX
+            // candidates meet in a tree whose upper operand wins only when strictly greater: the first index
+            // among equal maxima (numpy.argmax), log2(NMAX) dependent steps instead of NMAX
+            double cnd[NMAX];
+            int idx[NMAX];
+            static_for<0, NMAX>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                cnd[i] = mov_bcast<i>(vcur) + a[i];
+                idx[i] = i;
+            });
 #pragma unroll
-                for (int wd = NMAX / 2; wd >= 1; wd /= 2)
+            for (int wd = NMAX / 2; wd >= 1; wd /= 2)
 #pragma unroll
-                    for (int i = 0; i < wd; ++i) {
-                        const bool win = cnd[2 * i + 1] > cnd[2 * i];
-                        cnd[i] = win ? cnd[2 * i + 1] : cnd[2 * i];
-                        idx[i] = win ? idx[2 * i + 1] : idx[2 * i];
-                    }
-                bi = idx[0];
-                vcur = rnd<TS>(cnd[0] + bt_);
-            }
-            if (act) vc[k * N + j] = vcur;
-            if (lane < NMAX) pc[k * NMAX + lane] = (uint8_t)bi;
+                for (int i = 0; i < wd; ++i) {
+                    const bool win = cnd[2 * i + 1] > cnd[2 * i];
+                    cnd[i] = win ? cnd[2 * i + 1] : cnd[2 * i];
+                    idx[i] = win ? idx[2 * i + 1] : idx[2 * i];
+                }
+            vcur = rnd<TS>(cnd[0] + bt_);
+            vc[act ? k * N + j : VDUMP] = vcur;
+            pc[lane < NMAX ? k * NMAX + lane : PDUMP] = (uint8_t)idx[0];
         }
         __builtin_amdgcn_wave_barrier();
         // the chunk's v and back-pointers leave in whole rows
