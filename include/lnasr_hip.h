@@ -196,6 +196,8 @@ int lnasr_pad_rows(lnasr_ctx* ctx, const double* packed, const int64_t* row_offs
 int lnasr_comm_unique_id(void* id_out /* LNASR_UNIQUE_ID_BYTES */);
 int lnasr_comm_init(lnasr_ctx* ctx, const void* id, int rank, int nranks);
 int lnasr_comm_destroy(lnasr_ctx* ctx);
+/* rank and size as RCCL reports them for the live communicator (ncclCommUserRank / ncclCommCount) */
+int lnasr_comm_info(lnasr_ctx* ctx, int* rank, int* nranks);
 /* gather of decoded state paths: every rank contributes count u32, receives nranks*count */
 int lnasr_allgather_u32(lnasr_ctx* ctx, const uint32_t* local, size_t count, uint32_t* all);
 /* same gather for state paths of a model with n_states states: indices below 256 travel as bytes (a quarter

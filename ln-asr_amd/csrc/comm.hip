@@ -30,6 +30,7 @@ int lnasr_comm_unique_id(void* id_out) {
 }
 
 int lnasr_comm_init(lnasr_ctx* ctx, const void* idb, int rank, int nranks) {
+    LN_ENTER(ctx);
     LN_REQUIRE(ctx && idb, "null argument");
     LN_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank %d / nranks %d", rank, nranks);
     LN_REQUIRE(!ctx->comm, "communicator already initialised");
@@ -45,6 +46,7 @@ int lnasr_comm_init(lnasr_ctx* ctx, const void* idb, int rank, int nranks) {
 }
 
 int lnasr_comm_destroy(lnasr_ctx* ctx) {
+    LN_ENTER(ctx);
     if (!ctx || !ctx->comm) return 0;
     (void)hipStreamSynchronize(ctx->stream);
     ncclCommDestroy((ncclComm_t)ctx->comm);
@@ -54,7 +56,20 @@ int lnasr_comm_destroy(lnasr_ctx* ctx) {
     return 0;
 }
 
+int lnasr_comm_info(lnasr_ctx* ctx, int* rank, int* nranks) {
+    LN_ENTER(ctx);
+    LN_REQUIRE(ctx, "null ctx");
+    if (!ctx->comm) return fail(LNASR_E_COMM, "communicator not initialised (lnasr_comm_init)");
+    int r = -1, n = 0;   // asked of RCCL itself, not echoed from lnasr_comm_init's arguments
+    LN_NCCL(ncclCommUserRank((ncclComm_t)ctx->comm, &r));
+    LN_NCCL(ncclCommCount((ncclComm_t)ctx->comm, &n));
+    if (rank) *rank = r;
+    if (nranks) *nranks = n;
+    return 0;
+}
+
 int lnasr_allgather_u32(lnasr_ctx* ctx, const uint32_t* local, size_t count, uint32_t* all) {
+    LN_ENTER(ctx);
     LN_REQUIRE(ctx && local && all, "null argument");
     if (!ctx->comm) return fail(LNASR_E_COMM, "communicator not initialised (lnasr_comm_init)");
     const size_t nr = (size_t)ctx->nranks;
@@ -81,6 +96,7 @@ __global__ void unpack_u8_kernel(const uint32_t* __restrict__ src, uint32_t* __r
 }
 
 int lnasr_allgather_paths(lnasr_ctx* ctx, const uint32_t* local, size_t count, int n_states, uint32_t* all) {
+    LN_ENTER(ctx);
     LN_REQUIRE(ctx && local && all, "null argument");
     if (!ctx->comm) return fail(LNASR_E_COMM, "communicator not initialised (lnasr_comm_init)");
     if (n_states > 256 || n_states < 1 || count % 4 != 0 || count == 0) return lnasr_allgather_u32(ctx, local, count, all);
@@ -102,6 +118,7 @@ int lnasr_allgather_paths(lnasr_ctx* ctx, const uint32_t* local, size_t count, i
 }
 
 int lnasr_allreduce_f64(lnasr_ctx* ctx, double* buf, size_t n) {
+    LN_ENTER(ctx);
     LN_REQUIRE(ctx && buf, "null argument");
     if (!ctx->comm) return fail(LNASR_E_COMM, "communicator not initialised (lnasr_comm_init)");
     const void* d_in;

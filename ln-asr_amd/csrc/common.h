@@ -38,6 +38,14 @@ int fail(int code, const char* fmt, ...);
         if (!(cond)) return lnasr::fail(LNASR_E_INVALID, __VA_ARGS__); \
     } while (0)
 
+// First statement of every C-ABI entry point that takes a context: the HIP "current device" is per thread, so a
+// call from a thread other than the one that created the context (or after torch moved the thread's device) would
+// otherwise allocate workspaces and launch on device 0.  hipSetDevice is a cheap thread-local store.
+#define LN_ENTER(ctx)                                          \
+    do {                                                       \
+        if (ctx) LN_HIP(hipSetDevice((ctx)->device));          \
+    } while (0)
+
 // ---- grow-only device buffer -----------------------------------------------------------
 struct DevBuf {
     void* p = nullptr;

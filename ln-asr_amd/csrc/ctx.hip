@@ -236,12 +236,14 @@ void lnasr_ctx_destroy(lnasr_ctx* ctx) {
 }
 
 int lnasr_sync(lnasr_ctx* ctx) {
+    LN_ENTER(ctx);
     LN_REQUIRE(ctx, "null ctx");
     LN_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
 }
 
 int lnasr_device_info(lnasr_ctx* ctx, char* name, int name_cap, int* cu_count, size_t* hbm_bytes) {
+    LN_ENTER(ctx);
     LN_REQUIRE(ctx, "null ctx");
     if (name && name_cap > 0) snprintf(name, name_cap, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
     if (cu_count) *cu_count = ctx->prop.multiProcessorCount;
@@ -250,6 +252,7 @@ int lnasr_device_info(lnasr_ctx* ctx, char* name, int name_cap, int* cu_count, s
 }
 
 int lnasr_dev_alloc(lnasr_ctx* ctx, size_t bytes, void** out) {
+    LN_ENTER(ctx);
     LN_REQUIRE(ctx && out, "null argument");
     *out = nullptr;
     LN_HIP(hipMalloc(out, bytes ? bytes : 256));
@@ -257,6 +260,7 @@ int lnasr_dev_alloc(lnasr_ctx* ctx, size_t bytes, void** out) {
 }
 
 int lnasr_dev_free(lnasr_ctx* ctx, void* p) {
+    LN_ENTER(ctx);
     LN_REQUIRE(ctx, "null ctx");
     if (!p) return 0;
     LN_HIP(hipStreamSynchronize(ctx->stream));
@@ -265,6 +269,7 @@ int lnasr_dev_free(lnasr_ctx* ctx, void* p) {
 }
 
 int lnasr_memcpy_h2d(lnasr_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    LN_ENTER(ctx);
     LN_REQUIRE(ctx && (bytes == 0 || (dst && src)), "null argument");
     if (!bytes) return 0;
     LN_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -273,6 +278,7 @@ int lnasr_memcpy_h2d(lnasr_ctx* ctx, void* dst, const void* src, size_t bytes) {
 }
 
 int lnasr_memcpy_d2h(lnasr_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    LN_ENTER(ctx);
     LN_REQUIRE(ctx && (bytes == 0 || (dst && src)), "null argument");
     if (!bytes) return 0;
     LN_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -281,6 +287,7 @@ int lnasr_memcpy_d2h(lnasr_ctx* ctx, void* dst, const void* src, size_t bytes) {
 }
 
 int lnasr_memset(lnasr_ctx* ctx, void* dst, int byte, size_t bytes) {
+    LN_ENTER(ctx);
     LN_REQUIRE(ctx && (bytes == 0 || dst), "null argument");
     if (!bytes) return 0;
     LN_HIP(hipMemsetAsync(dst, byte, bytes, ctx->stream));
@@ -288,6 +295,7 @@ int lnasr_memset(lnasr_ctx* ctx, void* dst, int byte, size_t bytes) {
 }
 
 int lnasr_prof_enable(lnasr_ctx* ctx, int on) {
+    LN_ENTER(ctx);
     LN_REQUIRE(ctx, "null ctx");
     if (!on) LN_TRY(prof_collect(ctx));
     ctx->prof_on = on != 0;
@@ -295,6 +303,7 @@ int lnasr_prof_enable(lnasr_ctx* ctx, int on) {
 }
 
 int lnasr_prof_reset(lnasr_ctx* ctx) {
+    LN_ENTER(ctx);
     LN_REQUIRE(ctx, "null ctx");
     LN_TRY(prof_collect(ctx));
     for (auto& v : ctx->prof_launches) v = 0;
@@ -303,6 +312,7 @@ int lnasr_prof_reset(lnasr_ctx* ctx) {
 }
 
 int lnasr_prof_count(lnasr_ctx* ctx, int* n) {
+    LN_ENTER(ctx);
     LN_REQUIRE(ctx && n, "null argument");
     LN_TRY(prof_collect(ctx));
     *n = (int)ctx->prof_names.size();
@@ -310,6 +320,7 @@ int lnasr_prof_count(lnasr_ctx* ctx, int* n) {
 }
 
 int lnasr_prof_get(lnasr_ctx* ctx, int i, char* name, int name_cap, int64_t* launches, double* total_ms) {
+    LN_ENTER(ctx);
     LN_REQUIRE(ctx, "null ctx");
     LN_TRY(prof_collect(ctx));
     LN_REQUIRE(i >= 0 && i < (int)ctx->prof_names.size(), "index %d out of range", i);

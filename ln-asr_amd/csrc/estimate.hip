@@ -492,6 +492,7 @@ using namespace lnasr;
 extern "C" {
 
 int lnasr_lse(lnasr_ctx* ctx, const double* x, size_t outer, size_t n, size_t inner, int base2, double* out) {
+    LN_ENTER(ctx);
     LN_REQUIRE(ctx, "null ctx");
     const size_t no = outer * inner;
     if (no == 0) return 0;
@@ -628,6 +629,7 @@ extern "C" {
 
 int lnasr_estimate_discrete(lnasr_ctx* ctx, const int32_t* obs, int T, int N, int K, int dtype, const void* xi,
                             const void* gamma, void* logA_out, void* logB_out, void* logpi_out) {
+    LN_ENTER(ctx);
     LN_REQUIRE(ctx, "null ctx");
     LN_REQUIRE(T >= 1 && N >= 1 && K >= 1, "bad shape");
     LN_REQUIRE(obs && xi && gamma && logA_out && logB_out && logpi_out, "null argument");
@@ -640,6 +642,7 @@ int lnasr_estimate_discrete(lnasr_ctx* ctx, const int32_t* obs, int T, int N, in
 int lnasr_estimate_gmm(lnasr_ctx* ctx, const double* obs, int T, int dtype, const void* bm, const void* alpha,
                        const void* beta, const void* xi, const void* gamma, double min_std, void* logA_out,
                        void* logpi_out, void* logw_out, double* mu_out, double* si_out) {
+    LN_ENTER(ctx);
     LN_REQUIRE(ctx, "null ctx");
     if (!ctx->model.has_gmm) return fail(LNASR_E_NOMODEL, "no GMM-HMM model uploaded");
     LN_REQUIRE(T >= 1, "bad T");
@@ -654,6 +657,7 @@ int lnasr_estimate_gmm(lnasr_ctx* ctx, const double* obs, int T, int dtype, cons
 }
 
 int lnasr_bw_stats_len(lnasr_ctx* ctx, size_t* n) {
+    LN_ENTER(ctx);
     LN_REQUIRE(ctx && n, "null argument");
     Model& md = ctx->model;
     if (!md.has_gmm) return fail(LNASR_E_NOMODEL, "no GMM-HMM model uploaded");
@@ -662,6 +666,7 @@ int lnasr_bw_stats_len(lnasr_ctx* ctx, size_t* n) {
 }
 
 int lnasr_bw_accumulate(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* lens, double* stats) {
+    LN_ENTER(ctx);
     LN_REQUIRE(ctx && stats, "null argument");
     Model& md = ctx->model;
     if (!md.has_gmm) return fail(LNASR_E_NOMODEL, "no GMM-HMM model uploaded");
@@ -738,6 +743,7 @@ int lnasr_bw_accumulate(lnasr_ctx* ctx, const double* obs, int U, int T, const i
 
 int lnasr_bw_mstep(lnasr_ctx* ctx, const double* stats, double min_std, double* logA, double* logpi, double* logw,
                    double* mu, double* sigma) {
+    LN_ENTER(ctx);
     LN_REQUIRE(ctx && stats && logA && logpi && logw && mu && sigma, "null argument");
     Model& md = ctx->model;
     if (!md.has_gmm) return fail(LNASR_E_NOMODEL, "no GMM-HMM model uploaded");

@@ -1055,21 +1055,25 @@ extern "C" {
 
 int lnasr_model_upload(lnasr_ctx* ctx, int N, int M, int D, const double* logA, const double* logpi,
                        const double* logw, const double* mu, const double* sigma, int sigma_kind) {
+    LN_ENTER(ctx);
     return model_upload_impl(ctx, N, M, D, logA, logpi, logw, mu, sigma, sigma_kind, true);
 }
 
 int lnasr_model_upload_full(lnasr_ctx* ctx, int N, int M, int D, const double* logA, const double* logpi,
                             const double* logw, const double* mu, const double* sigma) {
+    LN_ENTER(ctx);
     return model_upload_impl(ctx, N, M, D, logA, logpi, logw, mu, sigma, 0, false);
 }
 
 int lnasr_hmm_upload(lnasr_ctx* ctx, int N, const double* logA, const double* logpi) {
+    LN_ENTER(ctx);
     LN_REQUIRE(ctx, "null ctx");
     ctx->model.has_gmm = false;
     return upload_hmm(ctx, N, logA, logpi);
 }
 
 int lnasr_model_is_diag(lnasr_ctx* ctx, int* out) {
+    LN_ENTER(ctx);
     LN_REQUIRE(ctx && out, "null argument");
     if (!ctx->model.has_gmm) return fail(LNASR_E_NOMODEL, "no GMM-HMM model uploaded");
     *out = ctx->model.diag ? 1 : 0;
@@ -1078,6 +1082,7 @@ int lnasr_model_is_diag(lnasr_ctx* ctx, int* out) {
 
 int lnasr_gmm_logprob(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* lens, int dtype, void* b,
                       void* bm_or_null) {
+    LN_ENTER(ctx);
     LN_REQUIRE(ctx, "null ctx");
     (void)lens;   // emission is per frame; padded frames are scored too and ignored downstream
     LN_REQUIRE(U >= 0 && T >= 0, "negative batch shape");
@@ -1100,6 +1105,7 @@ int lnasr_gmm_logprob(lnasr_ctx* ctx, const double* obs, int U, int T, const int
 }
 
 int lnasr_gauss1d(lnasr_ctx* ctx, const double* x, size_t L, double mu, double sigma2, int want_log, double* out) {
+    LN_ENTER(ctx);
     LN_REQUIRE(ctx, "null ctx");
     if (L == 0) return 0;
     const void* d_x;
@@ -1132,6 +1138,7 @@ static int gauss_components(lnasr_ctx* ctx, int M, const double* x, size_t L, in
 
 int lnasr_gauss_multi(lnasr_ctx* ctx, const double* x, size_t L, int D, const double* mu, const double* Sigma,
                       int want_log, double* out) {
+    LN_ENTER(ctx);
     LN_REQUIRE(ctx, "null ctx");
     if (L == 0) return 0;
     const double* d_comp;
@@ -1145,6 +1152,7 @@ int lnasr_gauss_multi(lnasr_ctx* ctx, const double* x, size_t L, int D, const do
 
 int lnasr_gauss_mixture(lnasr_ctx* ctx, const double* c, int M, const double* x, size_t L, int D, const double* mu,
                         const double* Sigma, int want_log, double* out) {
+    LN_ENTER(ctx);
     LN_REQUIRE(ctx, "null ctx");
     LN_REQUIRE(M >= 1, "M must be >= 1");
     if (L == 0) return 0;

@@ -818,6 +818,7 @@ int lnasr_num_frames(int64_t n_samples, int frame_len, int frame_step, int64_t* 
 }
 
 int lnasr_preemphasis(lnasr_ctx* ctx, const double* x, int64_t n, double alpha, double* y) {
+    LN_ENTER(ctx);
     LN_REQUIRE(ctx, "null ctx");
     if (n <= 0) return 0;
     LN_REQUIRE(x && y, "null argument");
@@ -831,6 +832,7 @@ int lnasr_preemphasis(lnasr_ctx* ctx, const double* x, int64_t n, double alpha, 
 }
 
 int lnasr_split_frames(lnasr_ctx* ctx, const double* signal, int64_t n, int L, int S, double* frames) {
+    LN_ENTER(ctx);
     LN_REQUIRE(ctx, "null ctx");
     LN_REQUIRE(L >= 1 && S >= 1 && n >= 0, "bad framing parameters");
     const int64_t nf = num_frames_host(n, L, S);
@@ -848,6 +850,7 @@ int lnasr_split_frames(lnasr_ctx* ctx, const double* signal, int64_t n, int L, i
 int lnasr_mfcc(lnasr_ctx* ctx, const void* signal, int sample_kind, const int64_t* offsets, int U,
                const lnasr_mfcc_cfg* cfg, const double* window, const double* fbank, double* power_or_null,
                double* cepstrum_or_null, double* features) {
+    LN_ENTER(ctx);
     LN_REQUIRE(ctx && cfg && offsets && window && fbank && features, "null argument");
     LN_REQUIRE(U >= 1, "U must be >= 1");
     LN_REQUIRE(sample_kind == 0 || sample_kind == 1, "sample_kind must be 0 (f64) or 1 (int16)");
@@ -1001,6 +1004,7 @@ int lnasr_mfcc(lnasr_ctx* ctx, const void* signal, int sample_kind, const int64_
 
 int lnasr_pad_rows(lnasr_ctx* ctx, const double* packed, const int64_t* row_offsets, int U, int W, int64_t pad_rows,
                    double* padded) {
+    LN_ENTER(ctx);
     LN_REQUIRE(ctx && packed && row_offsets && padded, "null argument");
     LN_REQUIRE(U >= 1 && U <= 65535 && W >= 1 && pad_rows >= 1, "bad U=%d / W=%d / pad_rows=%lld", U, W, (long long)pad_rows);
     LN_REQUIRE(!is_device_ptr(row_offsets), "row_offsets must be a host array");

@@ -2397,6 +2397,7 @@ extern "C" {
 
 int lnasr_discrete_map_b(lnasr_ctx* ctx, const double* logB, int N, int K, const int32_t* obs, int U, int T,
                          int dtype, void* b) {
+    LN_ENTER(ctx);
     LN_REQUIRE(ctx, "null ctx");
     LN_REQUIRE(N >= 1 && K >= 1 && U >= 0 && T >= 0, "bad shape");
     LN_REQUIRE(dtype == LNASR_F64 || dtype == LNASR_F32, "bad dtype %d", dtype);
@@ -2423,6 +2424,7 @@ int lnasr_discrete_map_b(lnasr_ctx* ctx, const double* logB, int N, int K, const
 
 int lnasr_viterbi(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* lens, int dtype, void* v_or_null,
                   uint32_t* bt_or_null, uint32_t* path, double* best_score_or_null) {
+    LN_ENTER(ctx);
     LN_CHECK_BATCH(ctx, U, T, dtype);
     if (U == 0 || T == 0) return 0;
     LN_REQUIRE(b && path, "null b/path");
@@ -2462,6 +2464,7 @@ int lnasr_viterbi(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* le
 
 int lnasr_decode(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* lens, uint32_t* path,
                  double* best_score_or_null) {
+    LN_ENTER(ctx);
     LN_CHECK_BATCH(ctx, U, T, LNASR_F64);
     if (!ctx->model.has_gmm) return fail(LNASR_E_NOMODEL, "no GMM-HMM model uploaded");
     if (U == 0 || T == 0) return 0;
@@ -2485,6 +2488,7 @@ int lnasr_decode(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t*
 
 int lnasr_forward(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* lens, int dtype, void* alpha_or_null,
                   double* loglik_or_null) {
+    LN_ENTER(ctx);
     LN_CHECK_BATCH(ctx, U, T, dtype);
     if (U == 0 || T == 0) return 0;
     LN_REQUIRE(b, "null b");
@@ -2504,6 +2508,7 @@ int lnasr_forward(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* le
 }
 
 int lnasr_backward(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* lens, int dtype, void* beta) {
+    LN_ENTER(ctx);
     LN_CHECK_BATCH(ctx, U, T, dtype);
     if (U == 0 || T == 0) return 0;
     LN_REQUIRE(b && beta, "null b/beta");
@@ -2520,6 +2525,7 @@ int lnasr_backward(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* l
 }
 
 int lnasr_calc_prob(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* lens, double* loglik) {
+    LN_ENTER(ctx);
     LN_CHECK_BATCH(ctx, U, T, LNASR_F64);
     if (!ctx->model.has_gmm) return fail(LNASR_E_NOMODEL, "no GMM-HMM model uploaded");
     if (U == 0 || T == 0) return 0;
@@ -2538,6 +2544,7 @@ int lnasr_calc_prob(lnasr_ctx* ctx, const double* obs, int U, int T, const int32
 
 int lnasr_baumwelch(lnasr_ctx* ctx, const void* b, const void* alpha, const void* beta, int U, int T,
                     const int32_t* lens, int dtype, void* xi, void* gamma) {
+    LN_ENTER(ctx);
     LN_CHECK_BATCH(ctx, U, T, dtype);
     if (U == 0 || T == 0) return 0;
     LN_REQUIRE(b && alpha && beta && gamma, "null argument");

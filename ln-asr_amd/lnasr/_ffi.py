@@ -79,6 +79,7 @@ SIGNATURES = {
     "lnasr_comm_unique_id": [_vp],
     "lnasr_comm_init": [_vp, _vp, _i, _i],
     "lnasr_comm_destroy": [_vp],
+    "lnasr_comm_info": [_vp, _P(_i), _P(_i)],
     "lnasr_allgather_u32": [_vp, _vp, _sz, _vp],
     "lnasr_allgather_paths": [_vp, _vp, _sz, _i, _vp],
     "lnasr_allreduce_f64": [_vp, _vp, _sz],
@@ -200,8 +201,9 @@ class Context:
             device = int(os.environ.get("LNASR_DEVICE", os.environ.get("LOCAL_RANK", "0")))
         n = C.c_int(0)
         check(lib().lnasr_device_count(C.byref(n)))
-        if n.value > 0:
-            device = device % n.value
+        if n.value > 0 and not 0 <= int(device) < n.value:
+            # never wrap: ranks that silently share a GPU would report success on the wrong device
+            raise LnasrError("device %d requested (LNASR_DEVICE / LOCAL_RANK) but only %d visible" % (device, n.value))
         h = C.c_void_p()
         check(lib().lnasr_ctx_create(int(device), C.byref(h)))
         self.handle = h.value
@@ -587,6 +589,12 @@ class Context:
         buf = C.create_string_buffer(bytes(unique_id), UNIQUE_ID_BYTES)
         check(lib().lnasr_comm_init(self.handle, buf, int(rank), int(nranks)))
         self.rank, self.nranks = int(rank), int(nranks)
+
+    def comm_info(self):
+        """(rank, nranks) of the live communicator as RCCL reports them."""
+        r, n = C.c_int(-1), C.c_int(0)
+        check(lib().lnasr_comm_info(self.handle, C.byref(r), C.byref(n)))
+        return r.value, n.value
 
     def comm_destroy(self):
         check(lib().lnasr_comm_destroy(self.handle))

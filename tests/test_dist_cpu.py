@@ -82,3 +82,36 @@ def test_world2_gloo(oracle, synth):
     for rank, allp, red in res:
         assert allp.dtype == np.uint32 and np.array_equal(allp, full)
         assert np.allclose(red, packed, rtol=1e-12, atol=1e-13)
+
+
+def _run_bench(*argv, timeout=300):
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + list(argv), capture_output=True, text=True,
+                       timeout=timeout, env=env)
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, lines
+
+
+def test_bench_self_launch_two_ranks():
+    """`bench.py --gpus 2` without a launcher starts two fresh ranks itself (torch.distributed.run), they
+    rendezvous on 127.0.0.1 and rank 0 prints one line; --dry-launch keeps the rehearsal on the CPU."""
+    r, lines = _run_bench("--gpus", "2", "--dry-launch")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1
+    out = lines[0]
+    assert out["dry_launch"] and out["n_ranks"] == 2 and out["ranks"] == [0, 1] and out["local_ranks"] == [0, 1]
+    assert out["distinct_pids"] == 2 and out["gather_ok"]
+    assert "torch.distributed.run" in r.stderr and "--nproc-per-node 2" in r.stderr
+
+
+def test_bench_launch_fails_loudly_without_gpus():
+    """No GPU here: the two ranks must fail and the launcher must hand a non-zero exit code on -- no line with
+    a number in it, no silent single-rank run."""
+    from conftest import has_gpu
+    if has_gpu():
+        pytest.skip("a GPU is present")
+    r, lines = _run_bench("--gpus", "2", "--steps", "1", "--warmup", "0")
+    assert r.returncode != 0
+    assert not [l for l in lines if l.get("value")]

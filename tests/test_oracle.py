@@ -167,6 +167,20 @@ def test_metric_slice(oracle, golden, synth):
     assert np.array_equal(p_ref, p_vec)
 
 
+def test_metric_slice_fused_baseline(oracle, golden, synth):
+    """The function bench.py's cpu_baseline leg times (GEMM emission + vectorised Viterbi) is pinned to the
+    reference's own paths on the metric slice: the baseline computes the same thing as the reference."""
+    g = golden("gmmhmm_metric_slice")
+    N, M, D, T, U = g["shape"]
+    mdl = synth.synth_model(N, M, D, seed=1)
+    obs = synth.synth_obs(U, T, D, seed=1000)
+    W = oracle.prep_diag_fused(mdl["w"], mdl["mu"], mdl["var"])
+    for u in range(U):
+        b = oracle.emit_b_fused(obs[u], W, N, M)
+        assert_close(b[g["sample_j"], g["sample_t"]], g["b_sample"][u], 1e-12)
+        assert np.array_equal(oracle.decode_diag_fused(obs[u], mdl["A"], mdl["pi"], W, N, M), g["path"][u])
+
+
 def test_gmm_funcs(oracle, golden):
     g = golden("gmm_funcs")
     assert_close(oracle.gaussian(g["x1"], 0, 4), g["g1"], 1e-14)
