@@ -95,6 +95,12 @@ int lnasr_model_upload_full(lnasr_ctx* ctx, int N, int M, int D,
 /* transition-only model for the trellis entry points (HMM.__init__, hmm.py:36-45) */
 int lnasr_hmm_upload(lnasr_ctx* ctx, int N, const double* logA, const double* logpi);
 int lnasr_model_is_diag(lnasr_ctx* ctx, int* out);
+/* Conditioning of the uploaded mixture model for the matrix-core emission kernels, which evaluate the expanded
+ * quadratic on observations centred on the mean of the component means: kappa = max over components of
+ * (mu - centre)^T Sigma^-1 (mu - centre), the size of the terms that expansion cancels (absolute error of a
+ * log-density ~ 3e-16 * kappa; the reference's direct (x - mu) form, gmm.py:59-68, has ~1e-14).  direct_form = 1:
+ * kappa exceeds 4096 (or is not finite) and the model is scored by the direct-form kernels instead. */
+int lnasr_model_conditioning(lnasr_ctx* ctx, double* kappa, int* direct_form);
 
 /* ---- emission --------------------------------------------------------------- */
 /* HMM._map_b (hmm.py:47-61): b[u,t,:] = B[:, obs[u,t]];  B is [N,K] */

@@ -82,9 +82,20 @@ struct Model {
     // scored on a padded copy of the parameters (padding components have weight -inf) and compacted afterwards
     DevBuf pad_mu, pad_ivar, pad_gconst, pad_logw, pad_prec;
     int pad_N = 0, pad_M = 0;    // padded sizes, 0 = the model is used as it is
-    DevBuf flags;                // small int scratch (diag detection)
+    DevBuf flags;                // small scratch: [0] int flag (diag detection / degenerate variance), [8] kappa bits
+    // The matrix-core emission kernels evaluate the EXPANDED quadratic  x'^T S x' + L.x' + K  on centred observations
+    // x' = x - centre (centre[d] = mean of the component means): the expansion cancels terms of size kappa =
+    // max_c (mu_c - centre)^T Sigma_c^-1 (mu_c - centre), so its absolute error is ~ 3e-16 * kappa where the direct
+    // (x - mu) form the reference uses (gmm.py:59-68) has ~1e-14.  Models with kappa > kKappaMax (means many standard
+    // deviations apart: MFMA result no longer good to 1e-12) are scored by the direct-form kernels instead.
+    DevBuf centre;               // [D]
+    DevBuf mu_c;                 // [N,M,D] mu - centre: what the coefficient packers see
+    double kappa = 0.0;
+    bool direct_form = false;    // kappa > kKappaMax (or not finite): expanded form refused
     void release();
 };
+
+constexpr double kKappaMax = 4096.0;
 
 struct ProfRec {
     int name_id;

@@ -88,6 +88,43 @@ __global__ void prep_diag_kernel(const double* __restrict__ var, double* __restr
     if (bad) atomicOr(degenerate, 1);
 }
 
+// centre[d] = mean over the components of mu[c][d] (0 if that mean is not finite: such a model is refused the
+// expanded form below anyway).  One block per dimension.
+__global__ void centre_kernel(const double* __restrict__ mu, int NM, int D, double* __restrict__ centre) {
+    __shared__ double scratch[8];
+    const int d = blockIdx.x;
+    double s = 0.0;
+    for (int c = threadIdx.x; c < NM; c += blockDim.x) s += mu[(size_t)c * D + d];
+    s = block_sum(s, scratch);
+    s /= (double)NM;
+    if (threadIdx.x == 0) centre[d] = (s - s == 0.0) ? s : 0.0;
+}
+
+// mu_c = mu - centre, and kappa = max_c (mu_c)^T P_c (mu_c): the size of the terms the expanded quadratic cancels.
+// One thread per component; prec == nullptr: diagonal model (ivar).  A non-finite value counts as +inf.
+__global__ void centre_mu_kernel(const double* __restrict__ mu, const double* __restrict__ centre,
+                                 const double* __restrict__ ivar, const double* __restrict__ prec, int NM, int D,
+                                 double* __restrict__ mu_c, unsigned long long* __restrict__ kappa_bits) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= NM) return;
+    const double* m = mu + (size_t)c * D;
+    double* mc = mu_c + (size_t)c * D;
+    for (int d = 0; d < D; ++d) mc[d] = m[d] - centre[d];
+    double k = 0.0;
+    if (prec) {
+        const double* P = prec + (size_t)c * D * D;
+        for (int i = 0; i < D; ++i) {
+            double t = 0.0;
+            for (int j = 0; j < D; ++j) t += fabs(P[(size_t)i * D + j] * mc[j]);
+            k += fabs(mc[i]) * t;
+        }
+    } else {
+        for (int d = 0; d < D; ++d) k += mc[d] * mc[d] * fabs(ivar[(size_t)c * D + d]);
+    }
+    if (!(k - k == 0.0)) k = __builtin_huge_val();
+    atomicMax(kappa_bits, (unsigned long long)__double_as_longlong(k));   // k >= 0: the bit patterns order like the values
+}
+
 // One block (64 threads) per component: Gauss-Jordan elimination with partial pivoting on
 // [Sigma | I] held in LDS.  LU semantics: Sigma need not be symmetric (test/gmm-test.py:42-43).
 __global__ void lu_invert_kernel(const double* __restrict__ S, double* __restrict__ P,
@@ -215,8 +252,8 @@ __global__ void pack_wfrag_kernel(const double* __restrict__ mu, const double* _
 template <int Q, int KS, int NWV, int TPS, bool WRITE_BM, int ABL = 0>
 __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 2))) void emit_diag_mfma(
     const double* __restrict__ obs, const double* __restrict__ wpack, const double* __restrict__ logw,
-    double* __restrict__ b, double* __restrict__ bm, long F, int N, int D, int NG, int GY,
-    long ntiles, int tiles_per_block, long nchunks) {
+    const double* __restrict__ centre, double* __restrict__ b, double* __restrict__ bm, long F, int N, int D, int NG,
+    int GY, long ntiles, int tiles_per_block, long nchunks) {
     constexpr int KP = 4 * KS;
     constexpr int NT = 64 * NWV;
     constexpr int SPB = 4 * NWV;                // states per block
@@ -275,12 +312,14 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 2))
     constexpr int MAXLD = (TPS * 16 * 64 + NT - 1) / NT;   // supports D <= 64
     const long lim = F * (long)D;
     double pre[MAXLD];
-    int foff[MAXLD];                                    // LDS offset (doubles) of this thread's x^2 slot; -1: none
-#pragma unroll
+    double cen[MAXLD];                                  // centre of this thread's dimension (a stage starts on a frame
+    int foff[MAXLD];                                    // boundary, so element e of every stage is dimension e mod D)
+#pragma unroll                                          // foff: LDS offset (doubles) of the x^2 slot; -1: none
     for (int r = 0; r < MAXLD; ++r) {
         const int e = tid + r * NT;
         const int f = e / D, d = e - f * D;             // f = frame within the stage
         foff[r] = e < EL ? (f >> 4) * (KP * FS) + d * FS + (f & 15) : -1;
+        cen[r] = centre[d];
     }
     auto load_stage = [&](long tile) {
         const long base = tile * 16 * (long)D;
@@ -297,7 +336,7 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
         for (int r = 0; r < MAXLD; ++r) {
             if (foff[r] >= 0) {
-                const double x = pre[r];
+                const double x = pre[r] - cen[r];       // centred: the coefficients are those of (x - centre)
                 Fd[foff[r]] = x * x;
                 Fd[foff[r] + xo] = x;
             }
@@ -442,7 +481,8 @@ __global__ void pack_single_direct_kernel(const double* __restrict__ mu, const d
 template <int KS, bool WRITE_BM>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void emit_single_direct(const double* __restrict__ obs,
                                                           const double* __restrict__ wdirect,
-                                                          const double* __restrict__ logw, double* __restrict__ b,
+                                                          const double* __restrict__ logw,
+                                                          const double* __restrict__ centre, double* __restrict__ b,
                                                           double* __restrict__ bm, long F, int M, int D, long ntiles) {
     constexpr int NL = KS / 2;                 // loads per lane and tile
     __shared__ double etab[kExpTab];
@@ -462,8 +502,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // slot 4 j + g of this lane: a real dimension, the constant (== D), or padding (> D: coefficient 0; the value
     // read there is the start of the next frame, or 0 past the end of obs)
     bool is_one[NL];
+    double cen[NL];                            // centre of the lane's dimensions: the coefficients are those of x - centre
 #pragma unroll
-    for (int j = 0; j < NL; ++j) is_one[j] = (4 * j + g) == D;
+    for (int j = 0; j < NL; ++j) {
+        is_one[j] = (4 * j + g) == D;
+        cen[j] = (4 * j + g) < D ? centre[4 * j + g] : 0.0;
+    }
     double pre[NL];
     auto load_tile = [&](long tile) {
         const long e0 = tile * 16 * (long)D;
@@ -483,8 +527,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         double bx[NL], bq[NL];
 #pragma unroll
         for (int j = 0; j < NL; ++j) {
-            bx[j] = pre[j];
-            bq[j] = is_one[j] ? 1.0 : pre[j] * pre[j];
+            bx[j] = pre[j] - cen[j];
+            bq[j] = is_one[j] ? 1.0 : bx[j] * bx[j];
         }
         load_tile(tile + nw);
         double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
@@ -708,6 +752,25 @@ static int copy_in(lnasr_ctx* ctx, DevBuf& dst, const void* src, size_t bytes) {
     return 0;
 }
 
+// LNASR_KAPPA_MAX overrides the conditioning gate (tests: show what the expanded form does beyond it)
+static double kappa_max() {
+    const char* e = getenv("LNASR_KAPPA_MAX");
+    return e ? atof(e) : kKappaMax;
+}
+
+// md.centre, md.mu_c and (into md.flags + 8) the bits of kappa; prec == nullptr for a diagonal model
+static int centre_and_kappa(lnasr_ctx* ctx, const double* prec) {
+    Model& md = ctx->model;
+    const int NM = md.N * md.M, D = md.D;
+    LN_TRY(md.centre.reserve((size_t)D * 8));
+    LN_TRY(md.mu_c.reserve((size_t)NM * D * 8));
+    LN_LAUNCH(ctx, "centre", centre_kernel, dim3(D), dim3(256), 0, md.mu.as<double>(), NM, D, md.centre.as<double>());
+    LN_LAUNCH(ctx, "centre_mu", centre_mu_kernel, dim3((NM + 63) / 64), dim3(64), 0, md.mu.as<double>(),
+              (const double*)md.centre.as<double>(), prec ? nullptr : (const double*)md.ivar.as<double>(), prec, NM, D,
+              md.mu_c.as<double>(), reinterpret_cast<unsigned long long*>(md.flags.as<char>() + 8));
+    return 0;
+}
+
 static int model_upload_impl(lnasr_ctx* ctx, int N, int M, int D, const double* logA, const double* logpi,
                              const double* logw, const double* mu, const double* sigma, int sigma_kind,
                              bool allow_diag_detect) {
@@ -755,12 +818,18 @@ static int model_upload_impl(lnasr_ctx* ctx, int N, int M, int D, const double* 
     if (diag) {
         LN_TRY(md.ivar.reserve(NMD * 8));
         LN_TRY(md.flags.reserve(256));
-        LN_HIP(hipMemsetAsync(md.flags.p, 0, 4, ctx->stream));
+        LN_HIP(hipMemsetAsync(md.flags.p, 0, 16, ctx->stream));
         LN_LAUNCH(ctx, "prep_diag", prep_diag_kernel, dim3((unsigned)((NM + 127) / 128)), dim3(128), 0,
                   md.var.as<double>(), md.ivar.as<double>(), md.gconst.as<double>(), (int)NM, D, md.flags.as<int>());
-        int degenerate = 0;
-        LN_HIP(hipMemcpyAsync(&degenerate, md.flags.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+        LN_TRY(centre_and_kappa(ctx, nullptr));
+        unsigned long long fl[2] = {0, 0};
+        LN_HIP(hipMemcpyAsync(fl, md.flags.p, 16, hipMemcpyDeviceToHost, ctx->stream));
         LN_HIP(hipStreamSynchronize(ctx->stream));
+        md.kappa = __builtin_bit_cast(double, fl[1]);
+        md.direct_form = !(md.kappa <= kappa_max());
+        // a singular / non-finite variance, or means too many standard deviations apart for the expanded quadratic:
+        // the direct-form kernels score this model
+        const int degenerate = (int)(fl[0] & 0xFFFFFFFFu) | (md.direct_form ? 1 : 0);
         int Q = 0, KS = 0;
         md.wdirect_KS = 0;
         if (!degenerate && N == 1 && M <= 16 && D <= 64) {
@@ -769,7 +838,7 @@ static int model_upload_impl(lnasr_ctx* ctx, int N, int M, int D, const double* 
             if (ksd) {
                 LN_TRY(md.wdirect.reserve((size_t)ksd * 64 * 8));
                 LN_LAUNCH(ctx, "pack_single_direct", pack_single_direct_kernel, dim3((ksd * 64 + 255) / 256), dim3(256), 0,
-                          md.mu.as<double>(), md.ivar.as<double>(), md.gconst.as<double>(), md.wdirect.as<double>(), M,
+                          md.mu_c.as<double>(), md.ivar.as<double>(), md.gconst.as<double>(), md.wdirect.as<double>(), M,
                           D, ksd);
                 md.wdirect_KS = ksd;
             }
@@ -786,7 +855,8 @@ static int model_upload_impl(lnasr_ctx* ctx, int N, int M, int D, const double* 
         md.wpack_virt = 1;
         md.pad_N = md.pad_M = 0;
         if (!degenerate && mfma_shape_supported(Nv, Mv, D, &Q, &KS) && ((Np == N && Mp == M) || !getenv("LNASR_NO_PAD"))) {
-            const double *mu_s = md.mu.as<double>(), *iv_s = md.ivar.as<double>(), *gc_s = md.gconst.as<double>(),
+            // the packers see the CENTRED means: the kernels subtract md.centre from every observation they load
+            const double *mu_s = md.mu_c.as<double>(), *iv_s = md.ivar.as<double>(), *gc_s = md.gconst.as<double>(),
                          *lw_s = md.logw.as<double>();
             if (Np != N || Mp != M) {
                 const size_t NMp = (size_t)Np * Mp;
@@ -821,7 +891,17 @@ static int model_upload_impl(lnasr_ctx* ctx, int N, int M, int D, const double* 
         size_t shmem = (size_t)D * 2 * D * 8;
         LN_LAUNCH(ctx, "lu_invert", lu_invert_kernel, dim3((unsigned)NM), dim3(64), shmem, md.sigma_raw.as<double>(),
                   md.prec.as<double>(), md.gconst.as<double>(), D);
-        LN_TRY(pack_full_model(ctx));
+        LN_TRY(md.flags.reserve(256));
+        LN_HIP(hipMemsetAsync(md.flags.p, 0, 16, ctx->stream));
+        LN_TRY(centre_and_kappa(ctx, md.prec.as<double>()));
+        unsigned long long fl[2] = {0, 0};
+        LN_HIP(hipMemcpyAsync(fl, md.flags.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+        LN_HIP(hipStreamSynchronize(ctx->stream));
+        md.kappa = __builtin_bit_cast(double, fl[1]);
+        md.direct_form = !(md.kappa <= kappa_max());
+        md.wfull_Q = 0;
+        md.pad_N = md.pad_M = 0;
+        if (!md.direct_form) LN_TRY(pack_full_model(ctx));
     }
     LN_HIP(hipStreamSynchronize(ctx->stream));
     md.has_gmm = true;
@@ -849,12 +929,12 @@ static int launch_mfma_cfg(lnasr_ctx* ctx, const double* obs, long F, double* b,
     const long grid = ((nchunks + 7) / 8) * 8 * GY;
     if (bm) {
         LN_LAUNCH(ctx, "emit_diag_mfma_bm", (emit_diag_mfma<Q, KS, NWV, TPS, true>), dim3((unsigned)grid),
-                  dim3(64 * NWV), 0, obs, md.wpack_nw.as<double>(), lw, b, bm, F, N, D, md.wpack_NG, GY,
-                  ntiles, (int)tpb, nchunks);
+                  dim3(64 * NWV), 0, obs, md.wpack_nw.as<double>(), lw, (const double*)md.centre.as<double>(), b, bm, F, N, D,
+                  md.wpack_NG, GY, ntiles, (int)tpb, nchunks);
     } else {
         LN_LAUNCH(ctx, "emit_diag_mfma", (emit_diag_mfma<Q, KS, NWV, TPS, false>), dim3((unsigned)grid),
-                  dim3(64 * NWV), 0, obs, md.wpack.as<double>(), lw, b, bm, F, N, D, md.wpack_NG, GY,
-                  ntiles, (int)tpb, nchunks);
+                  dim3(64 * NWV), 0, obs, md.wpack.as<double>(), lw, (const double*)md.centre.as<double>(), b, bm, F, N, D,
+                  md.wpack_NG, GY, ntiles, (int)tpb, nchunks);
     }
     return 0;
 }
@@ -874,10 +954,10 @@ static int launch_mfma(lnasr_ctx* ctx, const double* obs, long F, double* b, dou
             const long grid = ((nchunks + 7) / 8) * 8 * GY;
             if (v == 'x')
                 LN_LAUNCH(ctx, "emit_ablate_no_lse", (emit_diag_mfma<4, 20, 8, 1, false, 1>), dim3((unsigned)grid), dim3(512), 0,
-                          obs, md.wpack.as<double>(), md.logw.as<double>(), b, bm, F, md.N, md.D, md.wpack_NG, GY, ntiles, (int)tpb, nchunks);
+                          obs, md.wpack.as<double>(), md.logw.as<double>(), (const double*)md.centre.as<double>(), b, bm, F, md.N, md.D, md.wpack_NG, GY, ntiles, (int)tpb, nchunks);
             else
                 LN_LAUNCH(ctx, "emit_ablate_no_mfma", (emit_diag_mfma<4, 20, 8, 1, false, 2>), dim3((unsigned)grid), dim3(512), 0,
-                          obs, md.wpack.as<double>(), md.logw.as<double>(), b, bm, F, md.N, md.D, md.wpack_NG, GY, ntiles, (int)tpb, nchunks);
+                          obs, md.wpack.as<double>(), md.logw.as<double>(), (const double*)md.centre.as<double>(), b, bm, F, md.N, md.D, md.wpack_NG, GY, ntiles, (int)tpb, nchunks);
             return 0;
         }
     }
@@ -911,10 +991,12 @@ int emit_device(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, v
     if (md.wdirect_KS == ks) {                                                                                    \
         if (bm)                                                                                                   \
             LN_LAUNCH(ctx, "emit_single_direct_bm", (emit_single_direct<ks, true>), dim3((unsigned)grid), dim3(256), 0, obs, \
-                      md.wdirect.as<double>(), md.logw.as<double>(), (double*)b, (double*)bm, F, M, D, ntiles);   \
+                      md.wdirect.as<double>(), md.logw.as<double>(), (const double*)md.centre.as<double>(), (double*)b, \
+                      (double*)bm, F, M, D, ntiles);                                                              \
         else                                                                                                      \
             LN_LAUNCH(ctx, "emit_single_direct", (emit_single_direct<ks, false>), dim3((unsigned)grid), dim3(256), 0, obs, \
-                      md.wdirect.as<double>(), md.logw.as<double>(), (double*)b, (double*)bm, F, M, D, ntiles);   \
+                      md.wdirect.as<double>(), md.logw.as<double>(), (const double*)md.centre.as<double>(), (double*)b, \
+                      (double*)bm, F, M, D, ntiles);                                                              \
         return 0;                                                                                                 \
     }
         LN_DCASE(20) LN_DCASE(14) LN_DCASE(8)
@@ -1077,6 +1159,15 @@ int lnasr_model_is_diag(lnasr_ctx* ctx, int* out) {
     LN_REQUIRE(ctx && out, "null argument");
     if (!ctx->model.has_gmm) return fail(LNASR_E_NOMODEL, "no GMM-HMM model uploaded");
     *out = ctx->model.diag ? 1 : 0;
+    return 0;
+}
+
+int lnasr_model_conditioning(lnasr_ctx* ctx, double* kappa, int* direct_form) {
+    LN_ENTER(ctx);
+    LN_REQUIRE(ctx, "null ctx");
+    if (!ctx->model.has_gmm) return fail(LNASR_E_NOMODEL, "no GMM-HMM model uploaded");
+    if (kappa) *kappa = ctx->model.kappa;
+    if (direct_form) *direct_form = ctx->model.direct_form ? 1 : 0;
     return 0;
 }
 

@@ -93,7 +93,7 @@ __global__ void pack_wfull_kernel(const double* __restrict__ mu, const double* _
 template <int Q, bool WRITE_BM>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void emit_full_mfma(
     const double* __restrict__ obs, const double* __restrict__ wfull, const int* __restrict__ pairtab,
-    const double* __restrict__ logw, double* __restrict__ b, double* __restrict__ bm, long F, int N, int D, int NG,
+    const double* __restrict__ logw, const double* __restrict__ centre, double* __restrict__ b, double* __restrict__ bm, long F, int N, int D, int NG,
     int GY, int NCH, long nsuper, int super_per_block, long nchunks) {
     constexpr int NWV = 8, NT = 512, SPB = 32, FT = 4, FS = 17, OS = SPB + 1;
     extern __shared__ double smem[];
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int f = e / D, d = e - f * D;
             long ge = fbase * D + e;
             ge = ge < lim ? ge : lim - 1;
-            xs[d * 64 + f] = obs[ge];
+            xs[d * 64 + f] = obs[ge] - centre[d];        // centred: the coefficients are those of (x - centre)
         }
         __syncthreads();
         // feature chunk builder: wave w fills rows kk = w, w+8, ... of chunk `ch` into buffer `buf`
@@ -280,7 +280,7 @@ int pack_full_model(lnasr_ctx* ctx) {
     const int NCH = (K + kFC - 1) / kFC;
     const size_t lds = ((size_t)D * 64 + 2 * 4 * kFC * 17 + 4 * 16 * 33 + kExpTab + 2 * kLogTab) * 8 + (size_t)NCH * kFC * 4;
     if (lds > 160 * 1024) return 0;
-    const double *mu_s = md.mu.as<double>(), *pr_s = md.prec.as<double>(), *gc_s = md.gconst.as<double>(),
+    const double *mu_s = md.mu_c.as<double>(), *pr_s = md.prec.as<double>(), *gc_s = md.gconst.as<double>(),
                  *lw_s = md.logw.as<double>();
     if (Np != N || Mp != M) {
         const size_t NMp = (size_t)Np * Mp;
@@ -331,11 +331,11 @@ static int launch_full(lnasr_ctx* ctx, const double* obs, long F, double* b, dou
     const size_t shm = ((size_t)D * 64 + 2 * 4 * kFC * 17 + 4 * 16 * 33 + kExpTab + 2 * kLogTab) * 8 + (size_t)NCH * kFC * 4;
     if (bm)
         LN_LAUNCH(ctx, "emit_full_mfma_bm", (emit_full_mfma<Q, true>), dim3((unsigned)grid), dim3(512), shm, obs,
-                  md.wfull_nw.as<double>(), md.pairtab.as<int>(), lw, b, bm, F, N, D, N / 4, GY, NCH,
+                  md.wfull_nw.as<double>(), md.pairtab.as<int>(), lw, (const double*)md.centre.as<double>(), b, bm, F, N, D, N / 4, GY, NCH,
                   nsuper, (int)spb, nchunks);
     else
         LN_LAUNCH(ctx, "emit_full_mfma", (emit_full_mfma<Q, false>), dim3((unsigned)grid), dim3(512), shm, obs,
-                  md.wfull.as<double>(), md.pairtab.as<int>(), lw, b, bm, F, N, D, N / 4, GY, NCH,
+                  md.wfull.as<double>(), md.pairtab.as<int>(), lw, (const double*)md.centre.as<double>(), b, bm, F, N, D, N / 4, GY, NCH,
                   nsuper, (int)spb, nchunks);
     return 0;
 }

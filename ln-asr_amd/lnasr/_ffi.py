@@ -54,6 +54,7 @@ SIGNATURES = {
     "lnasr_model_upload_full": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "lnasr_hmm_upload": [_vp, _i, _vp, _vp],
     "lnasr_model_is_diag": [_vp, _P(_i)],
+    "lnasr_model_conditioning": [_vp, _P(_dbl), _P(_i)],
     "lnasr_discrete_map_b": [_vp, _vp, _i, _i, _vp, _i, _i, _i, _vp],
     "lnasr_gmm_logprob": [_vp, _vp, _i, _i, _vp, _i, _vp, _vp],
     "lnasr_gauss1d": [_vp, _vp, _sz, _dbl, _dbl, _i, _vp],
@@ -316,6 +317,13 @@ class Context:
         v = C.c_int(0)
         check(lib().lnasr_model_is_diag(self.handle, C.byref(v)))
         return bool(v.value)
+
+    def model_conditioning(self):
+        """(kappa, direct_form): size of the terms the expanded-quadratic emission kernels cancel, and whether the
+        model is therefore scored by the direct-form kernels (include/lnasr_hip.h)."""
+        k, d = C.c_double(0), C.c_int(0)
+        check(lib().lnasr_model_conditioning(self.handle, C.byref(k), C.byref(d)))
+        return k.value, bool(d.value)
 
     # -- helpers ---------------------------------------------------------------------------
     def _out(self, like_device, shape, dtype):

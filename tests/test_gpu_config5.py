@@ -1,0 +1,107 @@
+"""GPU, BASELINE.json configs[4] ("config 5"): Baum-Welch re-estimation at N=256 states, M=32 mixtures,
+D=39 -- the multi-utterance statistics pass (gmmhmm.py:69-156 + hmm.py:63-131,174-200 restated per
+utterance and summed) and the M-step every rank runs on the all-reduced statistics.
+
+(a) the kernel combination of that shape (on-chip 256-state trellises, 32-mixture emission as two virtual
+    16-mixture states, two-tile mixture moments, xi GEMM) against the oracle at a size the oracle finishes
+    in seconds;
+(b) the full size (T=2000, 64 utterances per GPU) through size-independent properties.
+"""
+import numpy as np
+import pytest
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+N, M, D = 256, 32, 39
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from lnasr import _ffi
+    return _ffi.default_ctx()
+
+
+def _split(st):
+    o, out = 0, {}
+    for key, n in (("xi_sum", N * N), ("gamma_sum", N), ("gamma0", N), ("mix", N * M), ("mix_x", N * M * D),
+                   ("mix_xx", N * M * D), ("loglik", 1), ("n_utt", 1), ("n_frames", 1)):
+        out[key] = st[o:o + n]
+        o += n
+    assert o == st.size
+    return out
+
+
+def test_config5_statistics_against_oracle(synth, oracle, ctx):
+    mdl = synth.synth_model(N, M, D, seed=5)
+    lens = np.array([24, 17, 9], dtype=np.int32)
+    U, T = 3, 24
+    obs = synth.synth_obs(U, T, D, seed=505)
+    ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
+    st = ctx.bw_accumulate(obs, lens=lens)
+    with np.errstate(divide="ignore", invalid="ignore", under="ignore"):
+        ref = oracle.bw_stats_diag([obs[u, :lens[u]] for u in range(U)], mdl["A"], mdl["pi"], mdl["w"], mdl["mu"],
+                                   mdl["var"])
+    s = _split(st)
+    for key in ("xi_sum", "gamma_sum", "gamma0", "mix", "mix_x", "mix_xx"):
+        assert_close(s[key], np.asarray(ref[key]).ravel(), 1e-9, 1e-12, msg=key)
+    assert abs(s["loglik"][0] - ref["loglik"]) <= 1e-10 * abs(ref["loglik"])
+    assert s["n_utt"][0] == U and s["n_frames"][0] == lens.sum()
+    m = ctx.bw_mstep(st)
+    mo = oracle.mstep_from_stats(ref)
+    for k in ("A", "pi", "w", "mu", "var"):
+        assert_close(m[k], mo[k], 1e-8, 1e-10, msg=k)
+    # U = 1 is the reference's single-sequence E-step (hmm.py:174-200): xi / gamma sums of the oracle's baumwelch
+    st1 = _split(ctx.bw_accumulate(obs[:1]))
+    b, _ = oracle.gmm_map_b_diag(obs[0], mdl["w"], mdl["mu"], mdl["var"])
+    alpha, beta = oracle.forward(mdl["A"], mdl["pi"], b), oracle.backward(mdl["A"], b)
+    xi, gamma = oracle.baumwelch(mdl["A"], b, alpha, beta)
+    assert_close(st1["xi_sum"], np.exp(xi[:-1]).sum(axis=0).ravel(), 1e-9, 1e-13, msg="xi")
+    assert_close(st1["gamma0"], np.exp(gamma[0]), 1e-9, 1e-13, msg="gamma0")
+
+
+def test_config5_full_size_properties(synth, ctx):
+    U, T = 64, 2000
+    mdl = synth.synth_model(N, M, D, seed=1)
+    obs = synth.synth_obs(U, T, D, seed=1000)
+    ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
+    d_obs = ctx.to_device(obs)
+    st = ctx.bw_accumulate(d_obs)
+    s = _split(st)
+    assert np.isfinite(st).all()
+    assert s["n_utt"][0] == U and s["n_frames"][0] == U * T
+    # posteriors are normalised per frame: gamma covers frames 0..T-2 of every utterance, the mixture
+    # posteriors (alpha + beta based, gmmhmm.py:98-100) every frame
+    assert abs(s["gamma_sum"].sum() - U * (T - 1)) < 1e-7 * U * T
+    assert abs(s["xi_sum"].sum() - U * (T - 1)) < 1e-7 * U * T
+    assert_close(s["xi_sum"].reshape(N, N).sum(axis=1), s["gamma_sum"], 1e-9, msg="sum_j xi = gamma")
+    assert abs(s["gamma0"].sum() - U) < 1e-9 * U
+    assert abs(s["mix"].sum() - U * T) < 1e-7 * U * T
+    # sum_m mix[j, m] = sum over ALL frames of the state posterior = gamma_sum[j] + the last frame's posterior
+    b = ctx.gmm_logprob(d_obs)
+    alpha, ll = ctx.forward(b)
+    ll = ll.to_host()
+    last = np.exp(alpha.to_host()[:, T - 1, :] - ll[:, None]).sum(axis=0)
+    assert_close(s["mix"].reshape(N, M).sum(axis=1), s["gamma_sum"] + last, 1e-9, msg="sum_m mix = sum_t posterior")
+    # the log-likelihood in the statistics is calc_prob's
+    cp = ctx.calc_prob(d_obs).to_host()
+    assert_close(cp, ll, 1e-13)
+    assert abs(s["loglik"][0] - cp.sum()) <= 1e-12 * abs(cp.sum())
+    # additive over batch splits (what the all-reduce over ranks relies on)
+    st_a = ctx.bw_accumulate(obs[:40])
+    st_b = ctx.bw_accumulate(obs[40:])
+    assert_close(st_a + st_b, st, 1e-10, 1e-9)
+    # a second run over the same batch reproduces the statistics (split-K sums meet in fp64 atomics, so the
+    # order of the last additions may differ: equal to rounding, not necessarily to the bit)
+    st2 = ctx.bw_accumulate(d_obs)
+    assert_close(st2, st, 1e-12, 1e-12)
+    # the M-step yields normalised rows and the variance floor
+    m = ctx.bw_mstep(st)
+    assert np.abs(np.exp(m["A"]).sum(axis=1) - 1).max() < 1e-12
+    assert np.abs(np.exp(m["w"]).sum(axis=1) - 1).max() < 1e-12
+    assert abs(np.exp(m["pi"]).sum() - 1) < 1e-12
+    assert (m["var"] >= 0.01).all() and np.isfinite(m["mu"]).all()
+    # weighted mean of the new means = weighted mean of the data, per state (first moments are consistent)
+    tot_x = (s["mix_x"].reshape(N, M, D)).sum(axis=(0, 1))
+    assert_close(tot_x, obs.reshape(-1, D).sum(axis=0), 1e-8, 1e-6, msg="sum of first moments = sum of data")

@@ -1,0 +1,118 @@
+"""GPU, N > 1: the launch path of bench.py and the two RCCL collectives with more than one rank.
+
+The two-rank parity test needs a lease with at least two GPUs and skips otherwise; the failure-path test runs
+on any GPU box: with both ranks pinned to ONE device RCCL refuses the communicator, and the bench must then
+time nothing, say so and exit non-zero.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO, PKG_ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.update(extra)
+    return env
+
+
+def test_bench_failed_communicator_times_nothing():
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--utts", "8", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600,
+                       env=_clean_env(LNASR_BENCH_DEVICE="0", LNASR_COMM_TIMEOUT="90"))
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode != 0, r.stdout[-2000:]
+    assert len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])
+    out = lines[0]
+    assert out["value"] is None and out["ms_per_step"] is None and out["n_gpus"] == 0
+    assert out["config"]["gather"].startswith("FAILED, nothing timed")
+
+
+def _rank(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, PKG_ROOT)
+    import torch.distributed as dist
+    from lnasr import _ffi, synth
+    from lnasr import dist as ldist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ctx = _ffi.Context(rank)
+        ids = [_ffi.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        comm = ldist.RcclComm(ctx, rank, world, ids[0])
+        out = {"info": ctx.comm_info()}
+        N, M, D = 12, 4, 6
+        mdl = synth.synth_model(N, M, D, seed=2)
+        ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
+        for tag, U, T in (("bytes", 5, 32), ("words", 5, 31)):      # 3 + 2 utterances; 3*31 is odd: plain u32 route
+            obs = synth.synth_obs(U, T, D, seed=42)
+            lo, hi = ldist.shard_range(U, rank, world)
+            local = ctx.decode(obs[lo:hi])
+            sizes = ldist.shard_sizes(U, world)
+            pad = np.zeros((max(sizes), T), dtype=np.uint32)
+            pad[:hi - lo] = local
+            allp = np.asarray(ctx.allgather_paths(pad, N)).reshape(world, max(sizes), T)
+            out[tag] = np.concatenate([allp[r, :sizes[r]] for r in range(world)], axis=0)
+            out[tag + "_generic"] = ldist.gather_paths(comm, local, U, T)
+        obs = synth.synth_obs(5, 32, D, seed=42)
+        lo, hi = ldist.shard_range(5, rank, world)
+        st = ctx.bw_accumulate(obs[lo:hi])
+        out["stats"] = ldist.allreduce_stats(comm, st.copy())
+        out["mstep"] = ctx.bw_mstep(out["stats"])
+        q.put((rank, out))
+        dist.barrier()
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_rccl_gather_and_allreduce(synth, oracle):
+    from lnasr import _ffi
+    if _ffi.device_count() < 2:
+        pytest.skip("needs a lease with two GPUs (one rank per GPU)")
+    import torch.multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    N, M, D = 12, 4, 6
+    mdl = synth.synth_model(N, M, D, seed=2)
+    for tag, U, T in (("bytes", 5, 32), ("words", 5, 31)):
+        obs = synth.synth_obs(U, T, D, seed=42)
+        want = np.stack([oracle.decode_diag(obs[u], mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"]) for u in range(U)])
+        for r in range(2):
+            assert res[r]["info"] == (r, 2)
+            assert np.array_equal(res[r][tag], want) and np.array_equal(res[r][tag + "_generic"], want)
+    obs = synth.synth_obs(5, 32, D, seed=42)
+    ref = oracle.bw_stats_diag(list(obs), mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"])
+    packed = np.concatenate([np.ravel(ref[k]) for k in ("xi_sum", "gamma_sum", "gamma0", "mix", "mix_x", "mix_xx")])
+    mo = oracle.mstep_from_stats(ref)
+    for r in range(2):
+        assert np.allclose(res[r]["stats"][:packed.size], packed, rtol=1e-9, atol=1e-12)
+        assert np.array_equal(res[r]["stats"], res[0]["stats"])          # every rank holds the same sums
+        for k in ("A", "pi", "w", "mu", "var"):
+            assert np.allclose(res[r]["mstep"][k], mo[k], rtol=1e-8, atol=1e-10), k
