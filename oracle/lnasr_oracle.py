@@ -253,6 +253,25 @@ def gmm_map_b_diag(obs, w, mu, var, precision=np.float64):
         np.ascontiguousarray(bm.transpose(1, 2, 0)).astype(precision)
 
 
+def gmm_map_b_diag_direct(obs, w, mu, var, precision=np.float64):
+    """gmm_map_b_diag with the reference's DIRECT arithmetic, sum_d (x - mu)^2 / var (gmm.py:66-68 for a diagonal
+    Sigma), instead of the expanded quadratic: the form to check against when means lie many standard deviations
+    from the origin or from each other (golden `gmmhmm_offset_means`), where the expansion cancels large terms."""
+    obs = np.asarray(obs, dtype=np.float64)
+    N, M, D = mu.shape
+    T = obs.shape[0]
+    const = -0.5 * (D * LOG2PI + np.log(np.prod(var, axis=2)))
+    bm = np.empty((N, M, T))
+    for n in range(N):
+        for m in range(M):
+            dx = obs - mu[n, m]
+            bm[n, m] = const[n, m] - 0.5 * ((dx / var[n, m]) * dx).sum(axis=1)
+    b = np.empty((N, T))
+    for n in range(N):
+        b[n] = lse(w[n].reshape(M, 1) + bm[n], axis=0)
+    return b.astype(precision), bm.astype(precision)
+
+
 # ----------------------------------------------------------------------------
 # H2-H9: HMM trellises                                        (hmm.py:47-283)
 # ----------------------------------------------------------------------------

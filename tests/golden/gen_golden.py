@@ -166,6 +166,39 @@ def gen_gmmhmm_d39():
         save("gmmhmm_d39_" + tag, **out)
 
 
+def gen_offset_means():
+    """Models of real-feature scale (not the unit-scale synthetic ones): means far from the origin and from each
+    other, small variances, observations near the means.  The reference scores with the direct (x - mu) form
+    (gmm.py:59-68); an expanded-quadratic implementation cancels large terms here.
+      wide_*      mu ~ N(0, 15^2), var ~ U(0.01, 0.1), obs = a random component's mean + sqrt(var) noise   (diagonal)
+      shift_*     the unit-scale synthetic model moved by one large common offset per dimension           (diagonal)
+      shiftfull_* the same with full covariances"""
+    N, M, D, T = 8, 4, 39, 48
+    out = {}
+    rng = np.random.default_rng(77)
+    base = synth.synth_model(N, M, D, seed=3)
+    mu = 15.0 * rng.standard_normal((N, M, D))
+    var = 0.01 + 0.09 * rng.random((N, M, D))
+    pick_n, pick_m = rng.integers(0, N, T), rng.integers(0, M, T)
+    obs = mu[pick_n, pick_m] + np.sqrt(var[pick_n, pick_m]) * rng.standard_normal((T, D))
+    si = np.zeros((N, M, D, D))
+    si[:, :, np.arange(D), np.arange(D)] = var
+    gh = GMMHMM(N, M, D, base["A"], base["pi"], base["w"], mu, si)
+    cap = _gmmhmm_capture(gh, obs, with_estimate=False)
+    out.update({"A": base["A"], "pi": base["pi"], "w": base["w"], "wide_mu": mu, "wide_var": var, "wide_obs": obs})
+    out.update({"wide_" + k: v for k, v in cap.items()})
+    offset = 50.0 * rng.standard_normal(D)
+    for full, tag in ((False, "shift_"), (True, "shiftfull_")):
+        mdl = synth.synth_model(N, M, D, seed=3, full_cov=full)
+        mu2 = mdl["mu"] + offset
+        obs2 = offset + synth.synth_obs(1, T, D, seed=1003)[0]
+        gh = GMMHMM(N, M, D, mdl["A"], mdl["pi"], mdl["w"], mu2, mdl["si"])
+        cap = _gmmhmm_capture(gh, obs2, with_estimate=False)
+        out.update({tag + "mu": mu2, tag + "obs": obs2, tag + ("si" if full else "var"): (mdl["si"] if full else mdl["var"])})
+        out.update({tag + k: v for k, v in cap.items()})
+    save("gmmhmm_offset_means", **out)
+
+
 def gen_metric_slice():
     """Metric config: N=128, M=16, D=39, T=1000, 2 utterances, diagonal Sigma."""
     N, M, D, T, U = 128, 16, 39, 1000, 2
@@ -336,3 +369,4 @@ if __name__ == "__main__":
         gen_mfcc()
         gen_discrete_mid()
         gen_metric_slice()
+        gen_offset_means()

@@ -98,9 +98,11 @@ def test_config5_full_size_properties(synth, ctx):
     assert_close(st2, st, 1e-12, 1e-12)
     # the M-step yields normalised rows and the variance floor
     m = ctx.bw_mstep(st)
+    # (log-likelihoods of 2000-frame utterances are ~ -1e5, one ulp of which is 1.5e-11: the posteriors
+    # exp(alpha + beta - loglik) carry that much relative error, and so do sums that should be exactly 1)
     assert np.abs(np.exp(m["A"]).sum(axis=1) - 1).max() < 1e-12
     assert np.abs(np.exp(m["w"]).sum(axis=1) - 1).max() < 1e-12
-    assert abs(np.exp(m["pi"]).sum() - 1) < 1e-12
+    assert abs(np.exp(m["pi"]).sum() - 1) < 1e-9
     assert (m["var"] >= 0.01).all() and np.isfinite(m["mu"]).all()
     # weighted mean of the new means = weighted mean of the data, per state (first moments are consistent)
     tot_x = (s["mix_x"].reshape(N, M, D)).sum(axis=(0, 1))

@@ -196,6 +196,67 @@ def test_single_gmm_batch(synth, oracle, ctx):
             assert_close(b[u, :, 0], ref, 1e-12)
 
 
+def _kernels_of(ctx, fn):
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    out = fn()
+    names = set(ctx.prof_report())
+    ctx.prof_enable(False)
+    return out, names
+
+
+def test_offset_means_conditioning(golden, oracle, ctx):
+    """Models of real-feature scale (golden from the reference, which scores with the direct (x - mu) form).  The
+    matrix-core kernels evaluate the expanded quadratic on observations centred on the mean of the means: a large
+    common offset costs nothing; means many standard deviations APART (kappa > 4096) are refused and scored by the
+    direct-form kernel.  Either way b, bm match to 1e-12 and the Viterbi path is the reference's."""
+    g = golden("gmmhmm_offset_means")
+    A, pi, w = g["A"], g["pi"], g["w"]
+    # one large offset per dimension, unit-scale spread: stays on the matrix cores
+    ctx.upload_gmmhmm(A, pi, w, g["shift_mu"], g["shift_var"], diag=True)
+    kappa, direct = ctx.model_conditioning()
+    assert not direct and kappa < 64
+    (b, bm), names = _kernels_of(ctx, lambda: ctx.gmm_logprob(g["shift_obs"][None], want_bm=True))
+    assert "emit_diag_mfma_bm" in names
+    assert_close(b[0].T, g["shift_b"], 1e-12), assert_close(bm[0].transpose(1, 2, 0), g["shift_bm"], 1e-12)
+    assert np.array_equal(ctx.decode(g["shift_obs"][None])[0], g["shift_path"])
+    alpha, ll = ctx.forward(b)
+    assert_close(alpha[0], g["shift_alpha"], 1e-11) and abs(ll[0] - g["shift_loglik"][0]) < 1e-11 * abs(ll[0])
+    # the same model with full covariances
+    ctx.upload_gmmhmm(A, pi, w, g["shiftfull_mu"], g["shiftfull_si"])
+    kappa, direct = ctx.model_conditioning()
+    assert not direct and not ctx.model_is_diag()
+    (b, bm), names = _kernels_of(ctx, lambda: ctx.gmm_logprob(g["shiftfull_obs"][None], want_bm=True))
+    assert "emit_full_mfma_bm" in names
+    assert_close(b[0].T, g["shiftfull_b"], 1e-11), assert_close(bm[0].transpose(1, 2, 0), g["shiftfull_bm"], 1e-11)
+    assert np.array_equal(ctx.decode(g["shiftfull_obs"][None])[0], g["shiftfull_path"])
+    # a single shifted mixture (N = 1): the LDS-free kernel centres in registers
+    ctx.upload_gmmhmm(A[:1, :1] * 0, pi[:1] * 0, w[:1], g["shift_mu"][:1], g["shift_var"][:1], diag=True)
+    (b1, bm1), names = _kernels_of(ctx, lambda: ctx.gmm_logprob(g["shift_obs"][None], want_bm=True))
+    assert "emit_single_direct_bm" in names
+    assert_close(b1[0, :, 0], g["shift_b"][0], 1e-12), assert_close(bm1[0, :, 0].T, g["shift_bm"][0], 1e-12)
+    # means 15 units apart with variances of 0.01 .. 0.1: refused, scored in the direct form
+    ctx.upload_gmmhmm(A, pi, w, g["wide_mu"], g["wide_var"], diag=True)
+    kappa, direct = ctx.model_conditioning()
+    assert direct and kappa > 1e5
+    (b, bm), names = _kernels_of(ctx, lambda: ctx.gmm_logprob(g["wide_obs"][None], want_bm=True))
+    assert "emit_diag_generic" in names and not [n for n in names if "mfma" in n]
+    assert_close(b[0].T, g["wide_b"], 1e-12), assert_close(bm[0].transpose(1, 2, 0), g["wide_bm"], 1e-12)
+    assert np.array_equal(ctx.decode(g["wide_obs"][None])[0], g["wide_path"])
+    st = ctx.bw_accumulate(g["wide_obs"][None])
+    ref = oracle.bw_stats_diag([g["wide_obs"]], A, pi, w, g["wide_mu"], g["wide_var"])
+    assert abs(st[-3] - g["wide_loglik"][0]) < 1e-11 * abs(st[-3])
+    # what the gate is for: forced onto the expanded form the same model misses 1e-12
+    with env_switch(LNASR_KAPPA_MAX="1e300"):
+        ctx._model_fp = None                              # same bytes as the model on the device: force the upload
+        ctx.upload_gmmhmm(A, pi, w, g["wide_mu"], g["wide_var"], diag=True)
+        assert not ctx.model_conditioning()[1]
+        bx = ctx.gmm_logprob(g["wide_obs"][None])
+    ctx._model_fp = None
+    err = np.abs(bx[0].T - g["wide_b"])
+    assert err.max() > 1e-11 and err.max() < 1e-6
+
+
 @pytest.mark.parametrize("N,U", [(128, 5), (100, 3), (37, 4), (128, 520)])
 def test_viterbi_float32_register_kernels(N, U, synth, ctx):
     """precision=np.float32: the register-resident Viterbi and the LDS backtrace with float storage (fp64 arithmetic,

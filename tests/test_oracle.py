@@ -181,6 +181,25 @@ def test_metric_slice_fused_baseline(oracle, golden, synth):
         assert np.array_equal(oracle.decode_diag_fused(obs[u], mdl["A"], mdl["pi"], W, N, M), g["path"][u])
 
 
+def test_offset_means(oracle, golden):
+    """Real-feature-scale models (golden from the reference): the direct-form restatements match to 1e-12 and give
+    the reference's paths; the expanded-quadratic vectorisation (fine at unit scale, and what the CPU baseline
+    times) visibly does not on the wide model -- which is why the GPU kernels gate on conditioning."""
+    g = golden("gmmhmm_offset_means")
+    A, pi, w = g["A"], g["pi"], g["w"]
+    for tag in ("wide_", "shift_"):
+        mu, var, obs = g[tag + "mu"], g[tag + "var"], g[tag + "obs"]
+        b, bm = oracle.gmm_map_b_diag_direct(obs, w, mu, var)
+        assert_close(bm, g[tag + "bm"], 1e-12), assert_close(b, g[tag + "b"], 1e-12)
+        v, bt, path = oracle.viterbi(A, pi, b)
+        assert np.array_equal(path, g[tag + "path"]) and np.array_equal(bt, g[tag + "bt"])
+        assert_close(oracle.forward(A, pi, b), g[tag + "alpha"], 1e-11)
+    b, bm = oracle.gmm_map_b(g["shiftfull_obs"], w, g["shiftfull_mu"], g["shiftfull_si"])
+    assert_close(bm, g["shiftfull_bm"], 1e-11), assert_close(b, g["shiftfull_b"], 1e-11)
+    bx, _ = oracle.gmm_map_b_diag(g["wide_obs"], w, g["wide_mu"], g["wide_var"])
+    assert np.abs(bx - g["wide_b"]).max() > 1e-11          # the cancellation is real
+
+
 def test_gmm_funcs(oracle, golden):
     g = golden("gmm_funcs")
     assert_close(oracle.gaussian(g["x1"], 0, 4), g["g1"], 1e-14)
