@@ -238,6 +238,32 @@ __device__ __forceinline__ double exp_nonpos_big(double x, const double* tab) {
     return fma(t, p, t);
 }
 
+// exp_nonpos_big with the exponent applied by ONE integer instruction: the table holds 2^(j/2048) with (j << 9)
+// already subtracted from its high word (exp_table_big_init), so that adding (k << 9) -- k = 2048 e + j -- leaves
+// exactly e << 20 on the exponent field: v_lshl_add_u32 instead of and + shift + add.
+__device__ __forceinline__ void exp_table_big_init(double* etab, int tid, int nt) {
+    for (int e = tid; e < kExpTabBig; e += nt) {
+        const double t = exp2((double)e * (1.0 / kExpTabBig));
+        etab[e] = __hiloint2double(__double2hiint(t) - (e << 9), __double2loint(t));
+    }
+}
+__device__ __forceinline__ double exp_nonpos_big2(double x, const double* tab) {
+    constexpr double kInvStep = 369.32993046757463 * 8.0;        // 2048 / ln 2
+    constexpr double kStepHi = 2.7076061740622863e-03 / 8.0;      // ln 2 / 2048
+    constexpr double kMagic = 6755399441055744.0;                 // 1.5 * 2^52
+    x = vmax_f64(x, -700.0);
+    const double kp = fma(x, kInvStep, kMagic);
+    const unsigned k = (unsigned)__double2loint(kp);
+    const double kd = kp - kMagic;
+    const double r = fma(-kd, kStepHi, x);                        // one-step reduction: see exp_nonpos_big
+    const double q = fma(r, 1.0 / 6.0, 0.5);
+    const double p = fma(q, r * r, r);
+    const double t0 = tab[k & (kExpTabBig - 1)];
+    const unsigned hi = (unsigned)__double2hiint(t0) + (k << 9);      // one v_lshl_add_u32
+    const double t = __hiloint2double((int)hi, __double2loint(t0));
+    return fma(t, p, t);
+}
+
 // log(s) for the sum of a max-shifted log-sum-exp: 1 <= s <= 2^20.  s = 2^e m, m in [1,2);
 // c_j = 1 + (j + 1/2)/128 from the top seven mantissa bits; r = m/c_j - 1 (|r| <= 1/256, formed exactly
 // by an fma with the tabulated reciprocal); log s = e ln2 + log c_j + (r - r^2/2 + ... - r^6/6)

@@ -265,7 +265,7 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 2))
     __shared__ double ltab[2 * kLogTab];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    for (int e = tid; e < kExpTabBig; e += NT) etab[e] = exp2((double)e * (1.0 / kExpTabBig));
+    exp_table_big_init(etab, tid, NT);
     log_table_init(ltab, tid, NT);
     const long bid = blockIdx.x;
     const int xcd = (int)(bid & 7);
@@ -373,9 +373,15 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
             for (int q = 0; q < Q; ++q) acc[q] = double4_t{0.0, 0.0, 0.0, 0.0};
             const double* Fc = &Fl[cur][tt][0];
+            // B operands two k-steps ahead of the MFMAs that use them: read right before its use, every LDS read's
+            // latency sat between two MFMA groups (both waves of a SIMD walk the tile in the same phase)
+            double bfq[2];
+#pragma unroll
+            for (int ks = 0; ks < 2 && ks < KS; ++ks) bfq[ks] = Fc[(4 * ks + g) * FS + fr];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const double bf = Fc[(4 * ks + g) * FS + fr];
+                const double bf = bfq[ks & 1];
+                if (ks + 2 < KS) bfq[ks & 1] = Fc[(4 * (ks + 2) + g) * FS + fr];
 #pragma unroll
                 for (int q = 0; q < Q; ++q) {
                     if (ABL == 2) acc[q][ks & 3] += bf * wr[q][ks];      // ablation: no matrix op
@@ -413,9 +419,10 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 2))
                     if (q + r > 0) mx = vmax_f64(mx, acc[q][r]);
             double s = 0.0;
 #pragma unroll
-            for (int q = 0; q < Q; ++q)
+            for (int q = 0; q < Q; ++q) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s += exp_nonpos_big(acc[q][r] - mx, etab);
+                for (int r = 0; r < 4; ++r) s += exp_nonpos_big2(acc[q][r] - mx, etab);
+            }
             // mx = -inf: every term is NaN -> clamped -> s = 0 -> log gives -inf; mx = +inf/NaN propagate
             ob[cur][tt][fr * OS + 4 * w + g] = (mx == LN_NEG_INF) ? mx : mx + log_sum(s, ltab);
 

@@ -9,6 +9,8 @@
 // recomputed during the backtrace with the same fp64 additions, so the result is bit-identical
 // while the inner loop is one add + one max per (i, j).  The full bt matrix is produced by a
 // separate, fully parallel kernel only when the caller asks for it.
+#include <utility>
+
 #include "common.h"
 #include "devmath.h"
 
@@ -1730,10 +1732,13 @@ constexpr int kT256End = kT256Lt + 2 * kLogTab;
 // (combine the slices, log / exp, emission, store) and therefore keep fewer rows of A in registers;
 // FIN = false: the twelve waves of slices 1..3, which only multiply.  The two roles are separate
 // instantiations so that each gets its own register allocation; both execute the same barriers.
-template <int MODE, bool FIN>
-__device__ __forceinline__ void trellis256_role(double* sm, const double* __restrict__ bu, const double* __restrict__ Amat,
+// TS = float (Viterbi only): `precision=np.float32` -- b and v are float arrays, every sum is formed in fp64 and
+// rounded to float where the reference's float32 array rounds it, i.e. at the store of v[t, j] (hmm.py:160-165).
+template <int MODE, bool FIN, typename TS = double>
+__device__ __forceinline__ void trellis256_role(double* sm, const TS* __restrict__ bu, const double* __restrict__ Amat,
                                                 const double* __restrict__ Alog, const double* __restrict__ pi,
-                                                double* __restrict__ ou, double* __restrict__ loglik_u, int L, int T, int N) {
+                                                TS* __restrict__ ou, double* __restrict__ loglik_u, int L, int T, int N) {
+    static_assert(MODE == 0 || std::is_same<TS, double>::value, "float storage: Viterbi only");
     constexpr bool VIT = MODE == 0, BACKWARD = MODE == 2;
     constexpr int NP = 256, RPS = 64;
     constexpr int NREG = FIN ? kT256FinReg : kT256CmpReg, NLDS = 64 - NREG;
@@ -1770,13 +1775,13 @@ __device__ __forceinline__ void trellis256_role(double* sm, const double* __rest
         double prev = LN_NEG_INF;
         if (jc < N) {
             const int t0 = frame_of(0);
-            const double bv = bu[(size_t)t0 * N + jc];
+            const double bv = (double)bu[(size_t)t0 * N + jc];
             if (BACKWARD) {
-                if (ou) ou[(size_t)t0 * N + jc] = 0.0;
+                if (ou) ou[(size_t)t0 * N + jc] = (TS)0.0;
                 prev = 0.0 + bv;
             } else {
-                prev = pi[jc] + bv;
-                if (ou) ou[(size_t)t0 * N + jc] = prev;
+                prev = rnd<TS>(pi[jc] + bv);
+                if (ou) ou[(size_t)t0 * N + jc] = (TS)prev;
             }
         }
         if (VIT) {
@@ -1786,7 +1791,7 @@ __device__ __forceinline__ void trellis256_role(double* sm, const double* __rest
             const double m = wave_max_dpp(prev);
             if (lane == 0) Ms[jc >> 6] = m;
         }
-        bnext = bu[(size_t)clampt(frame_of(1)) * N + jcl];
+        bnext = (double)bu[(size_t)clampt(frame_of(1)) * N + jcl];
     }
     __syncthreads();
     if (FIN && !VIT) {
@@ -1801,7 +1806,7 @@ __device__ __forceinline__ void trellis256_role(double* sm, const double* __rest
         const int cur = (step - 1) & 1, nxt = step & 1;
         const double* Vc = Vs + cur * NP + rs * RPS + (lane & 15);
         double bcur = bnext;
-        if (FIN) bnext = bu[(size_t)clampt(frame_of(step + 1)) * N + jcl];
+        if (FIN) bnext = (double)bu[(size_t)clampt(frame_of(step + 1)) * N + jcl];
         // The 64 previous-frame values of this row slice sit in four VGPR pairs, 16 per DPP row
         // (lane l holds V[16k + (l & 15)]); row_newbcast:n hands value n of the pair to every lane,
         // so a transition costs one v_fmac_f64_dpp and no LDS broadcast read (the LDS pipe would
@@ -1842,8 +1847,8 @@ __device__ __forceinline__ void trellis256_role(double* sm, const double* __rest
                 const double m = vmax_f64(vmax_f64(part, Ps[jc]), vmax_f64(Ps[NP + jc], Ps[2 * NP + jc]));
                 double val = LN_NEG_INF;
                 if (jc < N) {
-                    val = m + bcur;
-                    ou[(size_t)t * N + jc] = val;
+                    val = rnd<TS>(m + bcur);
+                    ou[(size_t)t * N + jc] = (TS)val;
                 }
                 Vs[nxt * NP + jc] = val;
             } else {
@@ -1858,11 +1863,11 @@ __device__ __forceinline__ void trellis256_role(double* sm, const double* __rest
                 double prev = LN_NEG_INF;
                 if (jc < N) {
                     if (BACKWARD) {
-                        if (ou) ou[(size_t)t * N + jc] = val;
+                        if (ou) ou[(size_t)t * N + jc] = (TS)val;
                         prev = val + bcur;
                     } else {
                         prev = val + bcur;
-                        if (ou) ou[(size_t)t * N + jc] = prev;
+                        if (ou) ou[(size_t)t * N + jc] = (TS)prev;
                     }
                 }
                 const double S = fmax(fmax(Ms[cur * 4], Ms[cur * 4 + 1]), fmax(Ms[cur * 4 + 2], Ms[cur * 4 + 3]));
@@ -1888,12 +1893,12 @@ __device__ __forceinline__ void trellis256_role(double* sm, const double* __rest
     }
 }
 
-template <int MODE>
-__global__ __launch_bounds__(1024) void trellis256_kernel(const double* __restrict__ b,
+template <int MODE, typename TS = double>
+__global__ __launch_bounds__(1024) void trellis256_kernel(const TS* __restrict__ b,
                                                           const double* __restrict__ Amat,   // logA / expA / expA^T
                                                           const double* __restrict__ Alog,   // logA or logA^T (fallback)
                                                           const double* __restrict__ pi,
-                                                          const int32_t* __restrict__ lens, double* __restrict__ out,
+                                                          const int32_t* __restrict__ lens, TS* __restrict__ out,
                                                           double* __restrict__ loglik, int U, int T, int N) {
     extern __shared__ double sm[];
     const int u = blockIdx.x;
@@ -1903,13 +1908,13 @@ __global__ __launch_bounds__(1024) void trellis256_kernel(const double* __restri
         exp_table_init(sm + kT256Et, threadIdx.x, 1024);
         log_table_init(sm + kT256Lt, threadIdx.x, 1024);
     }
-    const double* bu = b + (size_t)u * T * N;
-    double* ou = out ? out + (size_t)u * T * N : nullptr;
+    const TS* bu = b + (size_t)u * T * N;
+    TS* ou = out ? out + (size_t)u * T * N : nullptr;
     // wave-uniform role split (threadIdx.x >> 8 is constant within a wave); the barriers of the two roles pair up
     if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 8) == 0)
-        trellis256_role<MODE, true>(sm, bu, Amat, Alog, pi, ou, loglik ? loglik + u : nullptr, L, T, N);
+        trellis256_role<MODE, true, TS>(sm, bu, Amat, Alog, pi, ou, loglik ? loglik + u : nullptr, L, T, N);
     else
-        trellis256_role<MODE, false>(sm, bu, Amat, Alog, pi, ou, nullptr, L, T, N);
+        trellis256_role<MODE, false, TS>(sm, bu, Amat, Alog, pi, ou, nullptr, L, T, N);
 }
 
 static inline size_t trellis256_lds() { return (size_t)kT256End * 8; }
@@ -2093,6 +2098,12 @@ int viterbi_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
                   A, pi, d_lens, (double*)v, (double*)nullptr, U, T, N);
         return 0;
     }
+    if (dtype == LNASR_F32 && N > 128 && N <= 256 && !getenv("LNASR_NO_T256") && !getenv("LNASR_F32_GENERIC")) {
+        // precision=np.float32 beyond 128 states: the on-chip kernel with float storage and rounding
+        LN_LAUNCH(ctx, "viterbi_onchip256_f32", (trellis256_kernel<0, float>), dim3(U), dim3(1024), trellis256_lds(),
+                  (const float*)b, A, A, pi, d_lens, (float*)v, (double*)nullptr, U, T, N);
+        return 0;
+    }
     if (dtype == LNASR_F64 && N > 256 && viterbi_framepar(N, U)) {
         // one launch per frame over the whole batch (see viterbi_frame_kernel)
         constexpr int UT = 8;
@@ -2188,6 +2199,11 @@ int backtrace_device(lnasr_ctx* ctx, const void* v, int U, int T, const int32_t*
     if (dtype == LNASR_F32 && md.N <= 128 && !getenv("LNASR_NO_LDSBT") && !getenv("LNASR_F32_GENERIC")) {
         LN_LAUNCH(ctx, "backtrace_lds_f32", (backtrace_lds_kernel<2, true, float>), dim3((U + wpb - 1) / wpb), dim3(64 * wpb),
                   (size_t)md.N * md.N * 8, (const float*)v, md.logAT.as<double>(), d_lens, path, best, U, T, md.N);
+        return 0;
+    }
+    if (dtype == LNASR_F32 && md.N <= 256 && !getenv("LNASR_NO_LDSBT") && !getenv("LNASR_F32_GENERIC")) {
+        LN_LAUNCH(ctx, "backtrace_wave256_f32", (backtrace_lds_kernel<4, false, float>), dim3(U), dim3(64), 0, (const float*)v,
+                  md.logAT.as<double>(), d_lens, path, best, U, T, md.N);
         return 0;
     }
     if (dtype == LNASR_F32)
@@ -2478,9 +2494,49 @@ int lnasr_decode(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t*
     LN_TRY(ctx->ws_v.reserve(cells * 8));
     LN_TRY(stage_out(ctx, path, (size_t)U * T * 4, ctx->ws_out, &d_path));
     if (best_score_or_null) LN_TRY(stage_out(ctx, best_score_or_null, (size_t)U * 8, ctx->ws_out2, &d_best));
-    LN_TRY(emit_batch(ctx, obs, U, T, ctx->ws_b.as<double>(), nullptr, nullptr));
-    LN_TRY(viterbi_device(ctx, ctx->ws_b.p, U, T, d_lens, LNASR_F64, ctx->ws_v.p));
-    LN_TRY(backtrace_device(ctx, ctx->ws_v.p, U, T, d_lens, LNASR_F64, (uint32_t*)d_path, (double*)d_best));
+    // Device-resident batches may be cut into chunks whose trellis work (side stream) runs beside the next chunk's
+    // emission (main stream); LNASR_DECODE_CHUNKS = 1 keeps the three launches in series on one stream.
+    int nch = 1;
+    if (const char* e = getenv("LNASR_DECODE_CHUNKS")) nch = atoi(e);
+    if (nch > 16) nch = 16;
+    if (nch < 2 || U < 64 * nch || !is_device_ptr(obs) || md.N > 128) {
+        LN_TRY(emit_batch(ctx, obs, U, T, ctx->ws_b.as<double>(), nullptr, nullptr));
+        LN_TRY(viterbi_device(ctx, ctx->ws_b.p, U, T, d_lens, LNASR_F64, ctx->ws_v.p));
+        LN_TRY(backtrace_device(ctx, ctx->ws_v.p, U, T, d_lens, LNASR_F64, (uint32_t*)d_path, (double*)d_best));
+    } else {
+        while ((int)ctx->copy_events.size() < nch) {
+            hipEvent_t e;
+            LN_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ctx->copy_events.push_back(e);
+        }
+        // the side stream must not start before earlier work on the main stream (lens, previous calls) is done
+        LN_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+        LN_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+        const size_t row = (size_t)T * md.N;
+        int rc = 0;
+        for (int c = 0; c < nch && rc == 0; ++c) {
+            const int u0 = (int)((long)U * c / nch), u1 = (int)((long)U * (c + 1) / nch), uc = u1 - u0;
+            double* bc = ctx->ws_b.as<double>() + (size_t)u0 * row;
+            double* vc = ctx->ws_v.as<double>() + (size_t)u0 * row;
+            rc = emit_device(ctx, obs + (size_t)u0 * T * md.D, (long)uc * T, LNASR_F64, bc, nullptr);
+            if (rc) break;
+            if (hipEventRecord(ctx->copy_events[c], ctx->stream) != hipSuccess ||
+                hipStreamWaitEvent(ctx->stream2, ctx->copy_events[c], 0) != hipSuccess) {
+                rc = fail(LNASR_E_HIP, "event plumbing of the chunked decode failed");
+                break;
+            }
+            std::swap(ctx->stream, ctx->stream2);          // LN_LAUNCH (and its profiling events) follow ctx->stream
+            rc = viterbi_device(ctx, bc, uc, T, d_lens + u0, LNASR_F64, vc);
+            if (rc == 0)
+                rc = backtrace_device(ctx, vc, uc, T, d_lens + u0, LNASR_F64, (uint32_t*)d_path + (size_t)u0 * T,
+                                      d_best ? (double*)d_best + u0 : nullptr);
+            std::swap(ctx->stream, ctx->stream2);
+        }
+        // join: later work on the main stream sees the side stream's results
+        (void)hipEventRecord(ctx->ev_join, ctx->stream2);
+        (void)hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);
+        LN_TRY(rc);
+    }
     LN_TRY(finish_out(ctx, path, d_path, (size_t)U * T * 4));
     if (best_score_or_null) LN_TRY(finish_out(ctx, best_score_or_null, d_best, (size_t)U * 8));
     return 0;

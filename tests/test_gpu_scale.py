@@ -55,6 +55,29 @@ def test_metric_config_full_size(synth, oracle):
     assert np.abs(tot - ll.to_host()[:, None]).max() < 1e-7
 
 
+def test_chunked_two_stream_decode_is_identical(synth):
+    """LNASR_DECODE_CHUNKS (off by default: measured slower) cuts a device-resident batch into chunks whose
+    trellis work runs on the side stream beside the next chunk's emission: same paths, same scores, ragged lengths."""
+    from lnasr import _ffi
+    ctx = _ffi.default_ctx()
+    N, M, D, T, U = 128, 16, 39, 60, 300
+    mdl = synth.synth_model(N, M, D, seed=1)
+    obs = synth.synth_obs(U, T, D, seed=77)
+    lens = np.random.default_rng(5).integers(2, T + 1, U).astype(np.int32)
+    ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
+    d_obs = ctx.to_device(obs)
+    p1, s1 = ctx.decode(d_obs, want_score=True, lens=lens)
+    p1, s1 = p1.to_host(), s1.to_host()
+    for nch in (2, 3, 4):
+        with env_switch(LNASR_DECODE_CHUNKS=nch):
+            p2, s2 = ctx.decode(d_obs, want_score=True, lens=lens)
+            p3, s3 = ctx.decode(d_obs, want_score=True, lens=lens)        # back to back: the join holds
+        for u in range(U):
+            assert np.array_equal(p2.to_host()[u, :lens[u]], p1[u, :lens[u]])
+        assert np.array_equal(s2.to_host(), s1) and np.array_equal(s3.to_host(), s1)
+        assert np.array_equal(p3.to_host(), p2.to_host())
+
+
 def test_segmentation_sized_discrete_hmm(oracle):
     """scripts/seg/seg.py shape: n = 4 (BMES), m = 65536 symbols, one long character sequence."""
     from lnasr.hmm import HMM
