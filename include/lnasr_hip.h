@@ -156,6 +156,12 @@ int lnasr_estimate_gmm(lnasr_ctx* ctx, const double* obs, int T, int dtype,
  * mix_xx[N*M*D] (diagonal model) or [N*M*D*D] (full), loglik_sum[1], n_utt[1], n_frames[1]. */
 int lnasr_bw_stats_len(lnasr_ctx* ctx, size_t* n_doubles);
 int lnasr_bw_accumulate(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* lens, double* stats);
+/* The same pass under the reference's `precision=` (hmm.py:38, gmmhmm.py:34-44).  LNASR_F32: component log-densities
+ * and posterior-weighted moments run on the fp32 matrix cores and are handed over as float (diagonal, well
+ * conditioned models with N % 4 == 0, M in {4, 8, 16, 32}, D <= 39; any other model takes the fp64 pass -- more
+ * precise than asked for, never less); the recursions, xi and the packed statistics stay fp64.  Results agree with
+ * the fp64 pass to float32 accuracy (~1e-5 relative). */
+int lnasr_bw_accumulate_p(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* lens, int dtype, double* stats);
 /* M-step from (all-reduced) statistics: new logA, logpi, logw, mu, sigma (diag [N,M,D] or full) */
 int lnasr_bw_mstep(lnasr_ctx* ctx, const double* stats, double min_std,
                    double* logA, double* logpi, double* logw, double* mu, double* sigma);

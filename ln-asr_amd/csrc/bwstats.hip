@@ -216,7 +216,7 @@ int xi_sum_device(lnasr_ctx* ctx, const double* alpha, const double* beta, const
 // Raw sums go to R[(j, m), col]; mix_finish_kernel turns them into the reference's three accumulators.
 // ------------------------------------------------------------------------------------------
 constexpr int kMixFrames = 32;       // frames per staged chunk (8 MFMA k-steps)
-constexpr int kMixRing = 4;          // bm prefetch ring (k-steps)
+constexpr int kMixRing = 8;          // bm prefetch ring (k-steps; must divide kMixFrames / 4)
 constexpr int kMixWaves = 8;         // waves (= states) per block; 4-wave blocks at 3 waves/SIMD were measured: slower (5.7 vs 4.1 ms)
 constexpr int kMixNT = 64 * kMixWaves;
 
@@ -623,6 +623,21 @@ int full_stats_device(lnasr_ctx* ctx, const double* obs, const double* alpha, co
     const size_t nel = (size_t)N * M * D * D;
     LN_LAUNCH(ctx, "full_finish", full_finish_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, (const double*)R,
               md.mu.as<double>(), (const double*)centre, N, M, D, MP, KF, mix, mix_x, mix_xx);
+    return 0;
+}
+
+// launch wrappers for f32stats.hip (kernels are launched from the translation unit that defines them)
+int mix_centre_launch(lnasr_ctx* ctx, double* centre) {
+    Model& md = ctx->model;
+    LN_LAUNCH(ctx, "mix_centre", mix_centre_kernel, dim3(md.D), dim3(256), 0, md.mu.as<double>(), md.N * md.M, md.D, centre);
+    return 0;
+}
+int mix_finish_launch(lnasr_ctx* ctx, const double* R, const double* centre, int MP, int NFP, double* mix, double* mix_x,
+                      double* mix_xx) {
+    Model& md = ctx->model;
+    const size_t nel = (size_t)md.N * md.M * md.D;
+    LN_LAUNCH(ctx, "mix_finish", mix_finish_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, R, md.mu.as<double>(),
+              centre, md.N, md.M, md.D, MP, NFP, mix, mix_x, mix_xx);
     return 0;
 }
 

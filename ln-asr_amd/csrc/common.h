@@ -92,6 +92,9 @@ struct Model {
     DevBuf mu_c;                 // [N,M,D] mu - centre: what the coefficient packers see
     double kappa = 0.0;
     bool direct_form = false;    // kappa > kKappaMax (or not finite): expanded form refused
+    // fp32 matrix-core pass (f32stats.hip): float coefficient fragments, packed on first use after an upload
+    DevBuf wpack32;
+    unsigned long upload_serial = 0, wpack32_for = ~0ul;
     void release();
 };
 
@@ -176,6 +179,13 @@ int mix_stats_device(lnasr_ctx* ctx, const double* obs, const double* alpha, con
                      double* mix_x, double* mix_xx);
 
 bool full_stats_mfma_ok(const Model& md);
+
+// `precision=np.float32` statistics pass on the fp32 matrix cores (f32stats.hip)
+bool f32_stats_ok(const Model& md);
+int emit_device_f32(lnasr_ctx* ctx, const double* obs, long F, double* b, float* q32);
+int mix_stats_device_f32(lnasr_ctx* ctx, const double* obs, const double* alpha, const double* beta, const double* b,
+                         const float* q32, const double* c1, const int32_t* d_lens, int U, int T, double* mix,
+                         double* mix_x, double* mix_xx);
 int full_stats_device(lnasr_ctx* ctx, const double* obs, const double* alpha, const double* beta, const double* b,
                       const double* bm, const double* c1, const int32_t* d_lens, int U, int T, double* mix,
                       double* mix_x, double* mix_xx);

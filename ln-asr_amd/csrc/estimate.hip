@@ -666,8 +666,13 @@ int lnasr_bw_stats_len(lnasr_ctx* ctx, size_t* n) {
 }
 
 int lnasr_bw_accumulate(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* lens, double* stats) {
+    return lnasr_bw_accumulate_p(ctx, obs, U, T, lens, LNASR_F64, stats);
+}
+
+int lnasr_bw_accumulate_p(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* lens, int dtype, double* stats) {
     LN_ENTER(ctx);
     LN_REQUIRE(ctx && stats, "null argument");
+    LN_REQUIRE(dtype == LNASR_F64 || dtype == LNASR_F32, "bad dtype %d", dtype);
     Model& md = ctx->model;
     if (!md.has_gmm) return fail(LNASR_E_NOMODEL, "no GMM-HMM model uploaded");
     LN_REQUIRE(U >= 1 && T >= 1 && obs, "bad batch");
@@ -681,8 +686,10 @@ int lnasr_bw_accumulate(lnasr_ctx* ctx, const double* obs, int U, int T, const i
     double* st = (double*)d_st;
     LN_HIP(hipMemsetAsync(st, 0, L.total * 8, ctx->stream));
     const size_t cells = (size_t)U * T * N;
+    // precision = float32: densities and moments on the fp32 matrix cores where the model allows it (f32stats.hip)
+    const bool f32 = dtype == LNASR_F32 && f32_stats_ok(md);
     LN_TRY(ctx->ws_b.reserve(cells * 8));
-    LN_TRY(ctx->ws_bm.reserve(cells * M * 8));
+    LN_TRY(ctx->ws_bm.reserve(cells * M * (f32 ? 4 : 8)));
     LN_TRY(ctx->ws_alpha.reserve(cells * 8));
     LN_TRY(ctx->ws_beta.reserve(cells * 8));
     LN_TRY(ctx->ws_misc.reserve(((size_t)U + (size_t)U * T) * 8));
@@ -692,7 +699,14 @@ int lnasr_bw_accumulate(lnasr_ctx* ctx, const double* obs, int U, int T, const i
     double* bm = ctx->ws_bm.as<double>();
     double* al = ctx->ws_alpha.as<double>();
     double* be = ctx->ws_beta.as<double>();
-    LN_TRY(emit_batch(ctx, obs, U, T, b, bm, &d_obs));      // host observations: upload overlapped with the emission
+    if (f32) {
+        const void* dv;
+        LN_TRY(stage_in(ctx, obs, (size_t)U * T * D * 8, ctx->ws_in, &dv));
+        d_obs = (const double*)dv;
+        LN_TRY(emit_device_f32(ctx, d_obs, (long)U * T, b, ctx->ws_bm.as<float>()));
+    } else {
+        LN_TRY(emit_batch(ctx, obs, U, T, b, bm, &d_obs));  // host observations: upload overlapped with the emission
+    }
     // forward and backward only share their input: with few utterances per GPU (config 5: 64 blocks on 256 CUs)
     // the backward pass runs on a side stream beside the forward pass
     LN_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
@@ -719,7 +733,10 @@ int lnasr_bw_accumulate(lnasr_ctx* ctx, const double* obs, int U, int T, const i
     // frames past an utterance's length hold stale alpha/beta; ab_lse covers them but acc_mix skips them
     LN_LAUNCH(ctx, "ab_lse", ab_lse_kernel<double>, dim3((unsigned)(((size_t)U * T + 3) / 4)), dim3(256), 0, al, be,
               (long)U * T, N, c1);
-    if (mix_stats_mfma_ok(md)) {
+    if (f32) {
+        LN_TRY(mix_stats_device_f32(ctx, (const double*)d_obs, al, be, b, ctx->ws_bm.as<float>(), c1, d_lens, U, T,
+                                    st + L.mix, st + L.mix_x, st + L.mix_xx));
+    } else if (mix_stats_mfma_ok(md)) {
         LN_TRY(mix_stats_device(ctx, (const double*)d_obs, al, be, b, bm, c1, d_lens, U, T, st + L.mix, st + L.mix_x,
                                 st + L.mix_xx));
     } else if (md.diag) {

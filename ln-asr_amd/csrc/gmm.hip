@@ -787,6 +787,7 @@ static int model_upload_impl(lnasr_ctx* ctx, int N, int M, int D, const double* 
     LN_REQUIRE(sigma, "null sigma");
     Model& md = ctx->model;
     md.has_gmm = false;
+    ++md.upload_serial;
     LN_TRY(upload_hmm(ctx, N, logA, logpi));
     const size_t NM = (size_t)N * M, NMD = NM * D;
     LN_TRY(copy_in(ctx, md.logw, logw, NM * 8));

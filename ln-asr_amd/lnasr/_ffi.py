@@ -70,6 +70,7 @@ SIGNATURES = {
     "lnasr_estimate_gmm": [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _dbl, _vp, _vp, _vp, _vp, _vp],
     "lnasr_bw_stats_len": [_vp, _P(_sz)],
     "lnasr_bw_accumulate": [_vp, _vp, _i, _i, _vp, _vp],
+    "lnasr_bw_accumulate_p": [_vp, _vp, _i, _i, _vp, _i, _vp],
     "lnasr_bw_mstep": [_vp, _vp, _dbl, _vp, _vp, _vp, _vp, _vp],
     "lnasr_lse": [_vp, _vp, _sz, _sz, _sz, _i, _vp],
     "lnasr_num_frames": [_i64, _i, _i, _P(_i64)],
@@ -489,11 +490,14 @@ class Context:
         check(lib().lnasr_bw_stats_len(self.handle, C.byref(n)))
         return n.value
 
-    def bw_accumulate(self, obs, lens=None, stats_out=None):
+    def bw_accumulate(self, obs, lens=None, stats_out=None, precision=np.float64):
+        """Packed fp64 statistics of a batch.  precision=np.float32: densities and moments on the fp32 matrix cores
+        (lnasr_bw_accumulate_p), statistics good to float32 accuracy."""
         obs = _in(obs, np.float64)
         U, T, D = obs.shape
         stats = stats_out if stats_out is not None else np.zeros(self.bw_stats_len(), dtype=np.float64)
-        check(lib().lnasr_bw_accumulate(self.handle, _ptr(obs), U, T, _ptr(self._lens(lens, U)), _ptr(stats)))
+        check(lib().lnasr_bw_accumulate_p(self.handle, _ptr(obs), U, T, _ptr(self._lens(lens, U)), dtype_code(precision),
+                                          _ptr(stats)))
         return stats
 
     def bw_mstep(self, stats, min_std=0.01):

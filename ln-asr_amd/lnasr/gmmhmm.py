@@ -174,8 +174,9 @@ class GMMHMM(HMM):
 
     def accumulate(self, obs_batch, lens=None):
         """Baum-Welch sufficient statistics of a batch (packed fp64 vector; sum over ranks
-        with Context.allreduce_f64, then `apply_stats`)."""
-        return self.ctx.bw_accumulate(obs_batch, lens=lens)
+        with Context.allreduce_f64, then `apply_stats`).  A model built with precision=np.float32 takes the
+        fp32 matrix-core pass."""
+        return self.ctx.bw_accumulate(obs_batch, lens=lens, precision=self.precision)
 
     def apply_stats(self, stats):
         """M-step from accumulated statistics; updates the parameters in place."""

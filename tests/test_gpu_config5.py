@@ -107,3 +107,99 @@ def test_config5_full_size_properties(synth, ctx):
     # weighted mean of the new means = weighted mean of the data, per state (first moments are consistent)
     tot_x = (s["mix_x"].reshape(N, M, D)).sum(axis=(0, 1))
     assert_close(tot_x, obs.reshape(-1, D).sum(axis=0), 1e-8, 1e-6, msg="sum of first moments = sum of data")
+
+
+def _kernels_of(ctx, fn):
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    out = fn()
+    names = set(ctx.prof_report())
+    ctx.prof_enable(False)
+    return out, names
+
+
+def _rel(a, b):
+    """max |a - b| relative to the largest magnitude of b (statistics of one kind share a scale)."""
+    a, b = np.asarray(a), np.asarray(b)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def test_config5_float32_pass_against_oracle(synth, oracle, ctx):
+    """`precision=np.float32` (config 5: "fp32 match to numpy"): component log-densities and posterior-weighted
+    moments on the fp32 matrix cores, float hand-off between them; statistics and the M-step agree with the fp64
+    oracle to float32 accuracy."""
+    mdl = synth.synth_model(N, M, D, seed=5)
+    lens = np.array([24, 17, 9], dtype=np.int32)
+    U, T = 3, 24
+    obs = synth.synth_obs(U, T, D, seed=505)
+    ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
+    st, names = _kernels_of(ctx, lambda: ctx.bw_accumulate(obs, lens=lens, precision=np.float32))
+    assert "emit_diag_mfma_f32" in names and "mix_mfma_f32" in names and not [n for n in names if n.startswith("emit_diag_mfma_bm")]
+    with np.errstate(divide="ignore", invalid="ignore", under="ignore"):
+        ref = oracle.bw_stats_diag([obs[u, :lens[u]] for u in range(U)], mdl["A"], mdl["pi"], mdl["w"], mdl["mu"],
+                                   mdl["var"])
+    s = _split(st)
+    for key in ("xi_sum", "gamma_sum", "gamma0", "mix", "mix_x", "mix_xx"):
+        assert _rel(s[key], np.asarray(ref[key]).ravel()) < 2e-4, key
+    assert abs(s["loglik"][0] - ref["loglik"]) <= 1e-6 * abs(ref["loglik"])
+    m = ctx.bw_mstep(st)
+    mo = oracle.mstep_from_stats(ref)
+    assert _rel(np.exp(m["A"]), np.exp(mo["A"])) < 2e-4 and _rel(np.exp(m["w"]), np.exp(mo["w"])) < 2e-4
+    assert np.abs(m["mu"] - mo["mu"]).max() < 2e-3 and _rel(m["var"], mo["var"]) < 2e-3
+    # and against the fp64 pass of the same library: float32 accuracy, not more
+    st64 = _split(ctx.bw_accumulate(obs, lens=lens))
+    for key in ("mix", "mix_x", "mix_xx", "xi_sum"):
+        assert 0 < _rel(s[key], st64[key]) < 2e-4, key
+
+
+@pytest.mark.parametrize("n,m,d", [(16, 4, 13), (8, 8, 39), (12, 16, 20), (4, 32, 5), (20, 16, 39)])
+def test_float32_pass_shapes(n, m, d, synth, oracle, ctx):
+    """Every tile path of the fp32 kernels: 4 / 8 / 16 / 32 mixtures, one to five feature tiles, ragged lengths,
+    a dead component; and the models it must refuse (padding needed, ill-conditioned, full covariance) take the
+    fp64 pass."""
+    mdl = synth.synth_model(n, m, d, seed=n + m)
+    w = mdl["w"].copy()
+    w[1, 0] = -np.inf
+    w[1] -= oracle.lse(w[1])
+    U, T = 3, 70
+    obs = synth.synth_obs(U, T, d, seed=9)
+    lens = np.array([T, T // 2, 1], dtype=np.int32)
+    ctx.upload_gmmhmm(mdl["A"], mdl["pi"], w, mdl["mu"], mdl["var"], diag=True)
+    st, names = _kernels_of(ctx, lambda: ctx.bw_accumulate(obs, lens=lens, precision=np.float32))
+    assert "mix_mfma_f32" in names
+    with np.errstate(divide="ignore", invalid="ignore", under="ignore"):
+        ref = oracle.bw_stats_diag([obs[u, :lens[u]] for u in range(U)], mdl["A"], mdl["pi"], w, mdl["mu"], mdl["var"])
+    o = 0
+    for key, cnt in (("xi_sum", n * n), ("gamma_sum", n), ("gamma0", n), ("mix", n * m), ("mix_x", n * m * d),
+                     ("mix_xx", n * m * d)):
+        assert _rel(st[o:o + cnt], np.asarray(ref[key]).ravel()) < 2e-4, key
+        o += cnt
+    assert st[n * n + 2 * n + m] == 0.0                    # the dead component's mass: exactly zero
+    if (n, m) == (16, 4):
+        # N = 15 needs padding: fp64 pass, silently (more precise than asked for)
+        m15 = synth.synth_model(15, m, d, seed=1)
+        ctx.upload_gmmhmm(m15["A"], m15["pi"], m15["w"], m15["mu"], m15["var"], diag=True)
+        _, names = _kernels_of(ctx, lambda: ctx.bw_accumulate(obs, lens=lens, precision=np.float32))
+        assert "mix_mfma_f32" not in names and "mix_mfma" in names
+
+
+def test_float32_pass_full_size_and_mirror(synth, ctx):
+    """Config 5 at full size under precision=float32: statistics within float32 accuracy of the fp64 pass; the
+    mirror class routes `accumulate` by its `precision=`."""
+    from lnasr.gmmhmm import GMMHMM
+    U, T = 64, 2000
+    mdl = synth.synth_model(N, M, D, seed=1)
+    obs = synth.synth_obs(U, T, D, seed=1000)
+    si = np.zeros((N, M, D, D))
+    si[:, :, np.arange(D), np.arange(D)] = mdl["var"]
+    gh32 = GMMHMM(N, M, D, mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], si, precision=np.float32, ctx=ctx)
+    d_obs = ctx.to_device(obs)
+    gh32.upload()
+    st32, names = _kernels_of(ctx, lambda: gh32.accumulate(d_obs))
+    assert "emit_diag_mfma_f32" in names and "mix_mfma_f32" in names
+    st64 = ctx.bw_accumulate(d_obs)
+    a, b = _split(st32), _split(st64)
+    for key in ("xi_sum", "gamma_sum", "gamma0", "mix", "mix_x", "mix_xx"):
+        assert _rel(a[key], b[key]) < 1e-3, key
+    assert abs(a["loglik"][0] - b["loglik"][0]) < 1e-6 * abs(b["loglik"][0])
+    assert abs(a["mix"].sum() - U * T) < 1e-4 * U * T

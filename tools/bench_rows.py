@@ -126,6 +126,8 @@ if what & {"bw", "all"}:
     lib = _ffi.lib()
     timed("Baum-Welch statistics N=256 M=32", lambda: _ffi.check(lib.lnasr_bw_accumulate(ctx.handle, obs.ptr, U, T, None, stats.ptr)),
           U * T, "frames", reps=2)
+    timed("Baum-Welch statistics, precision=float32", lambda: _ffi.check(lib.lnasr_bw_accumulate_p(ctx.handle, obs.ptr, U, T, None, 1, stats.ptr)),
+          U * T, "frames", reps=2)
 
 if what & {"full", "all"}:
     # full-covariance bank (the reference's own M-step produces full Sigma): N=128, M=16, D=39
