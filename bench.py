@@ -233,9 +233,15 @@ def main():
 
     dist = None
     torch = None
-    if world > 1:
+    # LNASR_BENCH_FORCE_COMM=1: take the N > 1 code path (gloo group, RCCL communicator under the watchdog, gather in
+    # the timed step) with however many ranks there are -- on a one-GPU box a one-rank rehearsal of everything but
+    # the links
+    use_comm = world > 1 or bool(os.environ.get("LNASR_BENCH_FORCE_COMM"))
+    if use_comm:
         import torch
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     else:
         try:
@@ -272,7 +278,7 @@ def main():
 
     # RCCL communicator for the gather of paths (N > 1)
     gather = "n/a (single GPU)"
-    if world > 1:
+    if use_comm:
         import threading
         state = {}
 

@@ -45,6 +45,22 @@ def test_bench_failed_communicator_times_nothing():
     assert out["config"]["gather"].startswith("FAILED, nothing timed")
 
 
+def test_bench_comm_path_one_rank_rehearsal():
+    """The N > 1 code path of bench.py with one rank (LNASR_BENCH_FORCE_COMM): gloo group, unique id, RCCL
+    communicator under the watchdog with torch already loaded in the process, RCCL gather inside the timed step,
+    n_gpus from ncclCommCount -- everything but the links."""
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "3", "--warmup", "1", "--utts", "64",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600,
+                       env=_clean_env(LNASR_BENCH_FORCE_COMM="1", LNASR_COMM_TIMEOUT="120"))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = lines[0]
+    assert out["n_gpus"] == 1 and out["value"] > 0
+    assert out["config"]["gather"].startswith("rccl all-gather of the state paths over 1 ranks")
+    assert "pack_paths_u8" in out["kernels"] and "unpack_paths_u8" in out["kernels"]
+
+
 def _rank(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
