@@ -123,8 +123,10 @@ int lnasr_gauss_mixture(lnasr_ctx* ctx, const double* c, int M, const double* x,
 /* HMM._viterbi (hmm.py:133-172): v, bt optional; path required.  best_score [U] optional. */
 int lnasr_viterbi(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* lens, int dtype,
                   void* v_or_null, uint32_t* bt_or_null, uint32_t* path, double* best_score_or_null);
-/* GMMHMM.decode (hmm.py:276-283 -> gmmhmm.py:46-67 + hmm.py:133-172): emission + trellis +
- * backtrace, b never leaves the device */
+/* GMMHMM.decode (hmm.py:276-283 -> gmmhmm.py:46-67 + hmm.py:133-172): emission, trellis and
+ * backtrace as three launches on the context's stream; b and v stay in HBM workspaces of the
+ * context (they are not on chip: 1 KB per frame each way, far from the binding resource) and
+ * only the paths come back */
 int lnasr_decode(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* lens,
                  uint32_t* path, double* best_score_or_null);
 /* HMM._forward (hmm.py:63-100) and calc_prob (hmm.py:268-274): alpha optional, loglik [U] optional */

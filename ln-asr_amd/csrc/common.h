@@ -92,6 +92,7 @@ struct Model {
     DevBuf mu_c;                 // [N,M,D] mu - centre: what the coefficient packers see
     double kappa = 0.0;
     bool direct_form = false;    // kappa > kKappaMax (or not finite): expanded form refused
+    bool centred = false;        // centre != 0 (the model was not well conditioned about the origin)
     // fp32 matrix-core pass (f32stats.hip): float coefficient fragments, packed on first use after an upload
     DevBuf wpack32;
     unsigned long upload_serial = 0, wpack32_for = ~0ul;

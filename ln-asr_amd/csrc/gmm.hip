@@ -485,7 +485,7 @@ __global__ void pack_single_direct_kernel(const double* __restrict__ mu, const d
     wdirect[idx] = val;
 }
 
-template <int KS, bool WRITE_BM>
+template <int KS, bool WRITE_BM, bool CEN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void emit_single_direct(const double* __restrict__ obs,
                                                           const double* __restrict__ wdirect,
                                                           const double* __restrict__ logw,
@@ -509,11 +509,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // slot 4 j + g of this lane: a real dimension, the constant (== D), or padding (> D: coefficient 0; the value
     // read there is the start of the next frame, or 0 past the end of obs)
     bool is_one[NL];
-    double cen[NL];                            // centre of the lane's dimensions: the coefficients are those of x - centre
-#pragma unroll
+    double cen[CEN ? NL : 1];                  // CEN (model re-centred, Model::centred): centre of the lane's dimensions;
+#pragma unroll                                 // a model conditioned about the origin pays neither registers nor subtractions
     for (int j = 0; j < NL; ++j) {
         is_one[j] = (4 * j + g) == D;
-        cen[j] = (4 * j + g) < D ? centre[4 * j + g] : 0.0;
+        if (CEN) cen[j] = (4 * j + g) < D ? centre[4 * j + g] : 0.0;
     }
     double pre[NL];
     auto load_tile = [&](long tile) {
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         double bx[NL], bq[NL];
 #pragma unroll
         for (int j = 0; j < NL; ++j) {
-            bx[j] = pre[j] - cen[j];
+            bx[j] = CEN ? pre[j] - cen[CEN ? j : 0] : pre[j];
             bq[j] = is_one[j] ? 1.0 : bx[j] * bx[j];
         }
         load_tile(tile + nw);
@@ -765,16 +765,33 @@ static double kappa_max() {
     return e ? atof(e) : kKappaMax;
 }
 
-// md.centre, md.mu_c and (into md.flags + 8) the bits of kappa; prec == nullptr for a diagonal model
+// md.centre, md.mu_c, md.kappa / direct_form; prec == nullptr for a diagonal model.  A model that is well conditioned
+// about the ORIGIN keeps centre = 0 (md.centred = false: kernels that would pay for the subtraction skip it); only a
+// model that is not is re-centred on the mean of its means.
 static int centre_and_kappa(lnasr_ctx* ctx, const double* prec) {
     Model& md = ctx->model;
     const int NM = md.N * md.M, D = md.D;
     LN_TRY(md.centre.reserve((size_t)D * 8));
     LN_TRY(md.mu_c.reserve((size_t)NM * D * 8));
-    LN_LAUNCH(ctx, "centre", centre_kernel, dim3(D), dim3(256), 0, md.mu.as<double>(), NM, D, md.centre.as<double>());
-    LN_LAUNCH(ctx, "centre_mu", centre_mu_kernel, dim3((NM + 63) / 64), dim3(64), 0, md.mu.as<double>(),
-              (const double*)md.centre.as<double>(), prec ? nullptr : (const double*)md.ivar.as<double>(), prec, NM, D,
-              md.mu_c.as<double>(), reinterpret_cast<unsigned long long*>(md.flags.as<char>() + 8));
+    LN_TRY(md.flags.reserve(256));
+    unsigned long long* kbits = reinterpret_cast<unsigned long long*>(md.flags.as<char>() + 8);
+    for (int pass = 0; pass < 2; ++pass) {
+        LN_HIP(hipMemsetAsync(kbits, 0, 8, ctx->stream));
+        if (pass == 0)
+            LN_HIP(hipMemsetAsync(md.centre.p, 0, (size_t)D * 8, ctx->stream));
+        else
+            LN_LAUNCH(ctx, "centre", centre_kernel, dim3(D), dim3(256), 0, md.mu.as<double>(), NM, D, md.centre.as<double>());
+        LN_LAUNCH(ctx, "centre_mu", centre_mu_kernel, dim3((NM + 63) / 64), dim3(64), 0, md.mu.as<double>(),
+                  (const double*)md.centre.as<double>(), prec ? nullptr : (const double*)md.ivar.as<double>(), prec, NM, D,
+                  md.mu_c.as<double>(), kbits);
+        unsigned long long kb = 0;
+        LN_HIP(hipMemcpyAsync(&kb, kbits, 8, hipMemcpyDeviceToHost, ctx->stream));
+        LN_HIP(hipStreamSynchronize(ctx->stream));
+        md.kappa = __builtin_bit_cast(double, kb);
+        md.direct_form = !(md.kappa <= kappa_max());
+        md.centred = pass == 1;
+        if (!md.direct_form) break;
+    }
     return 0;
 }
 
@@ -829,12 +846,10 @@ static int model_upload_impl(lnasr_ctx* ctx, int N, int M, int D, const double* 
         LN_HIP(hipMemsetAsync(md.flags.p, 0, 16, ctx->stream));
         LN_LAUNCH(ctx, "prep_diag", prep_diag_kernel, dim3((unsigned)((NM + 127) / 128)), dim3(128), 0,
                   md.var.as<double>(), md.ivar.as<double>(), md.gconst.as<double>(), (int)NM, D, md.flags.as<int>());
-        LN_TRY(centre_and_kappa(ctx, nullptr));
         unsigned long long fl[2] = {0, 0};
-        LN_HIP(hipMemcpyAsync(fl, md.flags.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+        LN_HIP(hipMemcpyAsync(fl, md.flags.p, 8, hipMemcpyDeviceToHost, ctx->stream));
         LN_HIP(hipStreamSynchronize(ctx->stream));
-        md.kappa = __builtin_bit_cast(double, fl[1]);
-        md.direct_form = !(md.kappa <= kappa_max());
+        LN_TRY(centre_and_kappa(ctx, nullptr));
         // a singular / non-finite variance, or means too many standard deviations apart for the expanded quadratic:
         // the direct-form kernels score this model
         const int degenerate = (int)(fl[0] & 0xFFFFFFFFu) | (md.direct_form ? 1 : 0);
@@ -899,14 +914,7 @@ static int model_upload_impl(lnasr_ctx* ctx, int N, int M, int D, const double* 
         size_t shmem = (size_t)D * 2 * D * 8;
         LN_LAUNCH(ctx, "lu_invert", lu_invert_kernel, dim3((unsigned)NM), dim3(64), shmem, md.sigma_raw.as<double>(),
                   md.prec.as<double>(), md.gconst.as<double>(), D);
-        LN_TRY(md.flags.reserve(256));
-        LN_HIP(hipMemsetAsync(md.flags.p, 0, 16, ctx->stream));
         LN_TRY(centre_and_kappa(ctx, md.prec.as<double>()));
-        unsigned long long fl[2] = {0, 0};
-        LN_HIP(hipMemcpyAsync(fl, md.flags.p, 16, hipMemcpyDeviceToHost, ctx->stream));
-        LN_HIP(hipStreamSynchronize(ctx->stream));
-        md.kappa = __builtin_bit_cast(double, fl[1]);
-        md.direct_form = !(md.kappa <= kappa_max());
         md.wfull_Q = 0;
         md.pad_N = md.pad_M = 0;
         if (!md.direct_form) LN_TRY(pack_full_model(ctx));
@@ -995,19 +1003,20 @@ int emit_device(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, v
         long grid = (ntiles + 3) / 4;
         // grid-stride over tiles, every wave resident: four 4-wave blocks per CU (128 VGPRs, 4 KB of LDS each)
         if (grid > (long)cus * 4) grid = (long)cus * 4;
+#define LN_DLAUNCH(ks, wbm, cen, name)                                                                            \
+    LN_LAUNCH(ctx, name, (emit_single_direct<ks, wbm, cen>), dim3((unsigned)grid), dim3(256), 0, obs,             \
+              md.wdirect.as<double>(), md.logw.as<double>(), (const double*)md.centre.as<double>(), (double*)b,   \
+              (double*)bm, F, M, D, ntiles)
 #define LN_DCASE(ks)                                                                                              \
     if (md.wdirect_KS == ks) {                                                                                    \
-        if (bm)                                                                                                   \
-            LN_LAUNCH(ctx, "emit_single_direct_bm", (emit_single_direct<ks, true>), dim3((unsigned)grid), dim3(256), 0, obs, \
-                      md.wdirect.as<double>(), md.logw.as<double>(), (const double*)md.centre.as<double>(), (double*)b, \
-                      (double*)bm, F, M, D, ntiles);                                                              \
-        else                                                                                                      \
-            LN_LAUNCH(ctx, "emit_single_direct", (emit_single_direct<ks, false>), dim3((unsigned)grid), dim3(256), 0, obs, \
-                      md.wdirect.as<double>(), md.logw.as<double>(), (const double*)md.centre.as<double>(), (double*)b, \
-                      (double*)bm, F, M, D, ntiles);                                                              \
+        if (bm && md.centred) LN_DLAUNCH(ks, true, true, "emit_single_direct_bm");                                \
+        else if (bm) LN_DLAUNCH(ks, true, false, "emit_single_direct_bm");                                        \
+        else if (md.centred) LN_DLAUNCH(ks, false, true, "emit_single_direct");                                   \
+        else LN_DLAUNCH(ks, false, false, "emit_single_direct");                                                  \
         return 0;                                                                                                 \
     }
         LN_DCASE(20) LN_DCASE(14) LN_DCASE(8)
+#undef LN_DLAUNCH
 #undef LN_DCASE
     }
     if (md.diag && dtype == LNASR_F64 && md.wpack_Q > 0 && !getenv("LNASR_NO_MFMA")) {

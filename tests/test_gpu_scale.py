@@ -55,6 +55,36 @@ def test_metric_config_full_size(synth, oracle):
     assert np.abs(tot - ll.to_host()[:, None]).max() < 1e-7
 
 
+def test_single_gmm_config_full_size(synth, oracle):
+    """BASELINE configs[2]: one 16-mixture diagonal GMM (N = 1), D = 39, T = 1000, 1024 utterances resident in HBM --
+    the HBM-bound kernel at its full size: spot checks against the oracle, b = lse_m(w + bm) everywhere, determinism."""
+    from lnasr import _ffi
+    ctx = _ffi.default_ctx()
+    M, D, T, U = 16, 39, 1000, 1024
+    mdl = synth.synth_model(1, M, D, seed=12)
+    obs = synth.synth_obs(U, T, D, seed=1000)
+    ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
+    d_obs = ctx.to_device(obs)
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    b1 = ctx.gmm_logprob(d_obs).to_host()
+    names = set(ctx.prof_report())
+    ctx.prof_enable(False)
+    assert "emit_single_direct" in names
+    assert np.array_equal(b1, ctx.gmm_logprob(d_obs).to_host())
+    assert np.isfinite(b1).all() and b1.shape == (U, T, 1)
+    rng = np.random.default_rng(3)
+    for u in rng.choice(U, 5, replace=False):
+        ob, _ = oracle.gmm_map_b_diag(obs[u], mdl["w"], mdl["mu"], mdl["var"])
+        assert_close(b1[u, :, 0], ob[0], 1e-12)
+    # the per-mixture output of a slice (bm for everything would be 131 MB: fine, but a slice says the same)
+    sl = ctx.to_device(obs[:64])
+    b2, bm2 = ctx.gmm_logprob(sl, want_bm=True)
+    b2, bm2 = b2.to_host(), bm2.to_host()
+    assert np.array_equal(b2, b1[:64])
+    assert_close(oracle.lse(mdl["w"][0][None, None, :] + bm2[:, :, 0, :], axis=2), b2[:, :, 0], 1e-13)
+
+
 def test_chunked_two_stream_decode_is_identical(synth):
     """LNASR_DECODE_CHUNKS (off by default: measured slower) cuts a device-resident batch into chunks whose
     trellis work runs on the side stream beside the next chunk's emission: same paths, same scores, ragged lengths."""
@@ -72,10 +102,10 @@ def test_chunked_two_stream_decode_is_identical(synth):
         with env_switch(LNASR_DECODE_CHUNKS=nch):
             p2, s2 = ctx.decode(d_obs, want_score=True, lens=lens)
             p3, s3 = ctx.decode(d_obs, want_score=True, lens=lens)        # back to back: the join holds
-        for u in range(U):
-            assert np.array_equal(p2.to_host()[u, :lens[u]], p1[u, :lens[u]])
+        h2, h3 = p2.to_host(), p3.to_host()
+        for u in range(U):                                 # frames past lens[u] are left untouched (header)
+            assert np.array_equal(h2[u, :lens[u]], p1[u, :lens[u]]) and np.array_equal(h3[u, :lens[u]], p1[u, :lens[u]])
         assert np.array_equal(s2.to_host(), s1) and np.array_equal(s3.to_host(), s1)
-        assert np.array_equal(p3.to_host(), p2.to_host())
 
 
 def test_segmentation_sized_discrete_hmm(oracle):
