@@ -58,6 +58,12 @@ def has_gpu():
 import contextlib
 
 
+def tuned():
+    """False when the process runs under fallback switches (tools/fallback_suite.sh): tests then check results only,
+    not WHICH kernel produced them."""
+    return not any(k.startswith("LNASR_NO_") or k in ("LNASR_F32_GENERIC", "LNASR_VIT") for k in os.environ)
+
+
 @contextlib.contextmanager
 def env_switch(**kv):
     """Set environment switches for the block and put back what was there before (the fallback-suite runs set
