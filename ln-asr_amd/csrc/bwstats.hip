@@ -670,7 +670,7 @@ static int mix_launch(lnasr_ctx* ctx, int CT, dim3 grid, const double* obs, cons
 
 int mix_stats_device(lnasr_ctx* ctx, const double* obs, const double* alpha, const double* beta, const double* b,
                      const double* bm, const double* c1, const int32_t* d_lens, int U, int T, double* mix, double* mix_x,
-                     double* mix_xx) {
+                     double* mix_xx, int phase) {
     Model& md = ctx->model;
     const int N = md.N, M = md.M, D = md.D;
     // M > 32: MG groups of 32 mixtures per state, one wave each
@@ -681,24 +681,30 @@ int mix_stats_device(lnasr_ctx* ctx, const double* obs, const double* alpha, con
     LN_TRY(ctx->ws_raw.reserve((nraw + 64) * 8));
     double* R = ctx->ws_raw.as<double>();
     double* centre = R + nraw;
-    LN_HIP(hipMemsetAsync(R, 0, nraw * 8, ctx->stream));
-    LN_LAUNCH(ctx, "mix_centre", mix_centre_kernel, dim3(D), dim3(256), 0, md.mu.as<double>(), N * M, D, centre);
-    const int SG = (N * MG + kMixWaves - 1) / kMixWaves;
-    const long nchunk = (F + kMixFrames - 1) / kMixFrames;
-    long G = (2L * ctx->prop.multiProcessorCount + SG - 1) / SG;
-    if (G > nchunk) G = nchunk;
-    if (G < 1) G = 1;
-    if (G > 65535) G = 65535;
-    const long FPB = ((nchunk + G - 1) / G) * kMixFrames;
-    G = (F + FPB - 1) / FPB;
-    const dim3 grid(SG, (unsigned)G);
-    if (MT == 1)
-        LN_TRY(mix_launch<1>(ctx, CT, grid, obs, alpha, beta, b, bm, c1, centre, d_lens, F, FPB, T, MG, MP, R));
-    else
-        LN_TRY(mix_launch<2>(ctx, CT, grid, obs, alpha, beta, b, bm, c1, centre, d_lens, F, FPB, T, MG, MP, R));
-    const size_t nel = (size_t)N * M * D;
-    LN_LAUNCH(ctx, "mix_finish", mix_finish_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, (const double*)R,
-              md.mu.as<double>(), (const double*)centre, N, M, D, MP, NFP, mix, mix_x, mix_xx);
+    if (phase & kMixBegin) {
+        LN_HIP(hipMemsetAsync(R, 0, nraw * 8, ctx->stream));
+        LN_LAUNCH(ctx, "mix_centre", mix_centre_kernel, dim3(D), dim3(256), 0, md.mu.as<double>(), N * M, D, centre);
+    }
+    if (phase & kMixAdd) {
+        const int SG = (N * MG + kMixWaves - 1) / kMixWaves;
+        const long nchunk = (F + kMixFrames - 1) / kMixFrames;
+        long G = (2L * ctx->prop.multiProcessorCount + SG - 1) / SG;
+        if (G > nchunk) G = nchunk;
+        if (G < 1) G = 1;
+        if (G > 65535) G = 65535;
+        const long FPB = ((nchunk + G - 1) / G) * kMixFrames;
+        G = (F + FPB - 1) / FPB;
+        const dim3 grid(SG, (unsigned)G);
+        if (MT == 1)
+            LN_TRY(mix_launch<1>(ctx, CT, grid, obs, alpha, beta, b, bm, c1, centre, d_lens, F, FPB, T, MG, MP, R));
+        else
+            LN_TRY(mix_launch<2>(ctx, CT, grid, obs, alpha, beta, b, bm, c1, centre, d_lens, F, FPB, T, MG, MP, R));
+    }
+    if (phase & kMixEnd) {
+        const size_t nel = (size_t)N * M * D;
+        LN_LAUNCH(ctx, "mix_finish", mix_finish_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, (const double*)R,
+                  md.mu.as<double>(), (const double*)centre, N, M, D, MP, NFP, mix, mix_x, mix_xx);
+    }
     return 0;
 }
 

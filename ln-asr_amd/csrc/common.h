@@ -112,7 +112,9 @@ struct lnasr_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;            // side stream: the backward pass runs beside the forward pass
+    hipStream_t stream3 = nullptr;            // second side stream: forward pass of the pipelined statistics pass
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    std::vector<hipEvent_t> pipe_events;      // emission / forward / backward of each utterance chunk (estimate.hip)
     std::vector<hipEvent_t> copy_events;      // one per upload chunk of emit_batch
     hipDeviceProp_t prop;
     lnasr::Model model;
@@ -175,9 +177,13 @@ int finish_out(lnasr_ctx* ctx, void* user, const void* dev, size_t bytes);
 int xi_sum_device(lnasr_ctx* ctx, const double* alpha, const double* beta, const double* b, const double* loglik,
                   const int32_t* d_lens, int U, int T, double* xi_sum);
 bool mix_stats_mfma_ok(const Model& md);
+// phase (mix_stats_device, mix_stats_device_f32): kMixBegin zeroes the raw sums, kMixAdd adds the batch given,
+// kMixEnd turns the raw sums into mix / mix_x / mix_xx.  One call with kMixAll does everything; the pipelined pass
+// (estimate.hip) begins once, adds chunk after chunk and ends once.
+constexpr int kMixBegin = 1, kMixAdd = 2, kMixEnd = 4, kMixAll = 7;
 int mix_stats_device(lnasr_ctx* ctx, const double* obs, const double* alpha, const double* beta, const double* b,
                      const double* bm, const double* c1, const int32_t* d_lens, int U, int T, double* mix,
-                     double* mix_x, double* mix_xx);
+                     double* mix_x, double* mix_xx, int phase = kMixAll);
 
 bool full_stats_mfma_ok(const Model& md);
 
@@ -186,7 +192,8 @@ bool f32_stats_ok(const Model& md);
 int emit_device_f32(lnasr_ctx* ctx, const double* obs, long F, double* b, float* q32);
 int mix_stats_device_f32(lnasr_ctx* ctx, const double* obs, const double* alpha, const double* beta, const double* b,
                          const float* q32, const double* c1, const int32_t* d_lens, int U, int T, double* mix,
-                         double* mix_x, double* mix_xx);
+                         double* mix_x, double* mix_xx, int phase = kMixAll);
+int emit_device(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, void* bm);
 int full_stats_device(lnasr_ctx* ctx, const double* obs, const double* alpha, const double* beta, const double* b,
                       const double* bm, const double* c1, const int32_t* d_lens, int U, int T, double* mix,
                       double* mix_x, double* mix_xx);

@@ -204,6 +204,7 @@ int lnasr_ctx_create(int device_id, lnasr_ctx** out) {
     }
     LN_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     LN_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    LN_HIP(hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
     LN_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     LN_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     *out = ctx;
@@ -226,11 +227,13 @@ void lnasr_ctx_destroy(lnasr_ctx* ctx) {
     }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     for (auto e : ctx->copy_events) (void)hipEventDestroy(e);
+    for (auto e : ctx->pipe_events) (void)hipEventDestroy(e);
     if (ctx->mfcc_meta_ev) (void)hipEventDestroy(ctx->mfcc_meta_ev);
     if (ctx->mfcc_meta) (void)hipHostFree(ctx->mfcc_meta);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -414,7 +414,7 @@ int emit_device_f32(lnasr_ctx* ctx, const double* obs, long F, double* b, float*
 
 int mix_stats_device_f32(lnasr_ctx* ctx, const double* obs, const double* alpha, const double* beta, const double* b,
                          const float* q32, const double* c1, const int32_t* d_lens, int U, int T, double* mix,
-                         double* mix_x, double* mix_xx) {
+                         double* mix_x, double* mix_xx, int phase) {
     Model& md = ctx->model;
     const int N = md.N, M = md.M, D = md.D;
     const int MT = (M + 15) / 16, CT = (2 * D + 1 + 15) / 16;
@@ -424,26 +424,31 @@ int mix_stats_device_f32(lnasr_ctx* ctx, const double* obs, const double* alpha,
     LN_TRY(ctx->ws_raw.reserve((nraw + 64) * 8));
     double* R = ctx->ws_raw.as<double>();
     double* centre = R + nraw;
-    LN_HIP(hipMemsetAsync(R, 0, nraw * 8, ctx->stream));
-    LN_TRY(mix_centre_launch(ctx, centre));
-    const int SG = (N + kMix32Waves - 1) / kMix32Waves;
-    const long nchunk = (F + kMix32Frames - 1) / kMix32Frames;
-    long G = (2L * ctx->prop.multiProcessorCount + SG - 1) / SG;
-    if (G > nchunk) G = nchunk;
-    if (G < 1) G = 1;
-    if (G > 65535) G = 65535;
-    const long FPB = ((nchunk + G - 1) / G) * kMix32Frames;
-    G = (F + FPB - 1) / FPB;
-    const dim3 grid(SG, (unsigned)G);
+    if (phase & kMixBegin) {
+        LN_HIP(hipMemsetAsync(R, 0, nraw * 8, ctx->stream));
+        LN_TRY(mix_centre_launch(ctx, centre));
+    }
+    if (phase & kMixAdd) {
+        const int SG = (N + kMix32Waves - 1) / kMix32Waves;
+        const long nchunk = (F + kMix32Frames - 1) / kMix32Frames;
+        long G = (2L * ctx->prop.multiProcessorCount + SG - 1) / SG;
+        if (G > nchunk) G = nchunk;
+        if (G < 1) G = 1;
+        if (G > 65535) G = 65535;
+        const long FPB = ((nchunk + G - 1) / G) * kMix32Frames;
+        G = (F + FPB - 1) / FPB;
+        const dim3 grid(SG, (unsigned)G);
 #define LN_MIX32(mt, ct)                                                                                             \
     if (MT == mt && CT == ct) {                                                                                      \
         LN_LAUNCH(ctx, "mix_mfma_f32", (mix_mfma_f32<mt, ct>), grid, dim3(kMix32NT), 0, obs, alpha, beta, b, q32, c1,  \
                   (const double*)centre, d_lens, F, FPB, T, N, M, D, R);                                              \
     }
-    LN_MIX32(1, 1) LN_MIX32(1, 2) LN_MIX32(1, 3) LN_MIX32(1, 4) LN_MIX32(1, 5)
-    LN_MIX32(2, 1) LN_MIX32(2, 2) LN_MIX32(2, 3) LN_MIX32(2, 4) LN_MIX32(2, 5)
+        LN_MIX32(1, 1) LN_MIX32(1, 2) LN_MIX32(1, 3) LN_MIX32(1, 4) LN_MIX32(1, 5)
+        LN_MIX32(2, 1) LN_MIX32(2, 2) LN_MIX32(2, 3) LN_MIX32(2, 4) LN_MIX32(2, 5)
 #undef LN_MIX32
-    return mix_finish_launch(ctx, R, centre, MP, NFP, mix, mix_x, mix_xx);
+    }
+    if (phase & kMixEnd) return mix_finish_launch(ctx, R, centre, MP, NFP, mix, mix_x, mix_xx);
+    return 0;
 }
 
 }  // namespace lnasr

@@ -10,7 +10,7 @@ utterance and summed) and the M-step every rank runs on the all-reduc
 import numpy as np
 import pytest
 
-from conftest import assert_close, tuned
+from conftest import assert_close, env_switch, tuned
 
 pytestmark = pytest.mark.gpu
 
@@ -204,3 +204,21 @@ def test_float32_pass_full_size_and_mirror(synth, ctx):
         assert _rel(a[key], b[key]) < 1e-3, key
     assert abs(a["loglik"][0] - b["loglik"][0]) < 1e-6 * abs(b["loglik"][0])
     assert abs(a["mix"].sum() - U * T) < 1e-4 * U * T
+
+
+def test_config5_pipelined_pass(synth, ctx):
+    """LNASR_BW_CHUNKS (off by default: measured slower): utterance chunks whose forward / backward passes
+    run on side streams beside the next chunk's emission; the statistics are those of the plain pass."""
+    mdl = synth.synth_model(N, M, D, seed=5)
+    U, T = 11, 40
+    obs = synth.synth_obs(U, T, D, seed=77)
+    lens = np.array([40, 3, 17, 40, 1, 22, 9, 40, 31, 2, 40], dtype=np.int32)
+    ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
+    for prec, tol in ((np.float64, 1e-11), (np.float32, 1e-5)):
+        want = ctx.bw_accumulate(obs, lens=lens, precision=prec)
+        for nch in (2, 3, 4):
+            with env_switch(LNASR_BW_CHUNKS=nch):
+                got = ctx.bw_accumulate(obs, lens=lens, precision=prec)
+                again = ctx.bw_accumulate(obs, lens=lens, precision=prec)
+            assert_close(got, want, tol, tol * 10, msg="chunks=%d" % nch)
+            assert_close(again, want, tol, tol * 10)
