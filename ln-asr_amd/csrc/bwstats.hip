@@ -315,23 +315,27 @@ __global__ __launch_bounds__(64 * kMixWaves) void mix_mfma_kernel(const double* 
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) acc[mt][ct] = double4_t{0.0, 0.0, 0.0, 0.0};
 
-    // bm prefetch ring: k-step s of the block covers frames fb0 + 4 s + kk
+    // bm prefetch ring: k-step s of the block covers frames fb0 + 4 s + kk.  A running pointer per mixture tile (one
+    // 64-bit add per load); the ring runs up to 4 kMixRing frames past the block's range: bm is allocated with that
+    // much slack (kMixPadFrames), and what is read there is never used (those frames carry a log posterior of -inf).
     double ring[kMixRing][MT];
-    const double* bmj = bm + (size_t)jc * M + mo;
     const size_t bstride = (size_t)N * M;
-    int boff[MT];                          // lanes past the last mixture read mixture `mo` instead (their log w is -inf):
+    const double* bptr[MT];                // lanes past the last mixture read mixture `mo` instead (their log w is -inf):
 #pragma unroll                             // an unconditional load, not a branch around one
-    for (int mt = 0; mt < MT; ++mt) boff[mt] = (mo + 16 * mt + l15 < M) ? 16 * mt + l15 : 0;
-    auto ring_load = [&](int slot, long f) {
-        const long fc = f < F ? f : F - 1;
+    for (int mt = 0; mt < MT; ++mt)
+        bptr[mt] = bm + ((size_t)(fb0 + kk) * N + jc) * M + mo + ((mo + 16 * mt + l15 < M) ? 16 * mt + l15 : 0);
+    auto ring_load = [&](int slot) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) ring[slot][mt] = bmj[(size_t)fc * bstride + boff[mt]];
+        for (int mt = 0; mt < MT; ++mt) {
+            ring[slot][mt] = *bptr[mt];
+            bptr[mt] += 4 * bstride;
+        }
     };
     __syncthreads();                       // cen, etab, constant columns
     stage_load(fb0);
     stage_store(0);
 #pragma unroll
-    for (int s = 0; s < kMixRing - 1; ++s) ring_load(s, fb0 + 4 * s + kk);
+    for (int s = 0; s < kMixRing - 1; ++s) ring_load(s);
     __syncthreads();
 
     int cur = 0;
@@ -342,7 +346,7 @@ __global__ __launch_bounds__(64 * kMixWaves) void mix_mfma_kernel(const double* 
 #pragma unroll
             for (int ks = 0; ks < CH / 4; ++ks) {
                 constexpr int RM = kMixRing;
-                ring_load((ks + RM - 1) % RM, f0 + 4 * (ks + RM - 1) + kk);
+                ring_load((ks + RM - 1) % RM);
                 const int fk = 4 * ks + kk;
                 const double ab = sab[cur][fk * kMixWaves + w], bb = sbb[cur][fk * kMixWaves + w];
                 double g[MT];

@@ -180,6 +180,7 @@ bool mix_stats_mfma_ok(const Model& md);
 // phase (mix_stats_device, mix_stats_device_f32): kMixBegin zeroes the raw sums, kMixAdd adds the batch given,
 // kMixEnd turns the raw sums into mix / mix_x / mix_xx.  One call with kMixAll does everything; the pipelined pass
 // (estimate.hip) begins once, adds chunk after chunk and ends once.
+constexpr int kMixPadFrames = 64;   // slack (frames) behind bm / q32: the moments kernels prefetch past their range
 constexpr int kMixBegin = 1, kMixAdd = 2, kMixEnd = 4, kMixAll = 7;
 int mix_stats_device(lnasr_ctx* ctx, const double* obs, const double* alpha, const double* beta, const double* b,
                      const double* bm, const double* c1, const int32_t* d_lens, int U, int T, double* mix,

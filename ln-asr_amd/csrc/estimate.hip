@@ -691,7 +691,7 @@ int lnasr_bw_accumulate_p(lnasr_ctx* ctx, const double* obs, int U, int T, const
     // precision = float32: densities and moments on the fp32 matrix cores where the model allows it (f32stats.hip)
     const bool f32 = dtype == LNASR_F32 && f32_stats_ok(md);
     LN_TRY(ctx->ws_b.reserve(cells * 8));
-    LN_TRY(ctx->ws_bm.reserve(cells * M * (f32 ? 4 : 8)));
+    LN_TRY(ctx->ws_bm.reserve((cells + (size_t)kMixPadFrames * N) * M * (f32 ? 4 : 8)));
     LN_TRY(ctx->ws_alpha.reserve(cells * 8));
     LN_TRY(ctx->ws_beta.reserve(cells * 8));
     LN_TRY(ctx->ws_misc.reserve(((size_t)U + (size_t)U * T) * 8));

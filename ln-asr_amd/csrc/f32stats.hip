@@ -278,27 +278,31 @@ __global__ __launch_bounds__(kMix32NT) void mix_mfma_f32(const double* __restric
                 }
     };
     zero_acc();
-    const float* qj = q32 + (size_t)jc * M;
+    // q of the lane's (mixture, frame of the k-step): a running pointer, one 64-bit add per load.  The ring runs up to
+    // 4 RM frames past the block's range; q32 is allocated with that much slack (kMixPadFrames, common.h), and what
+    // is read there is never used (frames past the range carry a log posterior of -inf).
     const size_t qstride = (size_t)N * M;
-    int qoff[MT];
     bool qok[MT];
+    const float* qptr[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         qok[mt] = 16 * mt + l15 < M;
-        qoff[mt] = qok[mt] ? 16 * mt + l15 : 0;
+        qptr[mt] = q32 + ((size_t)(fb0 + kk) * N + jc) * M + (qok[mt] ? 16 * mt + l15 : 0);
     }
     constexpr int RM = 8;                                    // q prefetch ring (k-steps; must divide CH / 4)
     float ring[RM][MT];
-    auto ring_load = [&](int slot, long f) {
-        const long fc = f < F ? f : F - 1;
+    auto ring_load = [&](int slot) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) ring[slot][mt] = qj[(size_t)fc * qstride + qoff[mt]];
+        for (int mt = 0; mt < MT; ++mt) {
+            ring[slot][mt] = *qptr[mt];
+            qptr[mt] += 4 * qstride;
+        }
     };
     __syncthreads();
     stage_load(fb0);
     stage_store(0);
 #pragma unroll
-    for (int s = 0; s < RM - 1; ++s) ring_load(s, fb0 + 4 * s + kk);
+    for (int s = 0; s < RM - 1; ++s) ring_load(s);
     __syncthreads();
     int cur = 0;
     long since = 0;
@@ -308,7 +312,7 @@ __global__ __launch_bounds__(kMix32NT) void mix_mfma_f32(const double* __restric
         if (active) {
 #pragma unroll
             for (int ks = 0; ks < CH / 4; ++ks) {
-                ring_load((ks + RM - 1) % RM, f0 + 4 * (ks + RM - 1) + kk);
+                ring_load((ks + RM - 1) % RM);
                 const int fk = 4 * ks + kk;
                 const float ab = sab[cur][fk * kMix32Waves + w];
                 float gq[MT];
@@ -374,7 +378,11 @@ static int launch_emit32(lnasr_ctx* ctx, const double* obs, long F, double* bv, 
     const int GY = (Nv + 31) / 32;
     const long ntiles = (F + 15) / 16;
     const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
-    long want_chunks = ((long)cus * 2) / GY;                 // two resident blocks per CU
+    // The kernel needs 138 registers (three waves per SIMD, a block brings two: one resident block per CU); forced
+    // down to 128 for two resident blocks it spills four W fragments into the MFMA chain (1.85 -> 2.05 ms at config
+    // 5).  Twice as many blocks as CUs, each walking half the tiles, measured better than one block per CU (1.85 vs
+    // 2.07 ms): the second round evens out the tail.
+    long want_chunks = ((long)cus * 2) / GY;
     if (want_chunks < 8) want_chunks = 8;
     want_chunks = (want_chunks / 8) * 8;
     long tpb = (ntiles + want_chunks - 1) / want_chunks;
