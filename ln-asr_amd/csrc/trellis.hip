@@ -563,7 +563,7 @@ __global__ __launch_bounds__(256) void backtrace_tiny_kernel(const TS* __restric
 // an LDS row read; arg-max = DPP wave max, then the first lane holding the max (ballot + ffs),
 // which is numpy.argmax's first-index rule because lane l holds states l and l+64.  Decoded
 // states are collected 64 frames at a time and written as one coalesced 256-byte row.
-template <int CPL, bool LDSAT, typename TS = double>
+template <int CPL, bool LDSAT, typename TS = double, bool FULL = false>
 __global__ __launch_bounds__(256) void backtrace_lds_kernel(const TS* __restrict__ v,
                                                            const double* __restrict__ AT,
                                                            const int32_t* __restrict__ lens,
@@ -584,11 +584,11 @@ __global__ __launch_bounds__(256) void backtrace_lds_kernel(const TS* __restrict
     if (L <= 0) return;
     const TS* vu = v + (size_t)u * T * N;
     uint32_t* pu = path + (size_t)u * T;
-    bool ok[CPL];
-    int jj[CPL];                                             // clamped: every load is a valid address
+    bool ok[CPL];                                            // FULL: N = 64 CPL, every lane owns CPL real states and the
+    int jj[CPL];                                             // selects below fold away; else clamped: every load is a valid address
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
-        ok[c] = lane + 64 * c < N;
+        ok[c] = FULL || lane + 64 * c < N;
         jj[c] = ok[c] ? lane + 64 * c : 0;
     }
     // first index among equal maxima (numpy.argmax): lowest column block first, lowest lane within it
@@ -2179,8 +2179,13 @@ int backtrace_device(lnasr_ctx* ctx, const void* v, int U, int T, const int32_t*
         return 0;
     }
     if (dtype == LNASR_F64 && md.N <= 128 && !getenv("LNASR_NO_LDSBT")) {
-        LN_LAUNCH(ctx, "backtrace_lds", (backtrace_lds_kernel<2, true>), dim3((U + wpb - 1) / wpb), dim3(64 * wpb),
-                  (size_t)md.N * md.N * 8, (const double*)v, md.logAT.as<double>(), d_lens, path, best, U, T, md.N);
+        if (md.N == 128)
+            LN_LAUNCH(ctx, "backtrace_lds", (backtrace_lds_kernel<2, true, double, true>), dim3((U + wpb - 1) / wpb),
+                      dim3(64 * wpb), (size_t)md.N * md.N * 8, (const double*)v, md.logAT.as<double>(), d_lens, path, best, U,
+                      T, md.N);
+        else
+            LN_LAUNCH(ctx, "backtrace_lds", (backtrace_lds_kernel<2, true>), dim3((U + wpb - 1) / wpb), dim3(64 * wpb),
+                      (size_t)md.N * md.N * 8, (const double*)v, md.logAT.as<double>(), d_lens, path, best, U, T, md.N);
         return 0;
     }
     if (dtype == LNASR_F64 && md.N <= 1024 && !getenv("LNASR_NO_LDSBT")) {
