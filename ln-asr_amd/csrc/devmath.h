@@ -62,9 +62,11 @@ __device__ __forceinline__ double wave_sum(double v) {
 // row_mirror = 0x140.
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double x) {
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    // every control used here (quad_perm, row_half_mirror, row_mirror, row_ror) writes every lane from a valid lane, so
+    // there is no `old` value to preserve: v_mov_b32_dpp straight from the source, one instruction per word (with
+    // update_dpp(old = x, x) the compiler copies x first: two)
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double readlane_f64(double x, int lane) {
@@ -72,22 +74,15 @@ __device__ __forceinline__ double readlane_f64(double x, int lane) {
     int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
     return __hiloint2double(hi, lo);
 }
-// one v_mov_b32_dpp per word (no `old` operand to copy first): only for controls that write every lane
-template <int CTRL>
-__device__ __forceinline__ double dpp_all_f64(double x) {
-    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
 // max over the wave, left in EVERY lane: four DPP steps inside the 16-lane rows, then the rows meet through
 // v_permlane16_swap / v_permlane32_swap (gfx950) -- 22 instructions where DPP with a copied `old` operand plus four
 // row leaders read back as scalars took 47, on the dependent chain of the backtrace and of the trellis finalisation.
 // max is exact, so the result is the same bits whatever the order.
 __device__ __forceinline__ double wave_max_dpp(double x) {
-    x = vmax_f64(x, dpp_all_f64<0xB1>(x));
-    x = vmax_f64(x, dpp_all_f64<0x4E>(x));
-    x = vmax_f64(x, dpp_all_f64<0x141>(x));
-    x = vmax_f64(x, dpp_all_f64<0x140>(x));
+    x = vmax_f64(x, dpp_f64<0xB1>(x));
+    x = vmax_f64(x, dpp_f64<0x4E>(x));
+    x = vmax_f64(x, dpp_f64<0x141>(x));
+    x = vmax_f64(x, dpp_f64<0x140>(x));
     {
         auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(x), false, false);
         auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(x), false, false);

@@ -494,7 +494,7 @@ __device__ __forceinline__ void preemph_row(const RawRow<double>& rw, int n1, do
 __device__ __forceinline__ void preemph_row(const RawRow<int16_t>& rw, int n1, double alpha, cplx v[16]) {
     int t[16];
 #pragma unroll
-    for (int n2 = 0; n2 < 16; ++n2) t[n2] = __builtin_amdgcn_update_dpp(rw.q[n2], rw.q[n2], 0x121, 0xf, 0xf, false);
+    for (int n2 = 0; n2 < 16; ++n2) t[n2] = __builtin_amdgcn_mov_dpp(rw.q[n2], 0x121, 0xf, 0xf, true);
 #pragma unroll
     for (int n2 = 0; n2 < 16; ++n2) {
         const int wrap = n2 == 0 ? rw.prev : (t[n2 - 1] >> 16);
