@@ -87,6 +87,43 @@ def test_random_shape(seed, synth, oracle, ctx):
         assert abs(st[o] - ref["loglik"]) <= 1e-9 * max(1.0, abs(ref["loglik"]))
 
 
+@pytest.mark.parametrize("seed", _SEEDS_DIAG)
+def test_random_shape_real_feature_scale(seed, synth, oracle, ctx):
+    """The same sweep at real-feature scale: a common offset per dimension (0, 5 or 50 units), means spread over 1, 3
+    or 15 units, variances down to 0.02 -- whichever side of the conditioning gate the model falls on (centred matrix
+    cores or direct form), emissions match the reference's direct (x - mu) arithmetic to 1e-11 and the decoded path is
+    the oracle's on those emissions; under precision=float32 the statistics stay within float accuracy of the fp64
+    pass."""
+    rng, N, M, D, T, U = _shape(seed)
+    rng = np.random.default_rng(3000 + seed)
+    mdl = synth.synth_model(N, M, D, seed=seed + 11)
+    offset = float(rng.choice([0.0, 5.0, 50.0])) * rng.standard_normal(D)
+    spread = float(rng.choice([1.0, 3.0, 15.0]))
+    vscale = float(rng.choice([1.0, 0.2, 0.04]))
+    mu = offset + spread * rng.standard_normal((N, M, D))
+    var = vscale * mdl["var"]
+    pick_n, pick_m = rng.integers(0, N, (U, T)), rng.integers(0, M, (U, T))
+    obs = mu[pick_n, pick_m] + np.sqrt(var[pick_n, pick_m]) * rng.standard_normal((U, T, D))
+    ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mu, var, diag=True)
+    kappa, direct = ctx.model_conditioning()
+    tag = "seed=%d N=%d M=%d D=%d T=%d U=%d offset=%.0f spread=%.0f vscale=%.2f kappa=%.3g direct=%s" % (
+        seed, N, M, D, T, U, np.abs(offset).max(), spread, vscale, kappa, direct)
+    assert direct == (not kappa <= 4096.0), tag
+    b, bm = ctx.gmm_logprob(obs, want_bm=True)
+    paths = np.asarray(ctx.decode(obs))
+    for u in range(U):
+        ob, obm = oracle.gmm_map_b_diag_direct(obs[u], mdl["w"], mu, var)
+        assert_close(b[u], ob.T, 1e-11, 1e-11, msg="b " + tag)
+        assert_close(bm[u], np.transpose(obm, (2, 0, 1)), 1e-11, 1e-11, msg="bm " + tag)
+        gb = np.ascontiguousarray(b[u].T)
+        assert np.array_equal(paths[u], oracle.viterbi(mdl["A"], mdl["pi"], gb)[2]), "decode " + tag
+    if T >= 2:
+        st64 = ctx.bw_accumulate(obs)
+        st32 = ctx.bw_accumulate(obs, precision=np.float32)
+        scale = np.abs(st64).max()
+        assert np.isfinite(st32).all() and np.abs(st32 - st64).max() <= 2e-4 * scale, "float32 pass " + tag
+
+
 @pytest.mark.parametrize("seed", _SEEDS_FULL)
 def test_random_shape_full_covariance(seed, synth, oracle, ctx):
     """Full covariance: emission against the oracle's (x-mu)^T Sigma^-1 (x-mu) form, the matrix-core statistics
