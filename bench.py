@@ -253,6 +253,8 @@ def main():
     # one GPU per rank: LOCAL_RANK, and Context raises if that device does not exist.  LNASR_BENCH_DEVICE pins every
     # rank to one device -- only the failure-path test uses it (RCCL refuses two ranks on one GPU)
     dev = int(os.environ.get("LNASR_BENCH_DEVICE", local_rank))
+    if "LNASR_BENCH_DEVICE" not in os.environ and world > 1 and _ffi.device_count() == 1:
+        dev = 0             # a launcher that isolates one GPU per rank (HIP_VISIBLE_DEVICES): the rank's only device
     ctx = _ffi.Context(dev)
     if torch is not None and torch.cuda.is_available():
         torch.cuda.set_device(dev)
