@@ -1722,8 +1722,8 @@ constexpr int kT256Al1 = kT256Al0 + kT256FinLds * 256;                   // [kT2
 constexpr int kT256Vs = kT256Al1 + kT256CmpLds * 3 * 256;                // [2][256] v[t-1] or e = exp(prev - shift)
 constexpr int kT256Cs = kT256Vs + 2 * 256;                               // [2][256] prev in the log domain
 constexpr int kT256Ps = kT256Cs + 2 * 256;                               // [3][256] partials of slices 1..3
-constexpr int kT256Ms = kT256Ps + 3 * 256;                               // [2][4]   per 64-column block max
-constexpr int kT256Ss = kT256Ms + 8;                                     // [2]      shift of each e buffer
+constexpr int kT256Ms = kT256Ps + 3 * 256;                               // [3][4]   per 64-column block max (ring of three frames)
+constexpr int kT256Ss = kT256Ms + 12;                                    // [2]      shift of each e buffer
 constexpr int kT256Et = kT256Ss + 2;                                     // [kExpTab]
 constexpr int kT256Lt = kT256Et + kExpTab;                               // [2 * kLogTab]
 constexpr int kT256End = kT256Lt + 2 * kLogTab;
@@ -1734,12 +1734,25 @@ constexpr int kT256End = kT256Lt + 2 * kLogTab;
 // instantiations so that each gets its own register allocation; both execute the same barriers.
 // TS = float (Viterbi only): `precision=np.float32` -- b and v are float arrays, every sum is formed in fp64 and
 // rounded to float where the reference's float32 array rounds it, i.e. at the store of v[t, j] (hmm.py:160-165).
-template <int MODE, bool FIN, typename TS = double>
+//
+// DEFER (forward / backward): the finalisation is taken off the frame's critical path.  With the shift of the new e
+// buffer chosen from the maxima of TWO frames back (known when the frame starts), the next e value is
+//     e' = exp(S_c + log(sum) + b - S') = sum * F,   F = exp((S_c - S') + b),
+// and F is formed by the slice-0 waves DURING the multiply phase, so that after the partial sums meet only three
+// additions, a range check and one multiplication stand between the barriers; the log-domain value of the frame
+// (the output row, the exact-fallback operand, the maxima) is computed one multiply phase later from the saved sum.
+// A sum outside the safe range takes the exact log-domain path on the spot, as before.  Ablation: the
+// finalisation was 1,200 of the 3,500 cycles of a frame.  MEASURED SLOWER and therefore off by default
+// (LNASR_T256_DEFER=1 selects it): forward 2.79 -> 2.84, backward 2.82 -> 3.2 ms at N = 256, T = 2000 -- the ~90
+// instructions moved into the multiply phase sit on ONE wave per SIMD, which shares the issue port with three
+// multiplying neighbours, and that wave becomes the phase's critical path (raising its priority recovers a third).
+template <int MODE, bool FIN, typename TS = double, bool DEFER = false>
 __device__ __forceinline__ void trellis256_role(double* sm, const TS* __restrict__ bu, const double* __restrict__ Amat,
                                                 const double* __restrict__ Alog, const double* __restrict__ pi,
                                                 TS* __restrict__ ou, double* __restrict__ loglik_u, int L, int T, int N) {
     static_assert(MODE == 0 || std::is_same<TS, double>::value, "float storage: Viterbi only");
     constexpr bool VIT = MODE == 0, BACKWARD = MODE == 2;
+    constexpr bool DEF = DEFER && !VIT;
     constexpr int NP = 256, RPS = 64;
     constexpr int NREG = FIN ? kT256FinReg : kT256CmpReg, NLDS = 64 - NREG;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1802,11 +1815,42 @@ __device__ __forceinline__ void trellis256_role(double* sm, const TS* __restrict
     }
     __syncthreads();
 
+    // DEF: what the previous step left to be finished (slice-0 lanes)
+    double d_sum = 1.0, d_sc = 0.0, d_b = 0.0, fac = 0.0, s_new = 0.0;    // d_sum holds the exact value when d_exact
+    bool d_exact = false;
+    int d_t = 0;
+    auto finish_prev = [&](int mslot, int cbuf) {             // log-domain value of the finished step: output row, Cs, maxima
+        const double val = d_exact ? d_sum : d_sc + log_sum(d_sum, ltab);
+        double prev = LN_NEG_INF;
+        if (jc < N) {
+            if (BACKWARD) {
+                if (ou) ou[(size_t)d_t * N + jc] = (TS)val;
+                prev = val + d_b;
+            } else {
+                prev = val + d_b;
+                if (ou) ou[(size_t)d_t * N + jc] = (TS)prev;
+            }
+        }
+        Cs[cbuf * NP + jc] = prev;
+        const double m = wave_max_dpp(prev);
+        if (lane == 0) Ms[mslot * 4 + (jc >> 6)] = m;
+    };
     for (int step = 1; step < L; ++step) {
         const int cur = (step - 1) & 1, nxt = step & 1;
         const double* Vc = Vs + cur * NP + rs * RPS + (lane & 15);
         double bcur = bnext;
         if (FIN) bnext = (double)bu[(size_t)clampt(frame_of(step + 1)) * N + jcl];
+        if (FIN && DEF) {
+            // the slice-0 wave of a SIMD carries ~90 more instructions than its three neighbours in this phase: let it
+            // issue whenever it can (its chain is dependent, the neighbours' multiplies fill the gaps)
+            __builtin_amdgcn_s_setprio(3);
+            if (step >= 2) finish_prev((step - 1) % 3, cur);     // step 0 was finished in the prologue
+            const double* Ml = Ms + (step >= 2 ? (step - 2) % 3 : 0) * 4;
+            s_new = fmax(fmax(Ml[0], Ml[1]), fmax(Ml[2], Ml[3]));
+            const double sc = Ss[cur];
+            fac = (s_new == LN_NEG_INF || sc == LN_NEG_INF || jc >= N) ? 0.0 : exp_clamped((sc - s_new) + bcur, etab);
+            __builtin_amdgcn_s_setprio(0);
+        }
         // The 64 previous-frame values of this row slice sit in four VGPR pairs, 16 per DPP row
         // (lane l holds V[16k + (l & 15)]); row_newbcast:n hands value n of the pair to every lane,
         // so a transition costs one v_fmac_f64_dpp and no LDS broadcast read (the LDS pipe would
@@ -1851,6 +1895,26 @@ __device__ __forceinline__ void trellis256_role(double* sm, const TS* __restrict
                     ou[(size_t)t * N + jc] = (TS)val;
                 }
                 Vs[nxt * NP + jc] = val;
+            } else if (DEF) {
+                const double sum = (part + Ps[jc]) + (Ps[NP + jc] + Ps[2 * NP + jc]);
+                const double Sc = Ss[cur];
+                double e;
+                if ((sum >= kSafeSum && sum <= 1e290 && Sc != LN_NEG_INF) || jc >= N) {   // padding columns: fac = 0
+                    e = sum * fac;
+                    d_exact = false;
+                    d_sum = sum;
+                } else {
+                    const double val = exact_column_lse(Cs + cur * NP, Alog + jcl, N);
+                    const double prev = val + bcur;
+                    e = (s_new == LN_NEG_INF || prev == LN_NEG_INF || jc >= N) ? 0.0 : exp_clamped(prev - s_new, etab);
+                    d_exact = true;
+                    d_sum = val;
+                }
+                d_sc = Sc;
+                d_b = bcur;
+                d_t = t;
+                Vs[nxt * NP + jc] = e;
+                if (jc == 0) Ss[nxt] = s_new;
             } else {
                 const double sum = (part + Ps[jc]) + (Ps[NP + jc] + Ps[2 * NP + jc]);
                 const double Sc = Ss[cur];
@@ -1880,9 +1944,15 @@ __device__ __forceinline__ void trellis256_role(double* sm, const TS* __restrict
         }
         __syncthreads();
     }
+    int mfin = (L - 1) & 1;                                   // slot of the last frame's maxima
+    if (DEF) {
+        mfin = L >= 2 ? (L - 1) % 3 : 0;
+        if (FIN && L >= 2) finish_prev(mfin, (L - 1) & 1);
+        __syncthreads();                                      // both roles: the last frame's Cs / Ms are complete
+    }
     if (FIN && MODE == 1 && loglik_u && tid < 64) {
         const int fin = (L - 1) & 1;
-        const double mx = fmax(fmax(Ms[fin * 4], Ms[fin * 4 + 1]), fmax(Ms[fin * 4 + 2], Ms[fin * 4 + 3]));
+        const double mx = fmax(fmax(Ms[mfin * 4], Ms[mfin * 4 + 1]), fmax(Ms[mfin * 4 + 2], Ms[mfin * 4 + 3]));
         double sacc = 0.0;
         for (int j = lane; j < NP; j += 64) {
             const double pv = Cs[fin * NP + j];
@@ -1893,7 +1963,7 @@ __device__ __forceinline__ void trellis256_role(double* sm, const TS* __restrict
     }
 }
 
-template <int MODE, typename TS = double>
+template <int MODE, typename TS = double, bool DEFER = false>
 __global__ __launch_bounds__(1024) void trellis256_kernel(const TS* __restrict__ b,
                                                           const double* __restrict__ Amat,   // logA / expA / expA^T
                                                           const double* __restrict__ Alog,   // logA or logA^T (fallback)
@@ -1912,9 +1982,9 @@ __global__ __launch_bounds__(1024) void trellis256_kernel(const TS* __restrict__
     TS* ou = out ? out + (size_t)u * T * N : nullptr;
     // wave-uniform role split (threadIdx.x >> 8 is constant within a wave); the barriers of the two roles pair up
     if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 8) == 0)
-        trellis256_role<MODE, true, TS>(sm, bu, Amat, Alog, pi, ou, loglik ? loglik + u : nullptr, L, T, N);
+        trellis256_role<MODE, true, TS, DEFER>(sm, bu, Amat, Alog, pi, ou, loglik ? loglik + u : nullptr, L, T, N);
     else
-        trellis256_role<MODE, false, TS>(sm, bu, Amat, Alog, pi, ou, nullptr, L, T, N);
+        trellis256_role<MODE, false, TS, DEFER>(sm, bu, Amat, Alog, pi, ou, nullptr, L, T, N);
 }
 
 static inline size_t trellis256_lds() { return (size_t)kT256End * 8; }
@@ -2256,9 +2326,14 @@ int forward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
         return 0;
     }
     if (dtype == LNASR_F64 && N > 128 && N <= 256 && !getenv("LNASR_NO_T256")) {
-        LN_LAUNCH(ctx, "forward_onchip256", trellis256_kernel<1>, dim3(U), dim3(1024), trellis256_lds(), (const double*)b,
-                  md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens, (double*)alpha, loglik, U, T,
-                  N);
+        if (!getenv("LNASR_T256_DEFER"))
+            LN_LAUNCH(ctx, "forward_onchip256", (trellis256_kernel<1, double, false>), dim3(U), dim3(1024), trellis256_lds(),
+                      (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
+                      (double*)alpha, loglik, U, T, N);
+        else
+            LN_LAUNCH(ctx, "forward_onchip256", (trellis256_kernel<1, double, true>), dim3(U), dim3(1024), trellis256_lds(),
+                      (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
+                      (double*)alpha, loglik, U, T, N);
         return 0;
     }
     if (dtype == LNASR_F64 && N > 256 && fwdbwd_framepar(N, U)) {
@@ -2343,8 +2418,14 @@ int backward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* 
         return 0;
     }
     if (dtype == LNASR_F64 && N > 128 && N <= 256 && !getenv("LNASR_NO_T256")) {
-        LN_LAUNCH(ctx, "backward_onchip256", trellis256_kernel<2>, dim3(U), dim3(1024), trellis256_lds(), (const double*)b,
-                  expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta, (double*)nullptr, U, T, N);
+        if (!getenv("LNASR_T256_DEFER"))
+            LN_LAUNCH(ctx, "backward_onchip256", (trellis256_kernel<2, double, false>), dim3(U), dim3(1024), trellis256_lds(),
+                      (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
+                      (double*)nullptr, U, T, N);
+        else
+            LN_LAUNCH(ctx, "backward_onchip256", (trellis256_kernel<2, double, true>), dim3(U), dim3(1024), trellis256_lds(),
+                      (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
+                      (double*)nullptr, U, T, N);
         return 0;
     }
     if (dtype == LNASR_F64 && N > 256 && fwdbwd_framepar(N, U))

@@ -484,3 +484,33 @@ def test_bw_statistics_full_covariance(golden, ctx):
     st2 = ctx.bw_accumulate(two)
     st_b = ctx.bw_accumulate(two[1:])
     assert_close(st + st_b, st2, 1e-10, 1e-12)
+
+
+def test_onchip256_deferred_finalisation_variant(synth, oracle, ctx):
+    """LNASR_T256_DEFER (off by default: measured slower): the on-chip 256-state forward / backward with the
+    log / exp of the finalisation taken off the frame's critical path (e' = sum * F, shift two frames old, output row
+    one phase later).  Same values as the default kernels and as the oracle; ragged lengths, a forbidden transition, the
+    thousand-nat emission gaps of the underflow test."""
+    for N, T, U in ((256, 37, 3), (200, 20, 2), (129, 9, 4)):
+        d = synth.synth_discrete(N, 4, 8, seed=N)
+        A = d["A"].copy()
+        A[3, :] = -np.inf
+        A[3, 2] = 0.0
+        rng = np.random.default_rng(N)
+        b = -60.0 * rng.random((U, T, N))
+        b[0, T // 2, : N // 2] -= 2000.0                     # sums leave the safe range: exact path
+        lens = rng.integers(1, T + 1, U).astype(np.int32)
+        lens[0] = T
+        ctx.upload_hmm(A, d["pi"])
+        a0, l0 = ctx.forward(b, lens=lens)
+        be0 = ctx.backward(b, lens=lens)
+        with env_switch(LNASR_T256_DEFER=1):
+            a1, l1 = ctx.forward(b, lens=lens)
+            be1 = ctx.backward(b, lens=lens)
+        for u in range(U):
+            L = int(lens[u])
+            with np.errstate(divide="ignore", invalid="ignore"):
+                ra, rb = oracle.forward(A, d["pi"], b[u, :L].T), oracle.backward(A, b[u, :L].T)
+            assert_close(a1[u, :L], ra, 1e-11, 1e-11), assert_close(be1[u, :L], rb, 1e-11, 1e-11)
+            assert_close(a1[u, :L], a0[u, :L], 1e-12, 1e-12), assert_close(be1[u, :L], be0[u, :L], 1e-12, 1e-12)
+        assert_close(l1, l0, 1e-13)
