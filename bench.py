@@ -178,6 +178,7 @@ def _pmc_traffic(kernel):
 def dry_launch(rank, world):
     import torch.distributed as dist
     from lnasr import dist as ldist
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     try:
         U, T = 4 * world + 1, 8                                           # ragged shards
@@ -242,6 +243,7 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # one node: never depend on the hostname resolving
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     else:
         try:
