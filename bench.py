@@ -244,6 +244,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(_free_port()))
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # one node: never depend on the hostname resolving
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")      # ... nor on which interface RCCL's bootstrap would pick
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     else:
         try:
