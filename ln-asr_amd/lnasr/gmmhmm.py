@@ -178,6 +178,42 @@ class GMMHMM(HMM):
         fp32 matrix-core pass."""
         return self.ctx.bw_accumulate(obs_batch, lens=lens, precision=self.precision)
 
+    def train_batch(self, obs_batch, lens=None, iters=1, eps=0.0001, verbose: bool = True, comm=None):
+        """Baum-Welch over a BATCH of utterances (the reference's `train`, hmm.py:285-313, is single
+        sequence): per iteration the statistics of this rank's utterances (`accumulate`, under the model's
+        `precision=`), their sum over ranks when `comm` is given (an object with `allreduce_sum_f64`, e.g.
+        `lnasr.dist.RcclComm`: one RCCL all-reduce of the packed vector), the M-step every rank runs identically,
+        and the reference's stopping rule on the summed log-likelihood with the reference's printed line.
+        Returns the list of (L(lambda|O), L(lambda_new|O)) pairs."""
+        n_ll = None
+        hist = []
+        for k in range(iters):
+            self.upload()
+            stats = np.asarray(self.accumulate(obs_batch, lens=lens))
+            if comm is not None:
+                stats = np.asarray(comm.allreduce_sum_f64(np.ascontiguousarray(stats, dtype=np.float64)))
+            if n_ll is None:
+                n_ll = len(stats) - 3                       # [..., loglik_sum, n_utt, n_frames]
+            prob_old = float(stats[n_ll])
+            self.apply_stats(stats)
+            self.upload()
+            ll = np.asarray(self.calc_prob_batch(obs_batch, lens=lens), dtype=np.float64)
+            new = np.array([ll.sum()])
+            if comm is not None:
+                new = np.asarray(comm.allreduce_sum_f64(new))
+            prob_new = float(new[0])
+            prod_d = abs(prob_old - prob_new)
+            hist.append((prob_old, prob_new))
+            if verbose:
+                print("Iter: {:3},"
+                      " L(lambda|O) = {:.6e},"
+                      " L(lambda_new|O) = {:.6e},"
+                      " eps = {:.6f}"
+                      .format(k, prob_old, prob_new, prod_d))
+            if prod_d < eps:
+                break
+        return hist
+
     def apply_stats(self, stats):
         """M-step from accumulated statistics; updates the parameters in place."""
         m = self.ctx.bw_mstep(stats, self.min_std)

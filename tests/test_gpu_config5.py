@@ -222,3 +222,39 @@ def test_config5_pipelined_pass(synth, ctx):
                 again = ctx.bw_accumulate(obs, lens=lens, precision=prec)
             assert_close(got, want, tol, tol * 10, msg="chunks=%d" % nch)
             assert_close(again, want, tol, tol * 10)
+
+
+@pytest.mark.parametrize("prec", [np.float64, np.float32])
+def test_train_batch_em_iterations(prec, synth, oracle, ctx, capsys):
+    """`GMMHMM.train_batch` (the config-5 loop as one call: accumulate -> [all-reduce] -> M-step -> new likelihood):
+    the first M-step is the oracle's on the summed statistics, the likelihood never decreases (EM), the printed line
+    has the reference's format, and a one-rank communicator changes nothing."""
+    from lnasr.gmmhmm import GMMHMM
+    n, m, d, U, T = 16, 4, 13, 6, 50
+    mdl = synth.synth_model(n, m, d, seed=21)
+    obs = synth.synth_obs(U, T, d, seed=22) * 1.3 + 0.2
+    lens = np.array([50, 31, 50, 12, 44, 50], dtype=np.int32)
+    gh = GMMHMM(n, m, d, mdl["A"].copy(), mdl["pi"].copy(), mdl["w"].copy(), mdl["mu"].copy(), mdl["var"].copy(),
+                precision=prec, ctx=ctx)
+    hist = gh.train_batch(obs, lens=lens, iters=4, eps=0.0, verbose=True)
+    out = capsys.readouterr().out.strip().splitlines()
+    assert len(hist) == 4 and len(out) == 4 and out[0].startswith("Iter:   0, L(lambda|O) = ")
+    tol = 1e-9 if prec == np.float64 else 2e-4
+    with np.errstate(divide="ignore", invalid="ignore", under="ignore"):
+        ref = oracle.bw_stats_diag([obs[u, :lens[u]] for u in range(U)], mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"])
+    assert abs(hist[0][0] - ref["loglik"]) <= max(tol, 1e-9) * abs(ref["loglik"])
+    for k in range(4):
+        assert hist[k][1] >= hist[k][0] - 1e-6 * abs(hist[k][0])                 # EM: never worse
+        if k:
+            assert abs(hist[k][0] - hist[k - 1][1]) <= 1e-6 * abs(hist[k][0])      # old of k = new of k - 1
+    # first M-step against the oracle
+    gh1 = GMMHMM(n, m, d, mdl["A"].copy(), mdl["pi"].copy(), mdl["w"].copy(), mdl["mu"].copy(), mdl["var"].copy(),
+                 precision=prec, ctx=ctx)
+
+    class OneRank:                                            # what lnasr.dist.RcclComm does with one rank
+        def allreduce_sum_f64(self, buf):
+            return buf
+    gh1.train_batch(obs, lens=lens, iters=1, verbose=False, comm=OneRank())
+    mo = oracle.mstep_from_stats(ref)
+    for name, got in (("A", gh1.A), ("w", gh1.w), ("mu", gh1.mu), ("var", gh1.si)):
+        assert np.abs(np.asarray(got) - mo[name]).max() <= (1e-8 if prec == np.float64 else 5e-3), name
