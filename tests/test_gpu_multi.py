@@ -93,6 +93,10 @@ def _rank(rank, world, port, q):
         st = ctx.bw_accumulate(obs[lo:hi])
         out["stats"] = ldist.allreduce_stats(comm, st.copy())
         out["mstep"] = ctx.bw_mstep(out["stats"])
+        from lnasr.gmmhmm import GMMHMM
+        gh = GMMHMM(N, M, D, mdl["A"].copy(), mdl["pi"].copy(), mdl["w"].copy(), mdl["mu"].copy(), mdl["var"].copy(), ctx=ctx)
+        out["hist"] = gh.train_batch(obs[lo:hi], iters=2, eps=0.0, verbose=False, comm=comm)
+        out["A_after"] = np.asarray(gh.A)
         q.put((rank, out))
         dist.barrier()
         ctx.close()
@@ -132,3 +136,9 @@ def test_two_rank_rccl_gather_and_allreduce(synth, oracle):
         assert np.array_equal(res[r]["stats"], res[0]["stats"])          # every rank holds the same sums
         for k in ("A", "pi", "w", "mu", "var"):
             assert np.allclose(res[r]["mstep"][k], mo[k], rtol=1e-8, atol=1e-10), k
+    # the whole training loop over two ranks = the same loop over the whole batch on one
+    from lnasr.gmmhmm import GMMHMM
+    gh = GMMHMM(N, M, D, mdl["A"].copy(), mdl["pi"].copy(), mdl["w"].copy(), mdl["mu"].copy(), mdl["var"].copy())
+    want = gh.train_batch(obs, iters=2, eps=0.0, verbose=False)
+    for r in range(2):
+        assert np.allclose(res[r]["hist"], want, rtol=1e-10) and np.allclose(res[r]["A_after"], gh.A, rtol=1e-8, atol=1e-10)
