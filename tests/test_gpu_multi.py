@@ -104,15 +104,19 @@ def _rank(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_rank_rccl_gather_and_allreduce(synth, oracle):
+@pytest.mark.parametrize("world", [1, 2])
+def test_rccl_gather_allreduce_and_training_loop(world, synth, oracle):
+    """One process per GPU: sharded decode + RCCL gather (byte and u32 routes), statistics all-reduce, M-step and the
+    whole training loop against the oracle / the single-process run.  world = 2 needs two GPUs and skips on a one-GPU
+    box; world = 1 runs the same code over a one-rank communicator."""
     from lnasr import _ffi
-    if _ffi.device_count() < 2:
-        pytest.skip("needs a lease with two GPUs (one rank per GPU)")
+    if _ffi.device_count() < world:
+        pytest.skip("needs a lease with %d GPUs (one rank per GPU)" % world)
     import torch.multiprocessing as mp
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
     port = _free_port()
-    procs = [mpc.Process(target=_rank, args=(r, 2, port, q)) for r in range(2)]
+    procs = [mpc.Process(target=_rank, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=300) for _ in procs)
@@ -124,14 +128,14 @@ def test_two_rank_rccl_gather_and_allreduce(synth, oracle):
     for tag, U, T in (("bytes", 5, 32), ("words", 5, 31)):
         obs = synth.synth_obs(U, T, D, seed=42)
         want = np.stack([oracle.decode_diag(obs[u], mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"]) for u in range(U)])
-        for r in range(2):
-            assert res[r]["info"] == (r, 2)
+        for r in range(world):
+            assert res[r]["info"] == (r, world)
             assert np.array_equal(res[r][tag], want) and np.array_equal(res[r][tag + "_generic"], want)
     obs = synth.synth_obs(5, 32, D, seed=42)
     ref = oracle.bw_stats_diag(list(obs), mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"])
     packed = np.concatenate([np.ravel(ref[k]) for k in ("xi_sum", "gamma_sum", "gamma0", "mix", "mix_x", "mix_xx")])
     mo = oracle.mstep_from_stats(ref)
-    for r in range(2):
+    for r in range(world):
         assert np.allclose(res[r]["stats"][:packed.size], packed, rtol=1e-9, atol=1e-12)
         assert np.array_equal(res[r]["stats"], res[0]["stats"])          # every rank holds the same sums
         for k in ("A", "pi", "w", "mu", "var"):
@@ -140,5 +144,5 @@ def test_two_rank_rccl_gather_and_allreduce(synth, oracle):
     from lnasr.gmmhmm import GMMHMM
     gh = GMMHMM(N, M, D, mdl["A"].copy(), mdl["pi"].copy(), mdl["w"].copy(), mdl["mu"].copy(), mdl["var"].copy())
     want = gh.train_batch(obs, iters=2, eps=0.0, verbose=False)
-    for r in range(2):
+    for r in range(world):
         assert np.allclose(res[r]["hist"], want, rtol=1e-10) and np.allclose(res[r]["A_after"], gh.A, rtol=1e-8, atol=1e-10)
