@@ -13,15 +13,27 @@ starts N fresh ranks, one per GPU, as a child
         --master-port P bench.py --gpus N --steps K --warmup W
 
 forwards their output and returns the launcher's exit code.  Started by such a launcher (the
-driver's own command line is the one above) the process is one rank.
+driver's own command line is the one above) the process is one rank; whoever launched it, the
+environment defaults a rank needs on this pool are set below, at import.
 
 A step = one pass of the hot path (fp64-MFMA emission -> Viterbi trellis -> backtrace, then for
 N > 1 the RCCL gather of paths) over this rank's 1024 utterances, with the observations already
-resident in HBM.  Rank 0 prints ONE JSON line.  torch is used for rendezvous / barrier /
-max-over-ranks only (gloo); the compute path is liblnasr_hip.so through ctypes, the gather is
-RCCL inside that library.  If the communicator or the rehearsal gather fails, NOTHING is timed:
-rank 0 prints the line with "value": null and the failure in config.gather, and every rank exits
-non-zero.
+resident in HBM.  Rank 0 prints ONE JSON line.  The compute path is liblnasr_hip.so through ctypes
+and the collectives are RCCL inside that library; with one rank no torch module is imported at all,
+with N > 1 torch.distributed (gloo, CPU) carries rendezvous / barrier / max-over-ranks only.
+
+Before anything is timed EVERY rank decodes the first N_CHECK utterances of its own shard with the
+CPU oracle and compares the paths bit for bit; a mismatch, a failed communicator or a failed
+rehearsal gather means NOTHING is timed: rank 0 prints the line with "value": null and the reason,
+and every rank exits non-zero.
+
+Besides the headline the line carries
+  end_to_end   host numpy observations in -> host paths out (the reference's decode(), hmm.py:276-283,
+               takes host arrays): page-locked buffers through the chunked upload pipeline, and the
+               same from pageable memory through the pinned staging ring; PCIe-inclusive, never `value`;
+  baum_welch   BASELINE configs[4]: one statistics pass per rank (N=256, M=32, T=2000, 64 utterances:
+               emission + forward/backward + accumulation) and the RCCL all-reduce of the packed
+               sufficient statistics (the second collective of the path), timed separately.
 
     --dry-launch    CPU rehearsal of the launch path (tests): the ranks rendezvous over gloo, shard
                     a toy batch, gather toy paths through the gloo transport and rank 0 prints a
@@ -29,8 +41,17 @@ non-zero.
 """
 import os
 
-for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
-    os.environ.setdefault(_v, "1")          # CPU-baseline workers: one BLAS thread per process
+# Defaults every rank needs, whoever started it (bench.py's own launcher, the driver's torch.distributed.run, a
+# test): set at import, before anything reads them.
+_ENV_DEFAULTS = {
+    "HSA_ENABLE_IPC_MODE_LEGACY": "0",      # dmabuf IPC: RCCL across processes fails without it on this pool
+    "GLOO_SOCKET_IFNAME": "lo",             # one node: never depend on the hostname resolving ...
+    "NCCL_SOCKET_IFNAME": "lo",             # ... nor on which interface RCCL's bootstrap would pick
+    "MASTER_ADDR": "127.0.0.1",
+    "OMP_NUM_THREADS": "1", "OPENBLAS_NUM_THREADS": "1", "MKL_NUM_THREADS": "1",   # CPU baseline: 1 BLAS thread / worker
+}
+for _k, _v in _ENV_DEFAULTS.items():
+    os.environ.setdefault(_k, _v)
 
 import argparse
 import importlib.util
@@ -52,7 +73,9 @@ BYTES_DECODE = 8 * N_DIM + 4                        # 316 B per frame (obs in, p
 PEAK_FP64_TFLOPS = 78.6                             # MI355X fp64 matrix = vector peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 METRIC = "frames/sec Viterbi decode, 128-state 16-mix GMM-HMM, D=39 MFCC"
-N_CHECK = 4                                         # utterances compared with the oracle before timing
+N_CHECK = 4                                         # utterances per rank compared with the oracle before timing
+BW_SHAPE = dict(N=256, M=32, D=39, T=2000, U=64)    # BASELINE configs[4], per GPU
+BW_STEPS = 5
 
 
 def _load_oracle():
@@ -75,8 +98,7 @@ def _free_port():
 def launch_ranks(args, argv):
     """Start N fresh ranks (one per GPU) from a parent that has made no GPU call, wait, return their exit code."""
     env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this pool
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK"):
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
@@ -122,10 +144,18 @@ def _lscpu():
     return out
 
 
-def cpu_baseline(check_obs):
+def oracle_paths(check_obs):
+    """The checker's answer: the oracle's Viterbi paths of a few utterances of the bench's own input."""
+    from lnasr import synth
+    o = _load_oracle()
+    mdl = synth.synth_model(N_STATES, N_MIX, N_DIM, seed=1)
+    Wc = o.prep_diag_fused(mdl["w"], mdl["mu"], mdl["var"])
+    return np.stack([o.decode_diag_fused(x, mdl["A"], mdl["pi"], Wc, N_STATES, N_MIX) for x in check_obs])
+
+
+def cpu_baseline():
     """Line B of BASELINE.md: best vectorised numpy form, one process per host core, one BLAS
-    thread each, disjoint utterances; plus line A (reference-shaped loops, 1 core) as context.
-    Also returns the oracle's paths of `check_obs` (the checker's answer for the pre-timing comparison)."""
+    thread each, disjoint utterances; plus line A (reference-shaped loops, 1 core) as context."""
     import multiprocessing as mp
     avail = len(os.sched_getaffinity(0))
     # a 1-GPU box owns 16 of the host's logical CPUs (pool guidance); LNASR_CPU_WORKERS overrides
@@ -139,12 +169,11 @@ def cpu_baseline(check_obs):
         wall = time.perf_counter() - t0
     frames = cores * per * T_FRAMES
     cpu = _lscpu()
-    import numpy
     out = {"value": frames / wall, "unit": "frames/s", "cores": cores, "kind": "port",
            "sample": "%d utterances x %d frames (same synthetic model/shape), oracle decode_diag_fused "
                      "(numpy %s GEMM emission + vectorised Viterbi), %d worker processes x 1 BLAS thread, %.1f s wall; "
                      "host: %s, %s socket(s) x %s cores x %s threads, %s logical CPUs (%d usable by this process)"
-                     % (cores * per, T_FRAMES, numpy.__version__, cores, wall, cpu.get("model", "?"), cpu.get("sockets", "?"),
+                     % (cores * per, T_FRAMES, np.__version__, cores, wall, cpu.get("model", "?"), cpu.get("sockets", "?"),
                         cpu.get("cores_per_socket", "?"), cpu.get("threads_per_core", "?"), cpu.get("logical_cpus", "?"),
                         avail),
            "host": cpu}
@@ -156,11 +185,9 @@ def cpu_baseline(check_obs):
     t0 = time.perf_counter()
     o.decode_refshaped(obs, mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["si"])
     ref_shaped = 200 / (time.perf_counter() - t0)
-    Wc = o.prep_diag_fused(mdl["w"], mdl["mu"], mdl["var"])
-    want = np.stack([o.decode_diag_fused(x, mdl["A"], mdl["pi"], Wc, N_STATES, N_MIX) for x in check_obs])
     return out, {"value": ref_shaped, "unit": "frames/s", "cores": 1,
                  "sample": "1 utterance x 200 frames, per-(state,mixture) density calls + per-(frame,state) "
-                           "trellis updates (the reference's loop structure)"}, want
+                           "trellis updates (the reference's loop structure)"}
 
 
 def _pmc_traffic(kernel):
@@ -178,7 +205,6 @@ def _pmc_traffic(kernel):
 def dry_launch(rank, world):
     import torch.distributed as dist
     from lnasr import dist as ldist
-    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     try:
         U, T = 4 * world + 1, 8                                           # ragged shards
@@ -188,16 +214,226 @@ def dry_launch(rank, world):
         allp = ldist.gather_paths(comm, truth[lo:hi], U, T)
         ok = bool(np.array_equal(allp, truth))
         seen = [None] * world
-        dist.all_gather_object(seen, (rank, int(os.environ.get("LOCAL_RANK", "-1")), os.getpid()))
+        dist.all_gather_object(seen, (rank, int(os.environ.get("LOCAL_RANK", "-1")), os.getpid(),
+                                      {k: os.environ.get(k) for k in _ENV_DEFAULTS}))
         if rank == 0:
             print(json.dumps({"dry_launch": True, "n_ranks": world, "ranks": sorted(s[0] for s in seen),
                               "local_ranks": sorted(s[1] for s in seen), "distinct_pids": len({s[2] for s in seen}),
-                              "gather_ok": ok, "transport": "gloo (CPU rehearsal, nothing timed)"}))
+                              "gather_ok": ok, "transport": "gloo (CPU rehearsal, nothing timed)",
+                              "env": [s[3] for s in sorted(seen, key=lambda s: s[0])]}))
             sys.stdout.flush()
         dist.barrier()
     finally:
         dist.destroy_process_group()
     return 0 if ok else 1
+
+
+# ---- the rank ---------------------------------------------------------------------------------------------
+class Ranks:
+    """Rendezvous / barrier / reductions between ranks.  One rank: no-ops, and torch is never imported."""
+
+    def __init__(self, rank, world, use_comm):
+        self.rank, self.world, self.dist = rank, world, None
+        if use_comm:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))       # one-rank rehearsal without a launcher
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            self.dist = dist
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def max(self, x):
+        if self.dist is None:
+            return float(x)
+        import torch
+        t = torch.tensor([float(x)], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather(self, obj):
+        if self.dist is None:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
+    def bcast(self, obj):
+        if self.dist is None:
+            return obj
+        box = [obj]
+        self.dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+def fail_line(rk, why):
+    """Nothing was timed: say so on rank 0 and leave non-zero on every rank (never through a re-exec; a wedged
+    helper thread may still sit inside the library, hence os._exit)."""
+    if rk.rank == 0:
+        print(json.dumps({"metric": METRIC, "value": None, "unit": "frames/s", "n_gpus": 0, "steps": 0, "warmup": 0,
+                          "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "f64", "data": "synthetic",
+                          "config": {"workload": "not run", "gather": "FAILED, nothing timed: %s" % why,
+                                     "parity": "FAILED, nothing timed: %s" % why}}))
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(1)
+
+
+def init_comm(ctx, rk, d_path, U, T):
+    """RCCL communicator + one rehearsal gather under a watchdog.  Returns (gather buffer, ranks RCCL counts)."""
+    import threading
+    from lnasr import _ffi
+    state = {}
+
+    def _work():
+        try:
+            ctx.comm_init(state["id"], rk.rank, rk.world)
+            buf = ctx.empty((rk.world, U, T), np.uint32)
+            ctx.allgather_paths(d_path, N_STATES, out=buf)
+            ctx.sync()
+            state["info"] = ctx.comm_info()
+            state["buf"] = buf
+        except Exception as e:                                   # noqa: BLE001
+            state["err"] = e
+
+    err = None
+    try:
+        state["id"] = rk.bcast(_ffi.comm_unique_id() if rk.rank == 0 else None)
+        th = threading.Thread(target=_work, daemon=True)
+        th.start()
+        th.join(float(os.environ.get("LNASR_COMM_TIMEOUT", "180")))
+        if th.is_alive():
+            raise RuntimeError("RCCL bootstrap / first all-gather did not finish in time")
+        if "err" in state:
+            raise state["err"]
+        if state["info"] != (rk.rank, rk.world):
+            raise RuntimeError("RCCL reports rank/size %r, the launcher %r" % (state["info"], (rk.rank, rk.world)))
+    except Exception as e:                                       # noqa: BLE001
+        err = "%s: %s" % (type(e).__name__, e)
+        sys.stderr.write("[rank %d] RCCL init failed: %s\n" % (rk.rank, err))
+    errs = rk.gather(err)
+    if any(errs):
+        fail_line(rk, "; ".join("rank %d: %s" % (r, e) for r, e in enumerate(errs) if e))
+    return state["buf"], state["info"][1]
+
+
+def timed(rk, ctx, fn, steps, warmup):
+    """W untimed + exactly K timed calls of fn, bracketed by barrier + device sync on both sides; max over ranks (s)."""
+    for _ in range(warmup):
+        fn()
+    ctx.device_sync()
+    rk.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    ctx.device_sync()
+    dt = time.perf_counter() - t0
+    rk.barrier()
+    return rk.max(dt)
+
+
+def end_to_end(rk, ctx, obs, want_paths, compute_ms, steps):
+    """Host observations in -> host paths out (the reference's decode() signature), PCIe inclusive."""
+    U, T = obs.shape[:2]
+    out = {}
+    pin_obs = ctx.pinned_copy(obs)
+    pin_path = ctx.pinned_empty((U, T), np.uint32)
+    d_tmp = ctx.empty(obs.shape, np.float64)
+    from lnasr import _ffi
+
+    def h2d():
+        _ffi.check(_ffi.lib().lnasr_memcpy_h2d(ctx.handle, d_tmp.ptr, pin_obs.ctypes.data, obs.nbytes))
+    h2d_s = timed(rk, ctx, h2d, 5, 1) / 5
+    d_tmp.free()
+
+    def run_pinned():
+        ctx.decode(pin_obs, path_out=pin_path)
+    t_pin = timed(rk, ctx, run_pinned, steps, 2) / steps
+    ok_pin = bool(np.array_equal(pin_path, want_paths))
+    page_path = np.empty((U, T), np.uint32)
+
+    def run_pageable():
+        ctx.decode(obs, path_out=page_path)
+    t_page = timed(rk, ctx, run_pageable, max(3, steps // 2), 2) / max(3, steps // 2)
+    ok_page = bool(np.array_equal(page_path, want_paths))
+    frames = rk.world * U * T
+    floor_ms = max(h2d_s * 1e3, compute_ms)
+    out = {"value": frames / t_pin, "unit": "frames/s", "ms_per_step": t_pin * 1e3,
+           "h2d_GBps": obs.nbytes / h2d_s / 1e9, "h2d_ms": h2d_s * 1e3, "compute_ms": compute_ms,
+           "over_max_h2d_compute": t_pin * 1e3 / floor_ms,
+           "what": "numpy float64 obs [%d,%d,%d] in page-locked host memory (lnasr_host_alloc) -> uint32 paths in "
+                   "page-locked host memory; upload in chunks on a side stream, emission starts on the first chunk; "
+                   "h2d_GBps = the same buffer copied alone" % obs.shape,
+           "paths_identical_to_resident_run": ok_pin,
+           "pageable": {"value": frames / t_page, "ms_per_step": t_page * 1e3,
+                        "what": "plain (pageable) numpy arrays in and out: host threads fill the context's pinned staging "
+                                "ring, DMA from there", "paths_identical_to_resident_run": ok_page}}
+    return out, ok_pin and ok_page
+
+
+def baum_welch(rk, ctx, use_rccl):
+    """BASELINE configs[4] per rank: statistics pass (fp64 and precision=float32) + RCCL all-reduce of the packed vector."""
+    from lnasr import synth
+    s = BW_SHAPE
+    mdl = synth.synth_model(s["N"], s["M"], s["D"], seed=5)
+    obs = synth.synth_obs(s["U"], s["T"], s["D"], seed=2000 + rk.rank)
+    ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
+    d_obs = ctx.to_device(obs)
+    n = ctx.bw_stats_len()
+    d_stats = ctx.empty((n,), np.float64)
+    out = {"workload": "Baum-Welch statistics pass, N=%(N)d M=%(M)d D=%(D)d T=%(T)d, %(U)d utterances per GPU "
+                       "(BASELINE configs[4]): emission + forward/backward + accumulation; then the RCCL sum "
+                       "all-reduce of the packed sufficient statistics" % s,
+           "steps": BW_STEPS, "allreduce_bytes": n * 8}
+    frames = s["U"] * s["T"]
+    for tag, prec in (("f64", np.float64), ("f32", np.float32)):
+        t = timed(rk, ctx, lambda: ctx.bw_accumulate(d_obs, stats_out=d_stats, precision=prec), BW_STEPS, 1) / BW_STEPS
+        out["bw_pass_ms" if tag == "f64" else "bw_pass_f32_ms"] = t * 1e3
+    ctx.bw_accumulate(d_obs, stats_out=d_stats, precision=np.float64)
+    ctx.sync()
+    mine = d_stats.to_host()
+    # size-independent checks of this rank's statistics: sum_j gamma = frames - U (the last frame of every utterance
+    # carries no transition), sum of the mixture posteriors = frames, n_utt / n_frames as counted
+    N, M = s["N"], s["M"]
+    g = mine[N * N:N * N + N].sum()
+    mix = mine[N * N + 2 * N:N * N + 2 * N + N * M].sum()
+    ok = abs(g - (frames - s["U"])) < 1e-6 * frames and abs(mix - frames) < 1e-6 * frames
+    ok = ok and mine[-2] == s["U"] and mine[-1] == frames
+    out["allreduce_ms"] = None
+    if use_rccl:
+        # the all-reduce alone, in place on the device-resident vector (re-filled before each call so that the
+        # values stay finite whatever the step count)
+        ts = []
+        for _ in range(BW_STEPS + 1):
+            ctx.bw_accumulate(d_obs, stats_out=d_stats, precision=np.float64)
+            ctx.device_sync()
+            rk.barrier()
+            t0 = time.perf_counter()
+            ctx.allreduce_f64(d_stats)
+            ctx.sync()
+            ts.append(time.perf_counter() - t0)
+        out["allreduce_ms"] = rk.max(float(np.median(ts[1:]))) * 1e3
+        total = d_stats.to_host()
+        sums = rk.gather(float(mine[-3]))                               # every rank's own log-likelihood sum
+        ok = ok and abs(total[-3] - sum(sums)) <= 1e-9 * abs(sum(sums))
+        ok = ok and total[-2] == s["U"] * rk.world and total[-1] == frames * rk.world
+        out["allreduce_GBps_algorithmic"] = n * 8 / (out["allreduce_ms"] * 1e-3) / 1e9
+        # every rank then runs the identical M-step on the summed statistics
+        m = ctx.bw_mstep(total)
+        ok = ok and bool(np.allclose(np.exp(m["A"]).sum(axis=1), 1.0, atol=1e-9))
+    out["frames_per_s"] = rk.world * frames / ((out["bw_pass_ms"] + (out["allreduce_ms"] or 0.0)) * 1e-3)
+    out["checks"] = "sum(gamma)=frames-U, sum(mix)=frames, counts%s: %s" % (
+        ", all-reduced loglik = sum of the ranks', normalised M-step" if use_rccl else "", "ok" if ok else "FAILED")
+    oks = rk.gather(bool(ok))
+    d_obs.free()
+    d_stats.free()
+    return out, all(oks)
 
 
 def main():
@@ -207,6 +443,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--utts", type=int, default=UTT_PER_GPU, help="utterances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the end_to_end and baum_welch sections")
     ap.add_argument("--dry-launch", action="store_true", help="CPU rehearsal of the N-rank launch path (no GPU)")
     args = ap.parse_args()
 
@@ -227,111 +464,41 @@ def main():
     from lnasr import synth
     obs = synth.synth_obs(U, T, N_DIM, seed=1000 + rank)            # this rank's shard
 
-    # CPU baseline first: fork-based workers must exist before this process touches the GPU
-    cpu, cpu_ref, want_paths = (None, None, None)
+    # everything that forks (CPU-baseline workers) or is pure CPU comes first: before this process touches the GPU
+    cpu, cpu_ref = (None, None)
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
-        cpu, cpu_ref, want_paths = cpu_baseline(obs[:N_CHECK])
+        cpu, cpu_ref = cpu_baseline()
+    n_check = min(N_CHECK, U)
+    want_head = oracle_paths(obs[:n_check])                         # every rank checks its own shard
+    if os.environ.get("LNASR_BENCH_TEST_CORRUPT_ORACLE"):           # tests only: prove that a mismatch times nothing
+        want_head[0, 0] ^= 1
 
-    dist = None
-    torch = None
     # LNASR_BENCH_FORCE_COMM=1: take the N > 1 code path (gloo group, RCCL communicator under the watchdog, gather in
-    # the timed step) with however many ranks there are -- on a one-GPU box a one-rank rehearsal of everything but
-    # the links
+    # the timed step, all-reduce of the statistics) with however many ranks there are -- on a one-GPU box a one-rank
+    # rehearsal of everything but the links
     use_comm = world > 1 or bool(os.environ.get("LNASR_BENCH_FORCE_COMM"))
-    if use_comm:
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", str(_free_port()))
-        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # one node: never depend on the hostname resolving
-        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")      # ... nor on which interface RCCL's bootstrap would pick
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-    else:
-        try:
-            import torch
-        except Exception:                                              # noqa: BLE001
-            torch = None
+    rk = Ranks(rank, world, use_comm)
 
     from lnasr import _ffi
-    # one GPU per rank: LOCAL_RANK, and Context raises if that device does not exist.  LNASR_BENCH_DEVICE pins every
-    # rank to one device -- only the failure-path test uses it (RCCL refuses two ranks on one GPU)
-    dev = int(os.environ.get("LNASR_BENCH_DEVICE", local_rank))
-    if "LNASR_BENCH_DEVICE" not in os.environ and world > 1 and _ffi.device_count() == 1:
-        dev = 0             # a launcher that isolates one GPU per rank (HIP_VISIBLE_DEVICES): the rank's only device
+    # one GPU per rank: LOCAL_RANK (a launcher that isolates one GPU per rank leaves one visible device: that one).
+    # LNASR_BENCH_DEVICE pins every rank to one device -- only the failure-path test uses it (RCCL refuses two ranks
+    # on one GPU)
+    if "LNASR_BENCH_DEVICE" in os.environ:
+        dev = int(os.environ["LNASR_BENCH_DEVICE"])
+    else:
+        dev = 0 if _ffi.device_count() == 1 else local_rank
     ctx = _ffi.Context(dev)
-    if torch is not None and torch.cuda.is_available():
-        torch.cuda.set_device(dev)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-
-    def sync():
-        ctx.sync()
-        if torch is not None and torch.cuda.is_available():
-            torch.cuda.synchronize()
 
     mdl = synth.synth_model(N_STATES, N_MIX, N_DIM, seed=1)
     ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
-    t0 = time.perf_counter()
     d_obs = ctx.to_device(obs)
-    h2d_s = time.perf_counter() - t0
     d_path = ctx.empty((U, T), np.uint32)
     d_score = ctx.empty((U,), np.float64)
     d_all = None
     n_ranks_rccl = 1
-
-    # RCCL communicator for the gather of paths (N > 1)
     gather = "n/a (single GPU)"
     if use_comm:
-        import threading
-        state = {}
-
-        def _init_comm():
-            # communicator + one rehearsal gather; under a watchdog so that a wedged bootstrap ends the run
-            try:
-                ctx.comm_init(state["id"], rank, world)
-                buf = ctx.empty((world, U, T), np.uint32)
-                ctx.allgather_paths(d_path, N_STATES, out=buf)
-                ctx.sync()
-                state["info"] = ctx.comm_info()
-                state["buf"] = buf
-            except Exception as e:                                   # noqa: BLE001
-                state["err"] = e
-
-        err = None
-        try:
-            ids = [_ffi.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            state["id"] = ids[0]
-            th = threading.Thread(target=_init_comm, daemon=True)
-            th.start()
-            th.join(float(os.environ.get("LNASR_COMM_TIMEOUT", "180")))
-            if th.is_alive():
-                raise RuntimeError("RCCL bootstrap / first all-gather did not finish in time")
-            if "err" in state:
-                raise state["err"]
-            if state["info"] != (rank, world):
-                raise RuntimeError("RCCL reports rank/size %r, the launcher %r" % (state["info"], (rank, world)))
-        except Exception as e:                                       # noqa: BLE001
-            err = "%s: %s" % (type(e).__name__, e)
-            sys.stderr.write("[rank %d] RCCL init failed: %s\n" % (rank, err))
-        errs = [None] * world
-        dist.all_gather_object(errs, err)
-        if any(errs):
-            # nothing is timed after a failed communicator (a wedged helper thread may still be inside the
-            # library on this context): say so and leave non-zero, never through a re-exec
-            if rank == 0:
-                print(json.dumps({"metric": METRIC, "value": None, "unit": "frames/s", "n_gpus": 0, "steps": 0,
-                                  "warmup": 0, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
-                                  "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                                  "config": {"workload": "not run", "gather": "FAILED, nothing timed: %s" % (
-                                      "; ".join("rank %d: %s" % (r, e) for r, e in enumerate(errs) if e))}}))
-            sys.stdout.flush()
-            sys.stderr.flush()
-            os._exit(1)
-        d_all = state["buf"]
-        n_ranks_rccl = state["info"][1]
+        d_all, n_ranks_rccl = init_comm(ctx, rk, d_path, U, T)
         gather = ("rccl all-gather of the state paths over %d ranks (ncclCommCount; u8 on the wire, u32 in memory), "
                   "%d B per GPU per step" % (n_ranks_rccl, U * T))
 
@@ -340,54 +507,64 @@ def main():
         if d_all is not None:
             ctx.allgather_paths(d_path, N_STATES, out=d_all)
 
-    # the checker's answer first: a fast kernel with different paths is not measured
-    parity = "not checked (N > 1 or --no-cpu-baseline)"
-    if want_paths is not None:
-        step()
-        sync()
-        got = d_path.to_host()[:N_CHECK]
-        if not np.array_equal(got, want_paths):
-            sys.stderr.write("GPU paths differ from the oracle's on the bench's own input; nothing timed\n")
-            return 1
-        parity = "paths of the first %d utterances bit-identical to the oracle's before timing" % N_CHECK
+    # the checker's answer first: a fast kernel with different paths is not measured -- on ANY rank
+    step()
+    ctx.sync()
+    resident_paths = d_path.to_host()
+    bad = None if np.array_equal(resident_paths[:n_check], want_head) else \
+        "rank %d: GPU paths differ from the oracle's on the bench's own input" % rank
+    bads = [b for b in rk.gather(bad) if b]
+    if bads:
+        sys.stderr.write("; ".join(bads) + "; nothing timed\n")
+        fail_line(rk, "; ".join(bads))
+    parity = ("paths of the first %d utterances of every rank's shard (%d rank%s) bit-identical to the oracle's "
+              "before timing" % (n_check, world, "" if world == 1 else "s"))
 
     for _ in range(args.warmup):
         step()
-    sync()
-    barrier()
+    ctx.device_sync()
+    rk.barrier()
     ctx.prof_enable(True)
     ctx.prof_reset()
-    sync()
+    ctx.device_sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    sync()
+    ctx.device_sync()
     elapsed = time.perf_counter() - t0
-    barrier()
+    rk.barrier()
     ctx.prof_enable(False)
     prof = ctx.prof_report()
-
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = rk.max(elapsed)
 
     # sanity: the decoded paths are valid state indices and every rank holds every shard
     p = d_path.to_host()
     rc = 0
-    if p.max() >= N_STATES:
-        sys.stderr.write("[rank %d] decoded state index out of range\n" % rank)
+    if p.max() >= N_STATES or not np.array_equal(p, resident_paths):
+        sys.stderr.write("[rank %d] decoded paths out of range or not reproducible\n" % rank)
         rc = 1
     if d_all is not None:
         allp = d_all.to_host()
         if not np.array_equal(allp[rank], p):
             sys.stderr.write("[rank %d] gathered paths do not match the local shard\n" % rank)
             rc = 1
-        sums = [None] * world
-        dist.all_gather_object(sums, int(p.astype(np.uint64).sum()))
+        sums = rk.gather(int(p.astype(np.uint64).sum()))
         if [int(allp[r].astype(np.uint64).sum()) for r in range(world)] != sums:
             sys.stderr.write("[rank %d] gathered shards differ from what their owners decoded\n" % rank)
             rc = 1
+
+    step_s = elapsed / args.steps
+    e2e = bw = None
+    if not args.no_extras:
+        e2e, ok = end_to_end(rk, ctx, obs, resident_paths, step_s * 1e3, max(5, args.steps // 2))
+        if not ok:
+            sys.stderr.write("[rank %d] end-to-end paths differ from the resident run\n" % rank)
+            rc = 1
+        bw, ok = baum_welch(rk, ctx, use_comm)
+        if not ok:
+            sys.stderr.write("[rank %d] Baum-Welch statistics failed their checks\n" % rank)
+            rc = 1
+    rc = int(max(rk.gather(rc)))
 
     if rank == 0:
         frames_total = n_ranks_rccl * U * T * args.steps
@@ -395,7 +572,7 @@ def main():
         dom = max(prof.items(), key=lambda kv: kv[1][1])
         name, (launches, ms) = dom
         avg_s = ms / launches * 1e-3
-        frames_launch = U * T * args.steps / launches                    # a step may cut the batch into chunks
+        frames_launch = U * T * args.steps / launches
         if name.startswith("emit"):
             flop = FLOP_EMIT
         elif name.startswith("viterbi"):
@@ -404,7 +581,6 @@ def main():
             flop = FLOP_DECODE
         achieved = flop * frames_launch / avg_s / 1e12
         kernels = {k: {"launches": n, "avg_ms": m / n} for k, (n, m) in sorted(prof.items(), key=lambda kv: -kv[1][1])}
-        step_s = elapsed / args.steps
         out = {
             "metric": METRIC,
             "value": value, "unit": "frames/s", "n_gpus": n_ranks_rccl, "steps": args.steps, "warmup": args.warmup,
@@ -415,8 +591,7 @@ def main():
                                    "utterances over 8 GPUs)" % U,
                        "utterances_per_gpu": U, "frames_per_utterance": T, "sharding": "utterances, dp%d" % n_ranks_rccl,
                        "gather": gather, "parity": parity,
-                       "inputs": "obs resident in HBM; H2D of this shard took %.1f ms "
-                                 "(%.2f GB/s) outside the timed region" % (h2d_s * 1e3, obs.nbytes / h2d_s / 1e9)},
+                       "inputs": "obs resident in HBM when the timed region starts (PCIe-inclusive: end_to_end)"},
             "roofline": {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": PEAK_FP64_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_TFLOPS,
                          "traffic": _pmc_traffic(name),
@@ -429,6 +604,9 @@ def main():
                                         "frac_of_hbm_peak": BYTES_DECODE * U * T / step_s / 1e9 / PEAK_HBM_GBS}},
             "kernels": kernels,
         }
+        if e2e is not None:
+            out["end_to_end"] = e2e
+            out["baum_welch"] = bw
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["cpu_baseline_reference_shaped"] = cpu_ref
@@ -436,10 +614,9 @@ def main():
         if rc == 0:
             print(json.dumps(out))
         sys.stdout.flush()
-    barrier()
+    rk.barrier()
     ctx.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    rk.close()
     return rc
 
 

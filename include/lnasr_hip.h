@@ -65,6 +65,10 @@ int lnasr_device_count(int* out);
 int lnasr_ctx_create(int device_id, lnasr_ctx** out);
 void lnasr_ctx_destroy(lnasr_ctx* ctx);
 int lnasr_sync(lnasr_ctx* ctx);
+/* every stream of the context's device has drained (hipDeviceSynchronize): the bracket of a timed region */
+int lnasr_device_sync(lnasr_ctx* ctx);
+/* LNASR_* test / ablation switches are read once per process; this re-reads them from the environment */
+int lnasr_reload_switches(void);
 int lnasr_device_info(lnasr_ctx* ctx, char* name, int name_cap, int* cu_count, size_t* hbm_bytes);
 
 /* device memory for HBM-resident inputs/outputs */
@@ -73,6 +77,11 @@ int lnasr_dev_free(lnasr_ctx* ctx, void* p);
 int lnasr_memcpy_h2d(lnasr_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int lnasr_memcpy_d2h(lnasr_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
 int lnasr_memset(lnasr_ctx* ctx, void* dst_dev, int byte, size_t bytes);
+/* Page-locked host memory (hipHostMalloc).  The reference hands host arrays to decode() (hmm.py:276-283); a host
+ * buffer from here is recognised by every entry point and moves at PCIe rate with no staging copy, a pageable one
+ * (plain numpy) goes through the context's pinned staging ring. */
+int lnasr_host_alloc(lnasr_ctx* ctx, size_t bytes, void** out);
+int lnasr_host_free(lnasr_ctx* ctx, void* p);
 
 /* per-kernel HIP-event timing on the context's own stream (bench.py roofline) */
 int lnasr_prof_enable(lnasr_ctx* ctx, int on);
@@ -136,6 +145,10 @@ int lnasr_forward(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* le
 int lnasr_backward(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* lens, int dtype, void* beta);
 /* GMMHMM.calc_prob: emission + forward, loglik [U] */
 int lnasr_calc_prob(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* lens, double* loglik);
+/* the same under the model's `precision=`: LNASR_F32 scores the emission exactly as lnasr_bw_accumulate_p(…, F32)
+ * does (fp32 matrix cores where the model allows it), so the two likelihoods of the reference's stopping rule
+ * (hmm.py:301-313) come from one arithmetic */
+int lnasr_calc_prob_p(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* lens, int dtype, double* loglik);
 
 /* ---- Baum-Welch --------------------------------------------------------------- */
 /* HMM._baumwelch (hmm.py:174-200): xi [U,T,N,N], gamma [U,T,N]; frame lens-1 is -inf */

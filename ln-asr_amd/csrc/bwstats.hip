@@ -217,6 +217,11 @@ int xi_sum_device(lnasr_ctx* ctx, const double* alpha, const double* beta, const
 // ------------------------------------------------------------------------------------------
 constexpr int kMixFrames = 32;       // frames per staged chunk (8 MFMA k-steps)
 constexpr int kMixRing = 8;          // bm prefetch ring (k-steps; must divide kMixFrames / 4)
+// The ring's running pointer is not clamped: the last block reads up to (kMixFrames - 1) frames of chunk rounding plus
+// 4 (kMixRing - 1) + 3 frames of prefetch past the batch.  Callers allocate bm with kMixPadFrames frames of slack
+// (lnasr_bw_accumulate_p); this ties the three constants together.
+static_assert((kMixFrames - 1) + 4 * (kMixRing - 1) + 3 < kMixPadFrames, "bm prefetch ring outruns kMixPadFrames");
+static_assert((kMixFrames / 4) % kMixRing == 0, "kMixRing must divide kMixFrames / 4");
 constexpr int kMixWaves = 8;         // waves (= states) per block; 4-wave blocks at 3 waves/SIMD were measured: slower (5.7 vs 4.1 ms)
 constexpr int kMixNT = 64 * kMixWaves;
 
@@ -592,7 +597,7 @@ __global__ void full_finish_kernel(const double* __restrict__ R, const double* _
 }
 
 bool full_stats_mfma_ok(const Model& md) {
-    return !md.diag && md.wfull_Q > 0 && md.D <= 39 && !getenv("LNASR_NO_MFMA_STATS");
+    return !md.diag && md.wfull_Q > 0 && md.D <= 39 && !sw().no_mfma_stats;
 }
 
 int full_stats_device(lnasr_ctx* ctx, const double* obs, const double* alpha, const double* beta, const double* b,
@@ -646,7 +651,7 @@ int mix_finish_launch(lnasr_ctx* ctx, const double* R, const double* centre, int
 }
 
 bool mix_stats_mfma_ok(const Model& md) {
-    return md.diag && md.D <= 39 && !getenv("LNASR_NO_MFMA_STATS");
+    return md.diag && md.D <= 39 && !sw().no_mfma_stats;
 }
 
 template <int MT>

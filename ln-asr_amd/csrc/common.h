@@ -100,6 +100,24 @@ struct Model {
 };
 
 constexpr double kKappaMax = 4096.0;
+// The fp32 matrix-core statistics pass (f32stats.hip) evaluates the same expanded quadratic in FLOAT: its
+// cancellation error is ~6e-8 * kappa in every component log-density, so it gets a tighter gate than the fp64
+// kernels (128 -> <= 8e-6 absolute, the float32 accuracy include/lnasr_hip.h promises); above it the fp64 pass runs.
+constexpr double kKappaMaxF32 = 128.0;
+
+// Test / ablation switches (LNASR_* environment variables).  Read ONCE per process, on first use;
+// lnasr_reload_switches() re-reads them (the test-suite toggles switches inside one process).
+struct Switches {
+    bool no_mfma = false, no_pad = false, no_tinyvit = false, no_regvit = false, no_regfwd = false, no_colfwd = false,
+         no_t256 = false, no_framepar = false, no_stream = false, no_ldsbt = false, no_mfma_stats = false,
+         no_fft512 = false, no_pipeline = false, f32_generic = false, no_f32_stats = false, no_pinned_ring = false;
+    char vit = 0;                 // LNASR_VIT: first character, 0 = unset
+    int framepar_maxu = -1;       // LNASR_FRAMEPAR_MAXU, -1 = unset (measured rule)
+    double kappa_max = kKappaMax; // LNASR_KAPPA_MAX
+    int h2d_threads = 4;          // LNASR_H2D_THREADS: host threads filling the pinned staging ring
+    char emit = 0;                // LNASR_EMIT (ablation builds only)
+};
+const Switches& sw();
 
 struct ProfRec {
     int name_id;
@@ -112,10 +130,13 @@ struct lnasr_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;            // side stream: the backward pass runs beside the forward pass
-    hipStream_t stream3 = nullptr;            // second side stream: forward pass of the pipelined statistics pass
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    std::vector<hipEvent_t> pipe_events;      // emission / forward / backward of each utterance chunk (estimate.hip)
     std::vector<hipEvent_t> copy_events;      // one per upload chunk of emit_batch
+    // pinned staging ring of the upload pipeline (pageable host observations -> pinned slots -> HBM); grow-only
+    static constexpr int kRingSlots = 4;
+    void* ring[kRingSlots] = {nullptr, nullptr, nullptr, nullptr};
+    size_t ring_cap = 0;                      // bytes per slot
+    hipEvent_t ring_ev[kRingSlots] = {nullptr, nullptr, nullptr, nullptr};   // the copy that last read the slot
     hipDeviceProp_t prop;
     lnasr::Model model;
     // workspace
@@ -166,6 +187,9 @@ void prof_end(lnasr_ctx* ctx, int rec);
 
 // Is `p` device memory?  (host pointers from numpy are unregistered)
 bool is_device_ptr(const void* p);
+// Is `p` page-locked host memory (lnasr_host_alloc / hipHostMalloc / hipHostRegister)?  Such buffers are copied
+// asynchronously at PCIe rate without a staging copy.
+bool is_pinned_host_ptr(const void* p);
 
 // Bring an input to the device (returns the device pointer to use; stages through `ws` if host).
 int stage_in(lnasr_ctx* ctx, const void* p, size_t bytes, DevBuf& ws, const void** out);

@@ -1,5 +1,6 @@
 // Runtime: context, device memory, staging, per-kernel HIP-event profiling, errors.
 #include <algorithm>
+#include <mutex>
 
 #include "common.h"
 
@@ -52,6 +53,62 @@ void Model::release() {
     has_hmm = has_gmm = false;
 }
 
+static Switches g_sw;
+static bool g_sw_loaded = false;
+static std::mutex g_sw_mu;
+
+static void load_switches(Switches& s) {
+    auto on = [](const char* name) { return getenv(name) != nullptr; };
+    s = Switches();
+    s.no_mfma = on("LNASR_NO_MFMA");
+    s.no_pad = on("LNASR_NO_PAD");
+    s.no_tinyvit = on("LNASR_NO_TINYVIT");
+    s.no_regvit = on("LNASR_NO_REGVIT");
+    s.no_regfwd = on("LNASR_NO_REGFWD");
+    s.no_colfwd = on("LNASR_NO_COLFWD");
+    s.no_t256 = on("LNASR_NO_T256");
+    s.no_framepar = on("LNASR_NO_FRAMEPAR");
+    s.no_stream = on("LNASR_NO_STREAM");
+    s.no_ldsbt = on("LNASR_NO_LDSBT");
+    s.no_mfma_stats = on("LNASR_NO_MFMA_STATS");
+    s.no_fft512 = on("LNASR_NO_FFT512");
+    s.no_pipeline = on("LNASR_NO_PIPELINE");
+    s.f32_generic = on("LNASR_F32_GENERIC");
+    s.no_f32_stats = on("LNASR_NO_F32_STATS");
+    s.no_pinned_ring = on("LNASR_NO_PINNED_RING");
+    if (const char* e = getenv("LNASR_VIT")) s.vit = e[0];
+    if (const char* e = getenv("LNASR_EMIT")) s.emit = e[0];
+    if (const char* e = getenv("LNASR_FRAMEPAR_MAXU")) s.framepar_maxu = atoi(e);
+    if (const char* e = getenv("LNASR_KAPPA_MAX")) s.kappa_max = atof(e);
+    if (const char* e = getenv("LNASR_H2D_THREADS")) {
+        s.h2d_threads = atoi(e);
+        if (s.h2d_threads < 1) s.h2d_threads = 1;
+        if (s.h2d_threads > 16) s.h2d_threads = 16;
+    }
+}
+
+const Switches& sw() {
+    if (!g_sw_loaded) {
+        std::lock_guard<std::mutex> lk(g_sw_mu);
+        if (!g_sw_loaded) {
+            load_switches(g_sw);
+            g_sw_loaded = true;
+        }
+    }
+    return g_sw;
+}
+
+bool is_pinned_host_ptr(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return attr.type == hipMemoryTypeHost;
+}
+
 bool is_device_ptr(const void* p) {
     if (!p) return false;
     hipPointerAttribute_t attr;
@@ -96,7 +153,7 @@ __global__ void widen_kernel(const float* __restrict__ s, double* __restrict__ d
 __global__ void narrow_kernel(const double* __restrict__ s, float* __restrict__ d, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d[i] = (float)s[i];
 }
-bool f32_via_f64() { return !getenv("LNASR_F32_GENERIC"); }
+bool f32_via_f64() { return !sw().f32_generic; }
 int widen_f32(lnasr_ctx* ctx, const void* src, size_t n, DevBuf& ws, double** out) {
     LN_TRY(ws.reserve(n * 8));
     *out = ws.as<double>();
@@ -204,7 +261,6 @@ int lnasr_ctx_create(int device_id, lnasr_ctx** out) {
     }
     LN_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     LN_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-    LN_HIP(hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
     LN_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     LN_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     *out = ctx;
@@ -227,13 +283,15 @@ void lnasr_ctx_destroy(lnasr_ctx* ctx) {
     }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     for (auto e : ctx->copy_events) (void)hipEventDestroy(e);
-    for (auto e : ctx->pipe_events) (void)hipEventDestroy(e);
+    for (int k = 0; k < lnasr_ctx::kRingSlots; ++k) {
+        if (ctx->ring_ev[k]) (void)hipEventDestroy(ctx->ring_ev[k]);
+        if (ctx->ring[k]) (void)hipHostFree(ctx->ring[k]);
+    }
     if (ctx->mfcc_meta_ev) (void)hipEventDestroy(ctx->mfcc_meta_ev);
     if (ctx->mfcc_meta) (void)hipHostFree(ctx->mfcc_meta);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
-    if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -242,6 +300,37 @@ int lnasr_sync(lnasr_ctx* ctx) {
     LN_ENTER(ctx);
     LN_REQUIRE(ctx, "null ctx");
     LN_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int lnasr_device_sync(lnasr_ctx* ctx) {
+    LN_ENTER(ctx);
+    LN_REQUIRE(ctx, "null ctx");
+    LN_HIP(hipDeviceSynchronize());
+    return 0;
+}
+
+int lnasr_reload_switches(void) {
+    std::lock_guard<std::mutex> lk(g_sw_mu);
+    load_switches(g_sw);
+    g_sw_loaded = true;
+    return 0;
+}
+
+int lnasr_host_alloc(lnasr_ctx* ctx, size_t bytes, void** out) {
+    LN_ENTER(ctx);
+    LN_REQUIRE(ctx && out, "null argument");
+    *out = nullptr;
+    LN_HIP(hipHostMalloc(out, bytes ? bytes : 256, hipHostMallocDefault));
+    return 0;
+}
+
+int lnasr_host_free(lnasr_ctx* ctx, void* p) {
+    LN_ENTER(ctx);
+    LN_REQUIRE(ctx, "null ctx");
+    if (!p) return 0;
+    LN_HIP(hipStreamSynchronize(ctx->stream));
+    LN_HIP(hipHostFree(p));
     return 0;
 }
 

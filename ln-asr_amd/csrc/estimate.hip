@@ -702,109 +702,9 @@ int lnasr_bw_accumulate_p(lnasr_ctx* ctx, const double* obs, int U, int T, const
     double* al = ctx->ws_alpha.as<double>();
     double* be = ctx->ws_beta.as<double>();
     LN_REQUIRE(U <= 65535, "U=%d too large for one statistics launch", U);
-    const bool mfma_stats = !getenv("LNASR_NO_MFMA_STATS");
-    // Pipelined pass (LNASR_BW_CHUNKS = n, default off).  With the on-chip 256-state trellises one block walks one
-    // utterance (config 5: 64 + 64 blocks on 256 CUs for 2.7 ms, every other CU idle), so the batch can be cut into
-    // chunks of utterances: while the forward and backward passes of chunk c run on their own streams, the main stream
-    // scores chunk c + 1 and then gathers the statistics of chunk c - 1.  Measured: 11.7 -> 12.8 (2
-    // chunks) -> 16.3 ms (4): a trellis block needs a whole CU (the transition matrix IS its register file), the
-    // emission blocks of the next chunk are spread over all CUs, so the trellises start only once the main stream
-    // stalls -- the chunks run one after the other.  Results are the same (test_config5_pipelined_pass).
-    int nch = 1;
-    if (mfma_stats && N > 128 && N <= 256 && !getenv("LNASR_NO_T256") && (f32 || mix_stats_mfma_ok(md))) {
-        if (const char* e = getenv("LNASR_BW_CHUNKS")) nch = atoi(e);
-        if (nch > U) nch = U;
-        if (nch > 16) nch = 16;
-        if (nch < 1) nch = 1;
-    }
-    if (nch > 1) {
-        const void* dv;
-        LN_TRY(stage_in(ctx, obs, (size_t)U * T * D * 8, ctx->ws_in, &dv));
-        d_obs = (const double*)dv;
-        while ((int)ctx->pipe_events.size() < 3 * nch) {
-            hipEvent_t e;
-            LN_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            ctx->pipe_events.push_back(e);
-        }
-        // every workspace the loop touches exists before the first side-stream launch (a growing DevBuf frees and
-        // reallocates, which must not happen under kernels in flight)
-        {
-            const int umax = (U + nch - 1) / nch + 1;
-            const int NP = (N + 15) / 16 * 16;
-            const long FPc = ((long)umax * T + 3) / 4 * 4;
-            LN_TRY(ctx->ws_p.reserve((size_t)FPc * NP * 8));
-            LN_TRY(ctx->ws_q.reserve((size_t)FPc * NP * 8));
-            LN_TRY(ctx->ws_misc2.reserve(std::max((size_t)umax * T * N * 4 * 8, ((size_t)umax * T + 2) * sizeof(int))));
-        }
-        LN_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
-        LN_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-        LN_HIP(hipStreamWaitEvent(ctx->stream3, ctx->ev_fork, 0));
-        float* q32 = ctx->ws_bm.as<float>();
-        if (f32)
-            LN_TRY(mix_stats_device_f32(ctx, d_obs, al, be, b, q32, c1, d_lens, 0, T, st + L.mix, st + L.mix_x, st + L.mix_xx,
-                                        kMixBegin));
-        else
-            LN_TRY(mix_stats_device(ctx, d_obs, al, be, b, bm, c1, d_lens, 0, T, st + L.mix, st + L.mix_x, st + L.mix_xx,
-                                    kMixBegin));
-        auto lo = [&](int c) { return (int)((long)U * c / nch); };
-        int rc = 0;
-        auto gather = [&](int c) -> int {           // statistics of chunk c: needs its forward and backward passes
-            const int u0 = lo(c), uc = lo(c + 1) - u0;
-            const size_t o = (size_t)u0 * T * N, fo = (size_t)u0 * T;
-            LN_HIP(hipStreamWaitEvent(ctx->stream, ctx->pipe_events[3 * c + 1], 0));
-            LN_HIP(hipStreamWaitEvent(ctx->stream, ctx->pipe_events[3 * c + 2], 0));
-            LN_TRY(xi_sum_device(ctx, al + o, be + o, b + o, ll + u0, d_lens + u0, uc, T, st + L.xi));
-            LN_LAUNCH(ctx, "acc_gamma0", acc_gamma0_kernel, dim3(uc), dim3(64), 0, (const double*)(al + o),
-                      (const double*)(be + o), (const double*)(ll + u0), d_lens + u0, uc, T, N, st + L.g0, st + L.ll,
-                      st + L.nutt, st + L.nfr);
-            LN_LAUNCH(ctx, "ab_lse", ab_lse_kernel<double>, dim3((unsigned)(((size_t)uc * T + 3) / 4)), dim3(256), 0,
-                      (const double*)(al + o), (const double*)(be + o), (long)uc * T, N, c1 + fo);
-            if (f32)
-                return mix_stats_device_f32(ctx, d_obs + fo * D, al + o, be + o, b + o, q32 + o * M, c1 + fo, d_lens + u0, uc,
-                                            T, st + L.mix, st + L.mix_x, st + L.mix_xx, kMixAdd);
-            return mix_stats_device(ctx, d_obs + fo * D, al + o, be + o, b + o, bm + o * M, c1 + fo, d_lens + u0, uc, T,
-                                    st + L.mix, st + L.mix_x, st + L.mix_xx, kMixAdd);
-        };
-        for (int c = 0; c < nch && rc == 0; ++c) {
-            const int u0 = lo(c), uc = lo(c + 1) - u0;
-            const size_t o = (size_t)u0 * T * N, fo = (size_t)u0 * T;
-            rc = f32 ? emit_device_f32(ctx, d_obs + fo * D, (long)uc * T, b + o, q32 + o * M)
-                     : emit_device(ctx, d_obs + fo * D, (long)uc * T, LNASR_F64, b + o, bm + o * M);
-            if (rc) break;
-            if (hipEventRecord(ctx->pipe_events[3 * c], ctx->stream) != hipSuccess ||
-                hipStreamWaitEvent(ctx->stream2, ctx->pipe_events[3 * c], 0) != hipSuccess ||
-                hipStreamWaitEvent(ctx->stream3, ctx->pipe_events[3 * c], 0) != hipSuccess) {
-                rc = fail(LNASR_E_HIP, "event plumbing of the pipelined statistics pass failed");
-                break;
-            }
-            std::swap(ctx->stream, ctx->stream2);
-            rc = backward_device(ctx, b + o, uc, T, d_lens + u0, LNASR_F64, be + o);
-            (void)hipEventRecord(ctx->pipe_events[3 * c + 2], ctx->stream);
-            std::swap(ctx->stream, ctx->stream2);
-            if (rc) break;
-            std::swap(ctx->stream, ctx->stream3);
-            rc = forward_device(ctx, b + o, uc, T, d_lens + u0, LNASR_F64, al + o, ll + u0);
-            (void)hipEventRecord(ctx->pipe_events[3 * c + 1], ctx->stream);
-            std::swap(ctx->stream, ctx->stream3);
-            if (rc) break;
-            if (c >= 1) rc = gather(c - 1);
-        }
-        if (rc == 0) rc = gather(nch - 1);
-        // whatever happened, the main stream must not run ahead of the side streams
-        (void)hipEventRecord(ctx->ev_join, ctx->stream2);
-        (void)hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);
-        (void)hipEventRecord(ctx->ev_join, ctx->stream3);
-        (void)hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);
-        LN_TRY(rc);
-        LN_LAUNCH(ctx, "rowsum", rowsum_kernel, dim3((N + 63) / 64), dim3(64), 0, st + L.xi, N, st + L.gsum);
-        if (f32)
-            LN_TRY(mix_stats_device_f32(ctx, d_obs, al, be, b, q32, c1, d_lens, 0, T, st + L.mix, st + L.mix_x, st + L.mix_xx,
-                                        kMixEnd));
-        else
-            LN_TRY(mix_stats_device(ctx, d_obs, al, be, b, bm, c1, d_lens, 0, T, st + L.mix, st + L.mix_x, st + L.mix_xx,
-                                    kMixEnd));
-        return finish_out(ctx, stats, d_st, L.total * 8);
-    }
+    const bool mfma_stats = !sw().no_mfma_stats;
+    // (Cutting the batch into utterance chunks so that the trellises of chunk c run beside the emission of chunk c + 1
+    // was measured slower in round 2, DESIGN 4.5, and removed in round 3.)
     if (f32) {
         const void* dv;
         LN_TRY(stage_in(ctx, obs, (size_t)U * T * D * 8, ctx->ws_in, &dv));

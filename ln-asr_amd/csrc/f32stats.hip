@@ -194,6 +194,10 @@ __global__ void merge_virtual32_kernel(const double* __restrict__ bv, size_t cel
 // = lane >> 4 of the k-step) and multiplies them with the block's feature rows from LDS.  Accumulators are float and
 // are added into the fp64 sums R every kFlush frames, so no float sum runs over more than kFlush terms.
 constexpr int kMix32Frames = 32, kMix32Waves = 8, kMix32NT = 64 * kMix32Waves, kMix32Flush = 4096;
+constexpr int kMix32Ring = 8;        // q prefetch ring (k-steps; must divide kMix32Frames / 4)
+// unclamped running pointer, as in bwstats.hip: the slack behind q32 must cover chunk rounding + prefetch depth
+static_assert((kMix32Frames - 1) + 4 * (kMix32Ring - 1) + 3 < kMixPadFrames, "q32 prefetch ring outruns kMixPadFrames");
+static_assert((kMix32Frames / 4) % kMix32Ring == 0, "kMix32Ring must divide kMix32Frames / 4");
 
 template <int MT, int CT>
 __global__ __launch_bounds__(kMix32NT) void mix_mfma_f32(const double* __restrict__ obs, const double* __restrict__ alpha,
@@ -289,7 +293,7 @@ __global__ __launch_bounds__(kMix32NT) void mix_mfma_f32(const double* __restric
         qok[mt] = 16 * mt + l15 < M;
         qptr[mt] = q32 + ((size_t)(fb0 + kk) * N + jc) * M + (qok[mt] ? 16 * mt + l15 : 0);
     }
-    constexpr int RM = 8;                                    // q prefetch ring (k-steps; must divide CH / 4)
+    constexpr int RM = kMix32Ring;
     float ring[RM][MT];
     auto ring_load = [&](int slot) {
 #pragma unroll
@@ -353,8 +357,11 @@ int mix_finish_launch(lnasr_ctx* ctx, const double* R, const double* centre, int
 // precise than asked for, never less.
 bool f32_stats_ok(const Model& md) {
     if (!md.diag || md.direct_form || md.wpack_Q == 0 || md.pad_N != 0) return false;
+    // the float expanded quadratic loses ~6e-8 * kappa: its own, tighter gate (common.h); LNASR_KAPPA_MAX below the
+    // default tightens it further, never loosens it
+    if (!(md.kappa <= (sw().kappa_max < kKappaMaxF32 ? sw().kappa_max : kKappaMaxF32))) return false;
     if (md.D > 39 || md.M > 32 || md.wpack_KS > 20) return false;
-    return !getenv("LNASR_NO_MFMA") && !getenv("LNASR_NO_MFMA_STATS") && !getenv("LNASR_NO_F32_STATS");
+    return !sw().no_mfma && !sw().no_mfma_stats && !sw().no_f32_stats;
 }
 
 static int pack32(lnasr_ctx* ctx) {

@@ -9,9 +9,11 @@
 //                         with the M-way log-sum-exp fused in-lane          (hot kernel)
 //   emit_diag_generic     any N/M/D, fp64 VALU, direct (x-mu)^2/var form
 //   emit_full_generic     full covariance: (x-mu)^T P (x-mu)
+#include <atomic>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
+#include <vector>
 
 #include "common.h"
 #include "devmath.h"
@@ -643,6 +645,28 @@ __global__ void emit_full_generic(const double* __restrict__ obs, const double* 
     }
 }
 
+// `precision=np.float32` emission in the reference's ROUNDING ORDER (gmmhmm.py:64-67): bm is stored into a float32
+// array first, then b = lse_m(w + bm) is formed in float64 from those ROUNDED values and rounded on its way into the
+// float32 `b`.  The fp64 kernels above produce bm in double; this pass rounds it, writes the float bm (if asked for)
+// and re-forms b from the rounded values: b and bm come out bit-equal to the reference's float32 arrays wherever the
+// fp64 density itself does not sit within ~1e-14 of a float32 rounding boundary (golden gmmhmm_f32_mid: everywhere).
+// One thread per (frame, state); bm64 [F, N, M].
+__global__ void round32_lse_kernel(const double* __restrict__ bm64, const double* __restrict__ logw, size_t cells, int N,
+                                   int M, float* __restrict__ b32, float* __restrict__ bm32) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= cells) return;
+    const int n = (int)(idx % N);
+    const double* src = bm64 + idx * M;
+    const double* lw = logw + (size_t)n * M;
+    Lse acc;
+    for (int m = 0; m < M; ++m) {
+        const float r = (float)src[m];
+        if (bm32) bm32[idx * M + m] = r;
+        acc.add(lw[m] + (double)r);
+    }
+    b32[idx] = (float)acc.value();
+}
+
 // free functions of gmm.py --------------------------------------------------------------
 __global__ void gauss1d_kernel(const double* __restrict__ x, size_t L, double mu, double s2, int want_log,
                                double* __restrict__ out) {
@@ -760,10 +784,7 @@ static int copy_in(lnasr_ctx* ctx, DevBuf& dst, const void* src, size_t bytes) {
 }
 
 // LNASR_KAPPA_MAX overrides the conditioning gate (tests: show what the expanded form does beyond it)
-static double kappa_max() {
-    const char* e = getenv("LNASR_KAPPA_MAX");
-    return e ? atof(e) : kKappaMax;
-}
+static double kappa_max() { return sw().kappa_max; }
 
 // md.centre, md.mu_c, md.kappa / direct_form; prec == nullptr for a diagonal model.  A model that is well conditioned
 // about the ORIGIN keeps centre = 0 (md.centred = false: kernels that would pay for the subtraction skip it); only a
@@ -877,7 +898,7 @@ static int model_upload_impl(lnasr_ctx* ctx, int N, int M, int D, const double* 
         const int Nv = Np * virt, Mv = Mp / virt;
         md.wpack_virt = 1;
         md.pad_N = md.pad_M = 0;
-        if (!degenerate && mfma_shape_supported(Nv, Mv, D, &Q, &KS) && ((Np == N && Mp == M) || !getenv("LNASR_NO_PAD"))) {
+        if (!degenerate && mfma_shape_supported(Nv, Mv, D, &Q, &KS) && ((Np == N && Mp == M) || !sw().no_pad)) {
             // the packers see the CENTRED means: the kernels subtract md.centre from every observation they load
             const double *mu_s = md.mu_c.as<double>(), *iv_s = md.ivar.as<double>(), *gc_s = md.gconst.as<double>(),
                          *lw_s = md.logw.as<double>();
@@ -958,8 +979,7 @@ static int launch_mfma_cfg(lnasr_ctx* ctx, const double* obs, long F, double* b,
 template <int Q, int KS>
 static int launch_mfma(lnasr_ctx* ctx, const double* obs, long F, double* b, double* bm) {
 #ifdef LNASR_ABLATION_BUILD          // developer builds only: -DLNASR_ABLATION_BUILD + LNASR_EMIT=x|y
-    const char* var = getenv("LNASR_EMIT");
-    const char v = var ? var[0] : 'a';
+    const char v = sw().emit ? sw().emit : 'a';
     if (Q == 4 && KS == 20) {
         if (v == 'x' || v == 'y') {      // ablation kernels (wrong results by design; timing only)
             Model& md = ctx->model;
@@ -990,14 +1010,18 @@ int emit_device(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, v
     if (F <= 0) return 0;
     const int N = md.N, M = md.M, D = md.D;
     if (dtype == LNASR_F32 && f32_via_f64()) {
+        // the tuned kernels are f64: score in double WITH the per-mixture densities (needed whether or not the caller
+        // wants them), then round in the reference's order (round32_lse_kernel)
         const size_t cells = (size_t)F * N;
         LN_TRY(ctx->ws_w1.reserve(cells * 8));
-        if (bm) LN_TRY(ctx->ws_w3.reserve(cells * M * 8));
-        LN_TRY(emit_device(ctx, obs, F, LNASR_F64, ctx->ws_w1.p, bm ? ctx->ws_w3.p : nullptr));
-        LN_TRY(narrow_f64(ctx, ctx->ws_w1.as<double>(), cells, b));
-        return bm ? narrow_f64(ctx, ctx->ws_w3.as<double>(), cells * M, bm) : 0;
+        LN_TRY(ctx->ws_w3.reserve(cells * M * 8));
+        LN_TRY(emit_device(ctx, obs, F, LNASR_F64, ctx->ws_w1.p, ctx->ws_w3.p));
+        LN_LAUNCH(ctx, "round32_lse", round32_lse_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0,
+                  (const double*)ctx->ws_w3.as<double>(), (const double*)md.logw.as<double>(), cells, N, M, (float*)b,
+                  (float*)bm);
+        return 0;
     }
-    if (md.diag && dtype == LNASR_F64 && md.wdirect_KS > 0 && !getenv("LNASR_NO_MFMA")) {
+    if (md.diag && dtype == LNASR_F64 && md.wdirect_KS > 0 && !sw().no_mfma) {
         const long ntiles = (F + 15) / 16;
         const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
         long grid = (ntiles + 3) / 4;
@@ -1019,7 +1043,7 @@ int emit_device(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, v
 #undef LN_DLAUNCH
 #undef LN_DCASE
     }
-    if (md.diag && dtype == LNASR_F64 && md.wpack_Q > 0 && !getenv("LNASR_NO_MFMA")) {
+    if (md.diag && dtype == LNASR_F64 && md.wpack_Q > 0 && !sw().no_mfma) {
         const int Q = md.wpack_Q, KS = md.wpack_KS;
         const int Np = md.pad_N ? md.pad_N : N, Mp = md.pad_M ? md.pad_M : M, virt = md.wpack_virt;
         const bool padded = md.pad_N != 0;
@@ -1082,67 +1106,165 @@ int emit_device(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, v
     return 0;
 }
 
+// Upload pipeline of emit_batch.  The host observations reach HBM in `nch` chunks on the side stream while the emission
+// kernel already runs on the chunks that have arrived.  Three sources:
+//   * page-locked host memory (lnasr_host_alloc / hipHostRegister): one hipMemcpyAsync per chunk, PCIe rate, no thread;
+//   * pageable memory (plain numpy): `h2d_threads` host threads copy each chunk -- split between them -- into a slot of
+//     the context's pinned staging ring, the thread that completes a chunk enqueues its DMA; a slot is reused once the
+//     DMA that read it has finished (its event);
+//   * LNASR_NO_PINNED_RING: hipMemcpyAsync straight from pageable memory in a helper thread (the runtime's own
+//     staging: ~39-48 GB/s measured), the round-1 path.
+namespace {
+
+struct ChunkPlan {
+    int U, nch;
+    size_t utt_bytes;
+    int lo(int c) const { return (int)((long)U * c / nch); }
+    size_t off(int c) const { return (size_t)lo(c) * utt_bytes; }
+    size_t len(int c) const { return (size_t)(lo(c + 1) - lo(c)) * utt_bytes; }
+};
+
+struct UploadState {
+    std::mutex mu;
+    std::condition_variable cv;
+    int enqueued = 0;                  // chunks 0 .. enqueued-1 have their DMA and event on the side stream
+    std::vector<char> done;            // per chunk: DMA enqueued (ring path completes chunks out of order)
+    hipError_t err = hipSuccess;
+    void mark(int c, hipError_t e) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (e != hipSuccess && err == hipSuccess) err = e;
+            done[c] = 1;
+            while (enqueued < (int)done.size() && done[enqueued]) ++enqueued;
+            if (e != hipSuccess) enqueued = (int)done.size();      // release every waiter
+        }
+        cv.notify_all();
+    }
+    bool wait_for(int c) {             // false: an upload failed
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return enqueued > c; });
+        return err == hipSuccess;
+    }
+};
+
+}  // namespace
+
+static int ensure_ring(lnasr_ctx* ctx, size_t slot_bytes) {
+    if (ctx->ring_cap >= slot_bytes && ctx->ring[0]) return 0;
+    LN_HIP(hipStreamSynchronize(ctx->stream2));
+    for (int k = 0; k < lnasr_ctx::kRingSlots; ++k) {
+        if (ctx->ring[k]) (void)hipHostFree(ctx->ring[k]);
+        ctx->ring[k] = nullptr;
+    }
+    ctx->ring_cap = 0;
+    for (int k = 0; k < lnasr_ctx::kRingSlots; ++k) {
+        LN_HIP(hipHostMalloc(&ctx->ring[k], slot_bytes, hipHostMallocDefault));
+        if (!ctx->ring_ev[k]) LN_HIP(hipEventCreateWithFlags(&ctx->ring_ev[k], hipEventDisableTiming));
+    }
+    ctx->ring_cap = slot_bytes;
+    return 0;
+}
+
 int emit_batch(lnasr_ctx* ctx, const double* obs, int U, int T, double* b, double* bm, const double** d_obs_out) {
     Model& md = ctx->model;
     const size_t utt = (size_t)T * md.D;                       // doubles per utterance
-    constexpr int kMinChunk = 64, kMaxChunks = 8;
+    constexpr int kMinChunk = 64, kMaxChunks = 16;
     int nch = U / kMinChunk;
     nch = nch > kMaxChunks ? kMaxChunks : nch;
-    if (is_device_ptr(obs) || nch < 2 || getenv("LNASR_NO_PIPELINE")) {
+    if (is_device_ptr(obs) || nch < 2 || sw().no_pipeline) {
         const void* d_obs;
         LN_TRY(stage_in(ctx, obs, (size_t)U * utt * 8, ctx->ws_in, &d_obs));
         if (d_obs_out) *d_obs_out = (const double*)d_obs;
         return emit_device(ctx, (const double*)d_obs, (long)U * T, LNASR_F64, b, bm);
     }
     LN_TRY(ctx->ws_in.reserve((size_t)U * utt * 8));
-    double* d_obs = ctx->ws_in.as<double>();
-    if (d_obs_out) *d_obs_out = d_obs;
+    char* d_obs = ctx->ws_in.as<char>();
+    const char* h_obs = reinterpret_cast<const char*>(obs);
+    if (d_obs_out) *d_obs_out = ctx->ws_in.as<double>();
     while ((int)ctx->copy_events.size() < nch) {
         hipEvent_t e;
         LN_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ctx->copy_events.push_back(e);
     }
+    const ChunkPlan plan{U, nch, utt * 8};
     // the side stream must not run ahead of work that still reads the staging buffer
     LN_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
     LN_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-    std::mutex mu;
-    std::condition_variable cv;
-    int ready = 0;
-    hipError_t cerr = hipSuccess;
-    auto bounds = [&](int c) { return (int)((long)U * c / nch); };
-    std::thread copier([&] {
-        (void)hipSetDevice(ctx->device);
+    auto emit_chunk = [&](int c) -> int {
+        const int u0 = plan.lo(c), u1 = plan.lo(c + 1);
+        if (hipStreamWaitEvent(ctx->stream, ctx->copy_events[c], 0) != hipSuccess)
+            return fail(LNASR_E_HIP, "hipStreamWaitEvent failed in the upload pipeline");
+        return emit_device(ctx, ctx->ws_in.as<double>() + (size_t)u0 * utt, (long)(u1 - u0) * T, LNASR_F64,
+                           b + (size_t)u0 * T * md.N, bm ? bm + (size_t)u0 * T * md.N * md.M : nullptr);
+    };
+
+    if (is_pinned_host_ptr(obs)) {
+        // page-locked source: the DMA engine reads it directly
         for (int c = 0; c < nch; ++c) {
-            const int u0 = bounds(c), u1 = bounds(c + 1);
-            hipError_t e = hipMemcpyAsync(d_obs + (size_t)u0 * utt, obs + (size_t)u0 * utt, (size_t)(u1 - u0) * utt * 8,
-                                          hipMemcpyHostToDevice, ctx->stream2);
-            if (e == hipSuccess) e = hipEventRecord(ctx->copy_events[c], ctx->stream2);
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                if (e != hipSuccess) cerr = e;
-                ready = e == hipSuccess ? c + 1 : nch;
-            }
-            cv.notify_one();
-            if (e != hipSuccess) return;
+            LN_HIP(hipMemcpyAsync(d_obs + plan.off(c), h_obs + plan.off(c), plan.len(c), hipMemcpyHostToDevice, ctx->stream2));
+            LN_HIP(hipEventRecord(ctx->copy_events[c], ctx->stream2));
         }
-    });
+        for (int c = 0; c < nch; ++c) LN_TRY(emit_chunk(c));
+        return 0;
+    }
+
+    UploadState st;
+    st.done.assign(nch, 0);
+    std::vector<std::thread> workers;
+    if (sw().no_pinned_ring) {
+        workers.emplace_back([&] {
+            (void)hipSetDevice(ctx->device);
+            for (int c = 0; c < nch; ++c) {
+                hipError_t e = hipMemcpyAsync(d_obs + plan.off(c), h_obs + plan.off(c), plan.len(c), hipMemcpyHostToDevice,
+                                              ctx->stream2);
+                if (e == hipSuccess) e = hipEventRecord(ctx->copy_events[c], ctx->stream2);
+                st.mark(c, e);
+                if (e != hipSuccess) return;
+            }
+        });
+    } else {
+        size_t slot = 0;
+        for (int c = 0; c < nch; ++c) slot = plan.len(c) > slot ? plan.len(c) : slot;
+        LN_TRY(ensure_ring(ctx, slot));
+        constexpr int K = lnasr_ctx::kRingSlots;
+        const int nth = sw().h2d_threads;
+        // pieces[c]: threads that have finished their part of chunk c
+        std::vector<std::atomic<int>> pieces(nch);
+        for (auto& p : pieces) p.store(0);
+        for (int t = 0; t < nth; ++t) {
+            workers.emplace_back([&, t] {
+                (void)hipSetDevice(ctx->device);
+                for (int c = 0; c < nch; ++c) {
+                    const int s = c % K;
+                    if (c >= K) {
+                        // the slot's previous DMA (chunk c - K) must have been enqueued, then finished
+                        if (!st.wait_for(c - K)) return;
+                        if (hipEventSynchronize(ctx->ring_ev[s]) != hipSuccess) {
+                            st.mark(c, hipErrorUnknown);
+                            return;
+                        }
+                    }
+                    const size_t len = plan.len(c);
+                    const size_t p0 = (len * t / nth) & ~(size_t)63, p1 = t + 1 == nth ? len : (len * (t + 1) / nth) & ~(size_t)63;
+                    memcpy((char*)ctx->ring[s] + p0, h_obs + plan.off(c) + p0, p1 - p0);
+                    if (pieces[c].fetch_add(1, std::memory_order_acq_rel) + 1 == nth) {
+                        hipError_t e = hipMemcpyAsync(d_obs + plan.off(c), ctx->ring[s], len, hipMemcpyHostToDevice, ctx->stream2);
+                        if (e == hipSuccess) e = hipEventRecord(ctx->copy_events[c], ctx->stream2);
+                        if (e == hipSuccess) e = hipEventRecord(ctx->ring_ev[s], ctx->stream2);
+                        st.mark(c, e);
+                        if (e != hipSuccess) return;
+                    }
+                }
+            });
+        }
+    }
     int rc = 0;
     for (int c = 0; c < nch && rc == 0; ++c) {
-        {
-            std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return ready > c; });
-            if (cerr != hipSuccess) break;
-        }
-        const int u0 = bounds(c), u1 = bounds(c + 1);
-        if (hipStreamWaitEvent(ctx->stream, ctx->copy_events[c], 0) != hipSuccess) {
-            rc = fail(LNASR_E_HIP, "hipStreamWaitEvent failed in the upload pipeline");
-            break;
-        }
-        rc = emit_device(ctx, d_obs + (size_t)u0 * utt, (long)(u1 - u0) * T, LNASR_F64, b + (size_t)u0 * T * md.N,
-                         bm ? bm + (size_t)u0 * T * md.N * md.M : nullptr);
+        if (!st.wait_for(c)) break;
+        rc = emit_chunk(c);
     }
-    copier.join();
-    if (cerr != hipSuccess) return fail(LNASR_E_HIP, "upload pipeline: %s", hipGetErrorString(cerr));
+    for (auto& w : workers) w.join();
+    if (st.err != hipSuccess) return fail(LNASR_E_HIP, "upload pipeline: %s", hipGetErrorString(st.err));
     return rc;
 }
 

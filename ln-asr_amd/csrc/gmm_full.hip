@@ -273,7 +273,7 @@ int pack_full_model(lnasr_ctx* ctx) {
     const int Nv = Np * virt, Mv = Mp / virt;
     md.pad_N = md.pad_M = 0;
     if (D > 64) return 0;
-    if ((Np != N || Mp != M) && getenv("LNASR_NO_PAD")) return 0;
+    if ((Np != N || Mp != M) && sw().no_pad) return 0;
     const int Q = Mv / 4;
     if (!(Q == 1 || Q == 2 || Q == 4)) return 0;
     const int K = D * (D + 1) / 2 + D + 1;
@@ -344,7 +344,7 @@ static int launch_full(lnasr_ctx* ctx, const double* obs, long F, double* b, dou
 // returns 1 if the launch was issued, 0 if this model / dtype is not covered, < 0 on error
 int emit_full_mfma_device(lnasr_ctx* ctx, const double* obs, long F, double* b, double* bm) {
     Model& md = ctx->model;
-    if (md.wfull_Q == 0 || getenv("LNASR_NO_MFMA")) return 0;
+    if (md.wfull_Q == 0 || sw().no_mfma) return 0;
     const int N = md.N, M = md.M, virt = md.wfull_virt;
     const int Np = md.pad_N ? md.pad_N : N, Mp = md.pad_M ? md.pad_M : M;
     const bool padded = md.pad_N != 0;

@@ -943,7 +943,7 @@ int lnasr_mfcc(lnasr_ctx* ctx, const void* signal, int sample_kind, const int64_
     const int nt = NFFT / 2 < 256 ? (NFFT / 2 < 64 ? 64 : NFFT / 2) : 256;
     bool fused_dct = false;
     const int n_out = cepstrum_or_null ? n_mel : W;   // cepstral columns the frame kernel has to produce
-    if (NFFT == 512 && L <= 512 && n_mel <= 48 && !getenv("LNASR_NO_FFT512")) {
+    if (NFFT == 512 && L <= 512 && n_mel <= 48 && !sw().no_fft512) {
         // four frames per wave, persistent waves walking groups of four frames with a grid stride; the LDS
         // (tables + a slice per wave) allows one block per CU
         const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;

@@ -1735,24 +1735,14 @@ constexpr int kT256End = kT256Lt + 2 * kLogTab;
 // TS = float (Viterbi only): `precision=np.float32` -- b and v are float arrays, every sum is formed in fp64 and
 // rounded to float where the reference's float32 array rounds it, i.e. at the store of v[t, j] (hmm.py:160-165).
 //
-// DEFER (forward / backward): the finalisation is taken off the frame's critical path.  With the shift of the new e
-// buffer chosen from the maxima of TWO frames back (known when the frame starts), the next e value is
-//     e' = exp(S_c + log(sum) + b - S') = sum * F,   F = exp((S_c - S') + b),
-// and F is formed by the slice-0 waves DURING the multiply phase, so that after the partial sums meet only three
-// additions, a range check and one multiplication stand between the barriers; the log-domain value of the frame
-// (the output row, the exact-fallback operand, the maxima) is computed one multiply phase later from the saved sum.
-// A sum outside the safe range takes the exact log-domain path on the spot, as before.  Ablation: the
-// finalisation was 1,200 of the 3,500 cycles of a frame.  MEASURED SLOWER and therefore off by default
-// (LNASR_T256_DEFER=1 selects it): forward 2.79 -> 2.84, backward 2.82 -> 3.2 ms at N = 256, T = 2000 -- the ~90
-// instructions moved into the multiply phase sit on ONE wave per SIMD, which shares the issue port with three
-// multiplying neighbours, and that wave becomes the phase's critical path (raising its priority recovers a third).
-template <int MODE, bool FIN, typename TS = double, bool DEFER = false>
+// (A variant that took log / exp off the frame's critical path -- e <- sum * F with F formed during the multiply
+// phase -- was built and measured slower in round 2, DESIGN 4.5, and removed in round 3.)
+template <int MODE, bool FIN, typename TS = double>
 __device__ __forceinline__ void trellis256_role(double* sm, const TS* __restrict__ bu, const double* __restrict__ Amat,
                                                 const double* __restrict__ Alog, const double* __restrict__ pi,
                                                 TS* __restrict__ ou, double* __restrict__ loglik_u, int L, int T, int N) {
     static_assert(MODE == 0 || std::is_same<TS, double>::value, "float storage: Viterbi only");
     constexpr bool VIT = MODE == 0, BACKWARD = MODE == 2;
-    constexpr bool DEF = DEFER && !VIT;
     constexpr int NP = 256, RPS = 64;
     constexpr int NREG = FIN ? kT256FinReg : kT256CmpReg, NLDS = 64 - NREG;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1815,42 +1805,11 @@ __device__ __forceinline__ void trellis256_role(double* sm, const TS* __restrict
     }
     __syncthreads();
 
-    // DEF: what the previous step left to be finished (slice-0 lanes)
-    double d_sum = 1.0, d_sc = 0.0, d_b = 0.0, fac = 0.0, s_new = 0.0;    // d_sum holds the exact value when d_exact
-    bool d_exact = false;
-    int d_t = 0;
-    auto finish_prev = [&](int mslot, int cbuf) {             // log-domain value of the finished step: output row, Cs, maxima
-        const double val = d_exact ? d_sum : d_sc + log_sum(d_sum, ltab);
-        double prev = LN_NEG_INF;
-        if (jc < N) {
-            if (BACKWARD) {
-                if (ou) ou[(size_t)d_t * N + jc] = (TS)val;
-                prev = val + d_b;
-            } else {
-                prev = val + d_b;
-                if (ou) ou[(size_t)d_t * N + jc] = (TS)prev;
-            }
-        }
-        Cs[cbuf * NP + jc] = prev;
-        const double m = wave_max_dpp(prev);
-        if (lane == 0) Ms[mslot * 4 + (jc >> 6)] = m;
-    };
     for (int step = 1; step < L; ++step) {
         const int cur = (step - 1) & 1, nxt = step & 1;
         const double* Vc = Vs + cur * NP + rs * RPS + (lane & 15);
         double bcur = bnext;
         if (FIN) bnext = (double)bu[(size_t)clampt(frame_of(step + 1)) * N + jcl];
-        if (FIN && DEF) {
-            // the slice-0 wave of a SIMD carries ~90 more instructions than its three neighbours in this phase: let it
-            // issue whenever it can (its chain is dependent, the neighbours' multiplies fill the gaps)
-            __builtin_amdgcn_s_setprio(3);
-            if (step >= 2) finish_prev((step - 1) % 3, cur);     // step 0 was finished in the prologue
-            const double* Ml = Ms + (step >= 2 ? (step - 2) % 3 : 0) * 4;
-            s_new = fmax(fmax(Ml[0], Ml[1]), fmax(Ml[2], Ml[3]));
-            const double sc = Ss[cur];
-            fac = (s_new == LN_NEG_INF || sc == LN_NEG_INF || jc >= N) ? 0.0 : exp_clamped((sc - s_new) + bcur, etab);
-            __builtin_amdgcn_s_setprio(0);
-        }
         // The 64 previous-frame values of this row slice sit in four VGPR pairs, 16 per DPP row
         // (lane l holds V[16k + (l & 15)]); row_newbcast:n hands value n of the pair to every lane,
         // so a transition costs one v_fmac_f64_dpp and no LDS broadcast read (the LDS pipe would
@@ -1895,26 +1854,6 @@ __device__ __forceinline__ void trellis256_role(double* sm, const TS* __restrict
                     ou[(size_t)t * N + jc] = (TS)val;
                 }
                 Vs[nxt * NP + jc] = val;
-            } else if (DEF) {
-                const double sum = (part + Ps[jc]) + (Ps[NP + jc] + Ps[2 * NP + jc]);
-                const double Sc = Ss[cur];
-                double e;
-                if ((sum >= kSafeSum && sum <= 1e290 && Sc != LN_NEG_INF) || jc >= N) {   // padding columns: fac = 0
-                    e = sum * fac;
-                    d_exact = false;
-                    d_sum = sum;
-                } else {
-                    const double val = exact_column_lse(Cs + cur * NP, Alog + jcl, N);
-                    const double prev = val + bcur;
-                    e = (s_new == LN_NEG_INF || prev == LN_NEG_INF || jc >= N) ? 0.0 : exp_clamped(prev - s_new, etab);
-                    d_exact = true;
-                    d_sum = val;
-                }
-                d_sc = Sc;
-                d_b = bcur;
-                d_t = t;
-                Vs[nxt * NP + jc] = e;
-                if (jc == 0) Ss[nxt] = s_new;
             } else {
                 const double sum = (part + Ps[jc]) + (Ps[NP + jc] + Ps[2 * NP + jc]);
                 const double Sc = Ss[cur];
@@ -1944,12 +1883,7 @@ __device__ __forceinline__ void trellis256_role(double* sm, const TS* __restrict
         }
         __syncthreads();
     }
-    int mfin = (L - 1) & 1;                                   // slot of the last frame's maxima
-    if (DEF) {
-        mfin = L >= 2 ? (L - 1) % 3 : 0;
-        if (FIN && L >= 2) finish_prev(mfin, (L - 1) & 1);
-        __syncthreads();                                      // both roles: the last frame's Cs / Ms are complete
-    }
+    const int mfin = (L - 1) & 1;                             // slot of the last frame's maxima
     if (FIN && MODE == 1 && loglik_u && tid < 64) {
         const int fin = (L - 1) & 1;
         const double mx = fmax(fmax(Ms[mfin * 4], Ms[mfin * 4 + 1]), fmax(Ms[mfin * 4 + 2], Ms[mfin * 4 + 3]));
@@ -1963,7 +1897,7 @@ __device__ __forceinline__ void trellis256_role(double* sm, const TS* __restrict
     }
 }
 
-template <int MODE, typename TS = double, bool DEFER = false>
+template <int MODE, typename TS = double>
 __global__ __launch_bounds__(1024) void trellis256_kernel(const TS* __restrict__ b,
                                                           const double* __restrict__ Amat,   // logA / expA / expA^T
                                                           const double* __restrict__ Alog,   // logA or logA^T (fallback)
@@ -1982,9 +1916,9 @@ __global__ __launch_bounds__(1024) void trellis256_kernel(const TS* __restrict__
     TS* ou = out ? out + (size_t)u * T * N : nullptr;
     // wave-uniform role split (threadIdx.x >> 8 is constant within a wave); the barriers of the two roles pair up
     if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 8) == 0)
-        trellis256_role<MODE, true, TS, DEFER>(sm, bu, Amat, Alog, pi, ou, loglik ? loglik + u : nullptr, L, T, N);
+        trellis256_role<MODE, true, TS>(sm, bu, Amat, Alog, pi, ou, loglik ? loglik + u : nullptr, L, T, N);
     else
-        trellis256_role<MODE, false, TS, DEFER>(sm, bu, Amat, Alog, pi, ou, nullptr, L, T, N);
+        trellis256_role<MODE, false, TS>(sm, bu, Amat, Alog, pi, ou, nullptr, L, T, N);
 }
 
 static inline size_t trellis256_lds() { return (size_t)kT256End * 8; }
@@ -2080,9 +2014,8 @@ constexpr size_t kStreamLdsMax = 160 * 1024;     // dynamic LDS a streaming bloc
 //   forward  N=320: 1.8/1.5  2.2/2.0  2.8/2.2    N=512: 2.6/3.1  3.4/4.3  5.0/4.4    N=1024: 4.7/24  10.8/25  17/50
 // LNASR_FRAMEPAR_MAXU (developer/test switch) replaces the rule by "U <= value".
 static bool framepar_env(int U, bool* use) {
-    if (getenv("LNASR_NO_FRAMEPAR")) { *use = false; return true; }
-    const char* e = getenv("LNASR_FRAMEPAR_MAXU");
-    if (e) { *use = U <= atoi(e); return true; }
+    if (sw().no_framepar) { *use = false; return true; }
+    if (sw().framepar_maxu >= 0) { *use = U <= sw().framepar_maxu; return true; }
     return false;
 }
 static bool viterbi_framepar(int N, int U) {
@@ -2102,7 +2035,7 @@ int viterbi_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
     const double* A = md.logA.as<double>();
     const double* pi = md.logpi.as<double>();
     ctx->bp_v = nullptr;
-    if (N <= 16 && !getenv("LNASR_NO_TINYVIT")) {
+    if (N <= 16 && !sw().no_tinyvit) {
         // one wave per utterance, byte back-pointers for the backtrace (viterbi_tiny_kernel)
         const int nmax = N <= 4 ? 4 : (N <= 8 ? 8 : 16);
         LN_TRY(ctx->ws_bp.reserve((size_t)U * T * nmax));
@@ -2127,9 +2060,8 @@ int viterbi_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
         ctx->bp_nmax = nmax;
         return 0;
     }
-    if (dtype == LNASR_F64 && !getenv("LNASR_NO_REGVIT")) {
-        const char* var = getenv("LNASR_VIT");
-        const char vsel = var ? var[0] : 'e';
+    if (dtype == LNASR_F64 && !sw().no_regvit) {
+        const char vsel = sw().vit ? sw().vit : 'e';
 #define LN_VIT(name, CPT, NW, RPT, UB, WPE)                                                                  \
     do {                                                                                                     \
         LN_LAUNCH(ctx, name, (viterbi_reg<CPT, NW, RPT, UB, WPE>), dim3((U + UB - 1) / UB), dim3(64 * NW), 0, \
@@ -2152,7 +2084,7 @@ int viterbi_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
         }
 #undef LN_VIT
     }
-    if (dtype == LNASR_F32 && N <= 128 && !getenv("LNASR_NO_REGVIT") && !getenv("LNASR_F32_GENERIC")) {
+    if (dtype == LNASR_F32 && N <= 128 && !sw().no_regvit && !sw().f32_generic) {
         // precision=np.float32: the same register-resident kernel, fp64 arithmetic, float storage and rounding
         if (U < 512)
             LN_LAUNCH(ctx, "viterbi_reg1b_n128_u1_f32", (viterbi_reg1b<2, 8, 16, 1, 4, float>), dim3(U), dim3(512), 0,
@@ -2163,12 +2095,12 @@ int viterbi_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
         return 0;
     }
     constexpr int UB = 4;
-    if (dtype == LNASR_F64 && N > 128 && N <= 256 && !getenv("LNASR_NO_T256")) {
+    if (dtype == LNASR_F64 && N > 128 && N <= 256 && !sw().no_t256) {
         LN_LAUNCH(ctx, "viterbi_onchip256", trellis256_kernel<0>, dim3(U), dim3(1024), trellis256_lds(), (const double*)b, A,
                   A, pi, d_lens, (double*)v, (double*)nullptr, U, T, N);
         return 0;
     }
-    if (dtype == LNASR_F32 && N > 128 && N <= 256 && !getenv("LNASR_NO_T256") && !getenv("LNASR_F32_GENERIC")) {
+    if (dtype == LNASR_F32 && N > 128 && N <= 256 && !sw().no_t256 && !sw().f32_generic) {
         // precision=np.float32 beyond 128 states: the on-chip kernel with float storage and rounding
         LN_LAUNCH(ctx, "viterbi_onchip256_f32", (trellis256_kernel<0, float>), dim3(U), dim3(1024), trellis256_lds(),
                   (const float*)b, A, A, pi, d_lens, (float*)v, (double*)nullptr, U, T, N);
@@ -2203,7 +2135,7 @@ int viterbi_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
         }
         return 0;
     }
-    if (dtype == LNASR_F64 && N > 128 && N <= 1024 && !getenv("LNASR_NO_STREAM")) {
+    if (dtype == LNASR_F64 && N > 128 && N <= 1024 && !sw().no_stream) {
         const int NP = ((N + 63) / 64) * 64, RS = 1024 / NP, RPS = (N + RS - 1) / RS;
         const size_t shm = (size_t)(2 + RS) * UB * NP * 8;
         LN_LAUNCH(ctx, "viterbi_stream", (viterbi_stream<UB>), dim3((U + UB - 1) / UB), dim3(NP * RS), shm,
@@ -2248,7 +2180,7 @@ int backtrace_device(lnasr_ctx* ctx, const void* v, int U, int T, const int32_t*
 #undef LN_TINY
         return 0;
     }
-    if (dtype == LNASR_F64 && md.N <= 128 && !getenv("LNASR_NO_LDSBT")) {
+    if (dtype == LNASR_F64 && md.N <= 128 && !sw().no_ldsbt) {
         if (md.N == 128)
             LN_LAUNCH(ctx, "backtrace_lds", (backtrace_lds_kernel<2, true, double, true>), dim3((U + wpb - 1) / wpb),
                       dim3(64 * wpb), (size_t)md.N * md.N * 8, (const double*)v, md.logAT.as<double>(), d_lens, path, best, U,
@@ -2258,7 +2190,7 @@ int backtrace_device(lnasr_ctx* ctx, const void* v, int U, int T, const int32_t*
                       (size_t)md.N * md.N * 8, (const double*)v, md.logAT.as<double>(), d_lens, path, best, U, T, md.N);
         return 0;
     }
-    if (dtype == LNASR_F64 && md.N <= 1024 && !getenv("LNASR_NO_LDSBT")) {
+    if (dtype == LNASR_F64 && md.N <= 1024 && !sw().no_ldsbt) {
         // one wave per block (with few utterances the waves should sit on different CUs), N / 64 states per lane
         if (md.N <= 256)
             LN_LAUNCH(ctx, "backtrace_wave256", (backtrace_lds_kernel<4, false>), dim3(U), dim3(64), 0, (const double*)v,
@@ -2271,12 +2203,12 @@ int backtrace_device(lnasr_ctx* ctx, const void* v, int U, int T, const int32_t*
                       md.logAT.as<double>(), d_lens, path, best, U, T, md.N);
         return 0;
     }
-    if (dtype == LNASR_F32 && md.N <= 128 && !getenv("LNASR_NO_LDSBT") && !getenv("LNASR_F32_GENERIC")) {
+    if (dtype == LNASR_F32 && md.N <= 128 && !sw().no_ldsbt && !sw().f32_generic) {
         LN_LAUNCH(ctx, "backtrace_lds_f32", (backtrace_lds_kernel<2, true, float>), dim3((U + wpb - 1) / wpb), dim3(64 * wpb),
                   (size_t)md.N * md.N * 8, (const float*)v, md.logAT.as<double>(), d_lens, path, best, U, T, md.N);
         return 0;
     }
-    if (dtype == LNASR_F32 && md.N <= 256 && !getenv("LNASR_NO_LDSBT") && !getenv("LNASR_F32_GENERIC")) {
+    if (dtype == LNASR_F32 && md.N <= 256 && !sw().no_ldsbt && !sw().f32_generic) {
         LN_LAUNCH(ctx, "backtrace_wave256_f32", (backtrace_lds_kernel<4, false, float>), dim3(U), dim3(64), 0, (const float*)v,
                   md.logAT.as<double>(), d_lens, path, best, U, T, md.N);
         return 0;
@@ -2305,7 +2237,7 @@ int forward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
         LN_TRY(forward_device(ctx, b64, U, T, d_lens, LNASR_F64, a64, loglik));
         return alpha ? narrow_f64(ctx, a64, cells, alpha) : 0;
     }
-    if (dtype == LNASR_F64 && N <= 128 && !getenv("LNASR_NO_REGFWD")) {
+    if (dtype == LNASR_F64 && N <= 128 && !sw().no_regfwd) {
         if (N <= 64)
             LN_LAUNCH(ctx, "forward_reg_n64", (fwdbwd_reg<false, 1, 2, 32, 2, 3>), dim3((U + 1) / 2), dim3(128), 0,
                       (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
@@ -2315,7 +2247,7 @@ int forward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
                 LN_LAUNCH(ctx, "forward_reg_n128", (fwdbwd_reg<false, 2, 8, 16, 2, 4>), dim3((U + 1) / 2), dim3(512), 0,
                           (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
                           (double*)alpha, loglik, U, T, N);
-            else if (!getenv("LNASR_NO_COLFWD"))            // four per block, column-owned waves
+            else if (!sw().no_colfwd)            // four per block, column-owned waves
                 LN_LAUNCH(ctx, "forward_cols_n128", (fwdbwd_cols<false>), dim3((U + 3) / 4), dim3(512), 0,
                           (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
                           (double*)alpha, loglik, U, T, N);
@@ -2325,15 +2257,10 @@ int forward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
                           (double*)alpha, loglik, U, T, N);
         return 0;
     }
-    if (dtype == LNASR_F64 && N > 128 && N <= 256 && !getenv("LNASR_NO_T256")) {
-        if (!getenv("LNASR_T256_DEFER"))
-            LN_LAUNCH(ctx, "forward_onchip256", (trellis256_kernel<1, double, false>), dim3(U), dim3(1024), trellis256_lds(),
-                      (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
-                      (double*)alpha, loglik, U, T, N);
-        else
-            LN_LAUNCH(ctx, "forward_onchip256", (trellis256_kernel<1, double, true>), dim3(U), dim3(1024), trellis256_lds(),
-                      (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
-                      (double*)alpha, loglik, U, T, N);
+    if (dtype == LNASR_F64 && N > 128 && N <= 256 && !sw().no_t256) {
+        LN_LAUNCH(ctx, "forward_onchip256", (trellis256_kernel<1, double>), dim3(U), dim3(1024), trellis256_lds(),
+                  (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
+                  (double*)alpha, loglik, U, T, N);
         return 0;
     }
     if (dtype == LNASR_F64 && N > 256 && fwdbwd_framepar(N, U)) {
@@ -2345,7 +2272,7 @@ int forward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
         return fwdbwd_frames<false>(ctx, (const double*)b, md.expA.as<double>(), md.logA.as<double>(), U, T, d_lens, a,
                                     loglik);
     }
-    if (dtype == LNASR_F64 && N > 128 && N <= 1024 && !getenv("LNASR_NO_STREAM")) {
+    if (dtype == LNASR_F64 && N > 128 && N <= 1024 && !sw().no_stream) {
         const int NP = ((N + 63) / 64) * 64, RS = 1024 / NP, RPS = (N + RS - 1) / RS, NB = NP / 64;
         // few utterances: one per block keeps more CUs busy (the frame chain is the critical path);
         // many: four per block share every read of exp(A)
@@ -2397,7 +2324,7 @@ int backward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* 
         return narrow_f64(ctx, ctx->ws_w2.as<double>(), cells, beta);
     }
     const double* expAT = md.expAT.as<double>();
-    if (dtype == LNASR_F64 && N <= 128 && !getenv("LNASR_NO_REGFWD")) {
+    if (dtype == LNASR_F64 && N <= 128 && !sw().no_regfwd) {
         if (N <= 64)
             LN_LAUNCH(ctx, "backward_reg_n64", (fwdbwd_reg<true, 1, 2, 32, 2, 3>), dim3((U + 1) / 2), dim3(128), 0,
                       (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
@@ -2407,7 +2334,7 @@ int backward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* 
                 LN_LAUNCH(ctx, "backward_reg_n128", (fwdbwd_reg<true, 2, 8, 16, 2, 4>), dim3((U + 1) / 2), dim3(512), 0,
                           (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
                           (double*)nullptr, U, T, N);
-            else if (!getenv("LNASR_NO_COLFWD"))
+            else if (!sw().no_colfwd)
                 LN_LAUNCH(ctx, "backward_cols_n128", (fwdbwd_cols<true>), dim3((U + 3) / 4), dim3(512), 0,
                           (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
                           (double*)nullptr, U, T, N);
@@ -2417,20 +2344,15 @@ int backward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* 
                           (double*)nullptr, U, T, N);
         return 0;
     }
-    if (dtype == LNASR_F64 && N > 128 && N <= 256 && !getenv("LNASR_NO_T256")) {
-        if (!getenv("LNASR_T256_DEFER"))
-            LN_LAUNCH(ctx, "backward_onchip256", (trellis256_kernel<2, double, false>), dim3(U), dim3(1024), trellis256_lds(),
-                      (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
-                      (double*)nullptr, U, T, N);
-        else
-            LN_LAUNCH(ctx, "backward_onchip256", (trellis256_kernel<2, double, true>), dim3(U), dim3(1024), trellis256_lds(),
-                      (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
-                      (double*)nullptr, U, T, N);
+    if (dtype == LNASR_F64 && N > 128 && N <= 256 && !sw().no_t256) {
+        LN_LAUNCH(ctx, "backward_onchip256", (trellis256_kernel<2, double>), dim3(U), dim3(1024), trellis256_lds(),
+                  (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
+                  (double*)nullptr, U, T, N);
         return 0;
     }
     if (dtype == LNASR_F64 && N > 256 && fwdbwd_framepar(N, U))
         return fwdbwd_frames<true>(ctx, (const double*)b, expAT, md.logAT.as<double>(), U, T, d_lens, (double*)beta, nullptr);
-    if (dtype == LNASR_F64 && N > 128 && N <= 1024 && !getenv("LNASR_NO_STREAM")) {
+    if (dtype == LNASR_F64 && N > 128 && N <= 1024 && !sw().no_stream) {
         const int NP = ((N + 63) / 64) * 64, RS = 1024 / NP, RPS = (N + RS - 1) / RS, NB = NP / 64;
         if (U < 2 * ctx->prop.multiProcessorCount) {
             constexpr int UB = 1;
@@ -2580,49 +2502,11 @@ int lnasr_decode(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t*
     LN_TRY(ctx->ws_v.reserve(cells * 8));
     LN_TRY(stage_out(ctx, path, (size_t)U * T * 4, ctx->ws_out, &d_path));
     if (best_score_or_null) LN_TRY(stage_out(ctx, best_score_or_null, (size_t)U * 8, ctx->ws_out2, &d_best));
-    // Device-resident batches may be cut into chunks whose trellis work (side stream) runs beside the next chunk's
-    // emission (main stream); LNASR_DECODE_CHUNKS = 1 keeps the three launches in series on one stream.
-    int nch = 1;
-    if (const char* e = getenv("LNASR_DECODE_CHUNKS")) nch = atoi(e);
-    if (nch > 16) nch = 16;
-    if (nch < 2 || U < 64 * nch || !is_device_ptr(obs) || md.N > 128) {
-        LN_TRY(emit_batch(ctx, obs, U, T, ctx->ws_b.as<double>(), nullptr, nullptr));
-        LN_TRY(viterbi_device(ctx, ctx->ws_b.p, U, T, d_lens, LNASR_F64, ctx->ws_v.p));
-        LN_TRY(backtrace_device(ctx, ctx->ws_v.p, U, T, d_lens, LNASR_F64, (uint32_t*)d_path, (double*)d_best));
-    } else {
-        while ((int)ctx->copy_events.size() < nch) {
-            hipEvent_t e;
-            LN_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            ctx->copy_events.push_back(e);
-        }
-        // the side stream must not start before earlier work on the main stream (lens, previous calls) is done
-        LN_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
-        LN_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-        const size_t row = (size_t)T * md.N;
-        int rc = 0;
-        for (int c = 0; c < nch && rc == 0; ++c) {
-            const int u0 = (int)((long)U * c / nch), u1 = (int)((long)U * (c + 1) / nch), uc = u1 - u0;
-            double* bc = ctx->ws_b.as<double>() + (size_t)u0 * row;
-            double* vc = ctx->ws_v.as<double>() + (size_t)u0 * row;
-            rc = emit_device(ctx, obs + (size_t)u0 * T * md.D, (long)uc * T, LNASR_F64, bc, nullptr);
-            if (rc) break;
-            if (hipEventRecord(ctx->copy_events[c], ctx->stream) != hipSuccess ||
-                hipStreamWaitEvent(ctx->stream2, ctx->copy_events[c], 0) != hipSuccess) {
-                rc = fail(LNASR_E_HIP, "event plumbing of the chunked decode failed");
-                break;
-            }
-            std::swap(ctx->stream, ctx->stream2);          // LN_LAUNCH (and its profiling events) follow ctx->stream
-            rc = viterbi_device(ctx, bc, uc, T, d_lens + u0, LNASR_F64, vc);
-            if (rc == 0)
-                rc = backtrace_device(ctx, vc, uc, T, d_lens + u0, LNASR_F64, (uint32_t*)d_path + (size_t)u0 * T,
-                                      d_best ? (double*)d_best + u0 : nullptr);
-            std::swap(ctx->stream, ctx->stream2);
-        }
-        // join: later work on the main stream sees the side stream's results
-        (void)hipEventRecord(ctx->ev_join, ctx->stream2);
-        (void)hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);
-        LN_TRY(rc);
-    }
+    // three launches in series on one stream (cutting the batch into chunks whose trellis work runs on a side stream
+    // beside the next chunk's emission was measured slower, DESIGN 4.8, and removed in round 3)
+    LN_TRY(emit_batch(ctx, obs, U, T, ctx->ws_b.as<double>(), nullptr, nullptr));
+    LN_TRY(viterbi_device(ctx, ctx->ws_b.p, U, T, d_lens, LNASR_F64, ctx->ws_v.p));
+    LN_TRY(backtrace_device(ctx, ctx->ws_v.p, U, T, d_lens, LNASR_F64, (uint32_t*)d_path, (double*)d_best));
     LN_TRY(finish_out(ctx, path, d_path, (size_t)U * T * 4));
     if (best_score_or_null) LN_TRY(finish_out(ctx, best_score_or_null, d_best, (size_t)U * 8));
     return 0;
@@ -2667,8 +2551,13 @@ int lnasr_backward(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* l
 }
 
 int lnasr_calc_prob(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* lens, double* loglik) {
+    return lnasr_calc_prob_p(ctx, obs, U, T, lens, LNASR_F64, loglik);
+}
+
+int lnasr_calc_prob_p(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* lens, int dtype, double* loglik) {
     LN_ENTER(ctx);
     LN_CHECK_BATCH(ctx, U, T, LNASR_F64);
+    LN_REQUIRE(dtype == LNASR_F64 || dtype == LNASR_F32, "bad dtype %d", dtype);
     if (!ctx->model.has_gmm) return fail(LNASR_E_NOMODEL, "no GMM-HMM model uploaded");
     if (U == 0 || T == 0) return 0;
     LN_REQUIRE(obs && loglik, "null obs/loglik");
@@ -2679,7 +2568,15 @@ int lnasr_calc_prob(lnasr_ctx* ctx, const double* obs, int U, int T, const int32
     void* d_ll;
     LN_TRY(ctx->ws_b.reserve(cells * 8));
     LN_TRY(stage_out(ctx, loglik, (size_t)U * 8, ctx->ws_out2, &d_ll));
-    LN_TRY(emit_batch(ctx, obs, U, T, ctx->ws_b.as<double>(), nullptr, nullptr));
+    if (dtype == LNASR_F32 && f32_stats_ok(md)) {
+        // the emission of the float32 statistics pass (lnasr_bw_accumulate_p): same b, hence the same likelihood
+        const void* d_obs;
+        LN_TRY(stage_in(ctx, obs, (size_t)U * T * md.D * 8, ctx->ws_in, &d_obs));
+        LN_TRY(ctx->ws_bm.reserve((cells + (size_t)kMixPadFrames * md.N) * md.M * 4));
+        LN_TRY(emit_device_f32(ctx, (const double*)d_obs, (long)U * T, ctx->ws_b.as<double>(), ctx->ws_bm.as<float>()));
+    } else {
+        LN_TRY(emit_batch(ctx, obs, U, T, ctx->ws_b.as<double>(), nullptr, nullptr));
+    }
     LN_TRY(forward_device(ctx, ctx->ws_b.p, U, T, d_lens, LNASR_F64, nullptr, (double*)d_ll));
     return finish_out(ctx, loglik, d_ll, (size_t)U * 8);
 }

@@ -16,7 +16,8 @@ except ImportError:                    # pragma: no cover
 
 F64, F32 = 0, 1
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "liblnasr_hip.so")
+# LNASR_LIB selects another build of the same library (the host-sanitizer build of build.py --host-asan)
+_LIB_PATH = os.environ.get("LNASR_LIB") or os.path.join(_HERE, "liblnasr_hip.so")
 UNIQUE_ID_BYTES = 128
 
 
@@ -40,6 +41,10 @@ SIGNATURES = {
     "lnasr_ctx_create": [_i, _P(_vp)],
     "lnasr_ctx_destroy": [_vp],
     "lnasr_sync": [_vp],
+    "lnasr_device_sync": [_vp],
+    "lnasr_reload_switches": [],
+    "lnasr_host_alloc": [_vp, _sz, _P(_vp)],
+    "lnasr_host_free": [_vp, _vp],
     "lnasr_device_info": [_vp, C.c_char_p, _i, _P(_i), _P(_sz)],
     "lnasr_dev_alloc": [_vp, _sz, _P(_vp)],
     "lnasr_dev_free": [_vp, _vp],
@@ -65,6 +70,7 @@ SIGNATURES = {
     "lnasr_forward": [_vp, _vp, _i, _i, _vp, _i, _vp, _vp],
     "lnasr_backward": [_vp, _vp, _i, _i, _vp, _i, _vp],
     "lnasr_calc_prob": [_vp, _vp, _i, _i, _vp, _vp],
+    "lnasr_calc_prob_p": [_vp, _vp, _i, _i, _vp, _i, _vp],
     "lnasr_baumwelch": [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp],
     "lnasr_estimate_discrete": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "lnasr_estimate_gmm": [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _dbl, _vp, _vp, _vp, _vp, _vp],
@@ -177,6 +183,25 @@ class DeviceArray:
             pass
 
 
+class _PinnedBlock:
+    """Owner of one lnasr_host_alloc block; the numpy arrays made over it keep it alive through `.base`."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx = ctx
+        p = C.c_void_p()
+        check(lib().lnasr_host_alloc(ctx.handle, nbytes, C.byref(p)))
+        self.ptr = p.value
+        self.buf = (C.c_char * max(1, nbytes)).from_address(self.ptr)
+
+    def __del__(self):
+        try:
+            if self.ptr and self.ctx.handle:
+                lib().lnasr_host_free(self.ctx.handle, self.ptr)
+        except Exception:
+            pass
+        self.ptr = None
+
+
 def _ptr(x):
     """void* of a numpy array / DeviceArray / None."""
     if x is None:
@@ -199,13 +224,22 @@ class Context:
     """One process = one GPU = one Context (one HIP stream)."""
 
     def __init__(self, device=None):
-        if device is None:
-            device = int(os.environ.get("LNASR_DEVICE", os.environ.get("LOCAL_RANK", "0")))
         n = C.c_int(0)
         check(lib().lnasr_device_count(C.byref(n)))
+        if device is None:
+            if "LNASR_DEVICE" in os.environ:
+                device = int(os.environ["LNASR_DEVICE"])
+            else:
+                device = int(os.environ.get("LOCAL_RANK", "0"))
+                if n.value == 1:
+                    # a launcher that isolates one GPU per rank (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES per task)
+                    # still sets LOCAL_RANK = k: the rank's only visible device is the right one
+                    device = 0
         if n.value > 0 and not 0 <= int(device) < n.value:
-            # never wrap: ranks that silently share a GPU would report success on the wrong device
-            raise LnasrError("device %d requested (LNASR_DEVICE / LOCAL_RANK) but only %d visible" % (device, n.value))
+            # an explicit request is never wrapped: ranks that silently share a GPU would report success on the
+            # wrong device
+            raise LnasrError("device %d requested (argument / LNASR_DEVICE / LOCAL_RANK) but only %d visible"
+                             % (device, n.value))
         h = C.c_void_p()
         check(lib().lnasr_ctx_create(int(device), C.byref(h)))
         self.handle = h.value
@@ -228,6 +262,24 @@ class Context:
     # -- runtime -----------------------------------------------------------------------
     def sync(self):
         check(lib().lnasr_sync(self.handle))
+
+    def device_sync(self):
+        """hipDeviceSynchronize on this context's device (every stream drained): the bracket of a timed region."""
+        check(lib().lnasr_device_sync(self.handle))
+
+    def pinned_empty(self, shape, dtype=np.float64):
+        """A numpy array in page-locked host memory (lnasr_host_alloc).  Entry points recognise such buffers and move
+        them at PCIe rate without a staging copy; the memory is freed when the last array over it is collected."""
+        dtype = np.dtype(dtype)
+        shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        n = int(np.prod(shape, dtype=np.int64))
+        blk = _PinnedBlock(self, n * dtype.itemsize)
+        return np.frombuffer(blk.buf, dtype=dtype, count=n).reshape(shape)
+
+    def pinned_copy(self, arr):
+        out = self.pinned_empty(np.shape(arr), np.asarray(arr).dtype)
+        out[...] = arr
+        return out
 
     def device_info(self):
         name = C.create_string_buffer(256)
@@ -436,11 +488,14 @@ class Context:
         check(lib().lnasr_backward(self.handle, _ptr(b), U, T, _ptr(self._lens(lens, U)), code, _ptr(beta)))
         return beta
 
-    def calc_prob(self, obs, lens=None):
+    def calc_prob(self, obs, lens=None, precision=np.float64):
+        """log P(O | model) per utterance.  precision=np.float32 scores the emission exactly as
+        bw_accumulate(precision=np.float32) does, so both likelihoods of a training loop share one arithmetic."""
         obs = _in(obs, np.float64)
         U, T, D = obs.shape
         ll = self._out(isinstance(obs, DeviceArray), (U,), np.float64)
-        check(lib().lnasr_calc_prob(self.handle, _ptr(obs), U, T, _ptr(self._lens(lens, U)), _ptr(ll)))
+        check(lib().lnasr_calc_prob_p(self.handle, _ptr(obs), U, T, _ptr(self._lens(lens, U)), dtype_code(precision),
+                                      _ptr(ll)))
         return ll
 
     def baumwelch(self, b, alpha, beta, want_xi=True, lens=None):
@@ -645,6 +700,12 @@ def comm_unique_id():
     buf = C.create_string_buffer(UNIQUE_ID_BYTES)
     check(lib().lnasr_comm_unique_id(buf))
     return buf.raw
+
+
+def reload_switches():
+    """Re-read the LNASR_* switches from the environment (the library reads them once per process)."""
+    if _lib is not None or os.path.exists(_LIB_PATH):
+        check(lib().lnasr_reload_switches())
 
 
 def num_frames(n, L, S):

@@ -15,7 +15,7 @@ Batch extras (not in the reference): `upload()`, `decode_batch`, `calc_prob_batc
 import numpy as np
 
 from . import _ffi
-from .hmm import HMM, _save, _load
+from .hmm import HMM, _save, _load, _log_normalised, _log_uniform, _report_iteration
 
 
 class GMMHMM(HMM):
@@ -105,18 +105,9 @@ class GMMHMM(HMM):
             if self.ctx.model_is_diag():               # the reference's M-step returns a FULL Sigma even then
                 self._upload_gmm(force_full=True)
             stats = self.ctx.bw_accumulate(obs[None])
-            model = self.ctx.bw_mstep(stats, self.min_std)
-            prob_old = self.precision(stats[ll_at])
-            self._updatemodel(model)
-            prob_new = self.calc_prob(obs)
-            prod_d = abs(prob_old - prob_new)
-            if verbose:
-                print("Iter: {:3},"
-                      " L(lambda|O) = {:.6e},"
-                      " L(lambda_new|O) = {:.6e},"
-                      " eps = {:.6f}"
-                      .format(k, prob_old, prob_new, prod_d))
-            if prod_d < eps:
+            before = self.precision(stats[ll_at])
+            self._updatemodel(self.ctx.bw_mstep(stats, self.min_std))
+            if _report_iteration(k, before, self.calc_prob(obs), verbose) < eps:
                 break
 
     def _updatemodel(self, model):
@@ -127,25 +118,18 @@ class GMMHMM(HMM):
         self.w = model["w"]
 
     def reset(self, init_type):
-        """'uniform': zero means, identity Sigma; 'random': A, pi, w from the global numpy RNG,
-        mu ~ U(-0.3, 0.3), Sigma = I  (gmmhmm.py:166-188)."""
+        """'uniform': zero means, identity Sigma; 'random': A, pi, w from the global numpy RNG (in that order, float64
+        whatever `precision`), mu ~ U(-0.3, 0.3), Sigma = I  (gmmhmm.py:166-188).  Other values: silent no-op."""
+        n, m, d = self.n, self.m, self.d
         if init_type == "uniform":
-            self.A = np.log(np.ones((self.n, self.n), dtype=self.precision) * (1.0 / self.n))
-            self.pi = np.log(np.ones(self.n, dtype=self.precision) * (1.0 / self.n))
-            self.w = np.log(np.ones((self.n, self.m), dtype=self.precision) * (1.0 / self.m))
-            self.mu = np.zeros((self.n, self.m, self.d), dtype=self.precision)
-            self.si = np.zeros((self.n, self.m, self.d, self.d), dtype=self.precision)
-            self.si[:, :] = np.eye(self.d, dtype=self.precision)
+            self.A, self.pi, self.w = (_log_uniform(shape, self.precision) for shape in ((n, n), (n,), (n, m)))
+            self.mu = np.zeros((n, m, d), dtype=self.precision)
         elif init_type == "random":
-            a = np.random.random_sample((self.n, self.n))
-            pi = np.random.random_sample((self.n))
-            w = np.random.random_sample((self.n, self.m))
-            self.A = np.log(a / a.sum(axis=1)[:, np.newaxis])
-            self.pi = np.log(pi / np.sum(pi))
-            self.w = np.log(w / w.sum(axis=1)[:, np.newaxis])
-            self.mu = np.array(0.6 * np.random.random_sample((self.n, self.m, self.d)) - 0.3, dtype=self.precision)
-            self.si = np.zeros((self.n, self.m, self.d, self.d), dtype=self.precision)
-            self.si[:, :] = np.eye((self.d), dtype=self.precision)
+            self.A, self.pi, self.w = (_log_normalised(np.random.random_sample(shape)) for shape in ((n, n), (n,), (n, m)))
+            self.mu = (0.6 * np.random.random_sample((n, m, d)) - 0.3).astype(self.precision)
+        else:
+            return
+        self.si = np.broadcast_to(np.eye(d, dtype=self.precision), (n, m, d, d)).copy()
 
     def save(self, filename):
         """Datasets 'A','pi','w','mu','si'  (gmmhmm.py:190-198)."""
@@ -185,32 +169,34 @@ class GMMHMM(HMM):
         `lnasr.dist.RcclComm`: one RCCL all-reduce of the packed vector), the M-step every rank runs identically,
         and the reference's stopping rule on the summed log-likelihood with the reference's printed line.
         Returns the list of (L(lambda|O), L(lambda_new|O)) pairs."""
-        n_ll = None
-        hist = []
-        for k in range(iters):
-            self.upload()
-            stats = np.asarray(self.accumulate(obs_batch, lens=lens))
+        def e_step():
+            st = np.asarray(self.accumulate(obs_batch, lens=lens))
             if comm is not None:
-                stats = np.asarray(comm.allreduce_sum_f64(np.ascontiguousarray(stats, dtype=np.float64)))
-            if n_ll is None:
-                n_ll = len(stats) - 3                       # [..., loglik_sum, n_utt, n_frames]
-            prob_old = float(stats[n_ll])
+                st = np.asarray(comm.allreduce_sum_f64(np.ascontiguousarray(st, dtype=np.float64)))
+            return st
+
+        hist = []
+        self.upload()
+        stats = e_step()
+        n_ll = len(stats) - 3                               # [..., loglik_sum, n_utt, n_frames]
+        for k in range(iters):
+            before = float(stats[n_ll])
             self.apply_stats(stats)
             self.upload()
-            ll = np.asarray(self.calc_prob_batch(obs_batch, lens=lens), dtype=np.float64)
-            new = np.array([ll.sum()])
-            if comm is not None:
-                new = np.asarray(comm.allreduce_sum_f64(new))
-            prob_new = float(new[0])
-            prod_d = abs(prob_old - prob_new)
-            hist.append((prob_old, prob_new))
-            if verbose:
-                print("Iter: {:3},"
-                      " L(lambda|O) = {:.6e},"
-                      " L(lambda_new|O) = {:.6e},"
-                      " eps = {:.6f}"
-                      .format(k, prob_old, prob_new, prod_d))
-            if prod_d < eps:
+            # L(lambda_new | O) from the SAME arithmetic as L(lambda | O): while another iteration may follow it is
+            # the likelihood the next E-step produces anyway (one statistics pass per iteration instead of a pass
+            # plus a scoring pass); on the last iteration a scoring pass under the model's precision
+            if k + 1 < iters:
+                stats = e_step()
+                after = float(stats[n_ll])
+            else:
+                ll = np.asarray(self.ctx.calc_prob(obs_batch, lens=lens, precision=self.precision), dtype=np.float64)
+                new = np.array([ll.sum()])
+                if comm is not None:
+                    new = np.asarray(comm.allreduce_sum_f64(new))
+                after = float(new[0])
+            hist.append((before, after))
+            if _report_iteration(k, before, after, verbose) < eps:
                 break
         return hist
 

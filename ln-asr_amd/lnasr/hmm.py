@@ -104,18 +104,15 @@ class HMM:
 
     def reset(self, init_type):
         """'uniform' or 'random' initial parameters; anything else is a silent no-op (hmm.py:233-250).
-        Uses the global numpy RNG exactly like the reference, so seeding reproduces its draws."""
+        Uses the global numpy RNG in the reference's draw order (A, then B, then pi), so seeding reproduces it."""
+        shapes = {"A": (self.n, self.n), "B": (self.n, self.m), "pi": (self.n,)}
         if init_type == "uniform":
-            self.A = np.log(np.ones((self.n, self.n), dtype=self.precision) * (1.0 / self.n))
-            self.B = np.log(np.ones((self.n, self.m), dtype=self.precision) * (1.0 / self.m))
-            self.pi = np.log(np.ones(self.n, dtype=self.precision) * (1.0 / self.n))
+            for name, shape in shapes.items():
+                setattr(self, name, _log_uniform(shape, self.precision))
         elif init_type == "random":
-            a = 1.0 - np.random.random_sample((self.n, self.n))     # (0, 1]: never log(0)
-            b = 1.0 - np.random.random_sample((self.n, self.m))
-            pi = 1.0 - np.random.random_sample((self.n))
-            self.A = np.log(a / a.sum(axis=1)[:, np.newaxis])
-            self.B = np.log(b / b.sum(axis=1)[:, np.newaxis])
-            self.pi = np.log(pi / np.sum(pi))
+            # 1 - U[0, 1) lies in (0, 1]: never log(0)
+            for name, shape in shapes.items():
+                setattr(self, name, _log_normalised(1.0 - np.random.random_sample(shape)))
 
     # ------------------------------------------------------------------ persistence
     def save(self, filename):
@@ -141,24 +138,17 @@ class HMM:
         return path
 
     def train(self, obs, iters=1, eps=0.0001, verbose: bool = True):
-        """Baum-Welch on one sequence, stopping when |delta loglik| < eps  (hmm.py:285-313)."""
+        """Baum-Welch on one sequence, stopping when |delta loglik| < eps  (hmm.py:285-313).  The E and M steps go
+        through the overridable methods in the reference's order, so subclasses that replace one of them keep working."""
         for k in range(iters):
             self._map_b(obs)
-            alpha = self._forward(obs)
-            beta = self._backward(obs)
-            xi, gamma = self._baumwelch(obs, alpha, beta)
-            model = self._estimate(obs, alpha, beta, xi, gamma)
-            prob_old = lse(alpha[-1])
-            self._updatemodel(model)
-            prob_new = self.calc_prob(obs)
-            prod_d = abs(prob_old - prob_new)
-            if verbose:
-                print("Iter: {:3},"
-                      " L(lambda|O) = {:.6e},"
-                      " L(lambda_new|O) = {:.6e},"
-                      " eps = {:.6f}"
-                      .format(k, prob_old, prob_new, prod_d))
-            if prod_d < eps:
+            alpha, beta = self._forward(obs), self._backward(obs)
+            posteriors = self._baumwelch(obs, alpha, beta)
+            new_model = self._estimate(obs, alpha, beta, *posteriors)
+            before = lse(alpha[-1])
+            self._updatemodel(new_model)
+            after = self.calc_prob(obs)
+            if _report_iteration(k, before, after, verbose) < eps:
                 break
 
     # ------------------------------------------------------------------ batch extras
@@ -174,6 +164,27 @@ class HMM:
         self._upload()
         b = self.ctx.discrete_map_b(np.asarray(self.B, dtype=np.float64), obs_batch, self.precision)
         return self.ctx.forward(b, want_alpha=False, want_loglik=True)[1]
+
+
+_ITER_LINE = "Iter: {:3}, L(lambda|O) = {:.6e}, L(lambda_new|O) = {:.6e}, eps = {:.6f}"
+
+
+def _report_iteration(k, before, after, verbose):
+    """|after - before|, printing the reference's progress line (hmm.py:306-311; the text is observable behaviour)."""
+    delta = abs(before - after)
+    if verbose:
+        print(_ITER_LINE.format(k, before, after, delta))
+    return delta
+
+
+def _log_uniform(shape, dtype):
+    """log of a uniform distribution over the last axis, in `dtype` like the reference's np.ones(..., dtype) / n."""
+    return np.log(np.ones(shape, dtype=dtype) * (1.0 / shape[-1]))
+
+
+def _log_normalised(draw):
+    """log of `draw` scaled so that its last axis sums to one (stays float64 whatever `precision`, as in the reference)."""
+    return np.log(draw / draw.sum(axis=-1, keepdims=True))
 
 
 def _save(filename, arrays):

@@ -245,12 +245,13 @@ def gmm_map_b_diag(obs, w, mu, var, precision=np.float64):
     q = (obs * obs) @ iv.reshape(N * M, D).T
     q -= 2.0 * (obs @ (mu * iv).reshape(N * M, D).T)
     q += np.sum(mu * mu * iv, axis=2).reshape(1, N * M)
-    bm = (const.reshape(1, N * M) - 0.5 * q).reshape(T, N, M)
-    z = w[None] + bm
+    # the reference stores bm into an array of `precision` FIRST and forms b from those stored values
+    # (gmmhmm.py:64-67): with float32 the mixture sum sees the rounded component log-densities
+    bm = (const.reshape(1, N * M) - 0.5 * q).reshape(T, N, M).astype(precision)
+    z = w[None] + bm.astype(np.float64)
     mx = z.max(axis=2, keepdims=True)
     b = (mx[..., 0] + np.log(np.exp(z - mx).sum(axis=2)))
-    return np.ascontiguousarray(b.T).astype(precision), \
-        np.ascontiguousarray(bm.transpose(1, 2, 0)).astype(precision)
+    return np.ascontiguousarray(b.T).astype(precision), np.ascontiguousarray(bm.transpose(1, 2, 0))
 
 
 def gmm_map_b_diag_direct(obs, w, mu, var, precision=np.float64):
@@ -261,15 +262,15 @@ def gmm_map_b_diag_direct(obs, w, mu, var, precision=np.float64):
     N, M, D = mu.shape
     T = obs.shape[0]
     const = -0.5 * (D * LOG2PI + np.log(np.prod(var, axis=2)))
-    bm = np.empty((N, M, T))
+    bm = np.empty((N, M, T), dtype=precision)                 # rounded at the store, as in the reference
     for n in range(N):
         for m in range(M):
             dx = obs - mu[n, m]
             bm[n, m] = const[n, m] - 0.5 * ((dx / var[n, m]) * dx).sum(axis=1)
-    b = np.empty((N, T))
+    b = np.empty((N, T), dtype=precision)
     for n in range(N):
         b[n] = lse(w[n].reshape(M, 1) + bm[n], axis=0)
-    return b.astype(precision), bm.astype(precision)
+    return b, bm
 
 
 # ----------------------------------------------------------------------------

@@ -69,8 +69,10 @@ def env_switch(**kv):
     """Set environment switches for the block and put back what was there before (the fallback-suite runs set
     some of them for the whole process: a test must not clear those)."""
     import os
+    from lnasr import _ffi
     before = {k: os.environ.get(k) for k in kv}
     os.environ.update({k: str(v) for k, v in kv.items()})
+    _ffi.reload_switches()                 # the library reads its switches once per process
     try:
         yield
     finally:
@@ -79,6 +81,7 @@ def env_switch(**kv):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+        _ffi.reload_switches()
 
 
 def assert_close(a, b, rtol=1e-10, atol=0.0, msg=""):

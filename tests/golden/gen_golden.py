@@ -166,6 +166,21 @@ def gen_gmmhmm_d39():
         save("gmmhmm_d39_" + tag, **out)
 
 
+def gen_gmmhmm_f32_mid():
+    """`precision=np.float32` at a size where the ROUNDING ORDER of the reference shows (gmmhmm.py:64-67: bm is stored
+    into a float32 array, then b = lse(w + bm) is formed in float64 from those rounded values and rounded again on its
+    way into the float32 `b`): N=32, M=8, D=39, T=512, diagonal Sigma handed over as [N,M,D,D], seeds 11 / 1011."""
+    N, M, D, T = 32, 8, 39, 512
+    mdl = synth.synth_model(N, M, D, seed=11)
+    obs = synth.synth_obs(1, T, D, seed=1011)[0]
+    gh = GMMHMM(N, M, D, mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["si"], precision=np.float32)
+    cap = _gmmhmm_capture(gh, obs, with_estimate=False)
+    assert cap["b"].dtype == np.float32 and cap["bm"].dtype == np.float32 and cap["v"].dtype == np.float32
+    out = dict(shape=np.array([N, M, D, T]), seeds=np.array([11, 1011]), b=cap["b"], bm=cap["bm"], v=cap["v"],
+               bt=cap["bt"].astype(np.uint8), path=cap["path"], alpha=cap["alpha"], beta=cap["beta"], loglik=cap["loglik"])
+    save("gmmhmm_f32_mid", **out)
+
+
 def gen_offset_means():
     """Models of real-feature scale (not the unit-scale synthetic ones): means far from the origin and from each
     other, small variances, observations near the means.  The reference scores with the direct (x - mu) form
@@ -358,6 +373,11 @@ def gen_discrete_mid():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:                       # python gen_golden.py gen_gmmhmm_f32_mid ...: only these fixtures
+        with np.errstate(divide="ignore"):
+            for _name in sys.argv[1:]:
+                globals()[_name]()
+        sys.exit(0)
     with np.errstate(divide="ignore"):
         gen_toy_hmm()
         gen_hmm_train()
@@ -370,3 +390,4 @@ if __name__ == "__main__":
         gen_discrete_mid()
         gen_metric_slice()
         gen_offset_means()
+        gen_gmmhmm_f32_mid()

@@ -106,6 +106,52 @@ def test_bench_self_launch_two_ranks():
     assert "torch.distributed.run" in r.stderr and "--nproc-per-node 2" in r.stderr
 
 
+def test_rank_started_by_a_foreign_launcher_gets_the_env_defaults():
+    """A rank that somebody else's launcher started (WORLD_SIZE already set: bench.py's own launcher is skipped) must
+    still see the environment this pool needs -- dmabuf IPC for RCCL, loopback interfaces, 127.0.0.1 rendezvous:
+    bench.py sets them at import."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("HSA_ENABLE_IPC_MODE_LEGACY", "GLOO_SOCKET_IFNAME", "NCCL_SOCKET_IFNAME", "MASTER_ADDR")}
+    env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--dry-launch"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "torch.distributed.run" not in r.stderr            # it did not start ranks of its own
+    out = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")][0]
+    seen = out["env"][0]
+    assert seen["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert seen["GLOO_SOCKET_IFNAME"] == "lo" and seen["NCCL_SOCKET_IFNAME"] == "lo" and seen["MASTER_ADDR"] == "127.0.0.1"
+    # and a value the launcher did set is left alone
+    env["NCCL_SOCKET_IFNAME"] = "eth9"
+    env["MASTER_PORT"] = str(_free_port())
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--dry-launch"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    out = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")][0]
+    assert out["env"][0]["NCCL_SOCKET_IFNAME"] == "eth9"
+
+
+def test_bench_n1_path_never_imports_torch():
+    """north_star: no PyTorch on the product path.  With one rank bench.py must not import torch at all (with N > 1
+    only torch.distributed over gloo, for rendezvous).  Checked on the source: every torch import sits inside the
+    Ranks / dry_launch helpers that a one-rank run without LNASR_BENCH_FORCE_COMM never enters."""
+    import ast
+    tree = ast.parse(open(os.path.join(REPO, "bench.py")).read())
+    allowed = {"dry_launch", "__init__", "max"}
+    for fn in ast.walk(tree):
+        if isinstance(fn, (ast.FunctionDef, ast.AsyncFunctionDef)):
+            for node in ast.walk(fn):
+                if isinstance(node, (ast.Import, ast.ImportFrom)):
+                    names = [a.name for a in node.names] + [getattr(node, "module", "") or ""]
+                    if any(n.split(".")[0] == "torch" for n in names):
+                        assert fn.name in allowed, fn.name
+    for node in tree.body:                                      # nothing at module level
+        if isinstance(node, (ast.Import, ast.ImportFrom)):
+            names = [a.name for a in node.names] + [getattr(node, "module", "") or ""]
+            assert not any(n.split(".")[0] == "torch" for n in names)
+
+
 def test_bench_launch_fails_loudly_without_gpus():
     """No GPU here: the two ranks must fail and the launcher must hand a non-zero exit code on -- no line with
     a number in it, no silent single-rank run."""

@@ -52,6 +52,48 @@ def test_gmmhmm_small(golden, tag):
     assert np.array_equal(gh.decode(g["obs"]), g["path"])
 
 
+def test_gmmhmm_f32_mid_rounding_order(golden, synth, ctx):
+    """precision=np.float32 at N=32, M=8, D=39, T=512 against the reference's own float32 run: the reference rounds bm
+    to float32 at the store and forms b from the ROUNDED values (gmmhmm.py:64-67).  The float32 emission route does
+    the same (round32_lse_kernel after the fp64 matrix-core kernels), so b and bm are BIT-EQUAL to the reference's
+    arrays -- on every emission route: MFMA diagonal, direct-form diagonal, full-covariance arithmetic, and the
+    storage-templated generic kernels.  v / bt / path follow bit for bit."""
+    from lnasr.gmmhmm import GMMHMM
+    g = golden("gmmhmm_f32_mid")
+    N, M, D, T = (int(x) for x in g["shape"])
+    mdl = synth.synth_model(N, M, D, seed=int(g["seeds"][0]))
+    obs = synth.synth_obs(1, T, D, seed=int(g["seeds"][1]))[0]
+
+    def check(gh, what):
+        gh._map_b(obs)
+        assert gh.b.dtype == np.float32 and gh.bm.dtype == np.float32, what
+        # a density within ~1e-14 of a float32 rounding boundary may fall on the other side (expected count over
+        # these 139,264 values: 0.03): allow two, each one float ulp off -- never the systematic 15 % of rounding once
+        nb, nbm = int((gh.b != g["b"]).sum()), int((gh.bm != g["bm"]).sum())
+        assert nb <= 2 and nbm <= 2, (what, nb, nbm)
+        assert_close(gh.b, g["b"], 1.3e-7), assert_close(gh.bm, g["bm"], 1.3e-7)
+        return nb + nbm
+
+    routes = [("mfma diag", {}, mdl["si"]), ("direct diag", dict(LNASR_NO_MFMA=1), mdl["si"]),
+              ("generic f32 storage", dict(LNASR_F32_GENERIC=1), mdl["si"])]
+    exact = 0
+    for what, switches, si in routes:
+        with env_switch(**switches):
+            gh = GMMHMM(N, M, D, mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], si, precision=np.float32, ctx=ctx)
+            exact += check(gh, what) == 0
+            if not switches:
+                v, bt, path = gh._viterbi(obs)
+                assert v.dtype == np.float32
+                assert np.array_equal(v, g["v"]) and np.array_equal(bt, g["bt"]) and np.array_equal(path, g["path"])
+                assert np.array_equal(gh.decode(obs), g["path"])
+                assert_close(gh._forward(obs), g["alpha"], 1e-6), assert_close(gh._backward(obs), g["beta"], 1e-6)
+    assert exact >= 2                                    # bit-equal on (at least) all but one route
+    # the reference's full-covariance arithmetic on the same (diagonal) model
+    ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["si"], force_full=True)
+    b, bm = ctx.gmm_logprob(obs[None], want_bm=True, precision=np.float32)
+    assert (b[0].T != g["b"]).sum() <= 2 and (bm[0].transpose(1, 2, 0) != g["bm"]).sum() <= 2
+
+
 @pytest.mark.parametrize("kind", ["diag", "full"])
 def test_gmmhmm_d39(golden, kind, ctx):
     from lnasr.gmmhmm import GMMHMM

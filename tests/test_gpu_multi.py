@@ -59,6 +59,29 @@ def test_bench_comm_path_one_rank_rehearsal():
     assert out["n_gpus"] == 1 and out["value"] > 0
     assert out["config"]["gather"].startswith("rccl all-gather of the state paths over 1 ranks")
     assert "pack_paths_u8" in out["kernels"] and "unpack_paths_u8" in out["kernels"]
+    # the oracle check runs on the N > 1 path too, before anything is timed
+    assert "bit-identical to the oracle's before timing" in out["config"]["parity"]
+    # second collective of the path: the config-5 statistics pass + the RCCL all-reduce of the packed vector
+    bw = out["baum_welch"]
+    assert bw["bw_pass_ms"] > 0 and bw["bw_pass_f32_ms"] > 0 and bw["allreduce_ms"] > 0
+    assert bw["allreduce_bytes"] == 8 * (256 * 256 + 2 * 256 + 256 * 32 * (1 + 2 * 39) + 3)
+    assert bw["checks"].endswith(": ok")
+    # host arrays in, host paths out, through the upload pipeline
+    e2e = out["end_to_end"]
+    assert e2e["value"] > 0 and e2e["h2d_GBps"] > 0 and e2e["paths_identical_to_resident_run"]
+    assert e2e["pageable"]["paths_identical_to_resident_run"]
+
+
+def test_bench_wrong_paths_time_nothing(tmp_path):
+    """A kernel whose paths differ from the oracle's is not measured: with the checker's answer falsified (a test hook
+    that flips one state of the expected paths) the bench prints the value-null line and exits non-zero."""
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "1", "--warmup", "0", "--utts", "8",
+                        "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=600,
+                       env=_clean_env(LNASR_BENCH_TEST_CORRUPT_ORACLE="1"))
+    assert r.returncode != 0
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and lines[0]["value"] is None
+    assert "differ from the oracle" in lines[0]["config"]["parity"]
 
 
 def _rank(rank, world, port, q):
