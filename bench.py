@@ -78,6 +78,16 @@ BW_SHAPE = dict(N=256, M=32, D=39, T=2000, U=64)    # BASELINE configs[4], per G
 BW_STEPS = 5
 
 
+_T0 = time.time()
+
+
+def note(msg):
+    """Progress line on stderr (rank 0 says where the run is; a hung stage is then visible in the log)."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        sys.stderr.write("[bench +%.1fs] %s\n" % (time.time() - _T0, msg))
+        sys.stderr.flush()
+
+
 def _load_oracle():
     spec = importlib.util.spec_from_file_location("lnasr_oracle", os.path.join(REPO, "oracle", "lnasr_oracle.py"))
     mod = importlib.util.module_from_spec(spec)
@@ -467,7 +477,9 @@ def main():
     # everything that forks (CPU-baseline workers) or is pure CPU comes first: before this process touches the GPU
     cpu, cpu_ref = (None, None)
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        note("CPU baseline (oracle on the host cores, ~20 s)")
         cpu, cpu_ref = cpu_baseline()
+    note("oracle paths of the first %d utterances" % min(N_CHECK, U))
     n_check = min(N_CHECK, U)
     want_head = oracle_paths(obs[:n_check])                         # every rank checks its own shard
     if os.environ.get("LNASR_BENCH_TEST_CORRUPT_ORACLE"):           # tests only: prove that a mismatch times nothing
@@ -487,6 +499,7 @@ def main():
         dev = int(os.environ["LNASR_BENCH_DEVICE"])
     else:
         dev = 0 if _ffi.device_count() == 1 else local_rank
+    note("context on device %d" % dev)
     ctx = _ffi.Context(dev)
 
     mdl = synth.synth_model(N_STATES, N_MIX, N_DIM, seed=1)
@@ -498,6 +511,7 @@ def main():
     n_ranks_rccl = 1
     gather = "n/a (single GPU)"
     if use_comm:
+        note("RCCL communicator + rehearsal gather")
         d_all, n_ranks_rccl = init_comm(ctx, rk, d_path, U, T)
         gather = ("rccl all-gather of the state paths over %d ranks (ncclCommCount; u8 on the wire, u32 in memory), "
                   "%d B per GPU per step" % (n_ranks_rccl, U * T))
@@ -508,6 +522,7 @@ def main():
             ctx.allgather_paths(d_path, N_STATES, out=d_all)
 
     # the checker's answer first: a fast kernel with different paths is not measured -- on ANY rank
+    note("parity check, then %d warm-up + %d timed steps" % (args.warmup, args.steps))
     step()
     ctx.sync()
     resident_paths = d_path.to_host()
@@ -556,15 +571,18 @@ def main():
     step_s = elapsed / args.steps
     e2e = bw = None
     if not args.no_extras:
+        note("end-to-end (host in, host out)")
         e2e, ok = end_to_end(rk, ctx, obs, resident_paths, step_s * 1e3, max(5, args.steps // 2))
         if not ok:
             sys.stderr.write("[rank %d] end-to-end paths differ from the resident run\n" % rank)
             rc = 1
+        note("Baum-Welch statistics pass%s" % (" + all-reduce" if use_comm else ""))
         bw, ok = baum_welch(rk, ctx, use_comm)
         if not ok:
             sys.stderr.write("[rank %d] Baum-Welch statistics failed their checks\n" % rank)
             rc = 1
     rc = int(max(rk.gather(rc)))
+    note("done, rc=%d" % rc)
 
     if rank == 0:
         frames_total = n_ranks_rccl * U * T * args.steps

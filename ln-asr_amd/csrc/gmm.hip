@@ -1211,6 +1211,11 @@ int emit_batch(lnasr_ctx* ctx, const double* obs, int U, int T, double* b, doubl
     UploadState st;
     st.done.assign(nch, 0);
     std::vector<std::thread> workers;
+    // everything the worker lambdas capture by reference lives in THIS scope, which also joins them
+    constexpr int K = lnasr_ctx::kRingSlots;
+    const int nth = sw().h2d_threads;
+    std::vector<std::atomic<int>> pieces(nch);          // pieces[c]: threads that have finished their part of chunk c
+    for (auto& p : pieces) p.store(0);
     if (sw().no_pinned_ring) {
         workers.emplace_back([&] {
             (void)hipSetDevice(ctx->device);
@@ -1226,11 +1231,6 @@ int emit_batch(lnasr_ctx* ctx, const double* obs, int U, int T, double* b, doubl
         size_t slot = 0;
         for (int c = 0; c < nch; ++c) slot = plan.len(c) > slot ? plan.len(c) : slot;
         LN_TRY(ensure_ring(ctx, slot));
-        constexpr int K = lnasr_ctx::kRingSlots;
-        const int nth = sw().h2d_threads;
-        // pieces[c]: threads that have finished their part of chunk c
-        std::vector<std::atomic<int>> pieces(nch);
-        for (auto& p : pieces) p.store(0);
         for (int t = 0; t < nth; ++t) {
             workers.emplace_back([&, t] {
                 (void)hipSetDevice(ctx->device);

@@ -184,14 +184,21 @@ class DeviceArray:
 
 
 class _PinnedBlock:
-    """Owner of one lnasr_host_alloc block; the numpy arrays made over it keep it alive through `.base`."""
+    """Owner of one lnasr_host_alloc block.  `buffer()` hands out a ctypes view that references this object, and a
+    numpy array made over that view references the view (`.base`): the block lives exactly as long as any array over
+    it and is freed when the last one is collected."""
 
     def __init__(self, ctx, nbytes):
         self.ctx = ctx
+        self.nbytes = max(1, int(nbytes))
         p = C.c_void_p()
-        check(lib().lnasr_host_alloc(ctx.handle, nbytes, C.byref(p)))
+        check(lib().lnasr_host_alloc(ctx.handle, self.nbytes, C.byref(p)))
         self.ptr = p.value
-        self.buf = (C.c_char * max(1, nbytes)).from_address(self.ptr)
+
+    def buffer(self):
+        buf = (C.c_char * self.nbytes).from_address(self.ptr)
+        buf._lnasr_owner = self                # the view keeps the block alive (no cycle: the block holds no view)
+        return buf
 
     def __del__(self):
         try:
@@ -273,8 +280,8 @@ class Context:
         dtype = np.dtype(dtype)
         shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
         n = int(np.prod(shape, dtype=np.int64))
-        blk = _PinnedBlock(self, n * dtype.itemsize)
-        return np.frombuffer(blk.buf, dtype=dtype, count=n).reshape(shape)
+        buf = _PinnedBlock(self, n * dtype.itemsize).buffer()
+        return np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
 
     def pinned_copy(self, arr):
         out = self.pinned_empty(np.shape(arr), np.asarray(arr).dtype)
