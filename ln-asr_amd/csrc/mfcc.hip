@@ -18,6 +18,23 @@ namespace lnasr {
 
 constexpr int kMaxFft = 4096;
 
+// Developer diagnostic (python ln-asr_amd/build.py is never run with it): -DLNASR_MFCC_STAMPS makes lane 0 of wave 0 of
+// block 0 add the shader cycles (s_memtime) each phase of the fft-512 frame kernel took into g_mfcc_stamps, which
+// tools/mfcc_stamps.py reads back.  The stamps drain the LDS counter at every phase boundary and cost ~10 %.
+#ifdef LNASR_MFCC_STAMPS
+__device__ unsigned long long g_mfcc_stamps[16];
+#define LN_STAMP_DECL unsigned long long st_prev = __builtin_amdgcn_s_memtime()
+#define LN_STAMP(i)                                                         \
+    do {                                                                    \
+        const unsigned long long st_now = __builtin_amdgcn_s_memtime();     \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_mfcc_stamps[i] += st_now - st_prev; \
+        st_prev = st_now;                                                   \
+    } while (0)
+#else
+#define LN_STAMP_DECL
+#define LN_STAMP(i)
+#endif
+
 __device__ __forceinline__ int find_utt(const int64_t* __restrict__ foff, int U, int64_t f) {
     int lo = 0, hi = U;                 // foff[lo] <= f < foff[hi]
     while (hi - lo > 1) {
@@ -135,11 +152,16 @@ __global__ void mfcc_frame_kernel(const SAMPLE* __restrict__ signal, const int64
 // A lane's constant share of the mel and DCT phases of the fft-512 kernels
 struct Mel512Lane {
     int m, cnt, flags, cmax, n_mel, n_out, dq;
-    const double* tp;          // its taps in the LDS
-    const double* fb;          // ... in global memory (filter banks too dense for the LDS table)
-    const double* Ct;          // DCT matrix, transposed, in the LDS
+    const double* fb;          // the lane's taps in global memory (filter banks too dense for the LDS table)
+    const double* C;           // DCT matrix C[k][m] in global memory (layout without the output split: n_out > 16)
     int lo;
     bool taps_in_lds, dct_split;
+    // padded, lane-major tables (fast path): tapT[i * 64] = tap i of this lane's window of cp bins starting at lo2
+    // (zero outside the lane's filter chunk), ctT[j * 64] = DCT coefficient of (output lane >> 2, input m0 + j),
+    // zero beyond the lane's quarter -- no index is ever clamped or selected in the loops
+    const double* tapT;
+    const double* ctT;
+    int cp, lo2, jp, m0;
 };
 
 // Block-level tables (three block barriers; waves are independent afterwards): DCT matrix transposed, the
@@ -147,59 +169,85 @@ struct Mel512Lane {
 // cnt taps gets ceil(cnt / C) consecutive lanes (at most 3), C the smallest chunk for which 64 lanes suffice.
 __device__ __forceinline__ void mel_plan_setup(int n_mel, int n_out, const int* __restrict__ mel_range,
                                                const double* __restrict__ fbank, const double* __restrict__ dctC,
-                                               double* taps, double* Ct, int* tap_off, int* asg, int* asg_cmax, int tid,
-                                               int NT, int lane, int w, int nwaves) {
+                                               double* taps, double* CtP, int* asg, int* asg_cmax, int tid, int NT,
+                                               int lane, int w, int nwaves) {
     constexpr int NBIN = 257, MAXTAP = 1024;
-    for (int e = tid; e < n_mel * n_mel; e += NT) Ct[(e % n_mel) * n_mel + e / n_mel] = dctC[e];
-    if (tid < n_mel) tap_off[tid + 1] = mel_range[2 * tid + 1] - mel_range[2 * tid];
-    __syncthreads();
-    if (tid == 0) {
-        int o = 0, cmx = 0;
-        for (int m = 0; m < n_mel; ++m) {
-            const int c = tap_off[m + 1];
-            tap_off[m] = o;
-            o += c;
-            cmx = c > cmx ? c : cmx;
+    // The lane plan, by wave 0 with lane m holding filter m's width: the widths never go through the LDS and nothing
+    // is divided.  (As a single-lane loop over LDS-resident widths this cost every block ~25k cycles, 8 % of the kernel:
+    // tools/mfcc_stamps.py.)  C >= ceil(widest / 3), so a filter takes 1, 2 or 3 lanes; the lanes of one filter never
+    // straddle a 16-lane row -- its partial sums then meet through row-shift DPP moves -- and the lanes skipped for
+    // that are idle.
+    if (w == 0) {
+        const int c = lane < n_mel ? mel_range[2 * lane + 1] - mel_range[2 * lane] : 0;
+        int cmx = c;
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) {
+            const int o = __shfl_xor(cmx, sft, 64);
+            cmx = o > cmx ? o : cmx;
         }
-        tap_off[n_mel] = o;
         int C = (cmx + 2) / 3;
         if (C < 1) C = 1;
+        int parts, start;
         for (;; ++C) {
-            int need = 0;
+            parts = 1 + (c > C ? 1 : 0) + (c > 2 * C ? 1 : 0);
+            start = 0;
+            int ln = 0;                                            // wave-uniform scan over the filters
             for (int m = 0; m < n_mel; ++m) {
-                const int c = tap_off[m + 1] - tap_off[m];
-                need += c > 0 ? (c + C - 1) / C : 1;
+                const int pm = __builtin_amdgcn_readlane(parts, m);
+                if ((ln & 15) + pm > 16) ln = (ln + 15) & ~15;
+                if (lane == m) start = ln;
+                ln += pm;
             }
-            if (need <= 64) break;
+            if (ln <= 64) break;
         }
-        int ln = 0;
-        for (int m = 0; m < n_mel; ++m) {
-            const int c = tap_off[m + 1] - tap_off[m];
-            const int parts = c > 0 ? (c + C - 1) / C : 1;
-            for (int q = 0; q < parts; ++q, ++ln) {
-                const int i0 = q * C, cnt = (c - i0) < C ? (c - i0) : C;
-                asg[4 * ln] = m;
+        asg[4 * lane] = -1, asg[4 * lane + 1] = 0, asg[4 * lane + 2] = 0, asg[4 * lane + 3] = 0;
+        __builtin_amdgcn_wave_barrier();                           // one wave's LDS stores land in program order
+        if (lane < n_mel)
+            for (int q = 0; q < parts; ++q) {
+                const int i0 = q * C, cnt = (c - i0) < C ? (c - i0) : C, ln = start + q;
+                asg[4 * ln] = lane;
                 asg[4 * ln + 1] = i0;
                 asg[4 * ln + 2] = cnt > 0 ? cnt : 0;
                 asg[4 * ln + 3] = (q == 0 ? 1 : 0) | ((q == 0 && parts > 1) ? 2 : 0) | ((q == 0 && parts > 2) ? 4 : 0);
             }
-        }
-        for (; ln < 64; ++ln) asg[4 * ln] = -1, asg[4 * ln + 1] = 0, asg[4 * ln + 2] = 0, asg[4 * ln + 3] = 0;
-        *asg_cmax = C;
+        if (lane == 0) *asg_cmax = C;
     }
     __syncthreads();
-    if (tap_off[n_mel] <= MAXTAP)
-        for (int m = w; m < n_mel; m += nwaves) {
-            const int lo = mel_range[2 * m], cnt = mel_range[2 * m + 1] - lo;
-            for (int e = lane; e < cnt; e += 64) taps[tap_off[m] + e] = fbank[(size_t)m * NBIN + lo + e];
+    // lane-major padded tap table [cp][64]: a lane's window is the cp = 4 ceil(C / 4) bins from lo2 = min(lo, 260 - cp)
+    // (so that the padding never reaches past the three unused slots behind the 257 bins), its taps sit at their bins'
+    // positions in that window and everything else is 0.0
+    const int C = *asg_cmax, cp = (C + 3) / 4 * 4;
+    if (cp * 64 <= MAXTAP) {
+        for (int e = tid; e < cp * 64; e += NT) {
+            const int i = e >> 6, ln = e & 63;
+            const int m = asg[4 * ln], i0 = asg[4 * ln + 1], cnt = asg[4 * ln + 2];
+            double v = 0.0;
+            if (m >= 0) {
+                const int lo = mel_range[2 * m] + i0;
+                const int lo2 = lo < 260 - cp ? lo : 260 - cp;
+                const int t = i - (lo - lo2);
+                if (t >= 0 && t < cnt) v = fbank[(size_t)m * NBIN + lo + t];
+            }
+            taps[e] = v;
         }
+    }
+    // lane-major padded DCT table [jp][64] for the split layout (lane = 4 k + part): coefficient of input m0 + j
+    {
+        const int dq = (n_mel + 3) / 4, jp = (dq + 3) / 4 * 4;
+        if (n_out * 4 <= 64)
+            for (int e = tid; e < jp * 64; e += NT) {
+                const int j = e >> 6, ln = e & 63, k = ln >> 2, part = ln & 3;
+                const int m = part * dq + j, m1 = (part * dq + dq) < n_mel ? (part * dq + dq) : n_mel;
+                CtP[e] = (k < n_out && j < dq && m < m1) ? dctC[(size_t)k * n_mel + m] : 0.0;
+            }
+    }
     __syncthreads();
 }
 
 __device__ __forceinline__ Mel512Lane mel_plan_lane(int n_mel, int n_out, const int* __restrict__ mel_range,
                                                     const double* __restrict__ fbank, const double* taps,
-                                                    const double* Ct, const int* tap_off, const int* asg, int cmax,
-                                                    int lane) {
+                                                    const double* __restrict__ dctC, const double* CtP,
+                                                    const int* asg, int cmax, int lane) {
     constexpr int NBIN = 257, MAXTAP = 1024;
     Mel512Lane ml;
     ml.m = asg[4 * lane];
@@ -211,11 +259,16 @@ __device__ __forceinline__ Mel512Lane mel_plan_lane(int n_mel, int n_out, const 
     ml.n_out = n_out;
     ml.dq = (n_mel + 3) / 4;
     ml.lo = ml.m >= 0 ? mel_range[2 * ml.m] + i0 : 0;
-    ml.tp = taps + (ml.m >= 0 ? tap_off[ml.m] + i0 : 0);
     ml.fb = fbank + (size_t)(ml.m >= 0 ? ml.m : 0) * NBIN + ml.lo;
-    ml.Ct = Ct;
-    ml.taps_in_lds = tap_off[n_mel] <= MAXTAP;
+    ml.C = dctC;
+    ml.cp = (cmax + 3) / 4 * 4;
+    ml.taps_in_lds = ml.cp * 64 <= MAXTAP;
+    ml.lo2 = ml.lo < 260 - ml.cp ? ml.lo : 260 - ml.cp;
+    ml.tapT = taps + lane;
     ml.dct_split = n_out * 4 <= 64;            // n_out <= 16 outputs x 4 quarter-sums fill the wave
+    ml.jp = (ml.dq + 3) / 4 * 4;
+    ml.m0 = (lane & 3) * ml.dq;
+    ml.ctT = CtP + lane;
     return ml;
 }
 
@@ -239,6 +292,23 @@ __device__ __forceinline__ void radix4(cplx v[4]) {
     v[1] = cadd(t1, t3);
     v[2] = csub(t0, t2);
     v[3] = csub(t1, t3);
+}
+
+// find_utt by the whole wave (f the same in every lane): 64 probes per round, so two dependent loads find the
+// utterance among 4096 where the binary search walks twelve
+__device__ __forceinline__ int find_utt_wave(const int64_t* __restrict__ foff, int U, int64_t f, int lane) {
+    int lo = 0, hi = U;                 // foff[lo] <= f < foff[hi]
+    while (hi - lo > 1) {
+        const int step = (hi - lo + 63) / 64;
+        const int pos = lo + step * (lane + 1);              // increasing with the lane; probes at or past hi say "greater"
+        const bool le = pos < hi && foff[pos] <= f;
+        const int nle = __popcll(__ballot(le));              // the probes that are <= f form a prefix of the lanes
+        const int nlo = nle ? lo + step * nle : lo;
+        const int nhi = lo + step * (nle + 1) < hi ? lo + step * (nle + 1) : hi;
+        lo = nlo;
+        hi = nhi;
+    }
+    return lo;
 }
 
 template <typename T>
@@ -265,18 +335,32 @@ __device__ __forceinline__ const T* uniform_ptr(const T* p) {
 // Against a one-frame-per-wave radix-4 Stockham (the first version of this kernel, 0.60 ms per 256k frames against
 // 0.35): one LDS round trip of the data instead of four, the split at half the arithmetic, and 16 independent
 // butterflies per lane to hide latencies behind.
-constexpr int kX4Waves = 8;
+constexpr int kX4Waves = 8;            // waves per block (two per SIMD)
 constexpr int kX4FS = 308;             // doubles per frame in a wave's LDS slice: 16 x 17 exchange tile, later
                                        // 257 power bins, log-mel row at 260
 
+// radix4 with a fourth input known to be zero (frame_len = 400 of 512: the last three input rows of the first pass)
+__device__ __forceinline__ void radix4_z3(cplx v[4]) {
+    const cplx t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]);
+    const cplx t2 = v[1], t3 = mul_neg_i(v[1]);
+    v[0] = cadd(t0, t2);
+    v[1] = cadd(t1, t3);
+    v[2] = csub(t0, t2);
+    v[3] = csub(t1, t3);
+}
+
+// NZ: inputs v[n], n >= NZ, are known to be zero (their butterflies lose the additions that would only add 0)
+template <int NZ = 16>
 __device__ __forceinline__ void fft16(cplx v[16]) {
     // index n = a + 4 a', output k = b + 4 c:  W16^(nk) = W4^(a'b) W16^(ab) W4^(ac)
     constexpr double C1 = 0.92387953251128674, S1 = 0.38268343236508977, R = 0.70710678118654752;
+    static_assert(NZ > 12, "only the last input of a butterfly may be a known zero");
     cplx u[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         cplx t[4] = {v[a], v[a + 4], v[a + 8], v[a + 12]};
-        radix4(t);
+        if (a + 12 >= NZ) radix4_z3(t);
+        else radix4(t);
 #pragma unroll
         for (int b = 0; b < 4; ++b) u[a][b] = t[b];
     }
@@ -352,22 +436,88 @@ __device__ __forceinline__ double log_fast(double x, const double* ltab) {
     return log_sum(x, ltab);
 }
 
+// Four logs at once: straight-line, so the four table reads travel together (one LDS round trip where four
+// calls of log_fast, each with its own range branch, took four).  The wave-uniform test sends everything to
+// log_fast if ANY active lane holds a value the table scheme does not take (0, denormal, huge, NaN).
+__device__ __forceinline__ void log_fast4(double x[4], const double* ltab) {
+    bool ok = true;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ok = ok && (x[r] >= 1e-300 && x[r] <= 1e300);
+    if (__builtin_expect(!__all(ok), 0)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = log_fast(x[r], ltab);
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x[r] = log_sum(x[r], ltab);
+}
+
+// the padded loops of the mel / DCT phase with a compile-time length: every LDS read is issued before the first
+// product, one round trip instead of one per group of four taps (the phase is bound by LDS latency, not by its FMAs:
+// tools/mfcc_stamps.py)
+template <int CP>
+__device__ __forceinline__ void padded_dot4(const double* tt, const double* pp, double s[4]) {
+    constexpr int FS = kX4FS;
+    double tap[CP], pv[4][CP];
+#pragma unroll
+    for (int i = 0; i < CP; ++i) {
+        tap[i] = tt[i * 64];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pv[r][i] = pp[r * FS + i];
+    }
+#pragma unroll
+    for (int i = 0; i < CP; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[r] = fma(pv[r][i], tap[i], s[r]);
+}
+// WIDE: whole length in one go (60 doubles in flight at cp = 12); otherwise four taps at a time -- the f64-sample kernel
+// carries the next group's prefetched samples through this phase (54 registers) and would spill
+template <bool WIDE>
+__device__ __forceinline__ void padded_dot4_n(int cp, const double* tt, const double* pp, double s[4]) {
+    constexpr int FS = kX4FS;
+    if (WIDE) {
+        if (cp == 12) return padded_dot4<12>(tt, pp, s);
+        if (cp == 8) return padded_dot4<8>(tt, pp, s);
+        if (cp == 16) return padded_dot4<16>(tt, pp, s);
+    }
+    for (int i = 0; i < cp; i += 4) {
+        double tap[4], pv[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            tap[q] = tt[(i + q) * 64];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pv[r][q] = pp[r * FS + i + q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[r] = fma(pv[r][q], tap[q], s[r]);
+    }
+}
+
 // mel -> log -> DCT of the four frames of a wave's slice in one walk: a lane keeps its filter chunk (and its
-// DCT output) for all four, so taps and DCT coefficients are read once and the four chains overlap; taps are
-// taken four at a time with every load ahead of the first product.
+// DCT output) for all four, so taps and DCT coefficients are read once and the four chains overlap.  Both loops run
+// over padded, lane-major tables (mel_plan_setup): straight-line groups of four taps, every address a constant offset
+// from one base, no clamped index and no select -- the LDS reads pair up (ds_read2_b64 / ds_read2st64_b64) and a tap
+// costs one FMA per frame plus its share of the reads.  (Round 2's loops clamped every index and selected every tap:
+// ~15 vector instructions per tap against the 4 FMAs that do the work.)
+template <bool WIDE>
 __device__ __forceinline__ void mel_dct_frames4(const Mel512Lane& ml, double* slice, const double* ltab, int lane,
                                                 double* __restrict__ cep_rows, int nlive) {
     constexpr int FS = kX4FS;
+    LN_STAMP_DECL;
     double s[4] = {0.0, 0.0, 0.0, 0.0};
-    const double* pp = slice + ml.lo;
-    auto mel = [&](const double* tp) {             // called once per source so that each keeps its address space
+    if (ml.taps_in_lds) {
+        padded_dot4_n<WIDE>(ml.cp, ml.tapT, slice + ml.lo2, s);
+    } else {                                       // filter bank too dense for the LDS table: taps from global memory
+        const double* pp = slice + ml.lo;
         for (int i = 0; i < ml.cmax; i += 4) {
             double tap[4], pv[4][4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const bool in = i + q < ml.cnt;     // past the lane's count: index 0, tap 0.0 (adds nothing)
                 const int ii = in ? i + q : 0;
-                const double t = tp[ii];
+                const double t = ml.fb[ii];
                 tap[q] = in ? t : 0.0;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pv[r][q] = pp[r * FS + ii];
@@ -377,47 +527,35 @@ __device__ __forceinline__ void mel_dct_frames4(const Mel512Lane& ml, double* sl
 #pragma unroll
                 for (int r = 0; r < 4; ++r) s[r] = fma(pv[r][q], tap[q], s[r]);
         }
-    };
-    if (ml.taps_in_lds) mel(ml.tp);                // taps in the LDS table
-    else mel(ml.fb);                               // filter bank too dense for it: from global memory
+    }
+    LN_STAMP(8);
+    // a filter's lanes share a 16-lane row (mel_plan_setup): its partial sums meet through row-shift DPP moves
+    // (row_shl:1 / row_shl:2: lane l <- lane l + 1 / l + 2 of the row, 0 from beyond it), no LDS round trip
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const double s1 = shfl_f64(s[r], (lane + 1) & 63), s2 = shfl_f64(s[r], (lane + 2) & 63);
+        const double s1 = dpp_f64<0x101>(s[r]), s2 = dpp_f64<0x102>(s[r]);
         if (ml.flags & 2) s[r] += s1;
         if (ml.flags & 4) s[r] += s2;
     }
     if (ml.flags & 1) {
+        double x[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            double x = s[r];
-            if (x == 0.0) x = 2.220446049250313e-16;                                  // mfcc.py:149
-            slice[r * FS + 260 + ml.m] = (20.0 / 2.302585092994045684) * log_fast(x, ltab);   // 20 log10: mfcc.py:150
-        }
+        for (int r = 0; r < 4; ++r) x[r] = s[r] == 0.0 ? 2.220446049250313e-16 : s[r];   // mfcc.py:149
+        log_fast4(x, ltab);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slice[r * FS + 260 + ml.m] = (20.0 / 2.302585092994045684) * x[r];   // 20 log10: mfcc.py:150
     }
     __builtin_amdgcn_wave_barrier();
+    LN_STAMP(9);
     const int n_mel = ml.n_mel, dq = ml.dq;
     const double* lm = slice + 260;
     if (ml.dct_split) {
+        // lane = 4 k + part: output k, quarter `part` of the inputs; the slots behind the n_mel log-mel values are
+        // never written (zero since the kernel's start) and their coefficients are zero
         const int k = lane >> 2, part = lane & 3;
-        const int m0 = part * dq, m1 = (m0 + dq) < n_mel ? (m0 + dq) : n_mel;
-        const int kc = k < ml.n_out ? k : 0;
         double acc[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int mb = m0; mb < m0 + dq; mb += 4) {
-            double c[4], x[4][4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const bool in = mb + q < m1;
-                const int m = in ? mb + q : 0;
-                const double cc = ml.Ct[m * n_mel + kc];
-                c[q] = in ? cc : 0.0;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) x[r][q] = lm[r * FS + m];
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[r] = fma(x[r][q], c[q], acc[r]);
-        }
+        padded_dot4_n<WIDE>(ml.jp, ml.ctT, lm + ml.m0, acc);
+        LN_STAMP(10);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             acc[r] += dpp_f64<0xB1>(acc[r]);       // (q0 + q1) + (q2 + q3)
@@ -433,7 +571,7 @@ __device__ __forceinline__ void mel_dct_frames4(const Mel512Lane& ml, double* sl
 #pragma unroll
                 for (int r = 0; r < 4; ++r) q[r][part] = 0.0;
                 for (int m = m0; m < m1; ++m) {
-                    const double c = ml.Ct[m * n_mel + k];
+                    const double c = ml.C[(size_t)k * n_mel + m];       // 13 KB at n_mel = 40: L1-resident
 #pragma unroll
                     for (int r = 0; r < 4; ++r) q[r][part] = fma(lm[r * FS + m], c, q[r][part]);
                 }
@@ -444,6 +582,7 @@ __device__ __forceinline__ void mel_dct_frames4(const Mel512Lane& ml, double* sl
         }
     }
     __builtin_amdgcn_wave_barrier();
+    LN_STAMP(11);
 }
 
 // raw samples of a lane for one group, as loaded: pairs (x[2n], x[2n+1]), n = n1 + 16 n2, and the one sample
@@ -464,39 +603,48 @@ struct __attribute__((aligned(8))) double_pair {
     double a, b;
 };
 
+// NR: rows n2 < NR of the 16 hold samples of the frame (2 (n1 + 16 n2) < frame_len for some n1); the others are zero
+template <int NR>
 __device__ __forceinline__ void load_row(const double* p, RawRow<double>& rw) {
 #pragma unroll
-    for (int n2 = 0; n2 < 16; ++n2) {
+    for (int n2 = 0; n2 < NR; ++n2) {
         const double_pair d = *reinterpret_cast<const double_pair*>(p + 32 * n2);
         rw.x0[n2] = d.a;
         rw.x1[n2] = d.b;
     }
 }
+template <int NR>
 __device__ __forceinline__ void load_row(const int16_t* p, RawRow<int16_t>& rw) {
 #pragma unroll
-    for (int n2 = 0; n2 < 16; ++n2) rw.q[n2] = *reinterpret_cast<const int_a2*>(p + 32 * n2);
+    for (int n2 = 0; n2 < NR; ++n2) rw.q[n2] = *reinterpret_cast<const int_a2*>(p + 32 * n2);
 }
 
 // y[2n], y[2n+1] of an interior frame: y[i] = x[i] - alpha x[i-1], multiply and subtract rounded separately
 // (mfcc.py:63)
+template <int NR>
 __device__ __forceinline__ void preemph_row(const RawRow<double>& rw, int n1, double alpha, cplx v[16]) {
     double t[16];
 #pragma unroll
-    for (int n2 = 0; n2 < 16; ++n2) t[n2] = dpp_f64<0x121>(rw.x1[n2]);      // row_ror:1: lane l <- lane l - 1 (mod 16)
+    for (int n2 = 0; n2 < NR; ++n2) t[n2] = dpp_f64<0x121>(rw.x1[n2]);      // row_ror:1: lane l <- lane l - 1 (mod 16)
 #pragma unroll
-    for (int n2 = 0; n2 < 16; ++n2) {
+    for (int n2 = NR; n2 < 16; ++n2) v[n2] = {0.0, 0.0};
+#pragma unroll
+    for (int n2 = 0; n2 < NR; ++n2) {
         // lane 0 received lane 15's pair n2, which precedes its own pair n2 + 1
         const double wrap = n2 == 0 ? rw.prev : t[n2 - 1];
         const double xm = n1 == 0 ? wrap : t[n2];
         v[n2] = {__dsub_rn(rw.x0[n2], __dmul_rn(alpha, xm)), __dsub_rn(rw.x1[n2], __dmul_rn(alpha, rw.x0[n2]))};
     }
 }
+template <int NR>
 __device__ __forceinline__ void preemph_row(const RawRow<int16_t>& rw, int n1, double alpha, cplx v[16]) {
     int t[16];
 #pragma unroll
-    for (int n2 = 0; n2 < 16; ++n2) t[n2] = __builtin_amdgcn_mov_dpp(rw.q[n2], 0x121, 0xf, 0xf, true);
+    for (int n2 = 0; n2 < NR; ++n2) t[n2] = __builtin_amdgcn_mov_dpp(rw.q[n2], 0x121, 0xf, 0xf, true);
 #pragma unroll
-    for (int n2 = 0; n2 < 16; ++n2) {
+    for (int n2 = NR; n2 < 16; ++n2) v[n2] = {0.0, 0.0};
+#pragma unroll
+    for (int n2 = 0; n2 < NR; ++n2) {
         const int wrap = n2 == 0 ? rw.prev : (t[n2 - 1] >> 16);
         const double xm = (double)(n1 == 0 ? wrap : (t[n2] >> 16));
         const double x0 = (double)(short)(rw.q[n2] & 0xffff), x1 = (double)(rw.q[n2] >> 16);
@@ -504,8 +652,10 @@ __device__ __forceinline__ void preemph_row(const RawRow<int16_t>& rw, int n1, d
     }
 }
 
-template <typename SAMPLE, bool POWER>
-__global__ __launch_bounds__(64 * kX4Waves) void mfcc_frame512x4_kernel(
+// NR = 13 when frame_len <= 416 (the reference's 400): input rows n2 >= 13 of the first pass are all zero, so they are
+// neither loaded nor windowed and their butterflies shrink (fft16<NR>); NR = 16 otherwise.
+template <typename SAMPLE, bool POWER, int NR, int NW>
+__global__ __launch_bounds__(64 * NW) void mfcc_frame512x4_kernel(
     const SAMPLE* __restrict__ signal, const int64_t* __restrict__ soff, const int64_t* __restrict__ foff, int U,
     int64_t F, int L, int S, int n_mel, int n_out, double alpha, const double* __restrict__ window,
     const double* __restrict__ fbank, const int* __restrict__ mel_range, const double* __restrict__ tw512,
@@ -517,13 +667,15 @@ __global__ __launch_bounds__(64 * kX4Waves) void mfcc_frame512x4_kernel(
     __shared__ double T16[2 * 256];                // W256^(n1 k2) at [k2][n1]
     __shared__ double ltab[2 * kLogTab];           // table-driven log (devmath.h)
     __shared__ double taps[MAXTAP];
-    __shared__ double Ct[MAXMEL * MAXMEL];
-    __shared__ int tap_off[MAXMEL + 1];
+    __shared__ double CtP[12 * 64];                // padded lane-major DCT table of the split layout (MAXMEL / 4 rows)
     __shared__ int asg[4 * 64];
     __shared__ int asg_cmax;
-    __shared__ double bufs[kX4Waves][4 * FS];
-    constexpr int NT = 64 * kX4Waves;
+    __shared__ double bufs[NW][4 * FS];
+    constexpr int NT = 64 * NW;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef LNASR_MFCC_STAMPS
+    const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
+#endif
     for (int e = tid; e < 2 * NC; e += NT) {
         tws[e] = tw512[e];
         wins[e] = e < L ? window[e] : 0.0;
@@ -536,16 +688,18 @@ __global__ __launch_bounds__(64 * kX4Waves) void mfcc_frame512x4_kernel(
         T16[2 * e + 1] = sg * tw512[2 * idx + 1];
     }
     log_table_init(ltab, tid, NT);
-    mel_plan_setup(n_mel, n_out, mel_range, fbank, dctC, taps, Ct, tap_off, asg, &asg_cmax, tid, NT, lane, w, kX4Waves);
-    const Mel512Lane ml = mel_plan_lane(n_mel, n_out, mel_range, fbank, taps, Ct, tap_off, asg, asg_cmax, lane);
+    // the slices start out zero: the padded loops of the mel / DCT phase read slots that are never written
+    for (int e = tid; e < NW * 4 * FS; e += NT) (&bufs[0][0])[e] = 0.0;
+    mel_plan_setup(n_mel, n_out, mel_range, fbank, dctC, taps, CtP, asg, &asg_cmax, tid, NT, lane, w, NW);
+    const Mel512Lane ml = mel_plan_lane(n_mel, n_out, mel_range, fbank, taps, dctC, CtP, asg, asg_cmax, lane);
 
     const int row = lane >> 4, n1 = lane & 15;     // pass 1: (frame row, n1); pass 2 and after: k2 = n1
     // a wave walks a contiguous range of groups: its rows change utterance rarely and the 240 samples that
     // successive frames share are still in the L1 when the next group asks for them
-    const int64_t G = (F + 3) / 4, nwv = (int64_t)gridDim.x * kX4Waves, per = (G + nwv - 1) / nwv;
+    const int64_t G = (F + 3) / 4, nwv = (int64_t)gridDim.x * NW, per = (G + nwv - 1) / nwv;
     double* slice = &bufs[w][0];
     double* X = slice + row * FS;
-    int64_t g = ((int64_t)blockIdx.x * kX4Waves + w) * per;
+    int64_t g = ((int64_t)blockIdx.x * NW + w) * per;
     const int64_t gend = g + per < G ? g + per : G;
     if (g >= gend) return;
     // The utterance of this row's frame: frames visited by a row only increase, so the bounds of the current
@@ -553,9 +707,8 @@ __global__ __launch_bounds__(64 * kX4Waves) void mfcc_frame512x4_kernel(
     int u;
     int64_t fbeg, fend, so, n;
     auto locate = [&](int64_t fc, bool first) {
-        if (first) u = find_utt(foff, U, fc);
-        else
-            while (foff[u + 1] <= fc) ++u;
+        if (first) u = find_utt_wave(foff, U, 4 * g < F ? 4 * g : F - 1, lane);    // row 0's frame; the rows walk on from there
+        while (foff[u + 1] <= fc) ++u;
         fbeg = foff[u];
         fend = foff[u + 1];
         so = soff[u];
@@ -572,27 +725,34 @@ __global__ __launch_bounds__(64 * kX4Waves) void mfcc_frame512x4_kernel(
         if (first || fc >= fend) locate(fc, first);
         base = (fc - fbeg) * S;
         xu = signal + so;
-        inner = __all(base >= 1 && base + 2 * NC <= n);
+        inner = __all(base >= 1 && base + 32 * NR <= n);       // every sample the rows n2 < NR read exists
     };
     RawRow<SAMPLE> rw;
     auto request = [&]() {                         // plain loads at constant offsets from one pointer
         const SAMPLE* p = xu + base + 2 * n1;
-        load_row(p, rw);
+        load_row<NR>(p, rw);
         rw.prev = (decltype(rw.prev))xu[base - 1];
     };
     place(g, true);
     if (inner) request();
+    // (Starting the waves w/8 of an iteration apart, so that they are not all in the LDS-heavy phases at once, was
+    // measured: no gain -- 0.315 against 0.313 ms; three waves per SIMD at 168 registers: 0.325, it spills.)
+    LN_STAMP_DECL;
+#ifdef LNASR_MFCC_STAMPS
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_mfcc_stamps[12] += st_prev - st_begin;    // tables + plan + first loads
+#endif
     for (;;) {
+        LN_STAMP(0);
         cplx v[16];
         if (inner) {
-            preemph_row(rw, n1, alpha, v);
+            preemph_row<NR>(rw, n1, alpha, v);
         } else {
             cplx vs[16];                           // through the stack (out-of-line call): v itself stays in registers
 #pragma unroll 1
             for (int r = 0; r < 4; ++r)
                 if (row == r) fetch_row(xu, n, base, n1, alpha, vs);
 #pragma unroll
-            for (int n2 = 0; n2 < 16; ++n2) v[n2] = vs[n2];
+            for (int n2 = 0; n2 < 16; ++n2) v[n2] = n2 < NR ? vs[n2] : cplx{0.0, 0.0};   // beyond NR: the window is zero
         }
         const int64_t fcur = f;
         const bool lcur = live;
@@ -600,18 +760,20 @@ __global__ __launch_bounds__(64 * kX4Waves) void mfcc_frame512x4_kernel(
         ++g;
         const bool more = g < gend;
         if (more) place(g, false);                 // the next group's whereabouts, ahead of its loads
+        LN_STAMP(1);
 #pragma unroll
-        for (int n2 = 0; n2 < 16; ++n2) {
+        for (int n2 = 0; n2 < NR; ++n2) {
             const int k0 = 2 * (n1 + 16 * n2);
             v[n2].re *= wins[k0];
             v[n2].im *= wins[k0 + 1];
         }
-        fft16(v);                                  // over n2
+        fft16<NR>(v);                              // over n2
 #pragma unroll
         for (int k2 = 1; k2 < 16; ++k2) {
             const cplx tw = {T16[2 * (16 * k2 + n1)], T16[2 * (16 * k2 + n1) + 1]};
             v[k2] = cmul(v[k2], tw);
         }
+        LN_STAMP(2);
         // exchange: tile [k2][n1] with rows of 17 (both sides free of bank conflicts)
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) X[k2 * 17 + n1] = v[k2].re;
@@ -625,13 +787,17 @@ __global__ __launch_bounds__(64 * kX4Waves) void mfcc_frame512x4_kernel(
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j].im = X[n1 * 17 + j];
         __builtin_amdgcn_wave_barrier();
+        LN_STAMP(3);
         fft16(v);                                  // over n1: v[k1] = Z[16 k1 + k2]
+        LN_STAMP(4);
         // mirror lane's upper half
+        // lane k2 needs lane (16 - k2) mod 16 of its row: row_mirror (l <- 15 - l) then row_ror:1 (l <- l - 1), two DPP
+        // moves per word and no trip through the LDS crossbar (ds_bpermute: one more latency-bound step, tools/mfcc_stamps.py)
         const int k2 = n1;
-        const int msrc = (lane & 48) | ((16 - k2) & 15);
+        auto mirror = [](double x) { return dpp_f64<0x121>(dpp_f64<0x140>(x)); };
         cplx mz[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) mz[j] = {shfl_f64(v[15 - j].re, msrc), shfl_f64(v[15 - j].im, msrc)};
+        for (int j = 0; j < 8; ++j) mz[j] = {mirror(v[15 - j].re), mirror(v[15 - j].im)};
         const bool lane0 = k2 == 0;
         double esum = 0.0;
         double* prow = POWER && lcur ? power_out + fcur * NBIN : nullptr;
@@ -671,10 +837,13 @@ __global__ __launch_bounds__(64 * kX4Waves) void mfcc_frame512x4_kernel(
         esum += dpp_f64<0x140>(esum);
         if (n1 == 0 && lcur) energy[fcur] = log_fast(esum, ltab);            // mfcc.py:158-160
         __builtin_amdgcn_wave_barrier();
+        LN_STAMP(5);
         // the next group's samples travel while the mel / DCT phase (few registers) runs
         if (more && inner) request();
+        LN_STAMP(6);
         const int64_t left = F - 4 * gcur;
-        mel_dct_frames4(ml, slice, ltab, lane, cepraw + 4 * gcur * n_out, left < 4 ? (int)left : 4);
+        mel_dct_frames4<sizeof(SAMPLE) == 2>(ml, slice, ltab, lane, cepraw + 4 * gcur * n_out, left < 4 ? (int)left : 4);
+        LN_STAMP(7);
         if (!more) break;
     }
 }
@@ -950,15 +1119,21 @@ int lnasr_mfcc(lnasr_ctx* ctx, const void* signal, int sample_kind, const int64_
         int64_t want = ((F + 3) / 4 + kX4Waves - 1) / kX4Waves;
         if (want > cus) want = cus;
         const unsigned grid = (unsigned)want;
-#define LN_X4(name, SAMPLE, POWER)                                                                                   \
-    LN_LAUNCH(ctx, name, (mfcc_frame512x4_kernel<SAMPLE, POWER>), dim3(grid), dim3(64 * kX4Waves), 0,                \
+#define LN_X4R(name, SAMPLE, POWER, NR, NW)                                                                           \
+    LN_LAUNCH(ctx, name, (mfcc_frame512x4_kernel<SAMPLE, POWER, NR, NW>), dim3(grid), dim3(64 * NW), 0,              \
               (const SAMPLE*)d_sig, d_soff, d_foff, U, F, L, S, n_mel, n_out, cfg->hpf_alpha, (const double*)d_win,  \
               (const double*)d_fb, d_range, d_tw, d_C, (double*)d_pow, cep, energy)
+#define LN_X4(name, SAMPLE, POWER)                                  \
+    do {                                                            \
+        if (L <= 416) LN_X4R(name, SAMPLE, POWER, 13, kX4Waves);    \
+        else LN_X4R(name, SAMPLE, POWER, 16, kX4Waves);             \
+    } while (0)
         if (sample_kind == 1 && d_pow) LN_X4("mfcc_frame512x4_i16", int16_t, true);
         else if (sample_kind == 1) LN_X4("mfcc_frame512x4_i16", int16_t, false);
         else if (d_pow) LN_X4("mfcc_frame512x4", double, true);
         else LN_X4("mfcc_frame512x4", double, false);
 #undef LN_X4
+#undef LN_X4R
         fused_dct = true;
     } else if (sample_kind == 1)
         LN_LAUNCH(ctx, "mfcc_frame_i16", mfcc_frame_kernel<int16_t>, dim3((unsigned)F), dim3(nt), shm,
@@ -1001,6 +1176,18 @@ int lnasr_mfcc(lnasr_ctx* ctx, const void* signal, int sample_kind, const int64_
     LN_TRY(finish_out(ctx, features, d_feat, (size_t)F * 3 * W * 8));
     return 0;
 }
+
+#ifdef LNASR_MFCC_STAMPS
+// developer diagnostic only (not in the header): read and clear the phase stamps
+int lnasr_dbg_mfcc_stamps(lnasr_ctx* ctx, unsigned long long* out16) {
+    LN_ENTER(ctx);
+    LN_HIP(hipDeviceSynchronize());
+    LN_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_mfcc_stamps), 16 * 8));
+    unsigned long long z[16] = {0};
+    LN_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_mfcc_stamps), z, 16 * 8));
+    return 0;
+}
+#endif
 
 int lnasr_pad_rows(lnasr_ctx* ctx, const double* packed, const int64_t* row_offsets, int U, int W, int64_t pad_rows,
                    double* padded) {
