@@ -23,6 +23,7 @@ constexpr int kMaxFft = 4096;
 // tools/mfcc_stamps.py reads back.  The stamps drain the LDS counter at every phase boundary and cost ~10 %.
 #ifdef LNASR_MFCC_STAMPS
 __device__ unsigned long long g_mfcc_stamps[16];
+__device__ unsigned long long g_mfcc_wave_times[2 * 4096];     // per wave: first and last 100 MHz tick (last launch)
 #define LN_STAMP_DECL unsigned long long st_prev = __builtin_amdgcn_s_memtime()
 #define LN_STAMP(i)                                                         \
     do {                                                                    \
@@ -621,8 +622,9 @@ __device__ __forceinline__ void load_row(const int16_t* p, RawRow<int16_t>& rw) 
 
 // y[2n], y[2n+1] of an interior frame: y[i] = x[i] - alpha x[i-1], multiply and subtract rounded separately
 // (mfcc.py:63)
+// at_start: the frame begins the utterance, so its first sample has no predecessor: y[0] = x[0] (mfcc.py:63)
 template <int NR>
-__device__ __forceinline__ void preemph_row(const RawRow<double>& rw, int n1, double alpha, cplx v[16]) {
+__device__ __forceinline__ void preemph_row(const RawRow<double>& rw, int n1, double alpha, bool at_start, cplx v[16]) {
     double t[16];
 #pragma unroll
     for (int n2 = 0; n2 < NR; ++n2) t[n2] = dpp_f64<0x121>(rw.x1[n2]);      // row_ror:1: lane l <- lane l - 1 (mod 16)
@@ -635,9 +637,10 @@ __device__ __forceinline__ void preemph_row(const RawRow<double>& rw, int n1, do
         const double xm = n1 == 0 ? wrap : t[n2];
         v[n2] = {__dsub_rn(rw.x0[n2], __dmul_rn(alpha, xm)), __dsub_rn(rw.x1[n2], __dmul_rn(alpha, rw.x0[n2]))};
     }
+    if (at_start && n1 == 0) v[0].re = rw.x0[0];
 }
 template <int NR>
-__device__ __forceinline__ void preemph_row(const RawRow<int16_t>& rw, int n1, double alpha, cplx v[16]) {
+__device__ __forceinline__ void preemph_row(const RawRow<int16_t>& rw, int n1, double alpha, bool at_start, cplx v[16]) {
     int t[16];
 #pragma unroll
     for (int n2 = 0; n2 < NR; ++n2) t[n2] = __builtin_amdgcn_mov_dpp(rw.q[n2], 0x121, 0xf, 0xf, true);
@@ -650,6 +653,7 @@ __device__ __forceinline__ void preemph_row(const RawRow<int16_t>& rw, int n1, d
         const double x0 = (double)(short)(rw.q[n2] & 0xffff), x1 = (double)(rw.q[n2] >> 16);
         v[n2] = {__dsub_rn(x0, __dmul_rn(alpha, xm)), __dsub_rn(x1, __dmul_rn(alpha, x0))};
     }
+    if (at_start && n1 == 0) v[0].re = (double)(short)(rw.q[0] & 0xffff);
 }
 
 // NR = 13 when frame_len <= 416 (the reference's 400): input rows n2 >= 13 of the first pass are all zero, so they are
@@ -657,7 +661,7 @@ __device__ __forceinline__ void preemph_row(const RawRow<int16_t>& rw, int n1, d
 template <typename SAMPLE, bool POWER, int NR, int NW>
 __global__ __launch_bounds__(64 * NW) void mfcc_frame512x4_kernel(
     const SAMPLE* __restrict__ signal, const int64_t* __restrict__ soff, const int64_t* __restrict__ foff, int U,
-    int64_t F, int L, int S, int n_mel, int n_out, double alpha, const double* __restrict__ window,
+    int64_t F, int64_t NS, int L, int S, int n_mel, int n_out, double alpha, const double* __restrict__ window,
     const double* __restrict__ fbank, const int* __restrict__ mel_range, const double* __restrict__ tw512,
     const double* __restrict__ dctC, double* __restrict__ power_out, double* __restrict__ cepraw,
     double* __restrict__ energy) {
@@ -670,11 +674,13 @@ __global__ __launch_bounds__(64 * NW) void mfcc_frame512x4_kernel(
     __shared__ double CtP[12 * 64];                // padded lane-major DCT table of the split layout (MAXMEL / 4 rows)
     __shared__ int asg[4 * 64];
     __shared__ int asg_cmax;
+    __shared__ int ticket;                         // next undrawn group of the block's range (relative)
     __shared__ double bufs[NW][4 * FS];
     constexpr int NT = 64 * NW;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef LNASR_MFCC_STAMPS
     const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
+    const unsigned long long st_rbegin = __builtin_amdgcn_s_memrealtime();     // 100 MHz
 #endif
     for (int e = tid; e < 2 * NC; e += NT) {
         tws[e] = tw512[e];
@@ -694,14 +700,34 @@ __global__ __launch_bounds__(64 * NW) void mfcc_frame512x4_kernel(
     const Mel512Lane ml = mel_plan_lane(n_mel, n_out, mel_range, fbank, taps, dctC, CtP, asg, asg_cmax, lane);
 
     const int row = lane >> 4, n1 = lane & 15;     // pass 1: (frame row, n1); pass 2 and after: k2 = n1
-    // a wave walks a contiguous range of groups: its rows change utterance rarely and the 240 samples that
-    // successive frames share are still in the L1 when the next group asks for them
-    const int64_t G = (F + 3) / 4, nwv = (int64_t)gridDim.x * NW, per = (G + nwv - 1) / nwv;
+    // Work distribution.  A block owns a contiguous range of groups (its rows change utterance rarely) and its waves
+    // draw chunks of kChunk consecutive groups from a ticket counter in the LDS (the 240 samples successive frames share
+    // are still in the L1 within a chunk).  A static split -- 1/8 of the range per wave, rounds 1-2 -- loses a fifth of
+    // the kernel to its own tail: the two waves of a SIMD are not served alike (the older one issues whenever it can,
+    // the younger fills the gaps), so waves 0-3 of every block finished after 194 us and waves 4-7 after 252 us, alone
+    // on their SIMDs for the difference (per-wave lifetimes: tools/mfcc_stamps.py); and ceil(G / waves) groups per wave
+    // left the last six blocks without work.  With tickets the fast waves simply take more chunks.
+    constexpr int kChunk = 2;
+    const int64_t G = (F + 3) / 4, per_block = (G + gridDim.x - 1) / gridDim.x;
+    const int64_t bbeg = (int64_t)blockIdx.x * per_block, bend = bbeg + per_block < G ? bbeg + per_block : G;
+    if (tid == 0) ticket = 0;
+    __syncthreads();
+    auto draw = [&]() -> int64_t {                 // first group of the next chunk (wave-uniform); >= bend: none left
+        int t = 0;
+        if (lane == 0) t = atomicAdd(&ticket, kChunk);
+        return bbeg + __builtin_amdgcn_readfirstlane(t);
+    };
     double* slice = &bufs[w][0];
     double* X = slice + row * FS;
-    int64_t g = ((int64_t)blockIdx.x * NW + w) * per;
-    const int64_t gend = g + per < G ? g + per : G;
-    if (g >= gend) return;
+    int64_t g = draw();
+    int64_t cend = g + kChunk;                     // end of the chunk in hand
+#ifdef LNASR_MFCC_STAMPS
+    if (g >= bend && lane == 0 && blockIdx.x * NW + w < 4096) {
+        g_mfcc_wave_times[2 * (blockIdx.x * NW + w)] = st_rbegin;
+        g_mfcc_wave_times[2 * (blockIdx.x * NW + w) + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+    if (g >= bend) return;
     // The utterance of this row's frame: frames visited by a row only increase, so the bounds of the current
     // utterance stay in registers and memory is touched again only when a row crosses into the next one.
     int u;
@@ -725,13 +751,20 @@ __global__ __launch_bounds__(64 * NW) void mfcc_frame512x4_kernel(
         if (first || fc >= fend) locate(fc, first);
         base = (fc - fbeg) * S;
         xu = signal + so;
-        inner = __all(base >= 1 && base + 32 * NR <= n);       // every sample the rows n2 < NR read exists
+        // The fast path takes every frame whose frame_len samples all exist.  It reads 32 NR samples (16 past a 400-sample
+        // frame): what lies behind the utterance -- the next one's first samples -- is multiplied by the window's zeros
+        // (and selected away, so that not even a NaN there can leak), it only has to be readable: inside the batch's
+        // buffer.  The first frame of an utterance is in too (its first sample has no predecessor: at_start).  Until
+        // round 3 both the first and the last frame of EVERY utterance took the row-by-row edge path below -- ~4x a
+        // group's time, and the waves that met one set the kernel's duration (tools/mfcc_stamps.py: wave lifetimes
+        // 232 us median, 293 us maximum).
+        inner = __all(base + L <= n && so + base + 32 * NR <= NS);
     };
     RawRow<SAMPLE> rw;
     auto request = [&]() {                         // plain loads at constant offsets from one pointer
         const SAMPLE* p = xu + base + 2 * n1;
         load_row<NR>(p, rw);
-        rw.prev = (decltype(rw.prev))xu[base - 1];
+        rw.prev = (decltype(rw.prev))signal[so + base > 0 ? so + base - 1 : 0];    // unused when base == 0 (at_start)
     };
     place(g, true);
     if (inner) request();
@@ -743,9 +776,12 @@ __global__ __launch_bounds__(64 * NW) void mfcc_frame512x4_kernel(
 #endif
     for (;;) {
         LN_STAMP(0);
+#ifdef LNASR_MFCC_STAMPS
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_mfcc_stamps[15] += 1;     // groups this lane's wave walked
+#endif
         cplx v[16];
         if (inner) {
-            preemph_row<NR>(rw, n1, alpha, v);
+            preemph_row<NR>(rw, n1, alpha, base == 0, v);
         } else {
             cplx vs[16];                           // through the stack (out-of-line call): v itself stays in registers
 #pragma unroll 1
@@ -758,7 +794,11 @@ __global__ __launch_bounds__(64 * NW) void mfcc_frame512x4_kernel(
         const bool lcur = live;
         const int64_t gcur = g;
         ++g;
-        const bool more = g < gend;
+        if (g == cend) {                           // chunk exhausted: the next one (a wave's groups only ever increase)
+            g = draw();
+            cend = g + kChunk;
+        }
+        const bool more = g < bend;
         if (more) place(g, false);                 // the next group's whereabouts, ahead of its loads
         LN_STAMP(1);
 #pragma unroll
@@ -766,6 +806,10 @@ __global__ __launch_bounds__(64 * NW) void mfcc_frame512x4_kernel(
             const int k0 = 2 * (n1 + 16 * n2);
             v[n2].re *= wins[k0];
             v[n2].im *= wins[k0 + 1];
+            if (n2 >= 12) {                        // rows that can reach past frame_len: zero whatever was read there
+                if (k0 >= L) v[n2].re = 0.0;
+                if (k0 + 1 >= L) v[n2].im = 0.0;
+            }
         }
         fft16<NR>(v);                              // over n2
 #pragma unroll
@@ -846,6 +890,19 @@ __global__ __launch_bounds__(64 * NW) void mfcc_frame512x4_kernel(
         LN_STAMP(7);
         if (!more) break;
     }
+#ifdef LNASR_MFCC_STAMPS
+    if (blockIdx.x == 0 && threadIdx.x == 0) {     // the wave's lifetime in shader cycles and in 100 MHz ticks: the clock it ran at
+        g_mfcc_stamps[13] += __builtin_amdgcn_s_memtime() - st_begin;
+        g_mfcc_stamps[14] += __builtin_amdgcn_s_memrealtime() - st_rbegin;
+    }
+    if (lane == 0) {
+        const int wi = blockIdx.x * NW + w;
+        if (wi < 4096) {
+            g_mfcc_wave_times[2 * wi] = st_rbegin;
+            g_mfcc_wave_times[2 * wi + 1] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
+#endif
 }
 
 // Column sums over the frames of each utterance of the first nc columns of X [F, ld].  grid = (U, P): an
@@ -915,10 +972,6 @@ __global__ void feat_kernel(const double* __restrict__ cepraw, const double* __r
     }
     __syncthreads();
     const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;      // < 2^32: checked by the host
-    const unsigned fi = idx / (unsigned)ncols;
-    const int64_t f = f0 + fi;
-    const int k = (int)(idx - fi * (unsigned)ncols);
-    if (f >= f1) return;
     const double shift0 = 1e-8 * sqrt((double)n_mel);
     auto cepv = [&](int64_t ff, int kk) -> double {
         double v = cepraw[ff * ld + kk] - mean_s[kk];
@@ -926,6 +979,12 @@ __global__ void feat_kernel(const double* __restrict__ cepraw, const double* __r
         if (kk >= 1 && kk <= nc) v -= 1e-8;
         return v;
     };
+    // (One thread per OUTPUT element -- 39 per frame, a wave writing 512 contiguous bytes -- was measured in round 3:
+    // 0.115 ms against 0.047: every element then re-reads and re-centres up to five cepstrum values.)
+    const unsigned fi = idx / (unsigned)ncols;
+    const int64_t f = f0 + fi;
+    const int k = (int)(idx - fi * (unsigned)ncols);
+    if (f >= f1) return;
     if (cep_out) cep_out[f * n_mel + k] = cepv(f, k);
     if (k >= W) return;
     const int c = k;                            // feature column
@@ -1121,7 +1180,7 @@ int lnasr_mfcc(lnasr_ctx* ctx, const void* signal, int sample_kind, const int64_
         const unsigned grid = (unsigned)want;
 #define LN_X4R(name, SAMPLE, POWER, NR, NW)                                                                           \
     LN_LAUNCH(ctx, name, (mfcc_frame512x4_kernel<SAMPLE, POWER, NR, NW>), dim3(grid), dim3(64 * NW), 0,              \
-              (const SAMPLE*)d_sig, d_soff, d_foff, U, F, L, S, n_mel, n_out, cfg->hpf_alpha, (const double*)d_win,  \
+              (const SAMPLE*)d_sig, d_soff, d_foff, U, F, NS, L, S, n_mel, n_out, cfg->hpf_alpha, (const double*)d_win, \
               (const double*)d_fb, d_range, d_tw, d_C, (double*)d_pow, cep, energy)
 #define LN_X4(name, SAMPLE, POWER)                                  \
     do {                                                            \
@@ -1185,6 +1244,12 @@ int lnasr_dbg_mfcc_stamps(lnasr_ctx* ctx, unsigned long long* out16) {
     LN_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_mfcc_stamps), 16 * 8));
     unsigned long long z[16] = {0};
     LN_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_mfcc_stamps), z, 16 * 8));
+    return 0;
+}
+int lnasr_dbg_mfcc_wave_times(lnasr_ctx* ctx, unsigned long long* out8192) {
+    LN_ENTER(ctx);
+    LN_HIP(hipDeviceSynchronize());
+    LN_HIP(hipMemcpyFromSymbol(out8192, HIP_SYMBOL(g_mfcc_wave_times), 8192 * 8));
     return 0;
 }
 #endif

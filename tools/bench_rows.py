@@ -128,6 +128,15 @@ if what & {"bw", "all"}:
           U * T, "frames", reps=2)
     timed("Baum-Welch statistics, precision=float32", lambda: _ffi.check(lib.lnasr_bw_accumulate_p(ctx.handle, obs.ptr, U, T, None, 1, stats.ptr)),
           U * T, "frames", reps=2)
+    # the two numbers that price the "recompute bm inside the moments kernel" alternative: the emission
+    # WITHOUT the per-mixture output (what a fused pass would still run before the trellises), and with it (what runs now)
+    bb = ctx.empty((U, T, N), np.float64)
+    timed("  emission, b only (config-5 shape)", lambda: _ffi.check(lib.lnasr_gmm_logprob(ctx.handle, obs.ptr, U, T, None, 0, bb.ptr, None)),
+          U * T, "frames", reps=2, algo_flop=U * T * 3.0 * N * M * D)
+    bm = ctx.empty((U, T, N, M), np.float64)
+    timed("  emission, b + bm (config-5 shape)", lambda: _ffi.check(lib.lnasr_gmm_logprob(ctx.handle, obs.ptr, U, T, None, 0, bb.ptr, bm.ptr)),
+          U * T, "frames", reps=2, algo_flop=U * T * 3.0 * N * M * D)
+    del bm, bb
 
 if what & {"full", "all"}:
     # full-covariance bank (the reference's own M-step produces full Sigma): N=128, M=16, D=39

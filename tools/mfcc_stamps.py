@@ -49,7 +49,7 @@ reps = 5
 for _ in range(reps):
     ctx.mfcc(d_sig, offs, cfg, win, bank, False, False, fo)
 raw.lnasr_dbg_mfcc_stamps(ctx.handle, buf)
-groups = reps * 32.0                     # groups walked by one wave per launch: 64,000 groups / 2048 waves
+groups = float(buf[15])                  # groups the stamped wave walked (waves draw chunks from a ticket counter)
 names = ["loop top -> stamp", "pre-emphasis (waits for the prefetched samples) + next group's whereabouts",
          "window + fft16 #1 + twiddle", "exchange through the LDS (4 phases)", "fft16 #2",
          "mirror shuffles + real-input split + power stores + energy", "request next samples",
@@ -59,4 +59,25 @@ print("cycles per group of four frames (lane 0 of one wave, %s samples): total %
                                                                                          tot / groups))
 for i, nm in enumerate(names):
     print("  %8.0f  %s" % (buf[i] / groups, nm))
+life, real = buf[13] / reps, buf[14] / reps
+print("  wave lifetime %.0f shader cycles = %.1f us of the 100 MHz counter -> in-kernel clock %.2f GHz" % (life, real / 100.0, life / (real * 10.0)))
 print("  %8.0f  kernel start -> first group (tables, lane plan, first loads), cycles per LAUNCH" % (buf[12] / reps))
+
+# when each wave of the LAST launch lived (100 MHz ticks): how much of the kernel's duration is start-up skew and tail
+wt = (C.c_ulonglong * 8192)()
+raw.lnasr_dbg_mfcc_wave_times.argtypes = [C.c_void_p, C.c_void_p]
+raw.lnasr_dbg_mfcc_wave_times(ctx.handle, wt)
+t = np.array(wt[:], dtype=np.float64).reshape(4096, 2)[:2048] / 100.0          # us
+t0 = t[:, 0].min()
+start, end = t[:, 0] - t0, t[:, 1] - t0
+dur = end - start
+print("waves: first start 0, last start %.1f us; first end %.1f, last end %.1f us; lifetime min / median / max %.1f / %.1f / %.1f us"
+      % (start.max(), end.min(), end.max(), dur.min(), np.median(dur), dur.max()))
+blk = dur.reshape(256, 8)
+print("per block (8 waves): median of block maxima %.1f us; slowest blocks %s" % (np.median(blk.max(axis=1)), np.round(np.sort(blk.max(axis=1))[-5:], 1)))
+print("starts by block: min %.1f median %.1f max %.1f us" % (start.reshape(256, 8).min(axis=1).min(), np.median(start.reshape(256, 8).min(axis=1)), start.reshape(256, 8).min(axis=1).max()))
+for bi in (0, 1, 7, 100, 255):
+    print("block %3d wave lifetimes (us): %s" % (bi, np.round(blk[bi], 1)))
+order = np.argsort(dur)
+print("fastest waves:", order[:8], "slowest waves:", order[-8:])
+print("mean lifetime by wave slot (w = 0..7):", np.round(blk.mean(axis=0), 1))
