@@ -488,17 +488,20 @@ __global__ void pack_single_direct_kernel(const double* __restrict__ mu, const d
 }
 
 template <int KS, bool WRITE_BM, bool CEN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void emit_single_direct(const double* __restrict__ obs,
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void emit_single_direct(const double* __restrict__ obs,
                                                           const double* __restrict__ wdirect,
                                                           const double* __restrict__ logw,
                                                           const double* __restrict__ centre, double* __restrict__ b,
                                                           double* __restrict__ bm, long F, int M, int D, long ntiles) {
     constexpr int NL = KS / 2;                 // loads per lane and tile
+    constexpr unsigned kTick = 2;              // tiles per draw (1: 0.079 ms, the draw then sits in front of every prefetch; 2: 0.074)
     __shared__ double etab[kExpTab];
     __shared__ double ltab[2 * kLogTab];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int e = tid; e < kExpTab; e += 256) etab[e] = exp2((double)e * (1.0 / kExpTab));
-    log_table_init(ltab, tid, 256);
+    __shared__ unsigned ticket;                // next undrawn tile of the block's range (relative)
+    for (int e = tid; e < kExpTab; e += 1024) etab[e] = exp2((double)e * (1.0 / kExpTab));
+    log_table_init(ltab, tid, 1024);
+    if (tid == 0) ticket = 16 * kTick;         // every wave's first chunk is its own
     __syncthreads();                           // tables ready; from here on waves never synchronise
     double wr[KS];
 #pragma unroll
@@ -528,18 +531,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         for (int j = 0; j < NL; ++j)
             pre[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, vo + 32 * j, 0, 0));
     };
-    const long wid = (long)blockIdx.x * 4 + w, nw = (long)gridDim.x * 4;
-    long tile = wid;
-    drain_vmem();                              // wr[] resident: no vmcnt guards inside the loop
-    load_tile(tile);
-    for (; tile < ntiles; tile += nw) {
+    // A block (16 waves, four per SIMD: one block per CU) owns a contiguous range of tiles and its waves draw them from a
+    // ticket counter in the LDS, kTick at a time.  A static stride gives every wave the same number of tiles, but the
+    // four waves of a SIMD are not served alike -- the oldest issues whenever it can -- so the youngest ones set the
+    // kernel's duration while the others have long finished (the MFCC frame kernel showed it: DESIGN 4.6).  (A
+    // device-wide counter was tried first: 32,000 atomics on one address serialise in the L2 -- 0.47 ms against 0.08.)
+    const long per_block = (ntiles + gridDim.x - 1) / gridDim.x;
+    const long tbeg = (long)blockIdx.x * per_block, tend = tbeg + per_block < ntiles ? tbeg + per_block : ntiles;
+    auto draw = [&]() -> long {                    // first tile of the next chunk (wave-uniform); >= tend: none left
+        unsigned t = 0;
+        if (lane == 0) t = atomicAdd(&ticket, kTick);
+        return tbeg + (long)__builtin_amdgcn_readfirstlane(t);
+    };
+    drain_vmem();                              // wr[] resident: no vmcnt guards on it inside the loop
+    long tile = tbeg + (long)w * kTick;
+    unsigned left = kTick;
+    load_tile(tile < tend ? tile : ntiles);
+    while (tile < tend) {
+        long nxt = tile + 1;
+        if (--left == 0) {
+            nxt = draw();
+            left = kTick;
+        }
+        if (nxt >= tend) nxt = ntiles;             // nothing left: the prefetch below then reads nothing
         double bx[NL], bq[NL];
 #pragma unroll
         for (int j = 0; j < NL; ++j) {
             bx[j] = CEN ? pre[j] - cen[CEN ? j : 0] : pre[j];
             bq[j] = is_one[j] ? 1.0 : bx[j] * bx[j];
         }
-        load_tile(tile + nw);
+        load_tile(nxt);
         double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int j = 0; j < NL; ++j) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wr[j], bq[j], acc, 0, 0, 0);
@@ -563,6 +584,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         sacc += shfl_xor_f64(sacc, 16);
         sacc += shfl_xor_f64(sacc, 32);
         if (g == 0 && frame < F) b[frame] = (mx == LN_NEG_INF) ? mx : mx + log_sum(sacc, ltab);
+        tile = nxt;
     }
 }
 
@@ -1024,11 +1046,12 @@ int emit_device(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, v
     if (md.diag && dtype == LNASR_F64 && md.wdirect_KS > 0 && !sw().no_mfma) {
         const long ntiles = (F + 15) / 16;
         const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
-        long grid = (ntiles + 3) / 4;
-        // grid-stride over tiles, every wave resident: four 4-wave blocks per CU (128 VGPRs, 4 KB of LDS each)
-        if (grid > (long)cus * 4) grid = (long)cus * 4;
+        // every wave resident: one 16-wave block per CU (128 VGPRs, 4 KB of LDS); each block walks its own range of
+        // tiles, its waves drawing them from a ticket counter in the LDS
+        long grid = (ntiles + 31) / 32;
+        if (grid > (long)cus) grid = (long)cus;
 #define LN_DLAUNCH(ks, wbm, cen, name)                                                                            \
-    LN_LAUNCH(ctx, name, (emit_single_direct<ks, wbm, cen>), dim3((unsigned)grid), dim3(256), 0, obs,             \
+    LN_LAUNCH(ctx, name, (emit_single_direct<ks, wbm, cen>), dim3((unsigned)grid), dim3(1024), 0, obs,            \
               md.wdirect.as<double>(), md.logw.as<double>(), (const double*)md.centre.as<double>(), (double*)b,   \
               (double*)bm, F, M, D, ntiles)
 #define LN_DCASE(ks)                                                                                              \
