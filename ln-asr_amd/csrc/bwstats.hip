@@ -247,6 +247,7 @@ __global__ __launch_bounds__(64 * kMixWaves) void mix_mfma_kernel(const double* 
     __shared__ double sab[2][CH * kMixWaves], sbb[2][CH * kMixWaves];
     __shared__ double etab[kExpTab];
     __shared__ double cen[40];
+    LN_BLOCK_T0;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l15 = lane & 15, kk = lane >> 4;
     // wave <-> (state j, group of 32 mixtures mg): M > 32 runs as G = ceil(M / 32) groups per state
@@ -385,7 +386,9 @@ __global__ __launch_bounds__(64 * kMixWaves) void mix_mfma_kernel(const double* 
                     if (v != 0.0) atomicAdd(&R[((size_t)j * MP + mo + m) * NFP + 16 * ct + l15], v);
                 }
     }
+    LN_BLOCK_T1;
 }
+LN_BLOCK_TIMES_EXPORT(lnasr_dbg_block_times_bwstats)
 
 // mix[j,m] = Sg;  mix_x = S1 + c Sg;  mix_xx = sum g (o - mu_old)^2 = S2 - 2 (mu - c) S1 + (mu - c)^2 Sg
 __global__ void mix_finish_kernel(const double* __restrict__ R, const double* __restrict__ mu,

@@ -10,6 +10,43 @@ constexpr double kLog2Pi = 1.8378770664093454835606594728112;   // ln(2 pi)
 
 #define LN_NEG_INF (-__builtin_huge_val())
 
+// Two blocks that share a CU are not served alike: the SIMD arbiter goes by priority, then AGE, so the older block runs
+// nearly unimpeded, the younger gets the leftover issue slots, finishes long after it and is alone on the CU (unable to
+// fill it) for the difference (tools/block_times.py).  Kernels whose grid is two resident blocks per CU call this once
+// per loop turn: the two halves of the grid (blocks b and b + nblocks / 2 go to the same CU: the first half fills every
+// CU once) raise their priority in alternate 164 us periods of the 100 MHz clock, each gets the arbiter's favour half of
+// the time, and they finish together.  If the pairing is not what is assumed nothing is lost: two blocks of one class
+// tie on priority and fall back on age.
+__device__ __forceinline__ void alternate_priority(unsigned block_class) {
+    if ((((unsigned)__builtin_amdgcn_s_memrealtime() >> 14) ^ block_class) & 1u) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+}
+
+// Developer diagnostic (-DLNASR_BLOCK_TIMES, tools/block_times.py; never in the shipped build): first and last 100 MHz
+// tick of every block of an instrumented kernel, per translation unit.  Shows start-up skew, tails and imbalance that
+// the kernel's duration alone hides (it found the MFCC kernel's 20 % tail: DESIGN 4.6).
+#ifdef LNASR_BLOCK_TIMES
+static __device__ unsigned long long g_block_times[2 * 16384];
+#define LN_BLOCK_T0 const unsigned long long bt0__ = __builtin_amdgcn_s_memrealtime()
+#define LN_BLOCK_T1                                                                  \
+    do {                                                                             \
+        const unsigned bid__ = blockIdx.x + gridDim.x * blockIdx.y;                  \
+        if (threadIdx.x == 0 && bid__ < 16384) {                                     \
+            g_block_times[2 * bid__] = bt0__;                                        \
+            g_block_times[2 * bid__ + 1] = __builtin_amdgcn_s_memrealtime();         \
+        }                                                                            \
+    } while (0)
+#define LN_BLOCK_TIMES_EXPORT(fn)                                                    \
+    extern "C" int fn(unsigned long long* out) {                                     \
+        if (hipDeviceSynchronize() != hipSuccess) return -1;                         \
+        return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_block_times), sizeof(g_block_times)) == hipSuccess ? 0 : -1; \
+    }
+#else
+#define LN_BLOCK_T0
+#define LN_BLOCK_T1
+#define LN_BLOCK_TIMES_EXPORT(fn)
+#endif
+
 template <typename TS>
 __device__ __forceinline__ double ld(const TS* p, size_t i) { return (double)p[i]; }
 template <typename TS>

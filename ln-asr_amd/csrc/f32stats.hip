@@ -211,6 +211,7 @@ __global__ __launch_bounds__(kMix32NT) void mix_mfma_f32(const double* __restric
     __shared__ float feat[2][CH * FST];
     __shared__ float sab[2][CH * kMix32Waves];
     __shared__ double cen[40];
+    LN_BLOCK_T0;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l15 = lane & 15, kk = lane >> 4;
     const int j = blockIdx.x * kMix32Waves + w;
@@ -345,7 +346,9 @@ __global__ __launch_bounds__(kMix32NT) void mix_mfma_f32(const double* __restric
         __syncthreads();
     }
     flush_acc();
+    LN_BLOCK_T1;
 }
+LN_BLOCK_TIMES_EXPORT(lnasr_dbg_block_times_f32stats)
 
 // bwstats.hip
 int mix_centre_launch(lnasr_ctx* ctx, double* centre);

@@ -267,6 +267,7 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 2))
     __shared__ double ltab[2 * kLogTab];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    LN_BLOCK_T0;
     exp_table_big_init(etab, tid, NT);
     log_table_init(ltab, tid, NT);
     const long bid = blockIdx.x;
@@ -443,7 +444,9 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 2))
         const long nst = (tile1 - tile0 + TPS - 1) / TPS;
         flush_stage((int)((nst - 1) & 1), tile0 + (nst - 1) * TPS);
     }
+    LN_BLOCK_T1;
 }
+LN_BLOCK_TIMES_EXPORT(lnasr_dbg_block_times_gmm)
 
 // ------------------------------------------------------------------------------------------
 // single GMM (N = 1, M <= 16): HBM-bound row of the path (gmm.py:90-100 over a batch)

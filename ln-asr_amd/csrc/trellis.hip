@@ -278,14 +278,23 @@ __global__ void backtrace_kernel(const TS* __restrict__ v, const double* __restr
 // TS = storage type of b and v.  float: the arithmetic stays fp64 and every v is rounded to float where the
 // reference's float32 array rounds it (hmm.py:165 with precision=np.float32) -- each row-slice maximum right
 // before the slices meet, which equals rounding their maximum (rounding is monotonic).
-template <int CPT, int NW, int RPT, int UB, int WPE, typename TS = double>
+// ALT: two of these blocks share a CU (UB = 2, U >= 512) and are not served alike -- the SIMD arbiter goes by priority,
+// then AGE, so the older block ran nearly unimpeded and finished after 0.93 ms while the younger, fed the leftover
+// slots, needed 1.40 ms: alone on the CU (and unable to fill it) for the difference, 83 % slot utilisation
+// (tools/block_times.py).  With ALT the two halves of the grid raise their priority in alternate periods of the 100 MHz
+// clock (alternate_priority, devmath.h; measured with periods of 10 us: 1.33 ms, 41 us: 1.27, 164 us: 1.25, 0.65 ms: 1.26,
+// 1.3 ms: 1.34) and finish together: 1.37 -> 1.25 ms.  (Merging the two blocks behind ONE barrier
+// -- 16 waves in lock-step -- was measured first: 2.68 ms; the independent blocks hide each other's per-frame latency.)
+template <int CPT, int NW, int RPT, int UB, int WPE, typename TS = double, bool ALT = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void viterbi_reg1b(
     const TS* __restrict__ b, const double* __restrict__ A, const double* __restrict__ pi,
     const int32_t* __restrict__ lens, TS* __restrict__ v, int U, int T, int N) {
     constexpr int NP = 64 * CPT;
     __shared__ double Vs[3][UB][NP];
+    LN_BLOCK_T0;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int u0 = blockIdx.x * UB;
+    const unsigned cls = ALT && blockIdx.x >= (gridDim.x + 1) / 2 ? 1u : 0u;
 
     double areg[CPT][RPT];
 #pragma unroll
@@ -337,6 +346,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
 
     int cur = 0;                                   // buffer holding v[t-1]
     for (int t = 1; t < maxlen; ++t) {
+        if (ALT && (t & 7) == 0) alternate_priority(cls);     // devmath.h
         const int nxt = cur == 2 ? 0 : cur + 1, rst = nxt == 2 ? 0 : nxt + 1;
         double bcur[UB][CPT];
         const int tn = t + 1 < T ? t + 1 : T - 1;
@@ -392,7 +402,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
         const int k = w / CPT, c = w % CPT, j = lane + 64 * c;
         if (j < N && maxlen - 1 < len[k]) st(v, ((size_t)(u0 + k) * T + (maxlen - 1)) * N + j, Vs[cur][k][j]);
     }
+    LN_BLOCK_T1;
 }
+LN_BLOCK_TIMES_EXPORT(lnasr_dbg_block_times_trellis)
 
 // ------------------------------------------------------------------------------------------
 // Tiny models (N <= 16): the character-segmentation HMM of scripts/seg/seg.py (n = 4, one sequence of tens of
@@ -2077,7 +2089,7 @@ int viterbi_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
                 LN_LAUNCH(ctx, "viterbi_reg1b_n128_u1", (viterbi_reg1b<2, 8, 16, 1, 4>), dim3(U), dim3(512), 0,
                           (const double*)b, A, pi, d_lens, (double*)v, U, T, N);
             } else {
-                LN_LAUNCH(ctx, "viterbi_reg1b_n128", (viterbi_reg1b<2, 8, 16, 2, 4>), dim3((U + 1) / 2), dim3(512), 0,
+                LN_LAUNCH(ctx, "viterbi_reg1b_n128", (viterbi_reg1b<2, 8, 16, 2, 4, double, true>), dim3((U + 1) / 2), dim3(512), 0,
                           (const double*)b, A, pi, d_lens, (double*)v, U, T, N);
             }
             return 0;
@@ -2090,7 +2102,7 @@ int viterbi_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
             LN_LAUNCH(ctx, "viterbi_reg1b_n128_u1_f32", (viterbi_reg1b<2, 8, 16, 1, 4, float>), dim3(U), dim3(512), 0,
                       (const float*)b, A, pi, d_lens, (float*)v, U, T, N);
         else
-            LN_LAUNCH(ctx, "viterbi_reg1b_n128_f32", (viterbi_reg1b<2, 8, 16, 2, 4, float>), dim3((U + 1) / 2), dim3(512), 0,
+            LN_LAUNCH(ctx, "viterbi_reg1b_n128_f32", (viterbi_reg1b<2, 8, 16, 2, 4, float, true>), dim3((U + 1) / 2), dim3(512), 0,
                       (const float*)b, A, pi, d_lens, (float*)v, U, T, N);
         return 0;
     }
