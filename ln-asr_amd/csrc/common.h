@@ -171,6 +171,16 @@ struct lnasr_ctx {
 
 namespace lnasr {
 
+// LN_LAUNCH (and its profiling events) follow ctx->stream: device helpers are sent to another stream of the context
+// by this guard, which puts the stream back on EVERY way out of the scope (an early return through LN_TRY included)
+struct StreamScope {
+    lnasr_ctx* c;
+    hipStream_t saved;
+    StreamScope(lnasr_ctx* ctx, hipStream_t s) : c(ctx), saved(ctx->stream) { ctx->stream = s; }
+    ~StreamScope() { c->stream = saved; }
+    StreamScope(const StreamScope&) = delete;
+    StreamScope& operator=(const StreamScope&) = delete;
+};
 int prof_begin(lnasr_ctx* ctx, const char* name);   // returns record index or -1
 void prof_end(lnasr_ctx* ctx, int rec);
 

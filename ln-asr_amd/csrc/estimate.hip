@@ -682,7 +682,7 @@ int lnasr_bw_accumulate_p(lnasr_ctx* ctx, const double* obs, int U, int T, const
     const StatsLayout L = stats_layout(N, M, D, md.diag);
     const int32_t* d_lens;
     LN_TRY(device_lens(ctx, lens, U, T, &d_lens));
-    const double* d_obs;
+    const double* d_obs = nullptr;
     void* d_st;
     LN_TRY(stage_out(ctx, stats, L.total * 8, ctx->ws_stats, &d_st));
     double* st = (double*)d_st;
@@ -703,8 +703,12 @@ int lnasr_bw_accumulate_p(lnasr_ctx* ctx, const double* obs, int U, int T, const
     double* be = ctx->ws_beta.as<double>();
     LN_REQUIRE(U <= 65535, "U=%d too large for one statistics launch", U);
     const bool mfma_stats = !sw().no_mfma_stats;
-    // (Cutting the batch into utterance chunks so that the trellises of chunk c run beside the emission of chunk c + 1
-    // was measured slower in round 2, DESIGN 4.5, and removed in round 3.)
+    // (Cutting the batch into halves so that the trellises of one half run beside the emission / the statistics of the
+    // other was built twice: round 2 with equal-priority streams (12.8 ms against 11.7), round 3 with highest-priority
+    // trellis streams and grids sized for the CUs that are left (13.0 ms, float32 pass 9.0 against 7.7): the trellis
+    // blocks then do get their CUs, but their frame loop waits for one fresh HBM row of b per frame, and beside the
+    // 8.4 GB write / read streams of the emission / moments kernels that wait exceeds a frame -- 2.8 -> 4.1 ms per pass;
+    // prefetching deeper costs registers the slice-0 role does not have.  DESIGN 4.5.)
     if (f32) {
         const void* dv;
         LN_TRY(stage_in(ctx, obs, (size_t)U * T * D * 8, ctx->ws_in, &dv));
@@ -717,10 +721,10 @@ int lnasr_bw_accumulate_p(lnasr_ctx* ctx, const double* obs, int U, int T, const
     // the backward pass runs on a side stream beside the forward pass
     LN_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
     LN_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-    std::swap(ctx->stream, ctx->stream2);
-    const int rc_b = backward_device(ctx, b, U, T, d_lens, LNASR_F64, be);
-    std::swap(ctx->stream, ctx->stream2);
-    LN_TRY(rc_b);
+    {
+        StreamScope on(ctx, ctx->stream2);
+        LN_TRY(backward_device(ctx, b, U, T, d_lens, LNASR_F64, be));
+    }
     LN_HIP(hipEventRecord(ctx->ev_join, ctx->stream2));
     LN_TRY(forward_device(ctx, b, U, T, d_lens, LNASR_F64, al, ll));
     LN_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
