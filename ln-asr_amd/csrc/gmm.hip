@@ -1142,6 +1142,9 @@ int emit_device(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, v
 //     staging: ~39-48 GB/s measured), the round-1 path.
 namespace {
 
+// (Chunk sizes growing geometrically from 16 utterances -- only the first chunk's transfer is exposed, so make it small --
+// were measured in round 3: 8.34 ms end to end against 8.05 with sixteen equal chunks; an emission launch on 16 or 32
+// utterances does not fill the chip for long enough to pay for its own ramp.)
 struct ChunkPlan {
     int U, nch;
     size_t utt_bytes;
