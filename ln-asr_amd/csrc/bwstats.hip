@@ -304,9 +304,12 @@ __global__ __launch_bounds__(64 * kMixWaves) void mix_mfma_kernel(const double* 
             const int e = tid + r * kMixNT;
             if (e < CH * D) {
                 const int fr = e / D, d = e % D;
-                const double x = oreg[r] - cen[d];
-                feat[bufi][fr * FST + d] = x;
-                feat[bufi][fr * FST + D + d] = x * x;
+                const double x = oreg[r] - cen[d], xx = x * x;
+                // a frame behind its utterance's end weighs 0, and 0 * inf is NaN on the matrix cores: whatever the caller
+                // left in the padding (NaN, inf, or anything whose square overflows) enters the sums as 0
+                const bool fin = __builtin_isfinite(xx);
+                feat[bufi][fr * FST + d] = fin ? x : 0.0;
+                feat[bufi][fr * FST + D + d] = fin ? xx : 0.0;
             }
         }
         if (tid < CH * kMixWaves) {
@@ -490,7 +493,9 @@ __global__ __launch_bounds__(64 * kFullWaves) void full_mfma_kernel(const double
             const int e = tid + r * kFullNT;
             if (e < CH * D) {
                 const int fr = e / D, d = e % D;
-                yrow[bufi][fr * YST + d] = oreg[r] - cen[d];
+                const double y = oreg[r] - cen[d];
+                yrow[bufi][fr * YST + d] = __builtin_fabs(y) < 1e150 ? y : 0.0;   // padding frames: see mix_mfma_kernel
+                                                                                 // (products of two entries must stay finite)
             }
         }
         if (tid < CH * kFullWaves) {

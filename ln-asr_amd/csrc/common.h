@@ -43,7 +43,10 @@ int fail(int code, const char* fmt, ...);
 // otherwise allocate workspaces and launch on device 0.  hipSetDevice is a cheap thread-local store.
 #define LN_ENTER(ctx)                                          \
     do {                                                       \
-        if (ctx) LN_HIP(hipSetDevice((ctx)->device));          \
+        if (ctx) {                                             \
+            LN_HIP(hipSetDevice((ctx)->device));               \
+            if (++(ctx)->nan_epoch == 0) (ctx)->nan_epoch = 1; \
+        }                                                      \
     } while (0)
 
 // ---- grow-only device buffer -----------------------------------------------------------
@@ -147,6 +150,10 @@ struct lnasr_ctx {
     lnasr::DevBuf ws_w1, ws_w2, ws_w3;                     // float32 storage: widened inputs / outputs of the f64 kernels
     lnasr::DevBuf ws_pad;                                  // bm of a padded model before compaction
     lnasr::DevBuf ws_bp;                                   // byte back-pointers of the tiny-model Viterbi (N <= 16)
+    // non-finite data (nanfix.hip): a device word the hot kernels set to the running call's epoch when they meet a NaN or
+    // an infinity, and the per-utterance slots of the scan that follows
+    lnasr::DevBuf nan_flag, nan_slots;
+    unsigned nan_epoch = 0;                                // number of the running API call (LN_ENTER); never 0
     const void* bp_v = nullptr;                            // the v array ws_bp belongs to (set by viterbi_device,
     int bp_U = 0, bp_T = 0, bp_nmax = 0;                   //   consumed by backtrace_device)
     // MFCC constants (twiddles, DCT matrix), kept on the device between calls with the same fft_n / n_mel;
@@ -229,6 +236,9 @@ int mix_stats_device_f32(lnasr_ctx* ctx, const double* obs, const double* alpha,
                          const float* q32, const double* c1, const int32_t* d_lens, int U, int T, double* mix,
                          double* mix_x, double* mix_xx, int phase = kMixAll);
 int emit_device(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, void* bm);
+// emit_device without the pass over non-finite frames; *scanned: the kernel tested the features it staged and raised
+// ctx->nan_flag itself (emit_batch runs the kernels chunk by chunk and the pass once)
+int emit_device_raw(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, void* bm, bool* scanned);
 int full_stats_device(lnasr_ctx* ctx, const double* obs, const double* alpha, const double* beta, const double* b,
                       const double* bm, const double* c1, const int32_t* d_lens, int U, int T, double* mix,
                       double* mix_x, double* mix_xx);
@@ -236,7 +246,10 @@ int full_stats_device(lnasr_ctx* ctx, const double* obs, const double* alpha, co
 // Emission of a batch whose observations may still be in host memory: the upload is cut into chunks that a helper
 // thread pushes through the side stream while the emission kernel already runs on the chunks that have arrived
 // (device-resident observations: one plain launch).  b [U*T, N], bm [U*T, N, M] or null are device pointers.
-int emit_batch(lnasr_ctx* ctx, const double* obs, int U, int T, double* b, double* bm, const double** d_obs_out);
+// scanned_or_null: given, the pass over non-finite frames (nan_rows_device) is left to the caller -- decode and calc_prob
+// repair their own outputs from the observations -- and *scanned says whether every kernel tested its features itself.
+int emit_batch(lnasr_ctx* ctx, const double* obs, int U, int T, double* b, double* bm, const double** d_obs_out,
+               bool* scanned_or_null = nullptr);
 
 // float32 storage (`precision=np.float32`): the tuned kernels are f64-only, so f32 inputs are widened, the f64
 // kernels run, and results are rounded to f32 on the way out (more accurate than rounding every stored
@@ -244,6 +257,17 @@ int emit_batch(lnasr_ctx* ctx, const double* obs, int U, int T, double* b, doubl
 bool f32_via_f64();
 int widen_f32(lnasr_ctx* ctx, const void* src, size_t n, DevBuf& ws, double** out);
 int narrow_f64(lnasr_ctx* ctx, const double* src, size_t n, void* dst);
+
+// Non-finite data, the reference's way (nanfix.hip).  force: scan the input; else act only when a kernel of this
+// API call raised ctx->nan_flag.
+int nan_rows_device(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, void* bm, bool force);
+int viterbi_nan_repair(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d_lens, int dtype, void* v,
+                       uint32_t* path, double* best, bool force);          // the caller's emissions
+int viterbi_nan_repair_obs(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* d_lens, double* v,
+                           uint32_t* path, double* best, bool force);       // decode: keyed on the observations
+int loglik_nan_repair(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* d_lens, double* loglik, bool force);
+int stats_nan_repair(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* d_lens, double* stats, long n,
+                     bool force);
 
 inline size_t dtype_size(int dtype) { return dtype == LNASR_F32 ? 4 : 8; }
 

@@ -703,6 +703,7 @@ int lnasr_bw_accumulate_p(lnasr_ctx* ctx, const double* obs, int U, int T, const
     double* be = ctx->ws_beta.as<double>();
     LN_REQUIRE(U <= 65535, "U=%d too large for one statistics launch", U);
     const bool mfma_stats = !sw().no_mfma_stats;
+    bool feat_tested = false;       // the emission kernel looked for NaN / infinite features itself (nanfix.hip)
     // (Cutting the batch into halves so that the trellises of one half run beside the emission / the statistics of the
     // other was built twice: round 2 with equal-priority streams (12.8 ms against 11.7), round 3 with highest-priority
     // trellis streams and grids sized for the CUs that are left (13.0 ms, float32 pass 9.0 against 7.7): the trellis
@@ -715,7 +716,8 @@ int lnasr_bw_accumulate_p(lnasr_ctx* ctx, const double* obs, int U, int T, const
         d_obs = (const double*)dv;
         LN_TRY(emit_device_f32(ctx, d_obs, (long)U * T, b, ctx->ws_bm.as<float>()));
     } else {
-        LN_TRY(emit_batch(ctx, obs, U, T, b, bm, &d_obs));  // host observations: upload overlapped with the emission
+        // host observations: upload overlapped with the emission
+        LN_TRY(emit_batch(ctx, obs, U, T, b, bm, &d_obs, &feat_tested));
     }
     // forward and backward only share their input: with few utterances per GPU (config 5: 64 blocks on 256 CUs)
     // the backward pass runs on a side stream beside the forward pass
@@ -763,6 +765,9 @@ int lnasr_bw_accumulate_p(lnasr_ctx* ctx, const double* obs, int U, int T, const
                   bm, c1, md.logw.as<double>(), md.mu.as<double>(), d_lens, T, N, M, D, st + L.mix, st + L.mix_x,
                   st + L.mix_xx);
     }
+    // a NaN or an infinite feature anywhere in the batch: every posterior of its utterance is NaN in the reference, and so
+    // is every sum it enters (one launch that returns at once unless the emission kernel raised the flag)
+    LN_TRY(stats_nan_repair(ctx, (const double*)d_obs, U, T, d_lens, st, (long)L.ll + 1, !feat_tested));   // the counts stay
     return finish_out(ctx, stats, d_st, L.total * 8);
 }
 

@@ -255,9 +255,10 @@ __global__ __launch_bounds__(kMix32NT) void mix_mfma_f32(const double* __restric
             const int e = tid + r * kMix32NT;
             if (e < CH * D) {
                 const int fr = e / D, d = e % D;
-                const double x = oreg[r] - cen[d];
-                feat[bufi][fr * FST + d] = (float)x;
-                feat[bufi][fr * FST + D + d] = (float)(x * x);
+                const float x = (float)(oreg[r] - cen[d]), xx = (float)((oreg[r] - cen[d]) * (oreg[r] - cen[d]));
+                const bool fin = __builtin_isfinite(xx);        // padding frames: see mix_mfma_kernel (bwstats.hip)
+                feat[bufi][fr * FST + d] = fin ? x : 0.0f;
+                feat[bufi][fr * FST + D + d] = fin ? xx : 0.0f;
             }
         }
         if (tid < CH * kMix32Waves) sab[bufi][tid] = s_ab;

@@ -255,7 +255,7 @@ template <int Q, int KS, int NWV, int TPS, bool WRITE_BM, int ABL = 0>
 __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 2))) void emit_diag_mfma(
     const double* __restrict__ obs, const double* __restrict__ wpack, const double* __restrict__ logw,
     const double* __restrict__ centre, double* __restrict__ b, double* __restrict__ bm, long F, int N, int D, int NG,
-    int GY, long ntiles, int tiles_per_block, long nchunks) {
+    int GY, long ntiles, int tiles_per_block, long nchunks, unsigned* __restrict__ nan_flag, unsigned nan_epoch) {
     constexpr int KP = 4 * KS;
     constexpr int NT = 64 * NWV;
     constexpr int SPB = 4 * NWV;                // states per block
@@ -333,11 +333,15 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 2))
             pre[r] = obs[ge];
         }
     };
+    // lanes that staged a NaN or an infinity (a compare into the scalar unit per element): the reference turns such a
+    // frame's densities into NaN, this arithmetic does not always (nanfix.hip) -- raise the flag and let that pass decide
+    unsigned long long nonfinite = 0;
     auto store_stage = [&](int buf) {
         double* Fd = &Fl[buf][0][0];
         const int xo = D * FS;
 #pragma unroll
         for (int r = 0; r < MAXLD; ++r) {
+            nonfinite |= __ballot(!__builtin_isfinite(pre[r]));
             if (foff[r] >= 0) {
                 const double x = pre[r] - cen[r];       // centred: the coefficients are those of (x - centre)
                 Fd[foff[r]] = x * x;
@@ -444,6 +448,7 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 2))
         const long nst = (tile1 - tile0 + TPS - 1) / TPS;
         flush_stage((int)((nst - 1) & 1), tile0 + (nst - 1) * TPS);
     }
+    if (nonfinite != 0 && lane == 0) *nan_flag = nan_epoch;
     LN_BLOCK_T1;
 }
 LN_BLOCK_TIMES_EXPORT(lnasr_dbg_block_times_gmm)
@@ -495,7 +500,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                                                           const double* __restrict__ wdirect,
                                                           const double* __restrict__ logw,
                                                           const double* __restrict__ centre, double* __restrict__ b,
-                                                          double* __restrict__ bm, long F, int M, int D, long ntiles) {
+                                                          double* __restrict__ bm, long F, int M, int D, long ntiles,
+                                                          unsigned* __restrict__ nan_flag, unsigned nan_epoch) {
     constexpr int NL = KS / 2;                 // loads per lane and tile
     constexpr unsigned kTick = 2;              // tiles per draw (1: 0.079 ms, the draw then sits in front of every prefetch; 2: 0.074)
     __shared__ double etab[kExpTab];
@@ -547,6 +553,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         return tbeg + (long)__builtin_amdgcn_readfirstlane(t);
     };
     drain_vmem();                              // wr[] resident: no vmcnt guards on it inside the loop
+    unsigned long long nonfinite = 0;
     long tile = tbeg + (long)w * kTick;
     unsigned left = kTick;
     load_tile(tile < tend ? tile : ntiles);
@@ -560,6 +567,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         double bx[NL], bq[NL];
 #pragma unroll
         for (int j = 0; j < NL; ++j) {
+            nonfinite |= __ballot(!__builtin_isfinite(pre[j]));     // see emit_diag_mfma
             bx[j] = CEN ? pre[j] - cen[CEN ? j : 0] : pre[j];
             bq[j] = is_one[j] ? 1.0 : bx[j] * bx[j];
         }
@@ -589,6 +597,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         if (g == 0 && frame < F) b[frame] = (mx == LN_NEG_INF) ? mx : mx + log_sum(sacc, ltab);
         tile = nxt;
     }
+    if (nonfinite != 0 && lane == 0) *nan_flag = nan_epoch;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -992,11 +1001,11 @@ static int launch_mfma_cfg(lnasr_ctx* ctx, const double* obs, long F, double* b,
     if (bm) {
         LN_LAUNCH(ctx, "emit_diag_mfma_bm", (emit_diag_mfma<Q, KS, NWV, TPS, true>), dim3((unsigned)grid),
                   dim3(64 * NWV), 0, obs, md.wpack_nw.as<double>(), lw, (const double*)md.centre.as<double>(), b, bm, F, N, D,
-                  md.wpack_NG, GY, ntiles, (int)tpb, nchunks);
+                  md.wpack_NG, GY, ntiles, (int)tpb, nchunks, ctx->nan_flag.as<unsigned>(), ctx->nan_epoch);
     } else {
         LN_LAUNCH(ctx, "emit_diag_mfma", (emit_diag_mfma<Q, KS, NWV, TPS, false>), dim3((unsigned)grid),
                   dim3(64 * NWV), 0, obs, md.wpack.as<double>(), lw, (const double*)md.centre.as<double>(), b, bm, F, N, D,
-                  md.wpack_NG, GY, ntiles, (int)tpb, nchunks);
+                  md.wpack_NG, GY, ntiles, (int)tpb, nchunks, ctx->nan_flag.as<unsigned>(), ctx->nan_epoch);
     }
     return 0;
 }
@@ -1015,10 +1024,10 @@ static int launch_mfma(lnasr_ctx* ctx, const double* obs, long F, double* b, dou
             const long grid = ((nchunks + 7) / 8) * 8 * GY;
             if (v == 'x')
                 LN_LAUNCH(ctx, "emit_ablate_no_lse", (emit_diag_mfma<4, 20, 8, 1, false, 1>), dim3((unsigned)grid), dim3(512), 0,
-                          obs, md.wpack.as<double>(), md.logw.as<double>(), (const double*)md.centre.as<double>(), b, bm, F, md.N, md.D, md.wpack_NG, GY, ntiles, (int)tpb, nchunks);
+                          obs, md.wpack.as<double>(), md.logw.as<double>(), (const double*)md.centre.as<double>(), b, bm, F, md.N, md.D, md.wpack_NG, GY, ntiles, (int)tpb, nchunks, ctx->nan_flag.as<unsigned>(), ctx->nan_epoch);
             else
                 LN_LAUNCH(ctx, "emit_ablate_no_mfma", (emit_diag_mfma<4, 20, 8, 1, false, 2>), dim3((unsigned)grid), dim3(512), 0,
-                          obs, md.wpack.as<double>(), md.logw.as<double>(), (const double*)md.centre.as<double>(), b, bm, F, md.N, md.D, md.wpack_NG, GY, ntiles, (int)tpb, nchunks);
+                          obs, md.wpack.as<double>(), md.logw.as<double>(), (const double*)md.centre.as<double>(), b, bm, F, md.N, md.D, md.wpack_NG, GY, ntiles, (int)tpb, nchunks, ctx->nan_flag.as<unsigned>(), ctx->nan_epoch);
             return 0;
         }
     }
@@ -1030,7 +1039,15 @@ static int launch_mfma(lnasr_ctx* ctx, const double* obs, long F, double* b, dou
 
 // device-resident emission over F = U*T flattened frames; b [F,N], bm [F,N,M] or null
 int emit_device(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, void* bm) {
+    bool scanned = false;
+    LN_TRY(emit_device_raw(ctx, obs, F, dtype, b, bm, &scanned));
+    // frames with a NaN or an infinite feature: NaN rows, as the reference's product with the full inverse gives
+    return nan_rows_device(ctx, obs, F, dtype, b, bm, !scanned);
+}
+
+int emit_device_raw(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, void* bm, bool* scanned) {
     Model& md = ctx->model;
+    *scanned = false;
     if (!md.has_gmm) return fail(LNASR_E_NOMODEL, "no GMM-HMM model uploaded");
     if (F <= 0) return 0;
     const int N = md.N, M = md.M, D = md.D;
@@ -1040,7 +1057,7 @@ int emit_device(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, v
         const size_t cells = (size_t)F * N;
         LN_TRY(ctx->ws_w1.reserve(cells * 8));
         LN_TRY(ctx->ws_w3.reserve(cells * M * 8));
-        LN_TRY(emit_device(ctx, obs, F, LNASR_F64, ctx->ws_w1.p, ctx->ws_w3.p));
+        LN_TRY(emit_device_raw(ctx, obs, F, LNASR_F64, ctx->ws_w1.p, ctx->ws_w3.p, scanned));
         LN_LAUNCH(ctx, "round32_lse", round32_lse_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0,
                   (const double*)ctx->ws_w3.as<double>(), (const double*)md.logw.as<double>(), cells, N, M, (float*)b,
                   (float*)bm);
@@ -1056,9 +1073,10 @@ int emit_device(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, v
 #define LN_DLAUNCH(ks, wbm, cen, name)                                                                            \
     LN_LAUNCH(ctx, name, (emit_single_direct<ks, wbm, cen>), dim3((unsigned)grid), dim3(1024), 0, obs,            \
               md.wdirect.as<double>(), md.logw.as<double>(), (const double*)md.centre.as<double>(), (double*)b,   \
-              (double*)bm, F, M, D, ntiles)
+              (double*)bm, F, M, D, ntiles, ctx->nan_flag.as<unsigned>(), ctx->nan_epoch)
 #define LN_DCASE(ks)                                                                                              \
     if (md.wdirect_KS == ks) {                                                                                    \
+        *scanned = true;                                                                                          \
         if (bm && md.centred) LN_DLAUNCH(ks, true, true, "emit_single_direct_bm");                                \
         else if (bm) LN_DLAUNCH(ks, true, false, "emit_single_direct_bm");                                        \
         else if (md.centred) LN_DLAUNCH(ks, false, true, "emit_single_direct");                                   \
@@ -1090,6 +1108,7 @@ int emit_device(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, v
         LN_CASE(4, 7) LN_CASE(2, 7) LN_CASE(1, 7) LN_CASE(2, 32) LN_CASE(1, 32)
 #undef LN_CASE
         LN_TRY(rc);
+        *scanned = true;
         if (virt > 1 || padded) {
             const size_t cells = (size_t)F * N;
             LN_LAUNCH(ctx, "merge_virtual_states", merge_virtual_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256),
@@ -1194,7 +1213,8 @@ static int ensure_ring(lnasr_ctx* ctx, size_t slot_bytes) {
     return 0;
 }
 
-int emit_batch(lnasr_ctx* ctx, const double* obs, int U, int T, double* b, double* bm, const double** d_obs_out) {
+int emit_batch(lnasr_ctx* ctx, const double* obs, int U, int T, double* b, double* bm, const double** d_obs_out,
+               bool* scanned_or_null) {
     Model& md = ctx->model;
     const size_t utt = (size_t)T * md.D;                       // doubles per utterance
     constexpr int kMinChunk = 64, kMaxChunks = 16;
@@ -1204,6 +1224,8 @@ int emit_batch(lnasr_ctx* ctx, const double* obs, int U, int T, double* b, doubl
         const void* d_obs;
         LN_TRY(stage_in(ctx, obs, (size_t)U * utt * 8, ctx->ws_in, &d_obs));
         if (d_obs_out) *d_obs_out = (const double*)d_obs;
+        if (scanned_or_null)
+            return emit_device_raw(ctx, (const double*)d_obs, (long)U * T, LNASR_F64, b, bm, scanned_or_null);
         return emit_device(ctx, (const double*)d_obs, (long)U * T, LNASR_F64, b, bm);
     }
     LN_TRY(ctx->ws_in.reserve((size_t)U * utt * 8));
@@ -1216,6 +1238,7 @@ int emit_batch(lnasr_ctx* ctx, const double* obs, int U, int T, double* b, doubl
         ctx->copy_events.push_back(e);
     }
     const ChunkPlan plan{U, nch, utt * 8};
+    bool all_scanned = true;
     // the side stream must not run ahead of work that still reads the staging buffer
     LN_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
     LN_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
@@ -1223,8 +1246,19 @@ int emit_batch(lnasr_ctx* ctx, const double* obs, int U, int T, double* b, doubl
         const int u0 = plan.lo(c), u1 = plan.lo(c + 1);
         if (hipStreamWaitEvent(ctx->stream, ctx->copy_events[c], 0) != hipSuccess)
             return fail(LNASR_E_HIP, "hipStreamWaitEvent failed in the upload pipeline");
-        return emit_device(ctx, ctx->ws_in.as<double>() + (size_t)u0 * utt, (long)(u1 - u0) * T, LNASR_F64,
-                           b + (size_t)u0 * T * md.N, bm ? bm + (size_t)u0 * T * md.N * md.M : nullptr);
+        bool scanned = false;
+        const int rc = emit_device_raw(ctx, ctx->ws_in.as<double>() + (size_t)u0 * utt, (long)(u1 - u0) * T, LNASR_F64,
+                                       b + (size_t)u0 * T * md.N, bm ? bm + (size_t)u0 * T * md.N * md.M : nullptr, &scanned);
+        all_scanned = all_scanned && scanned;
+        return rc;
+    };
+    // non-finite frames (nanfix.hip): once for the whole batch, behind the last chunk
+    auto fix_rows = [&]() -> int {
+        if (scanned_or_null) {
+            *scanned_or_null = all_scanned;
+            return 0;
+        }
+        return nan_rows_device(ctx, ctx->ws_in.as<double>(), (long)U * T, LNASR_F64, b, bm, !all_scanned);
     };
 
     if (is_pinned_host_ptr(obs)) {
@@ -1234,7 +1268,7 @@ int emit_batch(lnasr_ctx* ctx, const double* obs, int U, int T, double* b, doubl
             LN_HIP(hipEventRecord(ctx->copy_events[c], ctx->stream2));
         }
         for (int c = 0; c < nch; ++c) LN_TRY(emit_chunk(c));
-        return 0;
+        return fix_rows();
     }
 
     UploadState st;
@@ -1294,7 +1328,7 @@ int emit_batch(lnasr_ctx* ctx, const double* obs, int U, int T, double* b, doubl
     }
     for (auto& w : workers) w.join();
     if (st.err != hipSuccess) return fail(LNASR_E_HIP, "upload pipeline: %s", hipGetErrorString(st.err));
-    return rc;
+    return rc != 0 ? rc : fix_rows();
 }
 
 }  // namespace lnasr

@@ -1,0 +1,292 @@
+// Non-finite data, the reference's way.
+//
+// numpy's max / argmax / logaddexp PROPAGATE NaN; the kernels' v_max_f64 / ds_max_f64 are IEEE maxNum and return the
+// other operand, and the table-driven exp clamps its argument, so a NaN that enters a trellis here stays in its own
+// cell while the reference turns every later frame into NaN.  What the reference returns is a closed form of where
+// the first NaN sits, so the tuned kernels stay as they are and a repair pass rewrites their outputs:
+//
+//   * emission (gmm.py:59-68, gmmhmm.py:64-67): a NaN OR an infinite feature in frame t makes every component
+//     density of that frame NaN -- the reference multiplies (x - mu) with the FULL inverse matrix, whose zero
+//     off-diagonals meet the infinity (inf * 0) -- hence bm[:, :, t] = b[:, t] = NaN (golden `gmmhmm_nonfinite`);
+//   * Viterbi (hmm.py:162-171): with t1 the first frame whose emissions hold a NaN and j1 the first such state,
+//     v[t1, j] = NaN for the NaN states, v[t > t1, :] = NaN, bt[t1+1, :] = j1, bt[t > t1+1, :] = 0, so
+//     path[t > t1] = 0, path[t1] = j1 and path[t < t1] is the back-trace from (t1, j1) over the untouched frames;
+//   * likelihood (hmm.py:97-99, 268-274): NaN for an utterance that holds a NaN frame.
+//
+// Cost on clean data: the hot kernels test what they read anyway and raise a flag word -- emit_diag_mfma and
+// emit_single_direct the features they stage (word 0 of ctx->nan_flag: "a NaN or an infinite feature"), the
+// back-trace kernel the cells of v (word 1: "a NaN or -inf cell", which is all a NaN emission can leave there) --
+// and every kernel here starts by comparing its word with the call's epoch and returns.  Paths without a fused test
+// scan their input once (`force`).  (Testing b inside viterbi_reg1b was measured: the kernel sits at its 128-VGPR
+// limit, seven more registers spilled, 1.26 -> 1.47 ms.)  The epoch makes resets unnecessary: a word is "raised" only
+// while it equals the number of the API call that is running (LN_ENTER).
+#include "common.h"
+#include "devmath.h"
+
+namespace lnasr {
+
+namespace {
+
+constexpr unsigned long long kNoBad = ~0ull;
+constexpr int kLocateMaxChunks = 64;
+
+template <typename T>
+__device__ __forceinline__ T quiet_nan();
+template <>
+__device__ __forceinline__ double quiet_nan<double>() { return __builtin_nan(""); }
+template <>
+__device__ __forceinline__ float quiet_nan<float>() { return __builtin_nanf(""); }
+
+// Frames with a non-finite feature: their rows of b [F,N] and bm [F,N,M] become NaN.  Flat coalesced scan of obs;
+// the wave that meets a bad element fills that frame's rows (several bad elements of a frame: filled again, harmless).
+template <typename TB>
+__global__ __launch_bounds__(256) void nan_rows_kernel(const double* __restrict__ obs, long F, int D, int N, int M,
+                                                       TB* __restrict__ b, TB* __restrict__ bm, unsigned* flag,
+                                                       unsigned epoch, int force) {
+    if (!force && *flag != epoch) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const long E = F * (long)D;
+    const TB nan = quiet_nan<TB>();
+    for (long base = (long)blockIdx.x * 256; base < E; base += (long)gridDim.x * 256) {
+        const long e = base + tid;
+        const bool bad = e < E && !__builtin_isfinite(obs[e]);
+        unsigned long long mask = __ballot(bad);
+        while (mask) {                                           // wave-uniform
+            const int l = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const long f = (base + (tid & ~63) + l) / D;
+            if (b)
+                for (int j = lane; j < N; j += 64) b[f * N + j] = nan;
+            if (bm)
+                for (long j = lane; j < (long)N * M; j += 64) bm[f * N * M + j] = nan;
+            if (lane == 0) *flag = epoch;
+        }
+    }
+}
+
+// First NaN of every utterance's emissions b [U,T,N] in row-major order -- i.e. (first bad frame, first bad state in
+// it) as ONE linear index.  grid (C, U): block c scans its share of the utterance's lens[u] * N values and leaves its
+// minimum in slot[u * C + c]; no atomics across blocks, nothing to initialise.
+template <typename TS>
+__global__ __launch_bounds__(256) void nan_locate_kernel(const TS* __restrict__ b, const int32_t* __restrict__ lens,
+                                                         int T, int N, unsigned long long* __restrict__ slot,
+                                                         unsigned* flag, unsigned epoch, int force) {
+    if (!force && *flag != epoch) return;
+    const int u = blockIdx.y, c = blockIdx.x, C = gridDim.x, tid = threadIdx.x;
+    const long total = (long)lens[u] * N;
+    const long per = (total + C - 1) / C;
+    const long e0 = (long)c * per, e1 = e0 + per < total ? e0 + per : total;
+    const TS* bu = b + (size_t)u * T * N;
+    unsigned long long first = kNoBad;
+    for (long e = e0 + tid; e < e1; e += 256) {
+        const TS x = bu[e];
+        if (x != x) {                                            // ascending per thread: its first hit is its minimum
+            first = (unsigned long long)e;
+            break;
+        }
+    }
+    __shared__ unsigned long long sm;
+    if (tid == 0) sm = kNoBad;
+    __syncthreads();
+    if (first != kNoBad) atomicMin(&sm, first);
+    __syncthreads();
+    if (tid == 0) {
+        slot[(size_t)u * C + c] = sm;
+        if (sm != kNoBad) *flag = epoch;
+    }
+}
+
+// Same for observations [U,T,D] (calc_prob: only "does the utterance hold a bad frame" is needed)
+__global__ __launch_bounds__(256) void nan_utt_obs_kernel(const double* __restrict__ obs, const int32_t* __restrict__ lens,
+                                                          int T, int D, double* __restrict__ loglik, int force,
+                                                          const unsigned* flag, unsigned epoch) {
+    if (!force && *flag != epoch) return;
+    const int u = blockIdx.x, tid = threadIdx.x;
+    const long total = (long)lens[u] * D;
+    const double* ou = obs + (size_t)u * T * D;
+    bool bad = false;
+    for (long e = tid; e < total; e += 256) bad |= !__builtin_isfinite(ou[e]);
+    if (__syncthreads_or(bad) && tid == 0) loglik[u] = quiet_nan<double>();
+}
+
+// Baum-Welch statistics (gmmhmm.py:69-156 over a batch): an utterance with a bad frame has NaN in alpha from that frame
+// on and in beta before it, so every posterior is NaN and so is every sum it enters -- the whole statistics block
+__global__ __launch_bounds__(256) void nan_stats_kernel(const double* __restrict__ obs, const int32_t* __restrict__ lens,
+                                                        int T, int D, double* __restrict__ stats, long n, int force,
+                                                        const unsigned* flag, unsigned epoch) {
+    if (!force && *flag != epoch) return;
+    const int u = blockIdx.x, tid = threadIdx.x;
+    const long total = (long)lens[u] * D;
+    const double* ou = obs + (size_t)u * T * D;
+    bool bad = false;
+    for (long e = tid; e < total; e += 256) bad |= !__builtin_isfinite(ou[e]);
+    if (!__syncthreads_or(bad)) return;
+    for (long e = tid; e < n; e += 256) stats[e] = quiet_nan<double>();
+}
+
+// One block per utterance: rewrite v, path and the best score of an utterance whose emissions hold a NaN (header).
+// Where the first NaN sits comes from the slots of nan_locate_kernel (emissions handed in by the caller), or -- obs
+// given: decode, whose emissions are its own -- from the block's own scan for the first frame with a NaN or an infinite
+// feature, every state of which is NaN then (j1 = 0); that scan only runs when the emission kernel raised the flag, or
+// had no fused test (force).
+template <typename TS>
+__global__ __launch_bounds__(256) void viterbi_nan_repair_kernel(const TS* __restrict__ b, TS* __restrict__ v,
+                                                                 const double* __restrict__ AT,
+                                                                 const int32_t* __restrict__ lens, int T, int N, int C,
+                                                                 const unsigned long long* __restrict__ slot,
+                                                                 const double* __restrict__ obs, int D, int force,
+                                                                 const unsigned* flag, unsigned epoch,
+                                                                 uint32_t* __restrict__ path, double* __restrict__ best) {
+    if (!force && *flag != epoch) return;
+    const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int L = lens[u];
+    int t1, j1;
+    if (obs) {
+        const double* ou = obs + (size_t)u * T * D;
+        const long total = (long)L * D;
+        unsigned long long mine = kNoBad;
+        for (long e = tid; e < total; e += 256)
+            if (!__builtin_isfinite(ou[e])) {
+                mine = (unsigned long long)e;
+                break;
+            }
+        __shared__ unsigned long long sm;
+        if (tid == 0) sm = kNoBad;
+        __syncthreads();
+        if (mine != kNoBad) atomicMin(&sm, mine);
+        __syncthreads();
+        if (sm == kNoBad) return;                                // block-uniform
+        t1 = (int)(sm / (unsigned long long)D);
+        j1 = 0;
+    } else {
+        unsigned long long first = kNoBad;
+        for (int c = 0; c < C; ++c) {
+            const unsigned long long s = slot[(size_t)u * C + c];
+            first = s < first ? s : first;
+        }
+        if (first == kNoBad) return;                             // block-uniform
+        t1 = (int)(first / (unsigned long long)N);
+        j1 = (int)(first % (unsigned long long)N);
+    }
+    uint32_t* pu = path + (size_t)u * T;
+    const TS nan = quiet_nan<TS>();
+    {
+        TS* vu = v + (size_t)u * T * N;
+        const TS* bu = b + (size_t)u * T * N;
+        for (int j = tid; j < N; j += 256) {
+            bool hit = obs != nullptr;
+            if (!hit) {
+                const TS x = bu[(size_t)t1 * N + j];
+                hit = x != x;
+            }
+            if (hit) vu[(size_t)t1 * N + j] = nan;
+        }
+        for (long e = (long)(t1 + 1) * N + tid; e < (long)L * N; e += 256) vu[e] = nan;
+    }
+    for (int t = t1 + 1 + tid; t < L; t += 256) pu[t] = 0u;
+    if (tid == 0) {
+        pu[t1] = (uint32_t)j1;
+        if (best) best[u] = quiet_nan<double>();
+    }
+    // back-trace from (t1, j1) over the frames the NaN never reached: the very additions and the first-index rule of
+    // the back-trace kernels (argmax_i(v[t-1, i] + A[i, p]), hmm.py:165,170)
+    const TS* vu = v + (size_t)u * T * N;
+    __shared__ double sx[4];
+    __shared__ int si[4];
+    int p = j1;
+    for (int t = t1; t >= 1; --t) {
+        const double* col = AT + (size_t)p * N;
+        double x = LN_NEG_INF;
+        int xi = 0x7fffffff;
+        for (int i = tid; i < N; i += 256) argmax_combine(x, xi, ld(vu, (size_t)(t - 1) * N + i) + col[i], i);
+        wave_argmax(x, xi);
+        if (lane == 0) {
+            sx[w] = x;
+            si[w] = xi;
+        }
+        __syncthreads();
+        x = sx[0];
+        xi = si[0];
+        for (int k = 1; k < 4; ++k) argmax_combine(x, xi, sx[k], si[k]);
+        __syncthreads();
+        p = xi;
+        if (tid == 0) pu[t - 1] = (uint32_t)p;
+    }
+}
+
+int locate_chunks(int U) {
+    int C = (2048 + U - 1) / U;
+    return C < 1 ? 1 : (C > kLocateMaxChunks ? kLocateMaxChunks : C);
+}
+
+}  // namespace
+
+int nan_rows_device(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, void* bm, bool force) {
+    if (F <= 0) return 0;
+    const Model& md = ctx->model;
+    const long E = F * (long)md.D;
+    long grid = (E + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    unsigned* flag = ctx->nan_flag.as<unsigned>();
+    if (dtype == LNASR_F32)
+        LN_LAUNCH(ctx, "nan_rows_f32", nan_rows_kernel<float>, dim3((unsigned)grid), dim3(256), 0, obs, F, md.D, md.N, md.M,
+                  (float*)b, (float*)bm, flag, ctx->nan_epoch, force ? 1 : 0);
+    else
+        LN_LAUNCH(ctx, "nan_rows", nan_rows_kernel<double>, dim3((unsigned)grid), dim3(256), 0, obs, F, md.D, md.N, md.M,
+                  (double*)b, (double*)bm, flag, ctx->nan_epoch, force ? 1 : 0);
+    return 0;
+}
+
+int viterbi_nan_repair(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d_lens, int dtype, void* v,
+                       uint32_t* path, double* best, bool force) {
+    if (U <= 0 || T <= 0) return 0;
+    const int N = ctx->model.N;
+    const int C = locate_chunks(U);
+    LN_REQUIRE(U <= 65535, "U=%d too large for the NaN scan", U);
+    LN_REQUIRE(v, "the repair pass needs the Viterbi lattice");
+    LN_TRY(ctx->nan_slots.reserve((size_t)U * C * 8));
+    unsigned* flag = ctx->nan_flag.as<unsigned>() + 1;      // the "suspect cell in v" word (backtrace_lds_kernel)
+    unsigned long long* slot = ctx->nan_slots.as<unsigned long long>();
+    const double* AT = ctx->model.logAT.as<double>();
+    const double* no_obs = nullptr;
+    if (dtype == LNASR_F32) {
+        LN_LAUNCH(ctx, "nan_locate_f32", nan_locate_kernel<float>, dim3(C, U), dim3(256), 0, (const float*)b, d_lens, T, N,
+                  slot, flag, ctx->nan_epoch, force ? 1 : 0);
+        LN_LAUNCH(ctx, "viterbi_nan_repair_f32", viterbi_nan_repair_kernel<float>, dim3(U), dim3(256), 0, (const float*)b,
+                  (float*)v, AT, d_lens, T, N, C, slot, no_obs, 0, 0, flag, ctx->nan_epoch, path, best);
+    } else {
+        LN_LAUNCH(ctx, "nan_locate", nan_locate_kernel<double>, dim3(C, U), dim3(256), 0, (const double*)b, d_lens, T, N,
+                  slot, flag, ctx->nan_epoch, force ? 1 : 0);
+        LN_LAUNCH(ctx, "viterbi_nan_repair", viterbi_nan_repair_kernel<double>, dim3(U), dim3(256), 0, (const double*)b,
+                  (double*)v, AT, d_lens, T, N, C, slot, no_obs, 0, 0, flag, ctx->nan_epoch, path, best);
+    }
+    return 0;
+}
+
+int viterbi_nan_repair_obs(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* d_lens, double* v,
+                           uint32_t* path, double* best, bool force) {
+    if (U <= 0 || T <= 0) return 0;
+    LN_REQUIRE(obs && v, "the repair pass needs the observations and the Viterbi lattice");
+    const unsigned long long* no_slot = nullptr;
+    LN_LAUNCH(ctx, "viterbi_nan_repair", viterbi_nan_repair_kernel<double>, dim3(U), dim3(256), 0, (const double*)nullptr,
+              v, (const double*)ctx->model.logAT.as<double>(), d_lens, T, ctx->model.N, 0, no_slot, obs, ctx->model.D,
+              force ? 1 : 0, (const unsigned*)ctx->nan_flag.as<unsigned>(), ctx->nan_epoch, path, best);
+    return 0;
+}
+
+int stats_nan_repair(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* d_lens, double* stats, long n,
+                     bool force) {
+    if (U <= 0 || T <= 0 || n <= 0) return 0;
+    LN_LAUNCH(ctx, "stats_nan_repair", nan_stats_kernel, dim3(U), dim3(256), 0, obs, d_lens, T, ctx->model.D, stats, n,
+              force ? 1 : 0, (const unsigned*)ctx->nan_flag.as<unsigned>(), ctx->nan_epoch);
+    return 0;
+}
+
+int loglik_nan_repair(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* d_lens, double* loglik, bool force) {
+    if (U <= 0 || T <= 0) return 0;
+    LN_LAUNCH(ctx, "loglik_nan_repair", nan_utt_obs_kernel, dim3(U), dim3(256), 0, obs, d_lens, T, ctx->model.D, loglik,
+              force ? 1 : 0, (const unsigned*)ctx->nan_flag.as<unsigned>(), ctx->nan_epoch);
+    return 0;
+}
+
+}  // namespace lnasr

@@ -580,7 +580,8 @@ __global__ __launch_bounds__(256) void backtrace_lds_kernel(const TS* __restrict
                                                            const double* __restrict__ AT,
                                                            const int32_t* __restrict__ lens,
                                                            uint32_t* __restrict__ path, double* __restrict__ best,
-                                                           int U, int T, int N) {
+                                                           int U, int T, int N, unsigned* __restrict__ suspect_flag,
+                                                           unsigned epoch) {
     // lane l holds states l, l+64, ... (CPL of them).  LDSAT: A^T [N][N] (ATs[p*N + i] = A[i][p]) lives in LDS
     // (N <= 128); otherwise the one row a step needs is read from L2 (128 < N <= 256: 512 KB does not fit)
     extern __shared__ double ATs[];
@@ -617,10 +618,16 @@ __global__ __launch_bounds__(256) void backtrace_lds_kernel(const TS* __restrict
         }
         return r;
     };
+    // A NaN emission leaves NaN or -inf in its cell of v (the Viterbi kernels' maximum drops a NaN operand) where numpy
+    // would have turned every later frame into NaN.  This kernel reads every cell anyway and has issue slots to spare:
+    // it raises a flag when it meets such a cell, and only then is b scanned for NaNs (nanfix.hip) -- a model with -inf
+    // transitions pays that scan for nothing, a dense one never pays it
+    unsigned long long suspect = 0;
     double x[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
         const double v0 = ld(vu, (size_t)(L - 1) * N + jj[c]);
+        suspect |= __ballot(!(v0 > LN_NEG_INF));
         x[c] = ok[c] ? v0 : LN_NEG_INF;
     }
     double bestv;
@@ -652,6 +659,7 @@ __global__ __launch_bounds__(256) void backtrace_lds_kernel(const TS* __restrict
 #pragma unroll
                 for (int c = 0; c < CPL; ++c) {
                     const double sum = cur[k][c] + col[jj[c]];          // unconditional (clamped index), then a select
+                    suspect |= __ballot(!(cur[k][c] > LN_NEG_INF));
                     x[c] = ok[c] ? sum : LN_NEG_INF;
                 }
                 double mx;
@@ -668,6 +676,7 @@ __global__ __launch_bounds__(256) void backtrace_lds_kernel(const TS* __restrict
 #pragma unroll
             for (int c = 0; c < CPL; ++c) cur[k][c] = nxt[k][c];
     }
+    if (suspect != 0 && lane == 0) *suspect_flag = epoch;
 }
 
 // full back-pointer matrix (hmm.py:165): bt[u,t,j] = argmax_i(v[u,t-1,i] + A[i,j]); bt[u,0,:] = 0
@@ -690,7 +699,8 @@ __global__ void bt_kernel(const TS* __restrict__ v, const double* __restrict__ A
         int bi = 0;
         for (int i = 1; i < N; ++i) {
             double val = vs[i] + A[(size_t)i * N + j];
-            if (val > best) { best = val; bi = i; }
+            // numpy.argmax: the first NaN wins over everything (v repaired by viterbi_nan_repair holds the reference's NaNs)
+            if (val > best || (val != val && best == best)) { best = val; bi = i; }
         }
         out[j] = (uint32_t)bi;
     }
@@ -2168,9 +2178,13 @@ int viterbi_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
 }
 
 int backtrace_device(lnasr_ctx* ctx, const void* v, int U, int T, const int32_t* d_lens, int dtype, uint32_t* path,
-                     double* best) {
+                     double* best, bool* v_tested = nullptr) {
+    // *v_tested: the kernel looked at every cell of v and raised the context's "suspect" word on NaN / -inf (nanfix.hip)
     Model& md = ctx->model;
     const int wpb = 4;
+    unsigned* const sflag = ctx->nan_flag.as<unsigned>() + 1;
+    const unsigned epoch = ctx->nan_epoch;
+    if (v_tested) *v_tested = false;
     if (ctx->bp_v == v && ctx->bp_U == U && ctx->bp_T == T && v != nullptr) {
         // v came from viterbi_tiny_kernel: its byte back-pointers are in ws_bp
         const uint8_t* bp = ctx->ws_bp.as<uint8_t>();
@@ -2193,36 +2207,40 @@ int backtrace_device(lnasr_ctx* ctx, const void* v, int U, int T, const int32_t*
         return 0;
     }
     if (dtype == LNASR_F64 && md.N <= 128 && !sw().no_ldsbt) {
+        if (v_tested) *v_tested = true;
         if (md.N == 128)
             LN_LAUNCH(ctx, "backtrace_lds", (backtrace_lds_kernel<2, true, double, true>), dim3((U + wpb - 1) / wpb),
                       dim3(64 * wpb), (size_t)md.N * md.N * 8, (const double*)v, md.logAT.as<double>(), d_lens, path, best, U,
-                      T, md.N);
+                      T, md.N, sflag, epoch);
         else
             LN_LAUNCH(ctx, "backtrace_lds", (backtrace_lds_kernel<2, true>), dim3((U + wpb - 1) / wpb), dim3(64 * wpb),
-                      (size_t)md.N * md.N * 8, (const double*)v, md.logAT.as<double>(), d_lens, path, best, U, T, md.N);
+                      (size_t)md.N * md.N * 8, (const double*)v, md.logAT.as<double>(), d_lens, path, best, U, T, md.N, sflag, epoch);
         return 0;
     }
     if (dtype == LNASR_F64 && md.N <= 1024 && !sw().no_ldsbt) {
+        if (v_tested) *v_tested = true;
         // one wave per block (with few utterances the waves should sit on different CUs), N / 64 states per lane
         if (md.N <= 256)
             LN_LAUNCH(ctx, "backtrace_wave256", (backtrace_lds_kernel<4, false>), dim3(U), dim3(64), 0, (const double*)v,
-                      md.logAT.as<double>(), d_lens, path, best, U, T, md.N);
+                      md.logAT.as<double>(), d_lens, path, best, U, T, md.N, sflag, epoch);
         else if (md.N <= 512)
             LN_LAUNCH(ctx, "backtrace_wave512", (backtrace_lds_kernel<8, false>), dim3(U), dim3(64), 0, (const double*)v,
-                      md.logAT.as<double>(), d_lens, path, best, U, T, md.N);
+                      md.logAT.as<double>(), d_lens, path, best, U, T, md.N, sflag, epoch);
         else
             LN_LAUNCH(ctx, "backtrace_wave1024", (backtrace_lds_kernel<16, false>), dim3(U), dim3(64), 0, (const double*)v,
-                      md.logAT.as<double>(), d_lens, path, best, U, T, md.N);
+                      md.logAT.as<double>(), d_lens, path, best, U, T, md.N, sflag, epoch);
         return 0;
     }
     if (dtype == LNASR_F32 && md.N <= 128 && !sw().no_ldsbt && !sw().f32_generic) {
+        if (v_tested) *v_tested = true;
         LN_LAUNCH(ctx, "backtrace_lds_f32", (backtrace_lds_kernel<2, true, float>), dim3((U + wpb - 1) / wpb), dim3(64 * wpb),
-                  (size_t)md.N * md.N * 8, (const float*)v, md.logAT.as<double>(), d_lens, path, best, U, T, md.N);
+                  (size_t)md.N * md.N * 8, (const float*)v, md.logAT.as<double>(), d_lens, path, best, U, T, md.N, sflag, epoch);
         return 0;
     }
     if (dtype == LNASR_F32 && md.N <= 256 && !sw().no_ldsbt && !sw().f32_generic) {
+        if (v_tested) *v_tested = true;
         LN_LAUNCH(ctx, "backtrace_wave256_f32", (backtrace_lds_kernel<4, false, float>), dim3(U), dim3(64), 0, (const float*)v,
-                  md.logAT.as<double>(), d_lens, path, best, U, T, md.N);
+                  md.logAT.as<double>(), d_lens, path, best, U, T, md.N, sflag, epoch);
         return 0;
     }
     if (dtype == LNASR_F32)
@@ -2477,8 +2495,12 @@ int lnasr_viterbi(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* le
     // float32 storage stays on the storage-templated kernels here: rounding v to f32 after every frame is what
     // makes v, bt and path bit-identical to the reference run with precision=np.float32 (golden gmmhmm_small_f32);
     // forward / backward / emission are tolerance-checked and take the widened f64 route (common.h)
+    bool nan_tested = false;
     LN_TRY(viterbi_device(ctx, d_b, U, T, d_lens, dtype, d_v));
-    LN_TRY(backtrace_device(ctx, d_v, U, T, d_lens, dtype, (uint32_t*)d_path, (double*)d_best));
+    LN_TRY(backtrace_device(ctx, d_v, U, T, d_lens, dtype, (uint32_t*)d_path, (double*)d_best, &nan_tested));
+    // emissions handed in by the caller: a NaN among them propagates as numpy's max / argmax do (nanfix.hip); kernels
+    // that did not look for one themselves cost a scan of b here
+    LN_TRY(viterbi_nan_repair(ctx, d_b, U, T, d_lens, dtype, d_v, (uint32_t*)d_path, (double*)d_best, !nan_tested));
     if (bt_or_null) {
         LN_TRY(stage_out(ctx, bt_or_null, cells * 4, ctx->ws_out3, &d_bt));
         LN_REQUIRE(U <= 65535, "U=%d too large for the bt kernel", U);
@@ -2516,9 +2538,15 @@ int lnasr_decode(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t*
     if (best_score_or_null) LN_TRY(stage_out(ctx, best_score_or_null, (size_t)U * 8, ctx->ws_out2, &d_best));
     // three launches in series on one stream (cutting the batch into chunks whose trellis work runs on a side stream
     // beside the next chunk's emission was measured slower, DESIGN 4.8, and removed in round 3)
-    LN_TRY(emit_batch(ctx, obs, U, T, ctx->ws_b.as<double>(), nullptr, nullptr));
+    const double* d_x = nullptr;
+    bool scanned = false;
+    LN_TRY(emit_batch(ctx, obs, U, T, ctx->ws_b.as<double>(), nullptr, &d_x, &scanned));
     LN_TRY(viterbi_device(ctx, ctx->ws_b.p, U, T, d_lens, LNASR_F64, ctx->ws_v.p));
     LN_TRY(backtrace_device(ctx, ctx->ws_v.p, U, T, d_lens, LNASR_F64, (uint32_t*)d_path, (double*)d_best));
+    // a NaN or an infinite feature makes its frame's emissions NaN in the reference, and np.max carries that through every
+    // later frame: one launch that returns at once unless the emission kernel raised the flag (nanfix.hip)
+    LN_TRY(viterbi_nan_repair_obs(ctx, d_x, U, T, d_lens, ctx->ws_v.as<double>(), (uint32_t*)d_path, (double*)d_best,
+                                  !scanned));
     LN_TRY(finish_out(ctx, path, d_path, (size_t)U * T * 4));
     if (best_score_or_null) LN_TRY(finish_out(ctx, best_score_or_null, d_best, (size_t)U * 8));
     return 0;
@@ -2580,16 +2608,21 @@ int lnasr_calc_prob_p(lnasr_ctx* ctx, const double* obs, int U, int T, const int
     void* d_ll;
     LN_TRY(ctx->ws_b.reserve(cells * 8));
     LN_TRY(stage_out(ctx, loglik, (size_t)U * 8, ctx->ws_out2, &d_ll));
+    const double* d_x = nullptr;
+    bool scanned = false;
     if (dtype == LNASR_F32 && f32_stats_ok(md)) {
         // the emission of the float32 statistics pass (lnasr_bw_accumulate_p): same b, hence the same likelihood
         const void* d_obs;
         LN_TRY(stage_in(ctx, obs, (size_t)U * T * md.D * 8, ctx->ws_in, &d_obs));
         LN_TRY(ctx->ws_bm.reserve((cells + (size_t)kMixPadFrames * md.N) * md.M * 4));
         LN_TRY(emit_device_f32(ctx, (const double*)d_obs, (long)U * T, ctx->ws_b.as<double>(), ctx->ws_bm.as<float>()));
+        d_x = (const double*)d_obs;                         // that kernel has no fused test
     } else {
-        LN_TRY(emit_batch(ctx, obs, U, T, ctx->ws_b.as<double>(), nullptr, nullptr));
+        LN_TRY(emit_batch(ctx, obs, U, T, ctx->ws_b.as<double>(), nullptr, &d_x, &scanned));
     }
     LN_TRY(forward_device(ctx, ctx->ws_b.p, U, T, d_lens, LNASR_F64, nullptr, (double*)d_ll));
+    // an utterance with a NaN or an infinite feature scores NaN (np.logaddexp carries it to the last frame, hmm.py:97-99)
+    LN_TRY(loglik_nan_repair(ctx, d_x, U, T, d_lens, (double*)d_ll, !scanned));
     return finish_out(ctx, loglik, d_ll, (size_t)U * 8);
 }
 

@@ -233,6 +233,14 @@ def gmm_map_b(obs, w, mu, si, precision=np.float64):
     return b, bm
 
 
+def _nonfinite_frames(obs):
+    """Frames holding a NaN or an infinite feature.  The reference multiplies (x - mu) with the FULL inverse matrix
+    (gmm.py:63-68): for a diagonal Sigma its off-diagonal zeros meet the infinite entry (inf * 0 = NaN), so every
+    component density of such a frame is NaN, not the -inf a diagonal-only sum of squares would give (golden
+    `gmmhmm_nonfinite`).  The diagonal shortcuts below restore exactly that."""
+    return ~np.isfinite(np.asarray(obs, dtype=np.float64)).all(axis=1)
+
+
 def gmm_map_b_diag(obs, w, mu, var, precision=np.float64):
     """Same quantity for diagonal Sigma given as var [N,M,D]; vectorised (the CPU
     baseline's 'best vectorised form', BASELINE.md section 3 line B)."""
@@ -248,6 +256,7 @@ def gmm_map_b_diag(obs, w, mu, var, precision=np.float64):
     # the reference stores bm into an array of `precision` FIRST and forms b from those stored values
     # (gmmhmm.py:64-67): with float32 the mixture sum sees the rounded component log-densities
     bm = (const.reshape(1, N * M) - 0.5 * q).reshape(T, N, M).astype(precision)
+    bm[_nonfinite_frames(obs)] = np.nan
     z = w[None] + bm.astype(np.float64)
     mx = z.max(axis=2, keepdims=True)
     b = (mx[..., 0] + np.log(np.exp(z - mx).sum(axis=2)))
@@ -267,6 +276,7 @@ def gmm_map_b_diag_direct(obs, w, mu, var, precision=np.float64):
         for m in range(M):
             dx = obs - mu[n, m]
             bm[n, m] = const[n, m] - 0.5 * ((dx / var[n, m]) * dx).sum(axis=1)
+    bm[:, :, _nonfinite_frames(obs)] = np.nan
     b = np.empty((N, T), dtype=precision)
     for n in range(N):
         b[n] = lse(w[n].reshape(M, 1) + bm[n], axis=0)

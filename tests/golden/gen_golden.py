@@ -181,6 +181,37 @@ def gen_gmmhmm_f32_mid():
     save("gmmhmm_f32_mid", **out)
 
 
+def gen_nonfinite():
+    """Non-finite observations through the reference (gmm.py:59-68 with a diagonal Sigma handed over as [N,M,D,D]: a NaN
+    or an infinite feature makes every component density of its frame NaN -- inf * 0 in the product with the inverse's
+    zero off-diagonals -- hence b[:, t] = NaN; hmm.py:162-171: np.max / np.argmax propagate it, every later frame of v is
+    NaN, bt there is the first NaN's index, then 0).  N=8, M=2, D=5, T=24, seeds 21 / 1021; cases: NaN mid-sequence,
+    +inf, -inf in frame 0, a NaN in the last frame, two bad frames."""
+    N, M, D, T = 8, 2, 5, 24
+    mdl = synth.synth_model(N, M, D, seed=21)
+    base = synth.synth_obs(1, T, D, seed=1021)[0]
+    cases = {"nan_mid": [(9, 3, np.nan)], "pinf": [(14, 0, np.inf)], "ninf_t0": [(0, 1, -np.inf)],
+             "nan_last": [(T - 1, 4, np.nan)], "two": [(17, 2, np.nan), (6, 1, np.inf)]}
+    out = dict(shape=np.array([N, M, D, T]), seeds=np.array([21, 1021]), names=np.array(sorted(cases)))
+    for prec, ptag in ((np.double, ""), (np.float32, "_f32")):
+        for name in sorted(cases):
+            obs = base.copy()
+            for t, d, val in cases[name]:
+                obs[t, d] = val
+            gh = GMMHMM(N, M, D, mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["si"], precision=prec)
+            with np.errstate(all="ignore"):
+                cap = _gmmhmm_capture(gh, obs, with_estimate=False)
+                dec = gh.decode(obs)
+            assert np.array_equal(dec, cap["path"])
+            k = name + ptag
+            if not ptag:
+                out[name + "_obs"] = obs
+            for a in ("b", "bm", "v", "path", "alpha", "beta", "loglik"):
+                out[k + "_" + a] = cap[a]
+            out[k + "_bt"] = cap["bt"].astype(np.uint8)
+    save("gmmhmm_nonfinite", **out)
+
+
 def gen_offset_means():
     """Models of real-feature scale (not the unit-scale synthetic ones): means far from the origin and from each
     other, small variances, observations near the means.  The reference scores with the direct (x - mu) form
@@ -391,3 +422,4 @@ if __name__ == "__main__":
         gen_metric_slice()
         gen_offset_means()
         gen_gmmhmm_f32_mid()
+        gen_nonfinite()

@@ -331,41 +331,6 @@ def test_viterbi_float32_register_kernels(N, U, synth, oracle, ctx):
     assert [n for n in names if n.startswith("viterbi") and n.endswith("_f32") and "generic" not in n] or not tuned(), names
 
 
-def test_nan_emissions_documented_deviation(synth, oracle, ctx):
-    """np.max / np.argmax PROPAGATE NaN (hmm.py:164-166): one NaN emission poisons every later frame of the
-    reference's trellis.  The kernels' max is IEEE maxNum (v_max_f64 / ds_max_f64 return the other operand), so here
-    the NaN stays in its own cell of v (or becomes -inf there) and later frames treat that state as unreachable.  DESIGN.md lists this as
-    a deviation; this test pins what actually happens (nothing hangs, nothing else turns NaN, and the path is the
-    one a -inf in that cell would give) for every Viterbi family."""
-    for N, T in ((6, 20), (40, 12), (128, 12), (200, 10)):
-        d = synth.synth_discrete(N, 4, 8, seed=N)
-        rng = np.random.default_rng(N)
-        b = -30.0 * rng.random((2, T, N))
-        tn, jn = 4, N // 2
-        b[0, tn, jn] = np.nan
-        ctx.upload_hmm(d["A"], d["pi"])
-        r = ctx.viterbi(b, want_score=True)
-        # the cell itself: NaN, or -inf where the row slices meet in an LDS atomic max (which drops a NaN operand too)
-        cell = r["v"][0, tn, jn]
-        assert np.isnan(cell) or cell == -np.inf
-        vv = r["v"].copy()
-        vv[0, tn, jn] = 0.0
-        assert not np.isnan(vv).any()
-        b_inf = b.copy()
-        b_inf[0, tn, jn] = -np.inf
-        for u in range(2):
-            ov, obt, opath = oracle.viterbi(d["A"], d["pi"], b_inf[u].T)
-            assert np.array_equal(r["path"][u], opath), (N, u)
-            ok = np.ones_like(ov, dtype=bool)
-            if u == 0:
-                ok[tn, jn] = False
-            assert np.array_equal(r["v"][u][ok], ov[ok])
-        # the reference's own behaviour, for the record: everything after the NaN frame is NaN
-        with np.errstate(invalid="ignore"):
-            rv, _, _ = oracle.viterbi(d["A"], d["pi"], b[0].T)
-        assert np.isnan(rv[tn + 1:]).all() and not np.isnan(rv[:tn]).any()
-
-
 @pytest.mark.parametrize("N", [1, 3, 4, 7, 8, 13, 16])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_viterbi_tiny_models_chunk_boundaries(N, dtype, synth, oracle, ctx):

@@ -1,0 +1,217 @@
+"""NaN and infinite data: the reference's propagation, reproduced (ln-asr_amd/csrc/nanfix.hip).
+
+numpy's max / argmax / logaddexp carry a NaN through every later frame (hmm.py:97-99,162-171) and the reference's
+product with the full inverse matrix turns a frame with a NaN OR an infinite feature into NaN densities (gmm.py:63-68).
+The tuned kernels use IEEE maxNum; a repair pass rewrites their outputs to the reference's closed form.  Everything here
+is compared with the golden `gmmhmm_nonfinite` (generated from the imported reference) or with the numpy oracle, NaN for
+NaN and path for path."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _eq_nan(a, b):
+    return np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from lnasr import _ffi
+    return _ffi.default_ctx()
+
+
+def _host(x):
+    return x.to_host() if hasattr(x, "to_host") else np.asarray(x)
+
+
+def test_reference_golden(golden, synth, ctx):
+    g = golden("gmmhmm_nonfinite")
+    N, M, D, T = (int(x) for x in g["shape"])
+    mdl = synth.synth_model(N, M, D, seed=int(g["seeds"][0]))
+    names = [str(x) for x in g["names"]]
+    obs = np.stack([g[n + "_obs"] for n in names])                       # one utterance per case
+    ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
+    path, score = ctx.decode(obs, want_score=True)
+    ll = ctx.calc_prob(obs)
+    for prec, tag, tol in ((np.float64, "", 1e-12), (np.float32, "_f32", 2e-6)):
+        b, bm = ctx.gmm_logprob(obs, want_bm=True, precision=prec)
+        for u, n in enumerate(names):
+            k = n + tag
+            gb, gbm = g[k + "_b"].T, g[k + "_bm"].transpose(2, 0, 1)     # [T,N], [T,N,M]
+            assert np.array_equal(np.isnan(b[u]), np.isnan(gb)), k
+            assert np.array_equal(np.isnan(bm[u]), np.isnan(gbm)), k
+            ok = ~np.isnan(gb)
+            assert np.allclose(b[u][ok], gb[ok], rtol=tol, atol=tol), k
+            # the trellis on the reference's own emissions
+            ctx.upload_hmm(mdl["A"], mdl["pi"])
+            r = ctx.viterbi(np.ascontiguousarray(gb[None]), want_score=True)
+            assert _eq_nan(r["v"][0], g[k + "_v"]), k
+            assert np.array_equal(r["bt"][0], g[k + "_bt"]), k
+            assert np.array_equal(r["path"][0], g[k + "_path"]), k
+            assert np.isnan(r["score"][0])
+            ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
+    for u, n in enumerate(names):
+        assert np.array_equal(path[u], g[n + "_path"]), n
+        assert np.isnan(score[u]) and np.isnan(ll[u]), n
+    # full-covariance route (the matrices as the reference stores them)
+    ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["si"], force_full=True)
+    path2 = ctx.decode(obs)
+    b2 = ctx.gmm_logprob(obs)
+    for u, n in enumerate(names):
+        assert np.array_equal(path2[u], g[n + "_path"]), n
+        assert np.array_equal(np.isnan(b2[u]), np.isnan(g[n + "_b"].T)), n
+
+
+@pytest.mark.parametrize("N,T,dtype", [(3, 40, np.float64), (6, 70, np.float64), (16, 33, np.float32), (40, 24, np.float64),
+                                       (128, 40, np.float64), (128, 40, np.float32), (200, 12, np.float64),
+                                       (256, 20, np.float64), (256, 20, np.float32), (300, 9, np.float64),
+                                       (520, 6, np.float64)])
+def test_viterbi_families_propagate_nan(synth, oracle, ctx, N, T, dtype):
+    """Every Viterbi kernel family (tiny, register, on-chip 256, streamed, per-frame; both storages): NaN cells in
+    caller-supplied emissions -- first frame, last frame, a single cell, a whole row, two frames, behind the utterance's
+    end (ignored) -- give the reference's v, bt, path and score."""
+    d = synth.synth_discrete(N, 4, 8, seed=N)
+    rng = np.random.default_rng(N + T)
+    U = 7
+    b = (-30.0 * rng.random((U, T, N))).astype(dtype)
+    lens = np.array([T, T, T, T - 2, T, max(1, T // 2), T], dtype=np.int32)
+    b[0, 0, N // 2] = np.nan                       # frame 0
+    b[1, T - 1, N - 1] = np.nan                    # last frame, last state
+    b[2, T // 2, 0] = np.nan                       # a single cell mid-sequence
+    b[3, T // 3, :] = np.nan                       # a whole row, ragged utterance
+    b[4, T // 4, 1:] = np.nan                      # two frames: the earlier one decides
+    b[4, T // 2, 0] = np.nan
+    b[5, lens[5]:, :] = np.nan                     # only behind the end: a clean utterance
+    ctx.upload_hmm(d["A"], d["pi"])
+    r = ctx.viterbi(b, want_score=True, lens=lens)
+    for u in range(U):
+        L = int(lens[u])
+        with np.errstate(invalid="ignore"):
+            ov, obt, opath = oracle.viterbi(d["A"], d["pi"], b[u, :L].T, dtype)
+        assert _eq_nan(r["v"][u, :L], ov), (N, u)
+        assert np.array_equal(r["bt"][u, :L], obt), (N, u)
+        assert np.array_equal(r["path"][u, :L], opath), (N, u)
+        want = np.max(ov[-1].astype(np.float64))
+        assert (np.isnan(r["score"][u]) and np.isnan(want)) or r["score"][u] == want, (N, u)
+    assert np.isnan(r["score"][:5]).all() and not np.isnan(r["score"][5:]).any()
+
+
+@pytest.mark.parametrize("N,M,D,U,T", [(128, 16, 39, 130, 48), (32, 8, 39, 20, 64), (12, 1, 13, 9, 50), (5, 3, 2, 4, 30)])
+def test_decode_with_bad_features(synth, oracle, ctx, N, M, D, U, T):
+    """decode / calc_prob on observations with NaN / +-inf features, device-resident and from host memory (U = 130 takes
+    the chunked upload), for the matrix-core kernel, the single-Gaussian kernel and the generic one: paths equal the
+    oracle's for every utterance, clean utterances are untouched."""
+    mdl = synth.synth_model(N, M, D, seed=7)
+    obs = synth.synth_obs(U, T, D, seed=77)
+    lens = np.full(U, T, dtype=np.int32)
+    lens[1] = T - 5
+    bad = {0: (T // 2, 3 % D, np.nan), 1: (T - 2, 0, np.nan), 2: (0, D - 1, np.inf), 3: (T - 1, 1, -np.inf)}
+    if U > 100:
+        bad[U - 1] = (7, 5, np.nan)
+        bad[70] = (T // 3, 2, np.inf)
+    for u, (t, dd, val) in bad.items():
+        obs[u, t, dd] = val
+    ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
+    want = []
+    with np.errstate(all="ignore"):
+        for u in range(U):
+            want.append(oracle.decode_diag(obs[u, :lens[u]], mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"]))
+    for src in (obs, ctx.to_device(obs)):
+        path, score = ctx.decode(src, want_score=True, lens=lens)
+        path, score, ll = (_host(x) for x in (path, score, ctx.calc_prob(src, lens=lens)))
+        for u in range(U):
+            assert np.array_equal(path[u, :lens[u]], want[u]), (N, u)
+            # utterance 1's bad frame lies behind its end: clean
+            hit = u in bad and bad[u][0] < lens[u]
+            assert np.isnan(score[u]) == hit and np.isnan(ll[u]) == hit, (N, u)
+    # emissions: whole NaN rows exactly where a feature is not finite
+    b = ctx.gmm_logprob(obs)
+    rows = ~np.isfinite(obs).all(axis=2)
+    assert np.array_equal(np.isnan(b).all(axis=2), rows) and np.array_equal(np.isnan(b).any(axis=2), rows)
+
+
+def test_clean_data_launches_only_the_checks(synth, ctx):
+    """On clean data the repair costs decode ONE launch that reads a word and returns (the emission kernel tested the
+    features it staged), and nothing changes in the results."""
+    mdl = synth.synth_model(128, 16, 39, seed=1)
+    obs = ctx.to_device(synth.synth_obs(64, 50, 39, seed=5))
+    ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
+    ctx.decode(obs)
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    p1 = ctx.decode(obs).to_host()
+    rep = ctx.prof_report()
+    ctx.prof_enable(False)
+    assert "viterbi_nan_repair" in rep and "nan_rows" not in rep and "nan_locate" not in rep, rep
+    assert rep["viterbi_nan_repair"][1] < 0.02, rep          # ms, event bracket included: it read one word and returned
+    assert not np.isnan(ctx.calc_prob(obs).to_host()).any()
+    assert p1.max() < 128
+
+
+def test_caller_emissions_clean_or_minus_inf(synth, oracle, ctx):
+    """lnasr_viterbi on caller-supplied emissions: the back-trace kernel flags NaN / -inf cells of v while it reads them,
+    so a dense model never pays the scan of b (the locate kernel returns at once); a model with -inf transitions or
+    emissions raises the flag for nothing -- the scan runs, finds no NaN, and the results stay the oracle's."""
+    N, U, T = 128, 16, 60
+    d = synth.synth_discrete(N, 4, 8, seed=5)
+    rng = np.random.default_rng(9)
+    b = -30.0 * rng.random((U, T, N))
+    ctx.upload_hmm(d["A"], d["pi"])
+    db = ctx.to_device(b)
+    ctx.viterbi(db)
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    r = ctx.viterbi(db, want_bt=False)
+    rep = ctx.prof_report()
+    ctx.prof_enable(False)
+    assert rep["nan_locate"][1] < 0.02 and rep["viterbi_nan_repair"][1] < 0.02, rep
+    assert np.array_equal(r["path"].to_host()[0], oracle.viterbi(d["A"], d["pi"], b[0].T)[2])
+    # left-to-right model and some impossible emissions: -inf cells everywhere, no NaN
+    A = d["A"].copy()
+    A[np.tril_indices(N, -1)] = -np.inf
+    b2 = b.copy()
+    b2[:, ::7, ::5] = -np.inf
+    ctx.upload_hmm(A, d["pi"])
+    r = ctx.viterbi(b2, want_score=True)
+    for u in (0, 7, 15):
+        with np.errstate(invalid="ignore"):
+            ov, obt, opath = oracle.viterbi(A, d["pi"], b2[u].T)
+        assert np.array_equal(r["v"][u], ov) and np.array_equal(r["bt"][u], obt) and np.array_equal(r["path"][u], opath)
+    assert not np.isnan(r["score"]).any()
+
+
+@pytest.mark.parametrize("precision", [np.float64, np.float32])
+def test_statistics_of_a_batch_with_a_bad_feature(synth, oracle, ctx, precision):
+    """Baum-Welch statistics (gmmhmm.py:69-156): alpha is NaN from the bad frame on, beta before it, so every posterior
+    of that utterance is NaN and every sum it enters -- the oracle's statistics are all NaN (the counts are not), and
+    so are these; the same batch without the bad feature is untouched by the check."""
+    N, M, D, U, T = 16, 4, 39, 6, 40
+    mdl = synth.synth_model(N, M, D, seed=3)
+    obs = synth.synth_obs(U, T, D, seed=4)
+    ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
+    def split(st):
+        st = _host(st)
+        o, out = 0, {}
+        for key, n in (("xi_sum", N * N), ("gamma_sum", N), ("gamma0", N), ("mix", N * M), ("mix_x", N * M * D),
+                       ("mix_xx", N * M * D), ("loglik", 1), ("n_utt", 1), ("n_frames", 1)):
+            out[key] = st[o:o + n]
+            o += n
+        assert o == st.size
+        return out
+
+    clean = split(ctx.bw_accumulate(obs, precision=precision))
+    assert all(not np.isnan(x).any() for x in clean.values())
+    bad = obs.copy()
+    bad[4, 17, 20] = np.inf
+    with np.errstate(all="ignore"):
+        want = oracle.bw_stats_diag(bad, mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"])
+    for src in (bad, ctx.to_device(bad)):
+        got = split(ctx.bw_accumulate(src, precision=precision))
+        for k in ("xi_sum", "gamma_sum", "gamma0", "mix", "mix_x", "mix_xx", "loglik"):
+            assert np.isnan(np.asarray(want[k])).all() and np.isnan(np.asarray(got[k])).all(), k
+        assert got["n_utt"][0] == U and got["n_frames"][0] == U * T
+    lens = np.full(U, T, dtype=np.int32)
+    lens[4] = 17                                       # the bad frame now lies behind the utterance's end
+    got = split(ctx.bw_accumulate(bad, lens=lens, precision=precision))
+    assert all(not np.isnan(x).any() for x in got.values())

@@ -133,6 +133,39 @@ def test_gmmhmm_f32_mid_rounding_order(oracle, golden, synth):
     assert_close(oracle.backward(mdl["A"], g["b"], f32), g["beta"], 1e-6)
 
 
+def test_nonfinite_observations(oracle, golden, synth):
+    """A NaN or an infinite feature: the reference makes the whole frame's densities NaN (inf * 0 against the inverse's
+    zero off-diagonals, gmm.py:63-68) and np.max / np.argmax / np.logaddexp carry the NaN through every later frame
+    (hmm.py:97-99,128-130,162-171).  All three emission restatements and the trellises reproduce the reference's
+    arrays NaN for NaN, and its paths exactly."""
+    g = golden("gmmhmm_nonfinite")
+    N, M, D, T = (int(x) for x in g["shape"])
+    mdl = synth.synth_model(N, M, D, seed=int(g["seeds"][0]))
+    for name in (str(x) for x in g["names"]):
+        obs = g[name + "_obs"]
+        assert not np.isfinite(obs).all()
+        for prec, tag in ((np.float64, ""), (np.float32, "_f32")):
+            k = name + tag
+            with np.errstate(all="ignore"):
+                outs = [oracle.gmm_map_b(obs, mdl["w"], mdl["mu"], mdl["si"], prec),
+                        oracle.gmm_map_b_diag_direct(obs, mdl["w"], mdl["mu"], mdl["var"], prec),
+                        oracle.gmm_map_b_diag(obs, mdl["w"], mdl["mu"], mdl["var"], prec)]
+                for b, bm in outs:
+                    assert np.array_equal(np.isnan(b), np.isnan(g[k + "_b"])), k
+                    assert np.array_equal(np.isnan(bm), np.isnan(g[k + "_bm"])), k
+                    assert_close(np.nan_to_num(b), np.nan_to_num(g[k + "_b"]), 1e-6 if tag else 1e-12)
+                v, bt, path = oracle.viterbi(mdl["A"], mdl["pi"], g[k + "_b"], prec)
+                assert np.array_equal(v, g[k + "_v"], equal_nan=True), k
+                assert np.array_equal(bt, g[k + "_bt"]) and np.array_equal(path, g[k + "_path"]), k
+                al = oracle.forward(mdl["A"], mdl["pi"], g[k + "_b"], prec)
+                be = oracle.backward(mdl["A"], g[k + "_b"], prec)
+                assert np.array_equal(np.isnan(al), np.isnan(g[k + "_alpha"])), k
+                assert np.array_equal(np.isnan(be), np.isnan(g[k + "_beta"])), k
+                assert np.isnan(oracle.loglik(al)) and np.isnan(g[k + "_loglik"][0])
+                assert np.array_equal(oracle.decode_diag(obs, mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"]),
+                                      g[name + "_path"])
+
+
 @pytest.mark.parametrize("kind", ["diag", "full"])
 def test_gmmhmm_d39(oracle, golden, kind):
     g = golden("gmmhmm_d39_" + kind)
