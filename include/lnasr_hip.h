@@ -115,7 +115,8 @@ int lnasr_model_conditioning(lnasr_ctx* ctx, double* kappa, int* direct_form);
 /* HMM._map_b (hmm.py:47-61): b[u,t,:] = B[:, obs[u,t]];  B is [N,K] */
 int lnasr_discrete_map_b(lnasr_ctx* ctx, const double* logB, int N, int K,
                          const int32_t* obs, int U, int T, int dtype, void* b);
-/* GMMHMM._map_b (gmmhmm.py:46-67): b and (optionally) the per-mixture bm */
+/* GMMHMM._map_b (gmmhmm.py:46-67): b and (optionally) the per-mixture bm.  A frame with a NaN or an infinite feature
+ * gets NaN rows, as the reference's product with the full inverse matrix gives (gmm.py:63-68: inf * 0). */
 int lnasr_gmm_logprob(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* lens,
                       int dtype, void* b, void* bm_or_null);
 /* free functions of gmm.py (one Gaussian / one mixture, no HMM):
@@ -129,13 +130,15 @@ int lnasr_gauss_mixture(lnasr_ctx* ctx, const double* c, int M, const double* x,
                         const double* mu, const double* Sigma, int want_log, double* out);
 
 /* ---- trellises (use the uploaded logA / logpi) ---------------------------------- */
-/* HMM._viterbi (hmm.py:133-172): v, bt optional; path required.  best_score [U] optional. */
+/* HMM._viterbi (hmm.py:133-172): v, bt optional; path required.  best_score [U] optional.
+ * NaN emissions propagate as numpy's max / argmax propagate them (hmm.py:164-171): from the first frame t1 that holds one,
+ * v[t > t1] is NaN, path[t > t1] = 0, path[t1] = the first NaN state, path[t < t1] the back-trace from there. */
 int lnasr_viterbi(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* lens, int dtype,
                   void* v_or_null, uint32_t* bt_or_null, uint32_t* path, double* best_score_or_null);
 /* GMMHMM.decode (hmm.py:276-283 -> gmmhmm.py:46-67 + hmm.py:133-172): emission, trellis and
  * backtrace as three launches on the context's stream; b and v stay in HBM workspaces of the
  * context (they are not on chip: 1 KB per frame each way, far from the binding resource) and
- * only the paths come back */
+ * only the paths come back.  NaN / infinite features: the reference's paths (see lnasr_viterbi), best_score NaN */
 int lnasr_decode(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* lens,
                  uint32_t* path, double* best_score_or_null);
 /* HMM._forward (hmm.py:63-100) and calc_prob (hmm.py:268-274): alpha optional, loglik [U] optional */
@@ -143,7 +146,7 @@ int lnasr_forward(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* le
                   void* alpha_or_null, double* loglik_or_null);
 /* HMM._backward (hmm.py:102-131) */
 int lnasr_backward(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* lens, int dtype, void* beta);
-/* GMMHMM.calc_prob: emission + forward, loglik [U] */
+/* GMMHMM.calc_prob: emission + forward, loglik [U] (NaN for an utterance with a NaN or an infinite feature) */
 int lnasr_calc_prob(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* lens, double* loglik);
 /* the same under the model's `precision=`: LNASR_F32 scores the emission exactly as lnasr_bw_accumulate_p(…, F32)
  * does (fp32 matrix cores where the model allows it), so the two likelihoods of the reference's stopping rule
