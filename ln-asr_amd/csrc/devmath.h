@@ -181,6 +181,9 @@ __device__ __forceinline__ void argmax_combine(double& v, int& i, double ov, int
         i = oi;
     }
 }
+// Callers start from (-inf, kNoIndex).  A NaN candidate never wins a comparison: a row of NaNs leaves kNoIndex standing,
+// which comes back as 0 -- numpy.argmax's answer for an all-NaN row, and never an address outside the row.
+constexpr int kNoIndex = 0x7fffffff;
 __device__ __forceinline__ void wave_argmax(double& v, int& i) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
@@ -188,6 +191,7 @@ __device__ __forceinline__ void wave_argmax(double& v, int& i) {
         int oi = __shfl_xor(i, m, 64);
         argmax_combine(v, i, ov, oi);
     }
+    i = i == kNoIndex ? 0 : i;
 }
 
 // Block-wide reductions through a small LDS scratch (>= 2 * nwaves doubles). All threads must call.

@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void viterbi_nan_repair_kernel(const TS* __res
     for (int t = t1; t >= 1; --t) {
         const double* col = AT + (size_t)p * N;
         double x = LN_NEG_INF;
-        int xi = 0x7fffffff;
+        int xi = kNoIndex;
         for (int i = tid; i < N; i += 256) argmax_combine(x, xi, ld(vu, (size_t)(t - 1) * N + i) + col[i], i);
         wave_argmax(x, xi);
         if (lane == 0) {

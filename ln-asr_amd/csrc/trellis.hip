@@ -227,7 +227,7 @@ __global__ void backtrace_kernel(const TS* __restrict__ v, const double* __restr
     const TS* vu = v + (size_t)u * T * N;
     uint32_t* pu = path + (size_t)u * T;
     double bv = LN_NEG_INF;
-    int bi = 0x7fffffff;
+    int bi = kNoIndex;
     for (int j = lane; j < N; j += 64) argmax_combine(bv, bi, ld(vu, (size_t)(L - 1) * N + j), j);
     wave_argmax(bv, bi);
     int p = bi;
@@ -251,7 +251,7 @@ __global__ void backtrace_kernel(const TS* __restrict__ v, const double* __restr
             }
             const double* col = AT + (size_t)p * N;
             double x = LN_NEG_INF;
-            int xi = 0x7fffffff;
+            int xi = kNoIndex;
             if (j0 < N) { x = c0 + col[j0]; xi = j0; }
             if (j1 < N) argmax_combine(x, xi, c1 + col[j1], j1);
             wave_argmax(x, xi);
@@ -262,7 +262,7 @@ __global__ void backtrace_kernel(const TS* __restrict__ v, const double* __restr
         for (int t = L - 2; t >= 0; --t) {
             const double* col = AT + (size_t)p * N;
             double x = LN_NEG_INF;
-            int xi = 0x7fffffff;
+            int xi = kNoIndex;
             for (int j = lane; j < N; j += 64) argmax_combine(x, xi, ld(vu, (size_t)t * N + j) + col[j], j);
             wave_argmax(x, xi);
             p = xi;
