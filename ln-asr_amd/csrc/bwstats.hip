@@ -215,13 +215,18 @@ int xi_sum_device(lnasr_ctx* ctx, const double* alpha, const double* beta, const
 // frames per instruction) and multiplies them with the block's shared feature rows [x-c, (x-c)^2, 1] from LDS.
 // Raw sums go to R[(j, m), col]; mix_finish_kernel turns them into the reference's three accumulators.
 // ------------------------------------------------------------------------------------------
-constexpr int kMixFrames = 32;       // frames per staged chunk (8 MFMA k-steps)
+constexpr int kMixFrames = 32;       // frames per staged chunk (8 MFMA k-steps): the full-covariance moments kernel
+constexpr int kMixDiagFrames = 32;   // ... and the diagonal one (mix_mfma_kernel).  Measured at config 5 (round 3, SQ counters in
+                                     // the matrix pipe is busy 64 % of the kernel, other VALU 21 %): 64 frames per
+                                     // chunk -- half the barriers -- 3.80 ms against 3.65; one generation of blocks instead of
+                                     // two (only one 206-register block fits a CU at a time anyway) 3.67
 constexpr int kMixRing = 8;          // bm prefetch ring (k-steps; must divide kMixFrames / 4)
 // The ring's running pointer is not clamped: the last block reads up to (kMixFrames - 1) frames of chunk rounding plus
 // 4 (kMixRing - 1) + 3 frames of prefetch past the batch.  Callers allocate bm with kMixPadFrames frames of slack
 // (lnasr_bw_accumulate_p); this ties the three constants together.
+static_assert((kMixDiagFrames - 1) + 4 * (kMixRing - 1) + 3 < kMixPadFrames, "bm prefetch ring outruns kMixPadFrames");
 static_assert((kMixFrames - 1) + 4 * (kMixRing - 1) + 3 < kMixPadFrames, "bm prefetch ring outruns kMixPadFrames");
-static_assert((kMixFrames / 4) % kMixRing == 0, "kMixRing must divide kMixFrames / 4");
+static_assert((kMixDiagFrames / 4) % kMixRing == 0, "kMixRing must divide kMixDiagFrames / 4");
 constexpr int kMixWaves = 8;         // waves (= states) per block; 4-wave blocks at 3 waves/SIMD were measured: slower (5.7 vs 4.1 ms)
 constexpr int kMixNT = 64 * kMixWaves;
 
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(64 * kMixWaves) void mix_mfma_kernel(const double* 
                                                        const double* __restrict__ logw, const double* __restrict__ centre,
                                                        const int32_t* __restrict__ lens, long F, long FPB, int T, int N,
                                                        int M, int D, int G, int MP, double* __restrict__ R) {
-    constexpr int CH = kMixFrames, NFP = 16 * CT, FST = NFP + ((CT & 1) ? 0 : 16);
+    constexpr int CH = kMixDiagFrames, NFP = 16 * CT, FST = NFP + ((CT & 1) ? 0 : 16);
     constexpr int OPT = (CH * 39 + kMixNT - 1) / kMixNT;             // obs doubles staged per thread (D <= 39)
     __shared__ double feat[2][CH * FST];
     __shared__ double sab[2][CH * kMixWaves], sbb[2][CH * kMixWaves];
@@ -704,12 +709,12 @@ int mix_stats_device(lnasr_ctx* ctx, const double* obs, const double* alpha, con
     }
     if (phase & kMixAdd) {
         const int SG = (N * MG + kMixWaves - 1) / kMixWaves;
-        const long nchunk = (F + kMixFrames - 1) / kMixFrames;
+        const long nchunk = (F + kMixDiagFrames - 1) / kMixDiagFrames;
         long G = (2L * ctx->prop.multiProcessorCount + SG - 1) / SG;
         if (G > nchunk) G = nchunk;
         if (G < 1) G = 1;
         if (G > 65535) G = 65535;
-        const long FPB = ((nchunk + G - 1) / G) * kMixFrames;
+        const long FPB = ((nchunk + G - 1) / G) * kMixDiagFrames;
         G = (F + FPB - 1) / FPB;
         const dim3 grid(SG, (unsigned)G);
         if (MT == 1)

@@ -60,7 +60,8 @@ template <int Q, int KS>
 __global__ __launch_bounds__(512) void emit_diag_mfma_f32(const double* __restrict__ obs, const float* __restrict__ wpack,
                                                           const double* __restrict__ centre, double* __restrict__ b,
                                                           float* __restrict__ q32, long F, int N, int D, int NG, int GY,
-                                                          long ntiles, int tiles_per_block, long nchunks) {
+                                                          long ntiles, int tiles_per_block, long nchunks,
+                                                          unsigned* __restrict__ nan_flag, unsigned nan_epoch) {
     constexpr int KP = 4 * KS, NT = 512, SPB = 32, FS = 17, OS = SPB + 1;
     __shared__ float Fl[2][KP * FS];
     __shared__ double ob[2][16 * OS];
@@ -116,11 +117,13 @@ __global__ __launch_bounds__(512) void emit_diag_mfma_f32(const double* __restri
             pre[r] = obs[ge];
         }
     };
+    unsigned long long nonfinite = 0;                        // NaN / infinite features staged: see emit_diag_mfma (gmm.hip)
     auto store_stage = [&](int buf) {
         float* Fd = &Fl[buf][0];
         const int xo = D * FS;
 #pragma unroll
         for (int r = 0; r < MAXLD; ++r) {
+            nonfinite |= __ballot(!__builtin_isfinite(pre[r]));
             if (foff[r] >= 0) {
                 const double x = pre[r] - cen[r];
                 Fd[foff[r]] = (float)(x * x);
@@ -178,6 +181,7 @@ __global__ __launch_bounds__(512) void emit_diag_mfma_f32(const double* __restri
         __syncthreads();
     }
     if (tile1 > tile0) flush_stage((int)((tile1 - tile0 - 1) & 1), tile1 - 1);
+    if (nonfinite != 0 && lane == 0) *nan_flag = nan_epoch;
 }
 
 // b[cell] = lse_h bv[cell * k + h]   (M = 16 k mixtures scored as k virtual 16-mixture states)
@@ -402,7 +406,7 @@ static int launch_emit32(lnasr_ctx* ctx, const double* obs, long F, double* bv, 
     const long grid = ((nchunks + 7) / 8) * 8 * GY;
     LN_LAUNCH(ctx, "emit_diag_mfma_f32", (emit_diag_mfma_f32<Q, KS>), dim3((unsigned)grid), dim3(512), 0, obs,
               (const float*)md.wpack32.as<float>(), (const double*)md.centre.as<double>(), bv, q32, F, Nv, D, md.wpack_NG,
-              GY, ntiles, (int)tpb, nchunks);
+              GY, ntiles, (int)tpb, nchunks, ctx->nan_flag.as<unsigned>(), ctx->nan_epoch);
     return 0;
 }
 

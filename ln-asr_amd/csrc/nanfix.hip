@@ -172,11 +172,10 @@ __global__ __launch_bounds__(256) void viterbi_nan_repair_kernel(const TS* __res
     const TS nan = quiet_nan<TS>();
     {
         TS* vu = v + (size_t)u * T * N;
-        const TS* bu = b + (size_t)u * T * N;
         for (int j = tid; j < N; j += 256) {
-            bool hit = obs != nullptr;
+            bool hit = obs != nullptr;                           // a bad feature: every state of the frame
             if (!hit) {
-                const TS x = bu[(size_t)t1 * N + j];
+                const TS x = b[((size_t)u * T + t1) * N + j];
                 hit = x != x;
             }
             if (hit) vu[(size_t)t1 * N + j] = nan;
@@ -263,29 +262,38 @@ int viterbi_nan_repair(lnasr_ctx* ctx, const void* b, int U, int T, const int32_
     return 0;
 }
 
+// force for the kernels that walk ONE utterance per block: a flat scan of the observations at memory speed raises the
+// flag first (it does not know the utterances' lengths: padding may raise it for nothing), the slow walk follows only then
+static int raise_flag_if_bad(lnasr_ctx* ctx, const double* obs, int U, int T) {
+    return nan_rows_device(ctx, obs, (long)U * T, LNASR_F64, nullptr, nullptr, true);
+}
+
 int viterbi_nan_repair_obs(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* d_lens, double* v,
                            uint32_t* path, double* best, bool force) {
     if (U <= 0 || T <= 0) return 0;
     LN_REQUIRE(obs && v, "the repair pass needs the observations and the Viterbi lattice");
+    if (force) LN_TRY(raise_flag_if_bad(ctx, obs, U, T));
     const unsigned long long* no_slot = nullptr;
     LN_LAUNCH(ctx, "viterbi_nan_repair", viterbi_nan_repair_kernel<double>, dim3(U), dim3(256), 0, (const double*)nullptr,
               v, (const double*)ctx->model.logAT.as<double>(), d_lens, T, ctx->model.N, 0, no_slot, obs, ctx->model.D,
-              force ? 1 : 0, (const unsigned*)ctx->nan_flag.as<unsigned>(), ctx->nan_epoch, path, best);
+              0, (const unsigned*)ctx->nan_flag.as<unsigned>(), ctx->nan_epoch, path, best);
     return 0;
 }
 
 int stats_nan_repair(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* d_lens, double* stats, long n,
                      bool force) {
     if (U <= 0 || T <= 0 || n <= 0) return 0;
+    if (force) LN_TRY(raise_flag_if_bad(ctx, obs, U, T));
     LN_LAUNCH(ctx, "stats_nan_repair", nan_stats_kernel, dim3(U), dim3(256), 0, obs, d_lens, T, ctx->model.D, stats, n,
-              force ? 1 : 0, (const unsigned*)ctx->nan_flag.as<unsigned>(), ctx->nan_epoch);
+              0, (const unsigned*)ctx->nan_flag.as<unsigned>(), ctx->nan_epoch);
     return 0;
 }
 
 int loglik_nan_repair(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* d_lens, double* loglik, bool force) {
     if (U <= 0 || T <= 0) return 0;
+    if (force) LN_TRY(raise_flag_if_bad(ctx, obs, U, T));
     LN_LAUNCH(ctx, "loglik_nan_repair", nan_utt_obs_kernel, dim3(U), dim3(256), 0, obs, d_lens, T, ctx->model.D, loglik,
-              force ? 1 : 0, (const unsigned*)ctx->nan_flag.as<unsigned>(), ctx->nan_epoch);
+              0, (const unsigned*)ctx->nan_flag.as<unsigned>(), ctx->nan_epoch);
     return 0;
 }
 
