@@ -1109,6 +1109,10 @@ int emit_device_raw(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* 
 #undef LN_CASE
         LN_TRY(rc);
         *scanned = true;
+        // (Merging the two virtual states of an M = 32 model inside the emission kernels' flush stage instead -- no
+        // second pass over b -- was built and measured at config 5 in round 3: the fp64 kernel went from 3.70 to 3.90 ms
+        // (at 256 registers the extra code spills into the tile loop) and the fp32 one from 1.85 to 2.20 ms, for 0.27 /
+        // 0.25 ms of merge kernel saved: not kept.)
         if (virt > 1 || padded) {
             const size_t cells = (size_t)F * N;
             LN_LAUNCH(ctx, "merge_virtual_states", merge_virtual_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256),
