@@ -215,3 +215,38 @@ def test_statistics_of_a_batch_with_a_bad_feature(synth, oracle, ctx, precision)
     lens[4] = 17                                       # the bad frame now lies behind the utterance's end
     got = split(ctx.bw_accumulate(bad, lens=lens, precision=precision))
     assert all(not np.isnan(x).any() for x in got.values())
+
+
+def test_mfcc_propagates_bad_samples(synth, oracle):
+    """MFCC of a signal with a NaN and an infinite sample (mfcc.py:108-175 is plain arithmetic: no max, nothing to
+    repair): the same frames and the same delta rows are NaN as in the oracle, every other value agrees -- on the
+    single-utterance path, in a ragged batch and for int16-free f64 samples through the 512-point fast path."""
+    from lnasr.mfcc import MFCC
+    s = synth.synth_signal(16000 + 240, seed=3)
+    bad = s.copy()
+    bad[4321] = np.nan
+    bad[9000] = np.inf
+    with np.errstate(all="ignore"):
+        op, oc, of = oracle.mfcc(bad)
+    p, c, f = MFCC().calc_mfcc(bad)
+    for got, want, name in ((p, op, "power"), (c, oc, "cepstrum"), (f, of, "features")):
+        # power: a NaN sample makes its frames' bins NaN here as there; an INFINITE one leaves inf in some bins and NaN
+        # (inf - inf) in the others, and which is which follows the FFT's butterfly order (numpy's pocketfft: 40-72 inf
+        # bins per frame, the radix-4/16 kernel here: 1) -- the bins that are not finite are the same, and one logarithm
+        # later both are NaN
+        bad_got, bad_want = (~np.isfinite(got), ~np.isfinite(want)) if name == "power" else (np.isnan(got), np.isnan(want))
+        assert np.array_equal(bad_got, bad_want), name
+        assert bad_want.any()
+        ok = ~bad_want
+        assert np.allclose(got[ok], want[ok], rtol=1e-9, atol=1e-6), name
+    nan_only = s.copy()
+    nan_only[4321] = np.nan
+    with np.errstate(all="ignore"):
+        assert np.array_equal(np.isnan(MFCC().calc_mfcc(nan_only)[0]), np.isnan(oracle.mfcc(nan_only)[0]))
+    # the six frames that see a bad sample are NaN in the power spectrum; the cepstral rows pass through a sum over ALL
+    # frames (mfcc.py:150-160), so every cepstrum and feature row is NaN -- in the reference and here
+    # (the log-energy column comes from each frame's own power and stays finite elsewhere)
+    assert (~np.isfinite(op)).any(axis=1).sum() == 6 and np.isnan(of[:, :12]).all() and not np.isnan(of[:, 12]).all()
+    feat, foff = MFCC().calc_mfcc_batch([s[:5000], bad, s[:3000]])
+    assert np.array_equal(feat[foff[1]:foff[2]], f, equal_nan=True)
+    assert not np.isnan(feat[:foff[1]]).any() and not np.isnan(feat[foff[2]:]).any()
