@@ -238,7 +238,8 @@ int mix_stats_device_f32(lnasr_ctx* ctx, const double* obs, const double* alpha,
 int emit_device(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, void* bm);
 // emit_device without the pass over non-finite frames; *scanned: the kernel tested the features it staged and raised
 // ctx->nan_flag itself (emit_batch runs the kernels chunk by chunk and the pass once)
-int emit_device_raw(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, void* bm, bool* scanned);
+int emit_device_raw(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, void* bm, bool* scanned,
+                    bool* rows_done_or_null);      // *rows_done: b / bm already hold NaN rows for such frames
 int full_stats_device(lnasr_ctx* ctx, const double* obs, const double* alpha, const double* beta, const double* b,
                       const double* bm, const double* c1, const int32_t* d_lens, int U, int T, double* mix,
                       double* mix_x, double* mix_xx);

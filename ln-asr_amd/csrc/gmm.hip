@@ -343,7 +343,11 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 2))
         for (int r = 0; r < MAXLD; ++r) {
             nonfinite |= __ballot(!__builtin_isfinite(pre[r]));
             if (foff[r] >= 0) {
-                const double x = pre[r] - cen[r];       // centred: the coefficients are those of (x - centre)
+                // centred: the coefficients are those of (x - centre).  (Turning a non-finite feature into NaN right here
+                // -- every density of the frame is NaN by itself then, no pass afterwards -- costs two selects per staged
+                // element: measured +0.02..0.03 ms on this kernel, three alternations on one box.  The compare above is
+                // free; decode does not need the rows, so the 128-state bank leaves them to nan_rows_device.)
+                const double x = pre[r] - cen[r];
                 Fd[foff[r]] = x * x;
                 Fd[foff[r] + xo] = x;
             }
@@ -522,13 +526,18 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     const long lim = F * (long)D;
     // slot 4 j + g of this lane: a real dimension, the constant (== D), or padding (> D: coefficient 0; the value
     // read there is the start of the next frame, or 0 past the end of obs)
-    bool is_one[NL];
+    bool is_one[NL], is_real[NL];
     double cen[CEN ? NL : 1];                  // CEN (model re-centred, Model::centred): centre of the lane's dimensions;
 #pragma unroll                                 // a model conditioned about the origin pays neither registers nor subtractions
     for (int j = 0; j < NL; ++j) {
         is_one[j] = (4 * j + g) == D;
+        is_real[j] = (4 * j + g) < D;
         if (CEN) cen[j] = (4 * j + g) < D ? centre[4 * j + g] : 0.0;
     }
+    // slots from D on hold what FOLLOWS the frame in memory.  Their coefficients are 0, but 0 * NaN is NaN on the matrix
+    // cores: a NaN or an infinity in a later frame would poison this one (seed 312 of the bad-feature sweep: D = 3 reads
+    // 12 values past its frame), so those slots are cleared -- only where a model has any (D = 39 has none beyond the
+    // constant's, whose x-block value is cleared with them)
     double pre[NL];
     auto load_tile = [&](long tile) {
         const long e0 = tile * 16 * (long)D;
@@ -567,8 +576,14 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         double bx[NL], bq[NL];
 #pragma unroll
         for (int j = 0; j < NL; ++j) {
-            nonfinite |= __ballot(!__builtin_isfinite(pre[j]));     // see emit_diag_mfma
+            const bool fin = __builtin_isfinite(pre[j]);
+            nonfinite |= __ballot(!fin && is_real[j]);
             bx[j] = CEN ? pre[j] - cen[CEN ? j : 0] : pre[j];
+            // a NaN OR an infinite feature enters as NaN: every product with it is NaN (0 * NaN too), so all densities of
+            // the frame, their maximum (maxNum of NaNs) and b come out NaN -- the reference's rows (gmm.py:63-68) without
+            // a pass afterwards, which this 0.09 ms call would feel (0.102 -> 0.095 ms); an infinity left as it is would
+            // give -inf or NaN depending on the signs it meets
+            bx[j] = is_real[j] ? (fin ? bx[j] : __builtin_nan("")) : 0.0;
             bq[j] = is_one[j] ? 1.0 : bx[j] * bx[j];
         }
         load_tile(nxt);
@@ -1039,15 +1054,19 @@ static int launch_mfma(lnasr_ctx* ctx, const double* obs, long F, double* b, dou
 
 // device-resident emission over F = U*T flattened frames; b [F,N], bm [F,N,M] or null
 int emit_device(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, void* bm) {
-    bool scanned = false;
-    LN_TRY(emit_device_raw(ctx, obs, F, dtype, b, bm, &scanned));
+    bool scanned = false, rows_done = false;
+    LN_TRY(emit_device_raw(ctx, obs, F, dtype, b, bm, &scanned, &rows_done));
     // frames with a NaN or an infinite feature: NaN rows, as the reference's product with the full inverse gives
+    if (scanned && rows_done) return 0;
     return nan_rows_device(ctx, obs, F, dtype, b, bm, !scanned);
 }
 
-int emit_device_raw(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, void* bm, bool* scanned) {
+int emit_device_raw(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, void* bm, bool* scanned, bool* rows_done) {
     Model& md = ctx->model;
+    bool rows_dummy = false;
+    if (!rows_done) rows_done = &rows_dummy;
     *scanned = false;
+    *rows_done = false;
     if (!md.has_gmm) return fail(LNASR_E_NOMODEL, "no GMM-HMM model uploaded");
     if (F <= 0) return 0;
     const int N = md.N, M = md.M, D = md.D;
@@ -1057,7 +1076,8 @@ int emit_device_raw(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* 
         const size_t cells = (size_t)F * N;
         LN_TRY(ctx->ws_w1.reserve(cells * 8));
         LN_TRY(ctx->ws_w3.reserve(cells * M * 8));
-        LN_TRY(emit_device_raw(ctx, obs, F, LNASR_F64, ctx->ws_w1.p, ctx->ws_w3.p, scanned));
+        LN_TRY(emit_device_raw(ctx, obs, F, LNASR_F64, ctx->ws_w1.p, ctx->ws_w3.p, scanned, nullptr));   // the rounding pass
+                                                                                        // below does not carry NaN rows through
         LN_LAUNCH(ctx, "round32_lse", round32_lse_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0,
                   (const double*)ctx->ws_w3.as<double>(), (const double*)md.logw.as<double>(), cells, N, M, (float*)b,
                   (float*)bm);
@@ -1077,6 +1097,7 @@ int emit_device_raw(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* 
 #define LN_DCASE(ks)                                                                                              \
     if (md.wdirect_KS == ks) {                                                                                    \
         *scanned = true;                                                                                          \
+        *rows_done = true;                                                                                        \
         if (bm && md.centred) LN_DLAUNCH(ks, true, true, "emit_single_direct_bm");                                \
         else if (bm) LN_DLAUNCH(ks, true, false, "emit_single_direct_bm");                                        \
         else if (md.centred) LN_DLAUNCH(ks, false, true, "emit_single_direct");                                   \
@@ -1109,6 +1130,7 @@ int emit_device_raw(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* 
 #undef LN_CASE
         LN_TRY(rc);
         *scanned = true;
+
         // (Merging the two virtual states of an M = 32 model inside the emission kernels' flush stage instead -- no
         // second pass over b -- was built and measured at config 5 in round 3: the fp64 kernel went from 3.70 to 3.90 ms
         // (at 256 registers the extra code spills into the tile loop) and the fp32 one from 1.85 to 2.20 ms, for 0.27 /
@@ -1229,7 +1251,7 @@ int emit_batch(lnasr_ctx* ctx, const double* obs, int U, int T, double* b, doubl
         LN_TRY(stage_in(ctx, obs, (size_t)U * utt * 8, ctx->ws_in, &d_obs));
         if (d_obs_out) *d_obs_out = (const double*)d_obs;
         if (scanned_or_null)
-            return emit_device_raw(ctx, (const double*)d_obs, (long)U * T, LNASR_F64, b, bm, scanned_or_null);
+            return emit_device_raw(ctx, (const double*)d_obs, (long)U * T, LNASR_F64, b, bm, scanned_or_null, nullptr);
         return emit_device(ctx, (const double*)d_obs, (long)U * T, LNASR_F64, b, bm);
     }
     LN_TRY(ctx->ws_in.reserve((size_t)U * utt * 8));
@@ -1242,7 +1264,7 @@ int emit_batch(lnasr_ctx* ctx, const double* obs, int U, int T, double* b, doubl
         ctx->copy_events.push_back(e);
     }
     const ChunkPlan plan{U, nch, utt * 8};
-    bool all_scanned = true;
+    bool all_scanned = true, all_rows_done = true;
     // the side stream must not run ahead of work that still reads the staging buffer
     LN_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
     LN_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
@@ -1250,10 +1272,12 @@ int emit_batch(lnasr_ctx* ctx, const double* obs, int U, int T, double* b, doubl
         const int u0 = plan.lo(c), u1 = plan.lo(c + 1);
         if (hipStreamWaitEvent(ctx->stream, ctx->copy_events[c], 0) != hipSuccess)
             return fail(LNASR_E_HIP, "hipStreamWaitEvent failed in the upload pipeline");
-        bool scanned = false;
+        bool scanned = false, rows_done = false;
         const int rc = emit_device_raw(ctx, ctx->ws_in.as<double>() + (size_t)u0 * utt, (long)(u1 - u0) * T, LNASR_F64,
-                                       b + (size_t)u0 * T * md.N, bm ? bm + (size_t)u0 * T * md.N * md.M : nullptr, &scanned);
+                                       b + (size_t)u0 * T * md.N, bm ? bm + (size_t)u0 * T * md.N * md.M : nullptr, &scanned,
+                                       &rows_done);
         all_scanned = all_scanned && scanned;
+        all_rows_done = all_rows_done && rows_done;
         return rc;
     };
     // non-finite frames (nanfix.hip): once for the whole batch, behind the last chunk
@@ -1262,6 +1286,7 @@ int emit_batch(lnasr_ctx* ctx, const double* obs, int U, int T, double* b, doubl
             *scanned_or_null = all_scanned;
             return 0;
         }
+        if (all_scanned && all_rows_done) return 0;
         return nan_rows_device(ctx, ctx->ws_in.as<double>(), (long)U * T, LNASR_F64, b, bm, !all_scanned);
     };
 

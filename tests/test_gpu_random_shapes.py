@@ -88,6 +88,45 @@ def test_random_shape(seed, synth, oracle, ctx):
 
 
 @pytest.mark.parametrize("seed", _SEEDS_DIAG)
+def test_random_shape_bad_features(seed, synth, oracle, ctx):
+    """The same sweep with a NaN or an infinite feature dropped into one utterance (inside or behind its end): on every
+    dispatch branch the emissions get the reference's NaN rows, decode and the Viterbi on those emissions return the
+    oracle's v / bt / path NaN for NaN, the likelihood is NaN exactly where the oracle's is, and the statistics block is
+    all NaN or untouched."""
+    rng, N, M, D, T, U = _shape(seed)
+    rng = np.random.default_rng(5000 + seed)
+    mdl = synth.synth_model(N, M, D, seed=seed + 7)
+    obs = synth.synth_obs(U, T, D, seed=seed + 50)
+    lens = rng.integers(1, T + 1, U).astype(np.int32)
+    lens[0] = T
+    ub, tb, db = int(rng.integers(0, U)), int(rng.integers(0, T)), int(rng.integers(0, D))
+    obs[ub, tb, db] = [np.nan, np.inf, -np.inf][seed % 3]
+    inside = tb < lens[ub]
+    ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
+    tag = "seed=%d N=%d M=%d D=%d T=%d U=%d bad=(%d,%d,%d) inside=%s" % (seed, N, M, D, T, U, ub, tb, db, inside)
+    b = ctx.gmm_logprob(obs)
+    rows = ~np.isfinite(obs).all(axis=2)
+    assert np.array_equal(np.isnan(b).all(axis=2), rows) and np.array_equal(np.isnan(b).any(axis=2), rows), "b " + tag
+    r = ctx.viterbi(b, lens=lens, want_score=True)
+    paths, score = ctx.decode(obs, lens=lens, want_score=True)
+    ll = ctx.calc_prob(obs, lens=lens)
+    for u in range(U):
+        L = int(lens[u])
+        gb = np.ascontiguousarray(b[u, :L].T)
+        with np.errstate(invalid="ignore"):
+            v, bt, path = oracle.viterbi(mdl["A"], mdl["pi"], gb)
+        assert np.array_equal(r["v"][u, :L], v, equal_nan=True), "v " + tag
+        assert np.array_equal(r["bt"][u, :L], bt) and np.array_equal(r["path"][u, :L], path), "path " + tag
+        assert np.array_equal(np.asarray(paths)[u, :L], path), "decode " + tag
+        hit = bool(inside and u == ub)
+        assert np.isnan(r["score"][u]) == hit and np.isnan(score[u]) == hit and np.isnan(ll[u]) == hit, "score " + tag
+    st = ctx.bw_accumulate(obs, lens=lens)
+    n_sums = st.size - 2                                   # everything but the two counts
+    assert np.isnan(st[:n_sums]).all() if inside else not np.isnan(st).any(), "stats " + tag
+    assert st[-2] == U and st[-1] == lens.sum()
+
+
+@pytest.mark.parametrize("seed", _SEEDS_DIAG)
 def test_random_shape_real_feature_scale(seed, synth, oracle, ctx):
     """The same sweep at real-feature scale: a common offset per dimension (0, 5 or 50 units), means spread over 1, 3
     or 15 units, variances down to 0.02 -- whichever side of the conditioning gate the model falls on (centred matrix
