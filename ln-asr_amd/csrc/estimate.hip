@@ -715,7 +715,6 @@ int lnasr_bw_accumulate_p(lnasr_ctx* ctx, const double* obs, int U, int T, const
         LN_TRY(stage_in(ctx, obs, (size_t)U * T * D * 8, ctx->ws_in, &dv));
         d_obs = (const double*)dv;
         LN_TRY(emit_device_f32(ctx, d_obs, (long)U * T, b, ctx->ws_bm.as<float>()));
-        feat_tested = true;
     } else {
         // host observations: upload overlapped with the emission
         LN_TRY(emit_batch(ctx, obs, U, T, b, bm, &d_obs, &feat_tested));

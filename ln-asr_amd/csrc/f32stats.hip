@@ -60,8 +60,7 @@ template <int Q, int KS>
 __global__ __launch_bounds__(512) void emit_diag_mfma_f32(const double* __restrict__ obs, const float* __restrict__ wpack,
                                                           const double* __restrict__ centre, double* __restrict__ b,
                                                           float* __restrict__ q32, long F, int N, int D, int NG, int GY,
-                                                          long ntiles, int tiles_per_block, long nchunks,
-                                                          unsigned* __restrict__ nan_flag, unsigned nan_epoch) {
+                                                          long ntiles, int tiles_per_block, long nchunks) {
     constexpr int KP = 4 * KS, NT = 512, SPB = 32, FS = 17, OS = SPB + 1;
     __shared__ float Fl[2][KP * FS];
     __shared__ double ob[2][16 * OS];
@@ -117,13 +116,14 @@ __global__ __launch_bounds__(512) void emit_diag_mfma_f32(const double* __restri
             pre[r] = obs[ge];
         }
     };
-    unsigned long long nonfinite = 0;                        // NaN / infinite features staged: see emit_diag_mfma (gmm.hip)
+    // (No test for NaN / infinite features here, unlike emit_diag_mfma: the same compare-and-ballot per staged element cost
+    // this kernel 0.25 ms of its 1.87 at config 5, three alternations on one box.  Its callers scan the observations -- 40 MB,
+    // ~15 us -- instead: nanfix.hip, `force`.)
     auto store_stage = [&](int buf) {
         float* Fd = &Fl[buf][0];
         const int xo = D * FS;
 #pragma unroll
         for (int r = 0; r < MAXLD; ++r) {
-            nonfinite |= __ballot(!__builtin_isfinite(pre[r]));
             if (foff[r] >= 0) {
                 const double x = pre[r] - cen[r];
                 Fd[foff[r]] = (float)(x * x);
@@ -181,7 +181,6 @@ __global__ __launch_bounds__(512) void emit_diag_mfma_f32(const double* __restri
         __syncthreads();
     }
     if (tile1 > tile0) flush_stage((int)((tile1 - tile0 - 1) & 1), tile1 - 1);
-    if (nonfinite != 0 && lane == 0) *nan_flag = nan_epoch;
 }
 
 // b[cell] = lse_h bv[cell * k + h]   (M = 16 k mixtures scored as k virtual 16-mixture states)
@@ -406,7 +405,7 @@ static int launch_emit32(lnasr_ctx* ctx, const double* obs, long F, double* bv, 
     const long grid = ((nchunks + 7) / 8) * 8 * GY;
     LN_LAUNCH(ctx, "emit_diag_mfma_f32", (emit_diag_mfma_f32<Q, KS>), dim3((unsigned)grid), dim3(512), 0, obs,
               (const float*)md.wpack32.as<float>(), (const double*)md.centre.as<double>(), bv, q32, F, Nv, D, md.wpack_NG,
-              GY, ntiles, (int)tpb, nchunks, ctx->nan_flag.as<unsigned>(), ctx->nan_epoch);
+              GY, ntiles, (int)tpb, nchunks);
     return 0;
 }
 

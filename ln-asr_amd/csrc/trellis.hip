@@ -2616,8 +2616,7 @@ int lnasr_calc_prob_p(lnasr_ctx* ctx, const double* obs, int U, int T, const int
         LN_TRY(stage_in(ctx, obs, (size_t)U * T * md.D * 8, ctx->ws_in, &d_obs));
         LN_TRY(ctx->ws_bm.reserve((cells + (size_t)kMixPadFrames * md.N) * md.M * 4));
         LN_TRY(emit_device_f32(ctx, (const double*)d_obs, (long)U * T, ctx->ws_b.as<double>(), ctx->ws_bm.as<float>()));
-        d_x = (const double*)d_obs;
-        scanned = true;                                     // emit_diag_mfma_f32 tests the features it stages
+        d_x = (const double*)d_obs;                         // emit_diag_mfma_f32 has no fused test (f32stats.hip)
     } else {
         LN_TRY(emit_batch(ctx, obs, U, T, ctx->ws_b.as<double>(), nullptr, &d_x, &scanned));
     }
