@@ -13,13 +13,17 @@
 //     path[t > t1] = 0, path[t1] = j1 and path[t < t1] is the back-trace from (t1, j1) over the untouched frames;
 //   * likelihood (hmm.py:97-99, 268-274): NaN for an utterance that holds a NaN frame.
 //
-// Cost on clean data: the hot kernels test what they read anyway and raise a flag word -- emit_diag_mfma and
-// emit_single_direct the features they stage (word 0 of ctx->nan_flag: "a NaN or an infinite feature"), the
-// back-trace kernel the cells of v (word 1: "a NaN or -inf cell", which is all a NaN emission can leave there) --
-// and every kernel here starts by comparing its word with the call's epoch and returns.  Paths without a fused test
-// scan their input once (`force`).  (Testing b inside viterbi_reg1b was measured: the kernel sits at its 128-VGPR
-// limit, seven more registers spilled, 1.26 -> 1.47 ms.)  The epoch makes resets unnecessary: a word is "raised" only
-// while it equals the number of the API call that is running (LN_ENTER).
+// Cost on clean data: nothing is scanned by default.  The hot kernels test what they read anyway and store the running
+// API call's number (ctx->nan_epoch, LN_ENTER) into a word of ctx->nan_flag -- emit_diag_mfma and emit_single_direct the
+// features they stage (word 0: "a NaN or an infinite feature"; the single-GMM kernel also produces its NaN rows itself),
+// the back-trace kernel the cells of v (word 1: "a NaN or -inf cell", which is all a NaN emission can leave there) -- and
+// every kernel here starts by comparing its word with the call's epoch and returns.  A word is "raised" only while it
+// EQUALS the running epoch, so nothing is ever reset.  Paths whose kernels have no fused test (`force`) scan their input
+// once at memory speed: b by nan_locate_kernel, the observations by nan_rows_kernel, which raises word 0 for the kernels
+// that walk one utterance per block.  Every fused test was A/B-measured before it stayed: inside viterbi_reg1b (at its
+// 128-VGPR limit) it spilled seven registers, 1.26 -> 1.47 ms; inside the float32 emission kernel it cost 0.25 ms of 1.87;
+// turning bad features into NaN inside emit_diag_mfma (rows for free afterwards) cost 0.02-0.03 ms that decode would
+// pay for rows it never reads.  None of those stayed.
 #include "common.h"
 #include "devmath.h"
 
@@ -98,9 +102,9 @@ __global__ __launch_bounds__(256) void nan_locate_kernel(const TS* __restrict__ 
 
 // Same for observations [U,T,D] (calc_prob: only "does the utterance hold a bad frame" is needed)
 __global__ __launch_bounds__(256) void nan_utt_obs_kernel(const double* __restrict__ obs, const int32_t* __restrict__ lens,
-                                                          int T, int D, double* __restrict__ loglik, int force,
+                                                          int T, int D, double* __restrict__ loglik,
                                                           const unsigned* flag, unsigned epoch) {
-    if (!force && *flag != epoch) return;
+    if (*flag != epoch) return;
     const int u = blockIdx.x, tid = threadIdx.x;
     const long total = (long)lens[u] * D;
     const double* ou = obs + (size_t)u * T * D;
@@ -112,9 +116,9 @@ __global__ __launch_bounds__(256) void nan_utt_obs_kernel(const double* __restri
 // Baum-Welch statistics (gmmhmm.py:69-156 over a batch): an utterance with a bad frame has NaN in alpha from that frame
 // on and in beta before it, so every posterior is NaN and so is every sum it enters -- the whole statistics block
 __global__ __launch_bounds__(256) void nan_stats_kernel(const double* __restrict__ obs, const int32_t* __restrict__ lens,
-                                                        int T, int D, double* __restrict__ stats, long n, int force,
+                                                        int T, int D, double* __restrict__ stats, long n,
                                                         const unsigned* flag, unsigned epoch) {
-    if (!force && *flag != epoch) return;
+    if (*flag != epoch) return;
     const int u = blockIdx.x, tid = threadIdx.x;
     const long total = (long)lens[u] * D;
     const double* ou = obs + (size_t)u * T * D;
@@ -127,17 +131,17 @@ __global__ __launch_bounds__(256) void nan_stats_kernel(const double* __restrict
 // One block per utterance: rewrite v, path and the best score of an utterance whose emissions hold a NaN (header).
 // Where the first NaN sits comes from the slots of nan_locate_kernel (emissions handed in by the caller), or -- obs
 // given: decode, whose emissions are its own -- from the block's own scan for the first frame with a NaN or an infinite
-// feature, every state of which is NaN then (j1 = 0); that scan only runs when the emission kernel raised the flag, or
-// had no fused test (force).
+// feature, every state of which is NaN then (j1 = 0); that scan only runs when the flag is raised (by the emission kernel,
+// or by the flat scan that stands in for it where a kernel has no fused test).
 template <typename TS>
 __global__ __launch_bounds__(256) void viterbi_nan_repair_kernel(const TS* __restrict__ b, TS* __restrict__ v,
                                                                  const double* __restrict__ AT,
                                                                  const int32_t* __restrict__ lens, int T, int N, int C,
                                                                  const unsigned long long* __restrict__ slot,
-                                                                 const double* __restrict__ obs, int D, int force,
+                                                                 const double* __restrict__ obs, int D,
                                                                  const unsigned* flag, unsigned epoch,
                                                                  uint32_t* __restrict__ path, double* __restrict__ best) {
-    if (!force && *flag != epoch) return;
+    if (*flag != epoch) return;
     const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int L = lens[u];
     int t1, j1;
@@ -252,12 +256,12 @@ int viterbi_nan_repair(lnasr_ctx* ctx, const void* b, int U, int T, const int32_
         LN_LAUNCH(ctx, "nan_locate_f32", nan_locate_kernel<float>, dim3(C, U), dim3(256), 0, (const float*)b, d_lens, T, N,
                   slot, flag, ctx->nan_epoch, force ? 1 : 0);
         LN_LAUNCH(ctx, "viterbi_nan_repair_f32", viterbi_nan_repair_kernel<float>, dim3(U), dim3(256), 0, (const float*)b,
-                  (float*)v, AT, d_lens, T, N, C, slot, no_obs, 0, 0, flag, ctx->nan_epoch, path, best);
+                  (float*)v, AT, d_lens, T, N, C, slot, no_obs, 0, flag, ctx->nan_epoch, path, best);
     } else {
         LN_LAUNCH(ctx, "nan_locate", nan_locate_kernel<double>, dim3(C, U), dim3(256), 0, (const double*)b, d_lens, T, N,
                   slot, flag, ctx->nan_epoch, force ? 1 : 0);
         LN_LAUNCH(ctx, "viterbi_nan_repair", viterbi_nan_repair_kernel<double>, dim3(U), dim3(256), 0, (const double*)b,
-                  (double*)v, AT, d_lens, T, N, C, slot, no_obs, 0, 0, flag, ctx->nan_epoch, path, best);
+                  (double*)v, AT, d_lens, T, N, C, slot, no_obs, 0, flag, ctx->nan_epoch, path, best);
     }
     return 0;
 }
@@ -276,7 +280,7 @@ int viterbi_nan_repair_obs(lnasr_ctx* ctx, const double* obs, int U, int T, cons
     const unsigned long long* no_slot = nullptr;
     LN_LAUNCH(ctx, "viterbi_nan_repair", viterbi_nan_repair_kernel<double>, dim3(U), dim3(256), 0, (const double*)nullptr,
               v, (const double*)ctx->model.logAT.as<double>(), d_lens, T, ctx->model.N, 0, no_slot, obs, ctx->model.D,
-              0, (const unsigned*)ctx->nan_flag.as<unsigned>(), ctx->nan_epoch, path, best);
+              (const unsigned*)ctx->nan_flag.as<unsigned>(), ctx->nan_epoch, path, best);
     return 0;
 }
 
@@ -285,7 +289,7 @@ int stats_nan_repair(lnasr_ctx* ctx, const double* obs, int U, int T, const int3
     if (U <= 0 || T <= 0 || n <= 0) return 0;
     if (force) LN_TRY(raise_flag_if_bad(ctx, obs, U, T));
     LN_LAUNCH(ctx, "stats_nan_repair", nan_stats_kernel, dim3(U), dim3(256), 0, obs, d_lens, T, ctx->model.D, stats, n,
-              0, (const unsigned*)ctx->nan_flag.as<unsigned>(), ctx->nan_epoch);
+              (const unsigned*)ctx->nan_flag.as<unsigned>(), ctx->nan_epoch);
     return 0;
 }
 
@@ -293,7 +297,7 @@ int loglik_nan_repair(lnasr_ctx* ctx, const double* obs, int U, int T, const int
     if (U <= 0 || T <= 0) return 0;
     if (force) LN_TRY(raise_flag_if_bad(ctx, obs, U, T));
     LN_LAUNCH(ctx, "loglik_nan_repair", nan_utt_obs_kernel, dim3(U), dim3(256), 0, obs, d_lens, T, ctx->model.D, loglik,
-              0, (const unsigned*)ctx->nan_flag.as<unsigned>(), ctx->nan_epoch);
+              (const unsigned*)ctx->nan_flag.as<unsigned>(), ctx->nan_epoch);
     return 0;
 }
 
