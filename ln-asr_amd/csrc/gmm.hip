@@ -524,20 +524,24 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
 #pragma unroll
     for (int r = 0; r < 4; ++r) lw[r] = (g + 4 * r < M) ? logw[g + 4 * r] : 0.0;
     const long lim = F * (long)D;
-    // slot 4 j + g of this lane: a real dimension, the constant (== D), or padding (> D: coefficient 0; the value
-    // read there is the start of the next frame, or 0 past the end of obs)
-    bool is_one[NL], is_real[NL];
+    // slot 4 j + g of this lane: a real dimension, the constant (== D), or padding (> D).  The slots from D on lie in the
+    // memory that FOLLOWS the frame; their coefficients are 0, but 0 * NaN is NaN on the matrix cores (a bad value in a later
+    // frame would poison this one: seed 312 of the bad-feature sweep), so they are not read at all: their lanes aim the load
+    // past the buffer's end, where the hardware returns 0.  Only the last NL - JT loads of a lane can hold such a slot (the
+    // model upload picks the smallest KS that takes D: D >= 4 JT), so only those carry a per-lane offset.
+    constexpr int JT = KS == 8 ? 0 : NL - 3;
+    constexpr int kPastEnd = 0x7FFFFFF8;       // byte offset beyond any num_records
+    bool is_one[NL - JT];
+    int tail_off[NL - JT];
+#pragma unroll
+    for (int j = JT; j < NL; ++j) {
+        is_one[j - JT] = (4 * j + g) == D;
+        tail_off[j - JT] = (4 * j + g) < D ? (fr * D + g) * 8 + 32 * j : kPastEnd;
+    }
     double cen[CEN ? NL : 1];                  // CEN (model re-centred, Model::centred): centre of the lane's dimensions;
 #pragma unroll                                 // a model conditioned about the origin pays neither registers nor subtractions
-    for (int j = 0; j < NL; ++j) {
-        is_one[j] = (4 * j + g) == D;
-        is_real[j] = (4 * j + g) < D;
+    for (int j = 0; j < NL; ++j)
         if (CEN) cen[j] = (4 * j + g) < D ? centre[4 * j + g] : 0.0;
-    }
-    // slots from D on hold what FOLLOWS the frame in memory.  Their coefficients are 0, but 0 * NaN is NaN on the matrix
-    // cores: a NaN or an infinity in a later frame would poison this one (seed 312 of the bad-feature sweep: D = 3 reads
-    // 12 values past its frame), so those slots are cleared -- only where a model has any (D = 39 has none beyond the
-    // constant's, whose x-block value is cleared with them)
     double pre[NL];
     auto load_tile = [&](long tile) {
         const long e0 = tile * 16 * (long)D;
@@ -547,7 +551,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         const int vo = (fr * D + g) * 8;
 #pragma unroll
         for (int j = 0; j < NL; ++j)
-            pre[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, vo + 32 * j, 0, 0));
+            pre[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, j < JT ? vo + 32 * j : tail_off[j < JT ? 0 : j - JT], 0, 0));
     };
     // A block (16 waves, four per SIMD: one block per CU) owns a contiguous range of tiles and its waves draw them from a
     // ticket counter in the LDS, kTick at a time.  A static stride gives every wave the same number of tiles, but the
@@ -574,17 +578,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         }
         if (nxt >= tend) nxt = ntiles;             // nothing left: the prefetch below then reads nothing
         double bx[NL], bq[NL];
+        unsigned long long bad_lanes = 0;          // lanes of this tile that hold a NaN or an infinite feature
 #pragma unroll
         for (int j = 0; j < NL; ++j) {
-            const bool fin = __builtin_isfinite(pre[j]);
-            nonfinite |= __ballot(!fin && is_real[j]);
+            bad_lanes |= __ballot(!__builtin_isfinite(pre[j]));     // (slots past D read 0)
             bx[j] = CEN ? pre[j] - cen[CEN ? j : 0] : pre[j];
-            // a NaN OR an infinite feature enters as NaN: every product with it is NaN (0 * NaN too), so all densities of
-            // the frame, their maximum (maxNum of NaNs) and b come out NaN -- the reference's rows (gmm.py:63-68) without
-            // a pass afterwards, which this 0.09 ms call would feel (0.102 -> 0.095 ms); an infinity left as it is would
-            // give -inf or NaN depending on the signs it meets
-            bx[j] = is_real[j] ? (fin ? bx[j] : __builtin_nan("")) : 0.0;
-            bq[j] = is_one[j] ? 1.0 : bx[j] * bx[j];
+            bq[j] = (j >= JT && is_one[j < JT ? 0 : j - JT]) ? 1.0 : bx[j] * bx[j];
         }
         load_tile(nxt);
         double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
@@ -593,6 +592,17 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
 #pragma unroll
         for (int j = 0; j < NL; ++j) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wr[NL + j], bx[j], acc, 0, 0, 0);
         const long frame = tile * 16 + fr;
+        bool bad_frame = false;
+        if (bad_lanes != 0) {                      // wave-uniform, and never taken on clean data
+            // a NaN OR an infinite feature: every density of its frame is NaN in the reference (gmm.py:63-68: inf * 0 against
+            // the inverse's zero off-diagonals); this arithmetic would give -inf or NaN depending on the signs an infinity
+            // meets, so the frame's outputs are overwritten -- here, not in a pass afterwards, which this 0.09 ms call would feel
+            nonfinite |= bad_lanes;
+            const unsigned long long fm = bad_lanes | (bad_lanes >> 16) | (bad_lanes >> 32) | (bad_lanes >> 48);
+            bad_frame = (fm >> fr) & 1ull;         // the frame's four lanes sit 16 apart
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = bad_frame ? __builtin_nan("") : acc[r];
+        }
         if (WRITE_BM && frame < F) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -609,7 +619,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         for (int r = 0; r < 4; ++r) sacc += exp_nonpos(c[r] - mx, etab);
         sacc += shfl_xor_f64(sacc, 16);
         sacc += shfl_xor_f64(sacc, 32);
-        if (g == 0 && frame < F) b[frame] = (mx == LN_NEG_INF) ? mx : mx + log_sum(sacc, ltab);
+        if (g == 0 && frame < F) b[frame] = bad_frame ? __builtin_nan("") : ((mx == LN_NEG_INF) ? mx : mx + log_sum(sacc, ltab));
         tile = nxt;
     }
     if (nonfinite != 0 && lane == 0) *nan_flag = nan_epoch;
@@ -1096,6 +1106,7 @@ int emit_device_raw(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* 
               (double*)bm, F, M, D, ntiles, ctx->nan_flag.as<unsigned>(), ctx->nan_epoch)
 #define LN_DCASE(ks)                                                                                              \
     if (md.wdirect_KS == ks) {                                                                                    \
+        LN_REQUIRE(D >= (ks == 8 ? 0 : 4 * (ks / 2 - 3)), "D=%d below what the KS=%d single-GMM kernel assumes", D, ks); \
         *scanned = true;                                                                                          \
         *rows_done = true;                                                                                        \
         if (bm && md.centred) LN_DLAUNCH(ks, true, true, "emit_single_direct_bm");                                \

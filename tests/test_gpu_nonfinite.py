@@ -8,6 +8,8 @@ NaN and path for path."""
 import numpy as np
 import pytest
 
+from conftest import tuned
+
 pytestmark = pytest.mark.gpu
 
 
@@ -143,8 +145,9 @@ def test_clean_data_launches_only_the_checks(synth, ctx):
     p1 = ctx.decode(obs).to_host()
     rep = ctx.prof_report()
     ctx.prof_enable(False)
-    assert "viterbi_nan_repair" in rep and "nan_rows" not in rep and "nan_locate" not in rep, rep
-    assert rep["viterbi_nan_repair"][1] < 0.05, rep          # ms, event bracket included: it read one word and returned
+    if tuned():                                            # under fallback switches other kernels run, and some of them scan
+        assert "viterbi_nan_repair" in rep and "nan_rows" not in rep and "nan_locate" not in rep, rep
+        assert rep["viterbi_nan_repair"][1] < 0.05, rep      # ms, event bracket included: it read one word and returned
     assert not np.isnan(ctx.calc_prob(obs).to_host()).any()
     assert p1.max() < 128
 
@@ -165,7 +168,8 @@ def test_caller_emissions_clean_or_minus_inf(synth, oracle, ctx):
     r = ctx.viterbi(db, want_bt=False)
     rep = ctx.prof_report()
     ctx.prof_enable(False)
-    assert rep["nan_locate"][1] < 0.05 and rep["viterbi_nan_repair"][1] < 0.05, rep
+    if tuned():
+        assert rep["nan_locate"][1] < 0.05 and rep["viterbi_nan_repair"][1] < 0.05, rep
     assert np.array_equal(r["path"].to_host()[0], oracle.viterbi(d["A"], d["pi"], b[0].T)[2])
     # left-to-right model and some impossible emissions: -inf cells everywhere, no NaN
     A = d["A"].copy()
