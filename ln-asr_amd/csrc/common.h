@@ -115,6 +115,7 @@ struct Switches {
          no_t256 = false, no_framepar = false, no_stream = false, no_ldsbt = false, no_mfma_stats = false,
          no_fft512 = false, no_pipeline = false, f32_generic = false, no_f32_stats = false, no_pinned_ring = false;
     char vit = 0;                 // LNASR_VIT: first character, 0 = unset
+    char fwd = 0;                 // LNASR_FWD: 'c' = the four-utterance column-owned forward / backward kernel (fwdbwd_cols)
     int framepar_maxu = -1;       // LNASR_FRAMEPAR_MAXU, -1 = unset (measured rule)
     double kappa_max = kKappaMax; // LNASR_KAPPA_MAX
     int h2d_threads = 4;          // LNASR_H2D_THREADS: host threads filling the pinned staging ring

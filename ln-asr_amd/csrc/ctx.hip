@@ -77,6 +77,7 @@ static void load_switches(Switches& s) {
     s.no_f32_stats = on("LNASR_NO_F32_STATS");
     s.no_pinned_ring = on("LNASR_NO_PINNED_RING");
     if (const char* e = getenv("LNASR_VIT")) s.vit = e[0];
+    if (const char* e = getenv("LNASR_FWD")) s.fwd = e[0];
     if (const char* e = getenv("LNASR_EMIT")) s.emit = e[0];
     if (const char* e = getenv("LNASR_FRAMEPAR_MAXU")) s.framepar_maxu = atoi(e);
     if (const char* e = getenv("LNASR_KAPPA_MAX")) s.kappa_max = atof(e);

@@ -1206,6 +1206,176 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+// The same column-owned scheme with TWO utterances per block of FOUR waves (round 3).  A wave owns 32 columns (two per
+// lane: 64 transition entries = 128 registers), so a block is one wave per SIMD and two blocks share a CU: two waves per SIMD
+// as before, but from blocks that do not share a barrier.  With four utterances behind one barrier all eight waves were in
+// the same phase -- SQ counters of fwdbwd_cols: vector issue 63 % of the kernel, 40 % of every wave's time in s_waitcnt (the e
+// vector right after the barrier, the log / exp table look-ups of the finalisation) with its SIMD partner waiting on the
+// same thing.  Independent blocks drift apart and one's product phase runs under the other's waits (what merging the two
+// Viterbi blocks of a CU behind one barrier had shown from the other side: 1.37 -> 2.68 ms).  The four accumulators of a
+// lane are now (utterance, column half) instead of four utterances; the swap network is unchanged and leaves combination
+// m = 2 k + h in row m: row g of a wave finalises utterance g >> 1, column 32 w + 16 (g & 1) + c.
+template <bool BACKWARD>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void fwdbwd_cols2(
+    const double* __restrict__ b, const double* __restrict__ Aexp, const double* __restrict__ Alog,
+    const double* __restrict__ pi, const int32_t* __restrict__ lens, double* __restrict__ out,
+    double* __restrict__ loglik, int U, int T, int N) {
+    constexpr int NP = 128, UB = 2, NW = 4, NM = 2 * NW;   // NM: partial maxima per utterance (wave x column half)
+    __shared__ double Es[2][UB][NP];      // exp(prev - shift) of the frame being consumed
+    __shared__ double Cs[2][UB][NP];      // prev itself (log domain) for the exact fallback
+    __shared__ double Ms[2][UB][NM];      // per DPP row (16 columns) max of prev
+    __shared__ double Ss[2][UB];          // shift the e values of this buffer were computed with
+    __shared__ double etab[kExpTab];
+    __shared__ double ltab[2 * kLogTab];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    exp_table_init(etab, threadIdx.x, 64 * NW);
+    log_table_init(ltab, threadIdx.x, 64 * NW);   // visible after the first __syncthreads below
+    const int u0 = blockIdx.x * UB;
+    const unsigned cls = blockIdx.x >= (gridDim.x + 1) / 2 ? 1u : 0u;      // the two blocks of a CU: alternate_priority
+    const int g = lane >> 4, c = lane & 15;
+
+    double areg[2][32];                            // product role: columns 32 w + 16 q + c, source rows 32 g + r
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            const int i = 32 * g + r, jq = 32 * w + 16 * q + c;
+            areg[q][r] = (i < N && jq < N) ? Aexp[(size_t)i * N + jq] : 0.0;
+        }
+    int maxlen = 0;
+#pragma unroll
+    for (int kk = 0; kk < UB; ++kk) {
+        const int l = (u0 + kk < U) ? lens[u0 + kk] : 0;
+        maxlen = l > maxlen ? l : maxlen;
+    }
+    // finalisation role: row g of the wave is utterance k, column half h
+    const int k = g >> 1, h = g & 1;
+    const int j = 32 * w + 16 * h + c;
+    const int jc = j < N ? j : N - 1;
+    const int uu = (u0 + k < U) ? u0 + k : U - 1;
+    const int klen = (u0 + k < U) ? lens[u0 + k] : 0;
+    const double* bp = b + (size_t)uu * T * N + jc;
+    double* op = out ? out + (size_t)uu * T * N + jc : nullptr;
+    auto frame_of = [&](int step) { return BACKWARD ? klen - 1 - step : step; };
+    auto clampt = [&](int t) { return t < 0 ? 0 : (t > T - 1 ? T - 1 : t); };
+
+    // step 0
+    {
+        double prev = LN_NEG_INF;
+        if (j < N && klen > 0) {
+            const int t0 = frame_of(0);
+            const double bv = bp[(size_t)t0 * N];
+            if (BACKWARD) {
+                if (op) op[(size_t)t0 * N] = 0.0;
+                prev = 0.0 + bv;
+            } else {
+                prev = pi[j] + bv;
+                if (op) op[0] = prev;
+            }
+        }
+        Cs[0][k][j] = prev;
+        const double m = row_max_dpp(prev);
+        if (c == 0) Ms[0][k][2 * w + h] = m;
+    }
+    __syncthreads();
+    {
+        double S = Ms[0][k][0];
+#pragma unroll
+        for (int e = 1; e < NM; ++e) S = fmax(S, Ms[0][k][e]);
+        const double prev = Cs[0][k][j];
+        Es[0][k][j] = (S == LN_NEG_INF || prev == LN_NEG_INF) ? 0.0 : exp_clamped(prev - S, etab);
+        if (w == 0 && h == 0 && c == 0) Ss[0][k] = S;
+    }
+    double bnext = bp[(size_t)clampt(frame_of(1)) * N];
+    drain_vmem();                                  // areg resident: no vmcnt guards in the loop
+    __syncthreads();
+
+    for (int step = 1; step < maxlen; ++step) {
+        if ((step & 7) == 0) alternate_priority(cls);
+        const int cur = (step - 1) & 1, nxt = step & 1;
+        const double bcur = bnext;
+        bnext = bp[(size_t)clampt(frame_of(step + 1)) * N];
+        // e values of both utterances for this lane's row group: lane (g, c) holds e[32 g + 16 q + c]
+        double ek[UB][2];
+#pragma unroll
+        for (int kk = 0; kk < UB; ++kk)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) ek[kk][q] = Es[cur][kk][32 * g + 16 * q + c];
+        double acc[UB][2];                         // [utterance][column half]
+#pragma unroll
+        for (int kk = 0; kk < UB; ++kk)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) acc[kk][q] = 0.0;
+        static_for<0, 32>([&](auto r) {
+#pragma unroll
+            for (int kk = 0; kk < UB; ++kk)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) fmac_bcast<(r.value & 15)>(acc[kk][q], ek[kk][r.value >> 4], areg[q][r.value]);
+        });
+        // row groups -> (utterance, column half): after the swaps row m of `sum` holds combination m = 2 k + h,
+        // ((g0 + g2) + (g1 + g3)) in every lane
+        swap32_f64(acc[0][0], acc[1][0]);
+        swap32_f64(acc[0][1], acc[1][1]);
+        double s02 = acc[0][0] + acc[1][0], s13 = acc[0][1] + acc[1][1];
+        swap16_f64(s02, s13);
+        const double sum = s02 + s13;
+
+        if (step < klen) {
+            const double Sc = Ss[cur][k];
+            double val;
+            if (sum >= kSafeSum && sum <= 1e290 && Sc != LN_NEG_INF) {
+                val = Sc + log_sum(sum, ltab);
+            } else {                               // exact log-domain column (rare)
+                val = exact_column_lse(&Cs[cur][k][0], Alog + jc, N);
+            }
+            const int t = frame_of(step);
+            double prev;
+            if (BACKWARD) {
+                if (j < N && op) op[(size_t)t * N] = val;
+                prev = val + bcur;
+            } else {
+                prev = val + bcur;
+                if (j < N && op) op[(size_t)t * N] = prev;
+            }
+            if (j >= N) prev = LN_NEG_INF;
+            double S = Ms[cur][k][0];
+#pragma unroll
+            for (int e = 1; e < NM; ++e) S = fmax(S, Ms[cur][k][e]);
+            Cs[nxt][k][j] = prev;
+            Es[nxt][k][j] = (S == LN_NEG_INF || prev == LN_NEG_INF) ? 0.0 : exp_clamped(prev - S, etab);
+            const double m = row_max_dpp(prev);
+            if (c == 0) Ms[nxt][k][2 * w + h] = m;
+            if (w == 0 && h == 0 && c == 0) Ss[nxt][k] = S;
+        } else {                                   // this utterance has ended: carry its state
+            Cs[nxt][k][j] = Cs[cur][k][j];
+            Es[nxt][k][j] = Es[cur][k][j];
+            if (c == 0) Ms[nxt][k][2 * w + h] = Ms[cur][k][2 * w + h];
+            if (w == 0 && h == 0 && c == 0) Ss[nxt][k] = Ss[cur][k];
+        }
+        __syncthreads();
+    }
+    // calc_prob: lse_j alpha[L-1, j]  (hmm.py:274)
+    if (!BACKWARD && loglik && w == 0) {
+        const int fin = (maxlen > 0 ? maxlen - 1 : 0) & 1;
+#pragma unroll
+        for (int kk = 0; kk < UB; ++kk) {
+            if (u0 + kk < U && lens[u0 + kk] > 0) {
+                double mx = Ms[fin][kk][0];
+#pragma unroll
+                for (int e = 1; e < NM; ++e) mx = fmax(mx, Ms[fin][kk][e]);
+                double sacc = 0.0;
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const double pv = Cs[fin][kk][lane + 64 * hh];
+                    sacc += (mx == LN_NEG_INF || pv == LN_NEG_INF) ? 0.0 : exp(pv - mx);
+                }
+                sacc = wave_sum(sacc);
+                if (lane == 0) loglik[u0 + kk] = (mx == LN_NEG_INF) ? mx : mx + log(sacc);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // N > 128: the transition matrix no longer fits the register file of a CU.  It is streamed from
 // L2 once per frame and shared by UB utterances; thread (column jc, row slice rs) accumulates over
@@ -2273,12 +2443,19 @@ int forward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
                       (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
                       (double*)alpha, loglik, U, T, N);
         else
-            if (U < 4 * ctx->prop.multiProcessorCount)      // few utterances: two per block keeps more CUs busy
-                LN_LAUNCH(ctx, "forward_reg_n128", (fwdbwd_reg<false, 2, 8, 16, 2, 4>), dim3((U + 1) / 2), dim3(512), 0,
+            // column-owned waves, two utterances per four-wave block, two blocks per CU (fwdbwd_cols2): measured against the
+            // eight-wave kernels at every batch size -- 16 ... 512 utterances 0.83-0.87 ms against 0.96-1.02 (fwdbwd_reg, two
+            // per block), 1000 utterances 1.23 against 1.45 (fwdbwd_cols, four per block)
+            if (!sw().no_colfwd && sw().fwd != 'c')
+                LN_LAUNCH(ctx, "forward_cols2_n128", (fwdbwd_cols2<false>), dim3((U + 1) / 2), dim3(256), 0,
                           (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
                           (double*)alpha, loglik, U, T, N);
-            else if (!sw().no_colfwd)            // four per block, column-owned waves
+            else if (!sw().no_colfwd)            // LNASR_FWD=c: four per eight-wave block
                 LN_LAUNCH(ctx, "forward_cols_n128", (fwdbwd_cols<false>), dim3((U + 3) / 4), dim3(512), 0,
+                          (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
+                          (double*)alpha, loglik, U, T, N);
+            else if (U < 4 * ctx->prop.multiProcessorCount)      // row-owned waves, partial sums through the LDS
+                LN_LAUNCH(ctx, "forward_reg_n128", (fwdbwd_reg<false, 2, 8, 16, 2, 4>), dim3((U + 1) / 2), dim3(512), 0,
                           (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
                           (double*)alpha, loglik, U, T, N);
             else
@@ -2360,12 +2537,16 @@ int backward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* 
                       (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
                       (double*)nullptr, U, T, N);
         else
-            if (U < 4 * ctx->prop.multiProcessorCount)
-                LN_LAUNCH(ctx, "backward_reg_n128", (fwdbwd_reg<true, 2, 8, 16, 2, 4>), dim3((U + 1) / 2), dim3(512), 0,
+            if (!sw().no_colfwd && sw().fwd != 'c')
+                LN_LAUNCH(ctx, "backward_cols2_n128", (fwdbwd_cols2<true>), dim3((U + 1) / 2), dim3(256), 0,
                           (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
                           (double*)nullptr, U, T, N);
             else if (!sw().no_colfwd)
                 LN_LAUNCH(ctx, "backward_cols_n128", (fwdbwd_cols<true>), dim3((U + 3) / 4), dim3(512), 0,
+                          (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
+                          (double*)nullptr, U, T, N);
+            else if (U < 4 * ctx->prop.multiProcessorCount)
+                LN_LAUNCH(ctx, "backward_reg_n128", (fwdbwd_reg<true, 2, 8, 16, 2, 4>), dim3((U + 1) / 2), dim3(512), 0,
                           (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
                           (double*)nullptr, U, T, N);
             else

@@ -379,10 +379,11 @@ def test_trellises_beyond_256_states_large_batch(N, synth, oracle, ctx):
 
 @pytest.mark.parametrize("N", [65, 100, 128])
 def test_forward_backward_column_owned_kernel(N, synth, oracle, ctx):
-    """64 < N <= 128 with a batch that fills the chip four utterances per block (U >= 4 x CUs): the column-owned
-    forward / backward kernel (row-group sums exchanged with permlane swaps) against the oracle on a sample of
-    utterances and against the row-sliced kernel (LNASR_NO_COLFWD) on all of them; ragged lengths, a forbidden
-    transition, an unreachable state, an utterance whose likelihood underflows the linear domain (exact fallback)."""
+    """64 < N <= 128: the column-owned forward / backward kernels (row-group sums exchanged with permlane swaps) --
+    two utterances per four-wave block (the default) and four per eight-wave block (LNASR_FWD=c) -- against the oracle on
+    a sample of utterances and against the row-sliced kernel (LNASR_NO_COLFWD) on all of them; an odd number of
+    utterances (a half-empty last block), ragged lengths, a forbidden transition, an unreachable state, an utterance
+    whose likelihood underflows the linear domain (exact fallback)."""
     rng = np.random.default_rng(N)
     d = synth.synth_discrete(N, 4, 8, seed=N)
     A = d["A"].copy()
@@ -390,7 +391,7 @@ def test_forward_backward_column_owned_kernel(N, synth, oracle, ctx):
     A[3, 5] = 0.0
     A[:, 7] = -np.inf
     ctx.upload_hmm(A, d["pi"])
-    U, T = 4 * ctx.device_info()["cu_count"] + 6, 7
+    U, T = 4 * ctx.device_info()["cu_count"] + 7, 7
     b = np.ascontiguousarray(-30.0 * rng.random((U, T, N)))
     b[5, 3] -= 2000.0                                      # a frame far below the shift: column sums underflow
     b[6, 2, : N // 2] = -np.inf
@@ -402,7 +403,15 @@ def test_forward_backward_column_owned_kernel(N, synth, oracle, ctx):
     with env_switch(LNASR_NO_COLFWD=1):
         alpha2, ll2 = ctx.forward(b, lens=lens)
         beta2 = ctx.backward(b, lens=lens)
+    with env_switch(LNASR_FWD="c"):
+        alpha3, ll3 = ctx.forward(b, lens=lens)
+        beta3 = ctx.backward(b, lens=lens)
     assert np.array_equal(ll_only, ll)
+    # same products, same swap network, same order of additions: the two column-owned kernels agree to the bit
+    for u in range(U):
+        L = lens[u]
+        assert np.array_equal(alpha[u, :L], alpha3[u, :L]) and np.array_equal(beta[u, :L], beta3[u, :L]), u
+    assert np.array_equal(ll, ll3)
     for u in range(U):
         L = lens[u]
         assert_close(alpha[u, :L], alpha2[u, :L], 1e-12, msg="alpha vs row-sliced kernel u=%d" % u)
