@@ -227,7 +227,10 @@ constexpr int kMixRing = 8;          // bm prefetch ring (k-steps; must divide k
 static_assert((kMixDiagFrames - 1) + 4 * (kMixRing - 1) + 3 < kMixPadFrames, "bm prefetch ring outruns kMixPadFrames");
 static_assert((kMixFrames - 1) + 4 * (kMixRing - 1) + 3 < kMixPadFrames, "bm prefetch ring outruns kMixPadFrames");
 static_assert((kMixDiagFrames / 4) % kMixRing == 0, "kMixRing must divide kMixDiagFrames / 4");
-constexpr int kMixWaves = 8;         // waves (= states) per block; 4-wave blocks at 3 waves/SIMD were measured: slower (5.7 vs 4.1 ms)
+constexpr int kMixWaves = 8;         // waves (= states) per block; 4-wave blocks at 3 waves/SIMD were measured: slower (5.7 vs 4.1 ms);
+                                     // round 3, after independent blocks had paid in fwdbwd_cols2: 4-wave blocks again, two or three
+                                     // per CU (218 / 140 registers): 3.98 / 3.96 ms against 3.65 -- this kernel is 85 % issue, and
+                                     // half-size blocks stage every feature row twice
 constexpr int kMixNT = 64 * kMixWaves;
 
 __global__ void mix_centre_kernel(const double* __restrict__ mu, int NM, int D, double* __restrict__ centre) {
