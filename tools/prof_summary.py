@@ -19,7 +19,7 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, trace = sys.argv[1], sys.argv[2]
 os.makedirs(os.path.join(REPO, "profiles"), exist_ok=True)
-ks = glob.glob(os.path.join(trace, "**", "*_kernel_stats.csv"), recursive=True)[0]
+ks = max(glob.glob(os.path.join(trace, "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime)   # gpurun merges runs: the newest
 shutil.copy(ks, os.path.join(REPO, "profiles", tag + "_kernel_stats.csv"))
 print(open(ks).read()[:1500])
 
@@ -32,7 +32,7 @@ def short(name):
 if len(sys.argv) >= 5:
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for d in sys.argv[3:5]:
-        f = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)[0]
+        f = max(glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)   # gpurun merges runs: the newest
         for r in csv.DictReader(open(f)):
             agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     out = {}
