@@ -284,7 +284,10 @@ __global__ void backtrace_kernel(const TS* __restrict__ v, const double* __restr
 // (tools/block_times.py).  With ALT the two halves of the grid raise their priority in alternate periods of the 100 MHz
 // clock (alternate_priority, devmath.h; measured with periods of 10 us: 1.33 ms, 41 us: 1.27, 164 us: 1.25, 0.65 ms: 1.26,
 // 1.3 ms: 1.34) and finish together: 1.37 -> 1.25 ms.  (Merging the two blocks behind ONE barrier
-// -- 16 waves in lock-step -- was measured first: 2.68 ms; the independent blocks hide each other's per-frame latency.)
+// -- 16 waves in lock-step -- was measured first: 2.68 ms; the independent blocks hide each other's per-frame latency.
+// The opposite direction, after four-wave blocks had paid in fwdbwd_cols2: <2, 4, 32, 2, 2> -- two utterances per FOUR-wave
+// block, 230 registers, two waves per SIMD -- 1.29 ms against 1.27; <2, 4, 32, 1, 3> -- one utterance, three blocks per CU,
+// 168 registers and six of them spilled -- 1.99 ms.  This kernel is 76 % vector issue (SQ counters), not waits.)
 template <int CPT, int NW, int RPT, int UB, int WPE, typename TS = double, bool ALT = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void viterbi_reg1b(
     const TS* __restrict__ b, const double* __restrict__ A, const double* __restrict__ pi,
