@@ -69,14 +69,14 @@ __global__ __launch_bounds__(256) void nan_rows_kernel(const double* __restrict_
 }
 
 // First NaN of every utterance's emissions b [U,T,N] in row-major order -- i.e. (first bad frame, first bad state in
-// it) as ONE linear index.  grid (C, U): block c scans its share of the utterance's lens[u] * N values and leaves its
+// it) as ONE linear index.  grid (U, C): block c scans its share of the utterance's lens[u] * N values and leaves its
 // minimum in slot[u * C + c]; no atomics across blocks, nothing to initialise.
 template <typename TS>
 __global__ __launch_bounds__(256) void nan_locate_kernel(const TS* __restrict__ b, const int32_t* __restrict__ lens,
                                                          int T, int N, unsigned long long* __restrict__ slot,
                                                          unsigned* flag, unsigned epoch, int force) {
     if (!force && *flag != epoch) return;
-    const int u = blockIdx.y, c = blockIdx.x, C = gridDim.x, tid = threadIdx.x;
+    const int u = blockIdx.x, c = blockIdx.y, C = gridDim.y, tid = threadIdx.x;
     const long total = (long)lens[u] * N;
     const long per = (total + C - 1) / C;
     const long e0 = (long)c * per, e1 = e0 + per < total ? e0 + per : total;
@@ -245,7 +245,6 @@ int viterbi_nan_repair(lnasr_ctx* ctx, const void* b, int U, int T, const int32_
     if (U <= 0 || T <= 0) return 0;
     const int N = ctx->model.N;
     const int C = locate_chunks(U);
-    LN_REQUIRE(U <= 65535, "U=%d too large for the NaN scan", U);
     LN_REQUIRE(v, "the repair pass needs the Viterbi lattice");
     LN_TRY(ctx->nan_slots.reserve((size_t)U * C * 8));
     unsigned* flag = ctx->nan_flag.as<unsigned>() + 1;      // the "suspect cell in v" word (backtrace_lds_kernel)
@@ -253,12 +252,12 @@ int viterbi_nan_repair(lnasr_ctx* ctx, const void* b, int U, int T, const int32_
     const double* AT = ctx->model.logAT.as<double>();
     const double* no_obs = nullptr;
     if (dtype == LNASR_F32) {
-        LN_LAUNCH(ctx, "nan_locate_f32", nan_locate_kernel<float>, dim3(C, U), dim3(256), 0, (const float*)b, d_lens, T, N,
+        LN_LAUNCH(ctx, "nan_locate_f32", nan_locate_kernel<float>, dim3(U, C), dim3(256), 0, (const float*)b, d_lens, T, N,
                   slot, flag, ctx->nan_epoch, force ? 1 : 0);
         LN_LAUNCH(ctx, "viterbi_nan_repair_f32", viterbi_nan_repair_kernel<float>, dim3(U), dim3(256), 0, (const float*)b,
                   (float*)v, AT, d_lens, T, N, C, slot, no_obs, 0, flag, ctx->nan_epoch, path, best);
     } else {
-        LN_LAUNCH(ctx, "nan_locate", nan_locate_kernel<double>, dim3(C, U), dim3(256), 0, (const double*)b, d_lens, T, N,
+        LN_LAUNCH(ctx, "nan_locate", nan_locate_kernel<double>, dim3(U, C), dim3(256), 0, (const double*)b, d_lens, T, N,
                   slot, flag, ctx->nan_epoch, force ? 1 : 0);
         LN_LAUNCH(ctx, "viterbi_nan_repair", viterbi_nan_repair_kernel<double>, dim3(U), dim3(256), 0, (const double*)b,
                   (double*)v, AT, d_lens, T, N, C, slot, no_obs, 0, flag, ctx->nan_epoch, path, best);
