@@ -1200,7 +1200,9 @@ namespace {
 
 // (Chunk sizes growing geometrically from 16 utterances -- only the first chunk's transfer is exposed, so make it small --
 // were measured in round 3: 8.34 ms end to end against 8.05 with sixteen equal chunks; an emission launch on 16 or 32
-// utterances does not fill the chip for long enough to pay for its own ramp.)
+// utterances does not fill the chip for long enough to pay for its own ramp.  ONE small first chunk (a quarter of the
+// others) and fifteen equal ones: 8.08-8.15 ms against 8.07 -- the exposed part is not the first transfer but the sixteen
+// launches' own ramps.)
 struct ChunkPlan {
     int U, nch;
     size_t utt_bytes;
