@@ -141,7 +141,8 @@ int lnasr_viterbi(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* le
  * only the paths come back.  NaN / infinite features: the reference's paths (see lnasr_viterbi), best_score NaN */
 int lnasr_decode(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* lens,
                  uint32_t* path, double* best_score_or_null);
-/* HMM._forward (hmm.py:63-100) and calc_prob (hmm.py:268-274): alpha optional, loglik [U] optional */
+/* HMM._forward (hmm.py:63-100) and calc_prob (hmm.py:268-274): alpha optional, loglik [U] optional.  A NaN emission
+ * propagates as np.logaddexp propagates it: alpha NaN from that frame on (forward), beta NaN before it (backward). */
 int lnasr_forward(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* lens, int dtype,
                   void* alpha_or_null, double* loglik_or_null);
 /* HMM._backward (hmm.py:102-131) */

@@ -155,6 +155,7 @@ struct lnasr_ctx {
     // an infinity, and the per-utterance slots of the scan that follows
     lnasr::DevBuf nan_flag, nan_slots;
     unsigned nan_epoch = 0;                                // number of the running API call (LN_ENTER); never 0
+    bool fwd_nan_tested = false;                           // the last forward / backward kernel tested its emissions itself
     const void* bp_v = nullptr;                            // the v array ws_bp belongs to (set by viterbi_device,
     int bp_U = 0, bp_T = 0, bp_nmax = 0;                   //   consumed by backtrace_device)
     // MFCC constants (twiddles, DCT matrix), kept on the device between calls with the same fft_n / n_mel;
@@ -268,6 +269,8 @@ int viterbi_nan_repair(lnasr_ctx* ctx, const void* b, int U, int T, const int32_
 int viterbi_nan_repair_obs(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* d_lens, double* v,
                            uint32_t* path, double* best, bool force);       // decode: keyed on the observations
 int loglik_nan_repair(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* d_lens, double* loglik, bool force);
+int trellis_nan_repair(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d_lens, int dtype, void* alpha_or_null,
+                       double* loglik_or_null, void* beta_or_null, bool force);     // lnasr_forward / lnasr_backward
 int stats_nan_repair(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* d_lens, double* stats, long n,
                      bool force);
 

@@ -11,12 +11,15 @@
 //   * Viterbi (hmm.py:162-171): with t1 the first frame whose emissions hold a NaN and j1 the first such state,
 //     v[t1, j] = NaN for the NaN states, v[t > t1, :] = NaN, bt[t1+1, :] = j1, bt[t > t1+1, :] = 0, so
 //     path[t > t1] = 0, path[t1] = j1 and path[t < t1] is the back-trace from (t1, j1) over the untouched frames;
-//   * likelihood (hmm.py:97-99, 268-274): NaN for an utterance that holds a NaN frame.
+//   * forward / backward (hmm.py:97-99, 128-130): np.logaddexp carries a NaN the same way -- alpha[t1, j] NaN for the NaN
+//     states and alpha[t > t1, :] NaN; beta[t] folds b[:, t+1], so beta[t < tl, :] is NaN for tl the LAST bad frame;
+//   * likelihood (hmm.py:268-274): NaN for an utterance that holds a NaN frame.
 //
 // Cost on clean data: nothing is scanned by default.  The hot kernels test what they read anyway and store the running
 // API call's number (ctx->nan_epoch, LN_ENTER) into a word of ctx->nan_flag -- emit_diag_mfma and emit_single_direct the
 // features they stage (word 0: "a NaN or an infinite feature"; the single-GMM kernel also produces its NaN rows itself),
-// the back-trace kernel the cells of v (word 1: "a NaN or -inf cell", which is all a NaN emission can leave there) -- and
+// the back-trace kernel the cells of v (word 1: "a NaN or -inf cell", which is all a NaN emission can leave there),
+// fwdbwd_cols2 the value its lanes finalise (word 2: NaN exactly when the emission is) -- and
 // every kernel here starts by comparing its word with the call's epoch and returns.  A word is "raised" only while it
 // EQUALS the running epoch, so nothing is ever reset.  Paths whose kernels have no fused test (`force`) scan their input
 // once at memory speed: b by nan_locate_kernel, the observations by nan_rows_kernel, which raises word 0 for the kernels
@@ -74,6 +77,7 @@ __global__ __launch_bounds__(256) void nan_rows_kernel(const double* __restrict_
 template <typename TS>
 __global__ __launch_bounds__(256) void nan_locate_kernel(const TS* __restrict__ b, const int32_t* __restrict__ lens,
                                                          int T, int N, unsigned long long* __restrict__ slot,
+                                                         unsigned long long* __restrict__ slot_last,
                                                          unsigned* flag, unsigned epoch, int force) {
     if (!force && *flag != epoch) return;
     const int u = blockIdx.x, c = blockIdx.y, C = gridDim.y, tid = threadIdx.x;
@@ -82,22 +86,79 @@ __global__ __launch_bounds__(256) void nan_locate_kernel(const TS* __restrict__ 
     const long e0 = (long)c * per, e1 = e0 + per < total ? e0 + per : total;
     const TS* bu = b + (size_t)u * T * N;
     unsigned long long first = kNoBad;
+    long last = -1;                                              // (the backward pass needs the LAST bad frame)
     for (long e = e0 + tid; e < e1; e += 256) {
         const TS x = bu[e];
         if (x != x) {                                            // ascending per thread: its first hit is its minimum
-            first = (unsigned long long)e;
-            break;
+            if (first == kNoBad) first = (unsigned long long)e;
+            if (!slot_last) break;
+            last = e;
         }
     }
     __shared__ unsigned long long sm;
-    if (tid == 0) sm = kNoBad;
+    __shared__ long long sl;
+    if (tid == 0) {
+        sm = kNoBad;
+        sl = -1;
+    }
     __syncthreads();
     if (first != kNoBad) atomicMin(&sm, first);
+    if (last >= 0) atomicMax(&sl, (long long)last);
     __syncthreads();
     if (tid == 0) {
         slot[(size_t)u * C + c] = sm;
+        if (slot_last) slot_last[(size_t)u * C + c] = sl < 0 ? kNoBad : (unsigned long long)sl;
         if (sm != kNoBad) *flag = epoch;
     }
+}
+
+// Forward pass (hmm.py:97-99): np.logaddexp carries a NaN emission of frame t1 into every state of every later frame:
+// alpha[t1, j] = NaN for the NaN states, alpha[t > t1, :] = NaN, the likelihood NaN.  Backward (hmm.py:128-130):
+// beta[t] folds b[:, t + 1], so with tl the LAST frame holding a NaN, beta[t < tl, :] = NaN and the rest stands.
+template <typename TS>
+__global__ __launch_bounds__(256) void alpha_nan_repair_kernel(const TS* __restrict__ b, TS* __restrict__ alpha,
+                                                               double* __restrict__ loglik,
+                                                               const int32_t* __restrict__ lens, int T, int N, int C,
+                                                               const unsigned long long* __restrict__ slot,
+                                                               const unsigned* flag, unsigned epoch) {
+    if (*flag != epoch) return;
+    const int u = blockIdx.x, tid = threadIdx.x;
+    unsigned long long first = kNoBad;
+    for (int c = 0; c < C; ++c) {
+        const unsigned long long s = slot[(size_t)u * C + c];
+        first = s < first ? s : first;
+    }
+    if (first == kNoBad) return;
+    const int L = lens[u], t1 = (int)(first / (unsigned long long)N);
+    const TS nan = quiet_nan<TS>();
+    if (alpha) {
+        TS* au = alpha + (size_t)u * T * N;
+        for (int j = tid; j < N; j += 256) {
+            const TS x = b[((size_t)u * T + t1) * N + j];
+            if (x != x) au[(size_t)t1 * N + j] = nan;
+        }
+        for (long e = (long)(t1 + 1) * N + tid; e < (long)L * N; e += 256) au[e] = nan;
+    }
+    if (loglik && tid == 0) loglik[u] = quiet_nan<double>();
+}
+
+template <typename TS>
+__global__ __launch_bounds__(256) void beta_nan_repair_kernel(TS* __restrict__ beta, const int32_t* __restrict__ lens,
+                                                              int T, int N, int C,
+                                                              const unsigned long long* __restrict__ slot_last,
+                                                              const unsigned* flag, unsigned epoch) {
+    if (*flag != epoch) return;
+    const int u = blockIdx.x, tid = threadIdx.x;
+    long long last = -1;
+    for (int c = 0; c < C; ++c) {
+        const unsigned long long s = slot_last[(size_t)u * C + c];
+        if (s != kNoBad && (long long)s > last) last = (long long)s;
+    }
+    if (last < 0) return;
+    const long tl = last / N;                                    // beta[t] reads b[:, t + 1]: frames below tl
+    TS* bu = beta + (size_t)u * T * N;
+    const TS nan = quiet_nan<TS>();
+    for (long e = tid; e < tl * N; e += 256) bu[e] = nan;
 }
 
 // Same for observations [U,T,D] (calc_prob: only "does the utterance hold a bad frame" is needed)
@@ -253,12 +314,12 @@ int viterbi_nan_repair(lnasr_ctx* ctx, const void* b, int U, int T, const int32_
     const double* no_obs = nullptr;
     if (dtype == LNASR_F32) {
         LN_LAUNCH(ctx, "nan_locate_f32", nan_locate_kernel<float>, dim3(U, C), dim3(256), 0, (const float*)b, d_lens, T, N,
-                  slot, flag, ctx->nan_epoch, force ? 1 : 0);
+                  slot, (unsigned long long*)nullptr, flag, ctx->nan_epoch, force ? 1 : 0);
         LN_LAUNCH(ctx, "viterbi_nan_repair_f32", viterbi_nan_repair_kernel<float>, dim3(U), dim3(256), 0, (const float*)b,
                   (float*)v, AT, d_lens, T, N, C, slot, no_obs, 0, flag, ctx->nan_epoch, path, best);
     } else {
         LN_LAUNCH(ctx, "nan_locate", nan_locate_kernel<double>, dim3(U, C), dim3(256), 0, (const double*)b, d_lens, T, N,
-                  slot, flag, ctx->nan_epoch, force ? 1 : 0);
+                  slot, (unsigned long long*)nullptr, flag, ctx->nan_epoch, force ? 1 : 0);
         LN_LAUNCH(ctx, "viterbi_nan_repair", viterbi_nan_repair_kernel<double>, dim3(U), dim3(256), 0, (const double*)b,
                   (double*)v, AT, d_lens, T, N, C, slot, no_obs, 0, flag, ctx->nan_epoch, path, best);
     }
@@ -269,6 +330,40 @@ int viterbi_nan_repair(lnasr_ctx* ctx, const void* b, int U, int T, const int32_
 // flag first (it does not know the utterances' lengths: padding may raise it for nothing), the slow walk follows only then
 static int raise_flag_if_bad(lnasr_ctx* ctx, const double* obs, int U, int T) {
     return nan_rows_device(ctx, obs, (long)U * T, LNASR_F64, nullptr, nullptr, true);
+}
+
+// caller-supplied emissions through the forward / backward entry points.  Word 2 of ctx->nan_flag: "a forward / backward
+// kernel met a NaN" (fwdbwd_cols2 tests the value it finalises; the other kernels leave the scan to `force`)
+int trellis_nan_repair(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d_lens, int dtype, void* alpha,
+                       double* loglik, void* beta, bool force) {
+    if (U <= 0 || T <= 0) return 0;
+    const int N = ctx->model.N;
+    const int C = locate_chunks(U);
+    LN_TRY(ctx->nan_slots.reserve((size_t)U * C * 8 * 2));
+    unsigned* flag = ctx->nan_flag.as<unsigned>() + 2;
+    unsigned long long* slot = ctx->nan_slots.as<unsigned long long>();
+    unsigned long long* slot_last = slot + (size_t)U * C;
+    const int f = force ? 1 : 0;
+    if (dtype == LNASR_F32) {
+        LN_LAUNCH(ctx, "nan_locate_f32", nan_locate_kernel<float>, dim3(U, C), dim3(256), 0, (const float*)b, d_lens, T, N,
+                  slot, beta ? slot_last : nullptr, flag, ctx->nan_epoch, f);
+        if (alpha || loglik)
+            LN_LAUNCH(ctx, "alpha_nan_repair_f32", alpha_nan_repair_kernel<float>, dim3(U), dim3(256), 0, (const float*)b,
+                      (float*)alpha, loglik, d_lens, T, N, C, slot, flag, ctx->nan_epoch);
+        if (beta)
+            LN_LAUNCH(ctx, "beta_nan_repair_f32", beta_nan_repair_kernel<float>, dim3(U), dim3(256), 0, (float*)beta, d_lens,
+                      T, N, C, slot_last, flag, ctx->nan_epoch);
+    } else {
+        LN_LAUNCH(ctx, "nan_locate", nan_locate_kernel<double>, dim3(U, C), dim3(256), 0, (const double*)b, d_lens, T, N,
+                  slot, beta ? slot_last : nullptr, flag, ctx->nan_epoch, f);
+        if (alpha || loglik)
+            LN_LAUNCH(ctx, "alpha_nan_repair", alpha_nan_repair_kernel<double>, dim3(U), dim3(256), 0, (const double*)b,
+                      (double*)alpha, loglik, d_lens, T, N, C, slot, flag, ctx->nan_epoch);
+        if (beta)
+            LN_LAUNCH(ctx, "beta_nan_repair", beta_nan_repair_kernel<double>, dim3(U), dim3(256), 0, (double*)beta, d_lens,
+                      T, N, C, slot_last, flag, ctx->nan_epoch);
+    }
+    return 0;
 }
 
 int viterbi_nan_repair_obs(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* d_lens, double* v,

@@ -1222,8 +1222,11 @@ template <bool BACKWARD>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void fwdbwd_cols2(
     const double* __restrict__ b, const double* __restrict__ Aexp, const double* __restrict__ Alog,
     const double* __restrict__ pi, const int32_t* __restrict__ lens, double* __restrict__ out,
-    double* __restrict__ loglik, int U, int T, int N) {
+    double* __restrict__ loglik, int U, int T, int N, unsigned* __restrict__ nan_flag, unsigned nan_epoch) {
     constexpr int NP = 128, UB = 2, NW = 4, NM = 2 * NW;   // NM: partial maxima per utterance (wave x column half)
+    // a NaN emission: np.logaddexp carries it into every later (earlier) frame, the maxima here drop it.  The value the
+    // lanes finalise is NaN exactly then; one compare into the scalar unit per frame raises the flag for nanfix.hip
+    unsigned long long saw_nan = 0;
     __shared__ double Es[2][UB][NP];      // exp(prev - shift) of the frame being consumed
     __shared__ double Cs[2][UB][NP];      // prev itself (log domain) for the exact fallback
     __shared__ double Ms[2][UB][NM];      // per DPP row (16 columns) max of prev
@@ -1276,6 +1279,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 if (op) op[0] = prev;
             }
         }
+        saw_nan |= __ballot(prev != prev);
         Cs[0][k][j] = prev;
         const double m = row_max_dpp(prev);
         if (c == 0) Ms[0][k][2 * w + h] = m;
@@ -1341,6 +1345,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 if (j < N && op) op[(size_t)t * N] = prev;
             }
             if (j >= N) prev = LN_NEG_INF;
+            saw_nan |= __ballot(prev != prev);
             double S = Ms[cur][k][0];
 #pragma unroll
             for (int e = 1; e < NM; ++e) S = fmax(S, Ms[cur][k][e]);
@@ -1357,6 +1362,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         __syncthreads();
     }
+    if (saw_nan != 0 && lane == 0) *nan_flag = nan_epoch;
     // calc_prob: lse_j alpha[L-1, j]  (hmm.py:274)
     if (!BACKWARD && loglik && w == 0) {
         const int fin = (maxlen > 0 ? maxlen - 1 : 0) & 1;
@@ -2142,12 +2148,16 @@ __global__ void baumwelch_kernel(const TS* __restrict__ b, const TS* __restrict_
         for (int i = threadIdx.x; i < N; i += blockDim.x) st(go, i, LN_NEG_INF);
         return;
     }
+    bool has_nan = false;
     for (int i = threadIdx.x; i < N; i += blockDim.x) {
         al[i] = ld(alpha, row * N + i);
         bb[i] = ld(b, (row + 1) * N + i);
         be[i] = ld(beta, (row + 1) * N + i);
+        has_nan |= al[i] != al[i] || bb[i] != bb[i] || be[i] != be[i];
     }
-    __syncthreads();
+    // one NaN among alpha[t], b[t+1], beta[t+1]: lse(numer) is NaN (np.logaddexp), so every xi[t, i, j] and gamma[t, i]
+    // is (hmm.py:192-199); xi follows from the arithmetic below, the row maxima of gamma would drop it
+    has_nan = __syncthreads_or(has_nan);
     auto numer = [&](int e) {
         const int i = e / N, j = e - i * N;
         return ((al[i] + A[e]) + bb[j]) + be[j];                           // hmm.py:192-195 order
@@ -2172,7 +2182,7 @@ __global__ void baumwelch_kernel(const TS* __restrict__ b, const TS* __restrict_
         if (m != LN_NEG_INF)
             for (int j = lane; j < N; j += 64) s += exp(rnd<TS>(numer(i * N + j) - denom) - m);
         s = wave_sum(s);
-        if (lane == 0) st(go, i, (m == LN_NEG_INF || m != m) ? m : m + log(s));
+        if (lane == 0) st(go, i, has_nan ? __builtin_nan("") : ((m == LN_NEG_INF || m != m) ? m : m + log(s)));
     }
 }
 
@@ -2429,6 +2439,7 @@ int forward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
                    double* loglik) {
     Model& md = ctx->model;
     const int N = md.N;
+    ctx->fwd_nan_tested = false;
     if (dtype == LNASR_F32 && f32_via_f64()) {
         const size_t cells = (size_t)U * T * N;
         double *b64, *a64 = nullptr;
@@ -2450,9 +2461,12 @@ int forward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
             // eight-wave kernels at every batch size -- 16 ... 512 utterances 0.83-0.87 ms against 0.96-1.02 (fwdbwd_reg, two
             // per block), 1000 utterances 1.23 against 1.45 (fwdbwd_cols, four per block)
             if (!sw().no_colfwd && sw().fwd != 'c')
+            {
                 LN_LAUNCH(ctx, "forward_cols2_n128", (fwdbwd_cols2<false>), dim3((U + 1) / 2), dim3(256), 0,
                           (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
-                          (double*)alpha, loglik, U, T, N);
+                          (double*)alpha, loglik, U, T, N, ctx->nan_flag.as<unsigned>() + 2, ctx->nan_epoch);
+                ctx->fwd_nan_tested = true;
+            }
             else if (!sw().no_colfwd)            // LNASR_FWD=c: four per eight-wave block
                 LN_LAUNCH(ctx, "forward_cols_n128", (fwdbwd_cols<false>), dim3((U + 3) / 4), dim3(512), 0,
                           (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
@@ -2525,6 +2539,7 @@ int forward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
 int backward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d_lens, int dtype, void* beta) {
     Model& md = ctx->model;
     const int N = md.N;
+    ctx->fwd_nan_tested = false;
     if (dtype == LNASR_F32 && f32_via_f64()) {
         const size_t cells = (size_t)U * T * N;
         double* b64;
@@ -2541,9 +2556,12 @@ int backward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* 
                       (double*)nullptr, U, T, N);
         else
             if (!sw().no_colfwd && sw().fwd != 'c')
+            {
                 LN_LAUNCH(ctx, "backward_cols2_n128", (fwdbwd_cols2<true>), dim3((U + 1) / 2), dim3(256), 0,
                           (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
-                          (double*)nullptr, U, T, N);
+                          (double*)nullptr, U, T, N, ctx->nan_flag.as<unsigned>() + 2, ctx->nan_epoch);
+                ctx->fwd_nan_tested = true;
+            }
             else if (!sw().no_colfwd)
                 LN_LAUNCH(ctx, "backward_cols_n128", (fwdbwd_cols<true>), dim3((U + 3) / 4), dim3(512), 0,
                           (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
@@ -2752,6 +2770,8 @@ int lnasr_forward(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* le
     if (alpha_or_null) LN_TRY(stage_out(ctx, alpha_or_null, cells * es, ctx->ws_alpha, &d_alpha));
     if (loglik_or_null) LN_TRY(stage_out(ctx, loglik_or_null, (size_t)U * 8, ctx->ws_out2, &d_ll));
     LN_TRY(forward_device(ctx, d_b, U, T, d_lens, dtype, d_alpha, (double*)d_ll));
+    // a NaN among the caller's emissions: alpha and the likelihood as np.logaddexp leaves them (nanfix.hip)
+    LN_TRY(trellis_nan_repair(ctx, d_b, U, T, d_lens, dtype, d_alpha, (double*)d_ll, nullptr, !ctx->fwd_nan_tested));
     if (alpha_or_null) LN_TRY(finish_out(ctx, alpha_or_null, d_alpha, cells * es));
     if (loglik_or_null) LN_TRY(finish_out(ctx, loglik_or_null, d_ll, (size_t)U * 8));
     return 0;
@@ -2771,6 +2791,7 @@ int lnasr_backward(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* l
     LN_TRY(stage_in(ctx, b, cells * es, ctx->ws_in, &d_b));
     LN_TRY(stage_out(ctx, beta, cells * es, ctx->ws_beta, &d_beta));
     LN_TRY(backward_device(ctx, d_b, U, T, d_lens, dtype, d_beta));
+    LN_TRY(trellis_nan_repair(ctx, d_b, U, T, d_lens, dtype, nullptr, nullptr, d_beta, !ctx->fwd_nan_tested));
     return finish_out(ctx, beta, d_beta, cells * es);
 }
 

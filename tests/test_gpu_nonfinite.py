@@ -52,6 +52,15 @@ def test_reference_golden(golden, synth, ctx):
             assert np.array_equal(r["bt"][0], g[k + "_bt"]), k
             assert np.array_equal(r["path"][0], g[k + "_path"]), k
             assert np.isnan(r["score"][0])
+            # forward / backward on the same emissions: np.logaddexp's propagation (hmm.py:97-99,128-130)
+            tol_t = 1e-10 if not tag else 2e-5
+            alpha, ll1 = ctx.forward(np.ascontiguousarray(gb[None]))
+            beta = ctx.backward(np.ascontiguousarray(gb[None]))
+            for got, want, nm in ((alpha[0], g[k + "_alpha"], "alpha"), (beta[0], g[k + "_beta"], "beta")):
+                assert np.array_equal(np.isnan(got), np.isnan(want)), (k, nm)
+                okc = ~np.isnan(want)
+                assert np.allclose(got[okc], want[okc], rtol=tol_t, atol=tol_t), (k, nm)
+            assert np.isnan(ll1[0]) and np.isnan(g[k + "_loglik"][0])
             ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
     for u, n in enumerate(names):
         assert np.array_equal(path[u], g[n + "_path"]), n
@@ -254,3 +263,46 @@ def test_mfcc_propagates_bad_samples(synth, oracle):
     feat, foff = MFCC().calc_mfcc_batch([s[:5000], bad, s[:3000]])
     assert np.array_equal(feat[foff[1]:foff[2]], f, equal_nan=True)
     assert not np.isnan(feat[:foff[1]]).any() and not np.isnan(feat[foff[2]:]).any()
+
+
+@pytest.mark.parametrize("N,T,dtype", [(3, 40, np.float64), (16, 33, np.float32), (40, 24, np.float64), (64, 30, np.float64),
+                                       (100, 26, np.float64), (128, 40, np.float64), (128, 40, np.float32),
+                                       (200, 12, np.float64), (256, 20, np.float64), (300, 9, np.float64),
+                                       (520, 6, np.float64)])
+def test_forward_backward_families_propagate_nan(synth, oracle, ctx, N, T, dtype):
+    """Every forward / backward kernel family on caller-supplied emissions with NaN cells (the placements of the Viterbi
+    test above): alpha is NaN in the NaN states of the first bad frame and everywhere after it, beta everywhere before
+    the LAST bad frame, the likelihood NaN -- cell for cell as the oracle's logaddexp folds leave them -- and the
+    posteriors of lnasr_baumwelch are NaN for every frame whose alpha / emission / beta slice holds one."""
+    d = synth.synth_discrete(N, 4, 8, seed=N)
+    rng = np.random.default_rng(N + T)
+    U = 7
+    b = (-30.0 * rng.random((U, T, N))).astype(dtype)
+    lens = np.array([T, T, T, T - 2, T, max(2, T // 2), T], dtype=np.int32)
+    b[0, 0, N // 2] = np.nan
+    b[1, T - 1, N - 1] = np.nan
+    b[2, T // 2, 0] = np.nan
+    b[3, T // 3, :] = np.nan
+    b[4, T // 4, 1:] = np.nan
+    b[4, T // 2, 0] = np.nan
+    b[5, lens[5]:, :] = np.nan
+    ctx.upload_hmm(d["A"], d["pi"])
+    alpha, ll = ctx.forward(b, lens=lens)
+    _, ll_only = ctx.forward(b, want_alpha=False, lens=lens)
+    beta = ctx.backward(b, lens=lens)
+    xi, gamma = ctx.baumwelch(b, alpha, beta, lens=lens)
+    tol = 1e-10 if dtype == np.float64 else 2e-5
+    for u in range(U):
+        L = int(lens[u])
+        ob = np.ascontiguousarray(b[u, :L].T)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            ra, rb = oracle.forward(d["A"], d["pi"], ob, dtype), oracle.backward(d["A"], ob, dtype)
+            rxi, rga = oracle.baumwelch(d["A"], ob, ra, rb, dtype)
+        for got, want, nm in ((alpha[u, :L], ra, "alpha"), (beta[u, :L], rb, "beta"), (gamma[u, :L], rga, "gamma"),
+                              (xi[u, :L], rxi, "xi")):
+            assert np.array_equal(np.isnan(got), np.isnan(want)), (N, u, nm)
+            ok = ~np.isnan(want) & np.isfinite(want)
+            assert np.allclose(got[ok], want[ok], rtol=tol, atol=tol), (N, u, nm)
+        want_ll = oracle.loglik(ra)
+        assert np.isnan(ll[u]) == np.isnan(want_ll) and np.isnan(ll_only[u]) == np.isnan(want_ll), (N, u)
+    assert np.isnan(ll[:5]).all() and not np.isnan(ll[5:]).any()
