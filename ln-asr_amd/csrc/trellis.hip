@@ -1327,6 +1327,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         swap16_f64(s02, s13);
         const double sum = s02 + s13;
 
+        bool prev_nan = false;
         if (step < klen) {
             const double Sc = Ss[cur][k];
             double val;
@@ -1345,7 +1346,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 if (j < N && op) op[(size_t)t * N] = prev;
             }
             if (j >= N) prev = LN_NEG_INF;
-            saw_nan |= __ballot(prev != prev);
+            prev_nan = prev != prev;
             double S = Ms[cur][k][0];
 #pragma unroll
             for (int e = 1; e < NM; ++e) S = fmax(S, Ms[cur][k][e]);
@@ -1360,6 +1361,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (c == 0) Ms[nxt][k][2 * w + h] = Ms[cur][k][2 * w + h];
             if (w == 0 && h == 0 && c == 0) Ss[nxt][k] = Ss[cur][k];
         }
+        saw_nan |= __ballot(prev_nan);             // outside the branch: the rows of a wave end at different frames
         __syncthreads();
     }
     if (saw_nan != 0 && lane == 0) *nan_flag = nan_epoch;

@@ -110,6 +110,8 @@ def test_random_shape_bad_features(seed, synth, oracle, ctx):
     r = ctx.viterbi(b, lens=lens, want_score=True)
     paths, score = ctx.decode(obs, lens=lens, want_score=True)
     ll = ctx.calc_prob(obs, lens=lens)
+    alpha, ll_fw = ctx.forward(b, lens=lens)
+    beta = ctx.backward(b, lens=lens)
     for u in range(U):
         L = int(lens[u])
         gb = np.ascontiguousarray(b[u, :L].T)
@@ -118,6 +120,13 @@ def test_random_shape_bad_features(seed, synth, oracle, ctx):
         assert np.array_equal(r["v"][u, :L], v, equal_nan=True), "v " + tag
         assert np.array_equal(r["bt"][u, :L], bt) and np.array_equal(r["path"][u, :L], path), "path " + tag
         assert np.array_equal(np.asarray(paths)[u, :L], path), "decode " + tag
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ra, rb = oracle.forward(mdl["A"], mdl["pi"], gb), oracle.backward(mdl["A"], gb)
+        for got, want, nm in ((alpha[u, :L], ra, "alpha "), (beta[u, :L], rb, "beta ")):
+            assert np.array_equal(np.isnan(got), np.isnan(want)), nm + tag
+            ok = np.isfinite(want)
+            assert np.allclose(got[ok], want[ok], rtol=1e-10, atol=1e-10), nm + tag
+        assert np.isnan(ll_fw[u]) == np.isnan(oracle.loglik(ra)), "forward loglik " + tag
         hit = bool(inside and u == ub)
         assert np.isnan(r["score"][u]) == hit and np.isnan(score[u]) == hit and np.isnan(ll[u]) == hit, "score " + tag
     st = ctx.bw_accumulate(obs, lens=lens)
