@@ -96,6 +96,13 @@ def test_random_shape_bad_features(seed, synth, oracle, ctx):
     rng, N, M, D, T, U = _shape(seed)
     rng = np.random.default_rng(5000 + seed)
     mdl = synth.synth_model(N, M, D, seed=seed + 7)
+    if seed % 3 == 0 and M > 1:                            # a dead component
+        mdl["w"][0, M - 1] = -np.inf
+        mdl["w"][0] -= oracle.lse(mdl["w"][0])
+    if seed % 4 == 1 and N > 2:                            # a forbidden transition and an unreachable state: -inf cells in v
+        mdl["A"][0, 1] = -np.inf
+        mdl["A"][:, N - 1] = -np.inf
+        mdl["A"] -= oracle.lse(mdl["A"], axis=1)[:, None]
     obs = synth.synth_obs(U, T, D, seed=seed + 50)
     lens = rng.integers(1, T + 1, U).astype(np.int32)
     lens[0] = T
