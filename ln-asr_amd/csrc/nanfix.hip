@@ -7,7 +7,9 @@
 //
 //   * emission (gmm.py:59-68, gmmhmm.py:64-67): a NaN OR an infinite feature in frame t makes every component
 //     density of that frame NaN -- the reference multiplies (x - mu) with the FULL inverse matrix, whose zero
-//     off-diagonals meet the infinity (inf * 0) -- hence bm[:, :, t] = b[:, t] = NaN (golden `gmmhmm_nonfinite`);
+//     off-diagonals meet the infinity (inf * 0) -- hence bm[:, :, t] = b[:, t] = NaN (golden `gmmhmm_nonfinite`).  (With a
+//     genuinely full Sigma an infinity meets no zeros and the reference's components come out -inf or NaN by the signs
+//     of the inverse's entries; the whole frame is NaN here all the same: the one deviation left)
 //   * Viterbi (hmm.py:162-171): with t1 the first frame whose emissions hold a NaN and j1 the first such state,
 //     v[t1, j] = NaN for the NaN states, v[t > t1, :] = NaN, bt[t1+1, :] = j1, bt[t > t1+1, :] = 0, so
 //     path[t > t1] = 0, path[t1] = j1 and path[t < t1] is the back-trace from (t1, j1) over the untouched frames;

@@ -206,3 +206,27 @@ def test_random_shape_full_covariance(seed, synth, oracle, ctx):
         with env_switch(LNASR_NO_MFMA_STATS=1):
             ref = ctx.bw_accumulate(obs, lens=lens)
         assert_close(st, ref, 1e-8, 1e-10, msg="stats " + tag)
+    # the same shapes with a NaN feature: whole NaN rows from the full-covariance kernels (matrix-core and scalar), the
+    # oracle's decode path, a NaN likelihood for the utterance that holds it, all-NaN statistics.  (An INFINITE feature
+    # under a genuinely full covariance is the one non-finite case left as a deviation: the reference's (x - mu) Sigma^-1
+    # (x - mu) then comes out +inf or NaN component by component, depending on the signs of the inverse's entries --
+    # inf - inf -- where these kernels give the whole frame NaN as for a diagonal Sigma)
+    ub, tb, db = int(rng.integers(0, U)), int(rng.integers(0, T)), int(rng.integers(0, D))
+    bad = obs.copy()
+    bad[ub, tb, db] = np.nan
+    inside = tb < lens[ub]
+    bb, bbm = ctx.gmm_logprob(bad, want_bm=True)
+    rows = ~np.isfinite(bad).all(axis=2)
+    assert np.array_equal(np.isnan(bb).all(axis=2), rows) and np.array_equal(np.isnan(bb).any(axis=2), rows), "b rows " + tag
+    assert np.array_equal(np.isnan(bbm).all(axis=(2, 3)), rows), "bm rows " + tag
+    paths = np.asarray(ctx.decode(bad, lens=lens))
+    ll = ctx.calc_prob(bad, lens=lens)
+    for u in range(U):
+        L = int(lens[u])
+        with np.errstate(all="ignore"):
+            ob, _ = oracle.gmm_map_b(bad[u, :L], mdl["w"], mdl["mu"], mdl["si"])
+            _, _, path = oracle.viterbi(mdl["A"], mdl["pi"], ob)
+        assert np.array_equal(paths[u, :L], path), "decode with a bad feature " + tag
+        assert np.isnan(ll[u]) == bool(inside and u == ub), "loglik " + tag
+    st = ctx.bw_accumulate(bad, lens=lens)
+    assert np.isnan(st[:st.size - 2]).all() if inside else not np.isnan(st).any(), "stats with a bad feature " + tag
