@@ -116,8 +116,8 @@ int lnasr_model_conditioning(lnasr_ctx* ctx, double* kappa, int* direct_form);
 int lnasr_discrete_map_b(lnasr_ctx* ctx, const double* logB, int N, int K,
                          const int32_t* obs, int U, int T, int dtype, void* b);
 /* GMMHMM._map_b (gmmhmm.py:46-67): b and (optionally) the per-mixture bm.  A frame with a NaN or an infinite feature
- * gets NaN rows, as the reference's product with the full inverse matrix gives (gmm.py:63-68: inf * 0 for a diagonal
- * Sigma; an infinity under a genuinely full Sigma gives NaN rows here too, -inf / NaN per component in the reference). */
+ * gets what the reference's product with the full inverse matrix gives (gmm.py:63-68): NaN rows (inf * 0 for a diagonal
+ * Sigma), or -inf / NaN component by component where an infinity meets no zero (a genuinely full Sigma, D = 1). */
 int lnasr_gmm_logprob(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* lens,
                       int dtype, void* b, void* bm_or_null);
 /* free functions of gmm.py (one Gaussian / one mixture, no HMM):

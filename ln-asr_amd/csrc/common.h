@@ -264,6 +264,9 @@ int narrow_f64(lnasr_ctx* ctx, const double* src, size_t n, void* dst);
 // Non-finite data, the reference's way (nanfix.hip).  force: scan the input; else act only when a kernel of this
 // API call raised ctx->nan_flag.
 int nan_rows_device(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, void* bm, bool force);
+// full covariance, or D = 1: an infinite feature meets no zero of the inverse, the reference's densities are -inf or NaN
+// component by component; nan_rows_device re-scores such frames and the trellises are repaired from the emissions
+bool nan_rows_rescored(const Model& md);
 int viterbi_nan_repair(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d_lens, int dtype, void* v,
                        uint32_t* path, double* best, bool force);          // the caller's emissions
 int viterbi_nan_repair_obs(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* d_lens, double* v,

@@ -1067,7 +1067,7 @@ int emit_device(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, v
     bool scanned = false, rows_done = false;
     LN_TRY(emit_device_raw(ctx, obs, F, dtype, b, bm, &scanned, &rows_done));
     // frames with a NaN or an infinite feature: NaN rows, as the reference's product with the full inverse gives
-    if (scanned && rows_done) return 0;
+    if (scanned && rows_done && !nan_rows_rescored(ctx->model)) return 0;
     return nan_rows_device(ctx, obs, F, dtype, b, bm, !scanned);
 }
 
@@ -1299,7 +1299,7 @@ int emit_batch(lnasr_ctx* ctx, const double* obs, int U, int T, double* b, doubl
             *scanned_or_null = all_scanned;
             return 0;
         }
-        if (all_scanned && all_rows_done) return 0;
+        if (all_scanned && all_rows_done && !nan_rows_rescored(md)) return 0;
         return nan_rows_device(ctx, ctx->ws_in.as<double>(), (long)U * T, LNASR_F64, b, bm, !all_scanned);
     };
 

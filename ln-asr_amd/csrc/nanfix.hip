@@ -7,9 +7,9 @@
 //
 //   * emission (gmm.py:59-68, gmmhmm.py:64-67): a NaN OR an infinite feature in frame t makes every component
 //     density of that frame NaN -- the reference multiplies (x - mu) with the FULL inverse matrix, whose zero
-//     off-diagonals meet the infinity (inf * 0) -- hence bm[:, :, t] = b[:, t] = NaN (golden `gmmhmm_nonfinite`).  (With a
-//     genuinely full Sigma an infinity meets no zeros and the reference's components come out -inf or NaN by the signs
-//     of the inverse's entries; the whole frame is NaN here all the same: the one deviation left)
+//     off-diagonals meet the infinity (inf * 0) -- hence bm[:, :, t] = b[:, t] = NaN (golden `gmmhmm_nonfinite`).  With a
+//     genuinely full Sigma, or D = 1, an infinity meets no zero and the reference's components come out -inf or NaN by
+//     the signs of the inverse's entries: those frames are re-scored in the reference's arithmetic (nan_rows_full_kernel);
 //   * Viterbi (hmm.py:162-171): with t1 the first frame whose emissions hold a NaN and j1 the first such state,
 //     v[t1, j] = NaN for the NaN states, v[t > t1, :] = NaN, bt[t1+1, :] = j1, bt[t > t1+1, :] = 0, so
 //     path[t > t1] = 0, path[t1] = j1 and path[t < t1] is the back-trace from (t1, j1) over the untouched frames;
@@ -68,6 +68,67 @@ __global__ __launch_bounds__(256) void nan_rows_kernel(const double* __restrict_
                 for (int j = lane; j < N; j += 64) b[f * N + j] = nan;
             if (bm)
                 for (long j = lane; j < (long)N * M; j += 64) bm[f * N * M + j] = nan;
+            if (lane == 0) *flag = epoch;
+        }
+    }
+}
+
+// np.logaddexp (the fold of utils.lse): equal operands (infinities of one sign included) x + ln 2; a NaN difference is NaN
+__device__ __forceinline__ double logaddexp_np(double x, double y) {
+    if (x == y) return x + 0.69314718055994530942;
+    const double d = x - y;
+    if (d > 0) return x + log1p(exp(-d));
+    if (d <= 0) return y + log1p(exp(d));
+    return d;
+}
+
+// Genuinely full covariance: an INFINITE feature meets no zeros in the inverse, and the reference's quadratic form
+// ((x - mu) P) . (x - mu) comes out +inf or NaN component by component (inf - inf where the signs of P's entries and of
+// the other coordinates disagree); and with D = 1 there is no off-diagonal at all, diagonal or not: the density is -inf.
+// The frames that hold a non-finite feature are therefore re-scored here in the
+// reference's own arithmetic and order (gmm.py:64-68, gmmhmm.py:64-67) instead of being filled with NaN: whether a sum of
+// infinities is an infinity or a NaN does not depend on the order of its terms, so the pattern is the reference's.
+template <typename TB>
+__global__ __launch_bounds__(256) void nan_rows_full_kernel(const double* __restrict__ obs, long F, int D, int N, int M,
+                                                            const double* __restrict__ mu, const double* __restrict__ prec,
+                                                            const double* __restrict__ ivar1,
+                                                            const double* __restrict__ gconst,
+                                                            const double* __restrict__ logw, TB* __restrict__ b,
+                                                            TB* __restrict__ bm, unsigned* flag, unsigned epoch, int force) {
+    if (!force && *flag != epoch) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const long E = F * (long)D;
+    for (long base = (long)blockIdx.x * 256; base < E; base += (long)gridDim.x * 256) {
+        const long e = base + tid;
+        const bool bad = e < E && !__builtin_isfinite(obs[e]);
+        unsigned long long mask = __ballot(bad);
+        while (mask) {                                           // wave-uniform
+            const int l = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const long f = (base + (tid & ~63) + l) / D;
+            const double* x = obs + f * D;
+            for (int j = lane; j < N; j += 64) {
+                double r = 0.0;
+                for (int m = 0; m < M; ++m) {
+                    const size_t c = (size_t)j * M + m;
+                    const double* mc = mu + c * D;
+                    double q = 0.0;
+                    if (prec) {
+                        const double* pc = prec + c * D * D;
+                        for (int d = 0; d < D; ++d) {
+                            double t = 0.0;                      // ((x - mu) P)[d]
+                            for (int k = 0; k < D; ++k) t += (x[k] - mc[k]) * pc[(size_t)k * D + d];
+                            q += t * (x[d] - mc[d]);
+                        }
+                    } else {                                     // D = 1: the 1 x 1 inverse has no zero to meet the infinity
+                        q = ((x[0] - mc[0]) * ivar1[c]) * (x[0] - mc[0]);
+                    }
+                    const double val = rnd<TB>(gconst[c] - 0.5 * q);
+                    if (bm) st<TB>(bm, ((size_t)f * N + j) * M + m, val);
+                    r = m == 0 ? logw[c] + val : logaddexp_np(r, logw[c] + val);
+                }
+                if (b) st<TB>(b, (size_t)f * N + j, r);
+            }
             if (lane == 0) *flag = epoch;
         }
     }
@@ -287,6 +348,8 @@ int locate_chunks(int U) {
 
 }  // namespace
 
+bool nan_rows_rescored(const Model& md) { return !md.diag || md.D == 1; }
+
 int nan_rows_device(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, void* bm, bool force) {
     if (F <= 0) return 0;
     const Model& md = ctx->model;
@@ -294,6 +357,21 @@ int nan_rows_device(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* 
     long grid = (E + 255) / 256;
     if (grid > 2048) grid = 2048;
     unsigned* flag = ctx->nan_flag.as<unsigned>();
+    if (nan_rows_rescored(md) && (b || bm)) {         // full covariance, or D = 1: re-score the bad frames
+        const double* prec = md.diag ? nullptr : (const double*)md.prec.as<double>();
+        const double* ivar1 = md.diag ? (const double*)md.ivar.as<double>() : nullptr;
+        if (dtype == LNASR_F32)
+            LN_LAUNCH(ctx, "nan_rows_full_f32", nan_rows_full_kernel<float>, dim3((unsigned)grid), dim3(256), 0, obs, F, md.D,
+                      md.N, md.M, (const double*)md.mu.as<double>(), prec, ivar1,
+                      (const double*)md.gconst.as<double>(), (const double*)md.logw.as<double>(), (float*)b, (float*)bm, flag,
+                      ctx->nan_epoch, force ? 1 : 0);
+        else
+            LN_LAUNCH(ctx, "nan_rows_full", nan_rows_full_kernel<double>, dim3((unsigned)grid), dim3(256), 0, obs, F, md.D,
+                      md.N, md.M, (const double*)md.mu.as<double>(), prec, ivar1,
+                      (const double*)md.gconst.as<double>(), (const double*)md.logw.as<double>(), (double*)b, (double*)bm,
+                      flag, ctx->nan_epoch, force ? 1 : 0);
+        return 0;
+    }
     if (dtype == LNASR_F32)
         LN_LAUNCH(ctx, "nan_rows_f32", nan_rows_kernel<float>, dim3((unsigned)grid), dim3(256), 0, obs, F, md.D, md.N, md.M,
                   (float*)b, (float*)bm, flag, ctx->nan_epoch, force ? 1 : 0);

@@ -2743,14 +2743,21 @@ int lnasr_decode(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t*
     // three launches in series on one stream (cutting the batch into chunks whose trellis work runs on a side stream
     // beside the next chunk's emission was measured slower, DESIGN 4.8, and removed in round 3)
     const double* d_x = nullptr;
-    bool scanned = false;
-    LN_TRY(emit_batch(ctx, obs, U, T, ctx->ws_b.as<double>(), nullptr, &d_x, &scanned));
+    bool scanned = false, v_tested = false;
+    // (full covariance: the emission pass re-scores frames with a non-finite feature itself -- an infinity gives -inf or
+    // NaN per component there -- and the trellis is repaired from the emissions, as for lnasr_viterbi)
+    const bool by_obs = !nan_rows_rescored(md);
+    LN_TRY(emit_batch(ctx, obs, U, T, ctx->ws_b.as<double>(), nullptr, &d_x, by_obs ? &scanned : nullptr));
     LN_TRY(viterbi_device(ctx, ctx->ws_b.p, U, T, d_lens, LNASR_F64, ctx->ws_v.p));
-    LN_TRY(backtrace_device(ctx, ctx->ws_v.p, U, T, d_lens, LNASR_F64, (uint32_t*)d_path, (double*)d_best));
+    LN_TRY(backtrace_device(ctx, ctx->ws_v.p, U, T, d_lens, LNASR_F64, (uint32_t*)d_path, (double*)d_best, &v_tested));
     // a NaN or an infinite feature makes its frame's emissions NaN in the reference, and np.max carries that through every
     // later frame: one launch that returns at once unless the emission kernel raised the flag (nanfix.hip)
-    LN_TRY(viterbi_nan_repair_obs(ctx, d_x, U, T, d_lens, ctx->ws_v.as<double>(), (uint32_t*)d_path, (double*)d_best,
-                                  !scanned));
+    if (by_obs)
+        LN_TRY(viterbi_nan_repair_obs(ctx, d_x, U, T, d_lens, ctx->ws_v.as<double>(), (uint32_t*)d_path, (double*)d_best,
+                                      !scanned));
+    else
+        LN_TRY(viterbi_nan_repair(ctx, ctx->ws_b.p, U, T, d_lens, LNASR_F64, ctx->ws_v.p, (uint32_t*)d_path, (double*)d_best,
+                                  !v_tested));
     LN_TRY(finish_out(ctx, path, d_path, (size_t)U * T * 4));
     if (best_score_or_null) LN_TRY(finish_out(ctx, best_score_or_null, d_best, (size_t)U * 8));
     return 0;
@@ -2817,6 +2824,7 @@ int lnasr_calc_prob_p(lnasr_ctx* ctx, const double* obs, int U, int T, const int
     LN_TRY(stage_out(ctx, loglik, (size_t)U * 8, ctx->ws_out2, &d_ll));
     const double* d_x = nullptr;
     bool scanned = false;
+    const bool by_obs = !nan_rows_rescored(md);
     if (dtype == LNASR_F32 && f32_stats_ok(md)) {
         // the emission of the float32 statistics pass (lnasr_bw_accumulate_p): same b, hence the same likelihood
         const void* d_obs;
@@ -2825,11 +2833,16 @@ int lnasr_calc_prob_p(lnasr_ctx* ctx, const double* obs, int U, int T, const int
         LN_TRY(emit_device_f32(ctx, (const double*)d_obs, (long)U * T, ctx->ws_b.as<double>(), ctx->ws_bm.as<float>()));
         d_x = (const double*)d_obs;                         // emit_diag_mfma_f32 has no fused test (f32stats.hip)
     } else {
-        LN_TRY(emit_batch(ctx, obs, U, T, ctx->ws_b.as<double>(), nullptr, &d_x, &scanned));
+        LN_TRY(emit_batch(ctx, obs, U, T, ctx->ws_b.as<double>(), nullptr, &d_x, by_obs ? &scanned : nullptr));
     }
     LN_TRY(forward_device(ctx, ctx->ws_b.p, U, T, d_lens, LNASR_F64, nullptr, (double*)d_ll));
-    // an utterance with a NaN or an infinite feature scores NaN (np.logaddexp carries it to the last frame, hmm.py:97-99)
-    LN_TRY(loglik_nan_repair(ctx, d_x, U, T, d_lens, (double*)d_ll, !scanned));
+    // an utterance with a NaN or an infinite feature scores NaN (np.logaddexp carries it to the last frame, hmm.py:97-99);
+    // full covariance: an utterance whose re-scored emissions hold a NaN does (an infinity may leave only -inf there)
+    if (by_obs)
+        LN_TRY(loglik_nan_repair(ctx, d_x, U, T, d_lens, (double*)d_ll, !scanned));
+    else
+        LN_TRY(trellis_nan_repair(ctx, ctx->ws_b.p, U, T, d_lens, LNASR_F64, nullptr, (double*)d_ll, nullptr,
+                                  !ctx->fwd_nan_tested));
     return finish_out(ctx, loglik, d_ll, (size_t)U * 8);
 }
 

@@ -237,8 +237,13 @@ def _nonfinite_frames(obs):
     """Frames holding a NaN or an infinite feature.  The reference multiplies (x - mu) with the FULL inverse matrix
     (gmm.py:63-68): for a diagonal Sigma its off-diagonal zeros meet the infinite entry (inf * 0 = NaN), so every
     component density of such a frame is NaN, not the -inf a diagonal-only sum of squares would give (golden
-    `gmmhmm_nonfinite`).  The diagonal shortcuts below restore exactly that."""
-    return ~np.isfinite(np.asarray(obs, dtype=np.float64)).all(axis=1)
+    `gmmhmm_nonfinite`).  The diagonal shortcuts below restore exactly that.  With D = 1 there is no off-diagonal: an
+    infinite feature then simply gives (inf)^2 / var = inf, a density of -inf, which the shortcuts' own arithmetic
+    yields; only a NaN makes the frame NaN."""
+    obs = np.asarray(obs, dtype=np.float64)
+    if obs.shape[1] == 1:
+        return np.isnan(obs).any(axis=1)
+    return ~np.isfinite(obs).all(axis=1)
 
 
 def gmm_map_b_diag(obs, w, mu, var, precision=np.float64):
@@ -257,6 +262,8 @@ def gmm_map_b_diag(obs, w, mu, var, precision=np.float64):
     # (gmmhmm.py:64-67): with float32 the mixture sum sees the rounded component log-densities
     bm = (const.reshape(1, N * M) - 0.5 * q).reshape(T, N, M).astype(precision)
     bm[_nonfinite_frames(obs)] = np.nan
+    if D == 1:                                   # the reference's direct form gives (inf)^2 / var = inf; the expansion above
+        bm[np.isinf(obs[:, 0])] = -np.inf        # would cancel inf - inf
     z = w[None] + bm.astype(np.float64)
     mx = z.max(axis=2, keepdims=True)
     b = (mx[..., 0] + np.log(np.exp(z - mx).sum(axis=2)))

@@ -112,8 +112,12 @@ def test_random_shape_bad_features(seed, synth, oracle, ctx):
     ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
     tag = "seed=%d N=%d M=%d D=%d T=%d U=%d bad=(%d,%d,%d) inside=%s" % (seed, N, M, D, T, U, ub, tb, db, inside)
     b = ctx.gmm_logprob(obs)
-    rows = ~np.isfinite(obs).all(axis=2)
+    # whole NaN rows where a feature is not finite -- except that with D = 1 there is no zero off-diagonal for an infinity
+    # to meet (gmm.py:63-68): the reference's density is then -inf, as the oracle's direct form says
+    rows = ~np.isfinite(obs).all(axis=2) if D > 1 else np.isnan(obs).any(axis=2)
     assert np.array_equal(np.isnan(b).all(axis=2), rows) and np.array_equal(np.isnan(b).any(axis=2), rows), "b " + tag
+    if D == 1:
+        assert np.array_equal(np.isneginf(b).all(axis=2), np.isinf(obs).any(axis=2)), "b -inf rows " + tag
     r = ctx.viterbi(b, lens=lens, want_score=True)
     paths, score = ctx.decode(obs, lens=lens, want_score=True)
     ll = ctx.calc_prob(obs, lens=lens)
@@ -134,7 +138,7 @@ def test_random_shape_bad_features(seed, synth, oracle, ctx):
             ok = np.isfinite(want)
             assert np.allclose(got[ok], want[ok], rtol=1e-10, atol=1e-10), nm + tag
         assert np.isnan(ll_fw[u]) == np.isnan(oracle.loglik(ra)), "forward loglik " + tag
-        hit = bool(inside and u == ub)
+        hit = bool(inside and u == ub) and bool(np.isnan(gb).any())           # (D = 1 with an infinity: -inf, no NaN)
         assert np.isnan(r["score"][u]) == hit and np.isnan(score[u]) == hit and np.isnan(ll[u]) == hit, "score " + tag
     st = ctx.bw_accumulate(obs, lens=lens)
     n_sums = st.size - 2                                   # everything but the two counts
@@ -206,27 +210,32 @@ def test_random_shape_full_covariance(seed, synth, oracle, ctx):
         with env_switch(LNASR_NO_MFMA_STATS=1):
             ref = ctx.bw_accumulate(obs, lens=lens)
         assert_close(st, ref, 1e-8, 1e-10, msg="stats " + tag)
-    # the same shapes with a NaN feature: whole NaN rows from the full-covariance kernels (matrix-core and scalar), the
-    # oracle's decode path, a NaN likelihood for the utterance that holds it, all-NaN statistics.  (An INFINITE feature
-    # under a genuinely full covariance is the one non-finite case left as a deviation: the reference's (x - mu) Sigma^-1
-    # (x - mu) then comes out +inf or NaN component by component, depending on the signs of the inverse's entries --
-    # inf - inf -- where these kernels give the whole frame NaN as for a diagonal Sigma)
+    # the same shapes with a NaN / +-inf feature.  A NaN makes the frame's densities NaN; an INFINITY under a genuinely full
+    # covariance meets no zeros in the inverse and the reference's quadratic form comes out +inf or NaN component by
+    # component (inf - inf where signs disagree): the bad frames are re-scored in the reference's own arithmetic, so b and
+    # bm hold NaN and -inf exactly where the oracle's do, decode returns the oracle's path, the likelihood is NaN or -inf
+    # as the oracle's, and the statistics are all NaN
     ub, tb, db = int(rng.integers(0, U)), int(rng.integers(0, T)), int(rng.integers(0, D))
     bad = obs.copy()
-    bad[ub, tb, db] = np.nan
+    bad[ub, tb, db] = [np.nan, np.inf, -np.inf][seed % 3]
     inside = tb < lens[ub]
     bb, bbm = ctx.gmm_logprob(bad, want_bm=True)
-    rows = ~np.isfinite(bad).all(axis=2)
-    assert np.array_equal(np.isnan(bb).all(axis=2), rows) and np.array_equal(np.isnan(bb).any(axis=2), rows), "b rows " + tag
-    assert np.array_equal(np.isnan(bbm).all(axis=(2, 3)), rows), "bm rows " + tag
     paths = np.asarray(ctx.decode(bad, lens=lens))
     ll = ctx.calc_prob(bad, lens=lens)
     for u in range(U):
         L = int(lens[u])
         with np.errstate(all="ignore"):
-            ob, _ = oracle.gmm_map_b(bad[u, :L], mdl["w"], mdl["mu"], mdl["si"])
-            _, _, path = oracle.viterbi(mdl["A"], mdl["pi"], ob)
+            ob, obm = oracle.gmm_map_b(bad[u], mdl["w"], mdl["mu"], mdl["si"])
+            _, _, path = oracle.viterbi(mdl["A"], mdl["pi"], ob[:, :L])
+            oll = oracle.loglik(oracle.forward(mdl["A"], mdl["pi"], ob[:, :L]))
+        for got, want, nm in ((bb[u], ob.T, "b "), (bbm[u], np.transpose(obm, (2, 0, 1)), "bm ")):
+            assert np.array_equal(np.isnan(got), np.isnan(want)), nm + "NaN pattern " + tag
+            assert np.array_equal(np.isneginf(got), np.isneginf(want)), nm + "-inf pattern " + tag
+            ok = np.isfinite(want)
+            assert np.allclose(got[ok], want[ok], rtol=1e-9, atol=1e-9), nm + tag
         assert np.array_equal(paths[u, :L], path), "decode with a bad feature " + tag
-        assert np.isnan(ll[u]) == bool(inside and u == ub), "loglik " + tag
-    st = ctx.bw_accumulate(bad, lens=lens)
-    assert np.isnan(st[:st.size - 2]).all() if inside else not np.isnan(st).any(), "stats with a bad feature " + tag
+        assert np.isnan(ll[u]) == np.isnan(oll) and (np.isnan(oll) or ll[u] == oll or abs(ll[u] - oll) <= 1e-9 * abs(oll)), \
+            "loglik " + tag
+    if D > 1 and not ctx.model_is_diag():
+        st = ctx.bw_accumulate(bad, lens=lens)
+        assert np.isnan(st[:st.size - 2]).all() if inside else not np.isnan(st).any(), "stats with a bad feature " + tag
