@@ -222,13 +222,17 @@ __device__ __forceinline__ double block_sum(double v, double* scratch) {
 // reference's logaddexp fold, utils.py:176-179).
 struct Lse {
     double m = LN_NEG_INF, s = 0.0;
+    // A NaN term poisons the sum, as np.logaddexp does (utils.py:140-179): it fails both comparisons below and becomes
+    // the running maximum, after which nothing compares either way and value() is NaN + log(s).
     __device__ __forceinline__ void add(double z) {
         if (z == LN_NEG_INF) return;
         if (z > m) {
             s = s * exp(m - z) + 1.0;   // m = -inf: s is 0, exp(-inf) = 0
             m = z;
-        } else {
+        } else if (z <= m) {
             s += exp(z - m);
+        } else if (m == m) {
+            m = z;                      // z is NaN
         }
     }
     __device__ __forceinline__ void merge(double om, double os) {
@@ -236,8 +240,10 @@ struct Lse {
         if (om > m) {
             s = s * exp(m - om) + os;
             m = om;
-        } else {
+        } else if (om <= m) {
             s += os * exp(om - m);
+        } else if (m == m) {
+            m = om;
         }
     }
     __device__ __forceinline__ double value() const { return (m == LN_NEG_INF) ? m : m + log(s); }

@@ -26,8 +26,10 @@ struct LseAcc {
         if (z > m) {
             s = s * (BASE2 ? exp2(m - z) : exp(m - z)) + 1.0;
             m = z;
-        } else {
+        } else if (z <= m) {
             s += BASE2 ? exp2(z - m) : exp(z - m);
+        } else if (m == m) {
+            m = z;                      // a NaN term poisons the sum, as np.logaddexp does (see Lse, devmath.h)
         }
     }
     __device__ __forceinline__ void merge(double om, double os) {
@@ -35,8 +37,10 @@ struct LseAcc {
         if (om > m) {
             s = s * (BASE2 ? exp2(m - om) : exp(m - om)) + os;
             m = om;
-        } else {
+        } else if (om <= m) {
             s += os * (BASE2 ? exp2(om - m) : exp(om - m));
+        } else if (m == m) {
+            m = om;
         }
     }
     __device__ __forceinline__ double value() const {

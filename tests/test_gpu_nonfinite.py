@@ -306,3 +306,58 @@ def test_forward_backward_families_propagate_nan(synth, oracle, ctx, N, T, dtype
         want_ll = oracle.loglik(ra)
         assert np.isnan(ll[u]) == np.isnan(want_ll) and np.isnan(ll_only[u]) == np.isnan(want_ll), (N, u)
     assert np.isnan(ll[:5]).all() and not np.isnan(ll[5:]).any()
+
+
+def test_gaussian_free_functions_with_bad_points(golden, oracle):
+    """gmm.py's free functions (gmm.py:16-100) are plain arithmetic: NaN and infinite points come out as the oracle's
+    NaN / 0 / -inf, cell for cell, in the linear and the log forms, for a diagonal-looking and a genuinely full Sigma."""
+    from lnasr import gmm
+    g = golden("gmm_funcs")
+
+    def same(got, want, tol=1e-12):
+        got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+        assert got.shape == want.shape
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        assert np.array_equal(np.isinf(got), np.isinf(want)) and np.array_equal(np.sign(got[np.isinf(got)]),
+                                                                                np.sign(want[np.isinf(want)]))
+        ok = np.isfinite(want)
+        assert np.allclose(got[ok], want[ok], rtol=tol, atol=tol)
+
+    x1 = np.array(g["x1"], dtype=np.float64).copy()
+    x1[[1, 5, 7]] = [np.nan, np.inf, -np.inf]
+    with np.errstate(all="ignore"):
+        same(gmm.gaussian_distribution(x1, 0, 4), oracle.gaussian(x1, 0, 4))
+        same(gmm.gaussian_distribution_log(x1, 0, 4), oracle.gaussian_log(x1, 0, 4))
+        for Sigma in (np.diag([2.0, 0.5]), np.asarray(g["Sigma"], dtype=np.float64)):
+            x2 = np.array(g["x2"], dtype=np.float64).copy()
+            x2[2, 0], x2[4, 1], x2[6, 0], x2[8] = np.nan, np.inf, -np.inf, [np.inf, np.inf]
+            mu0 = np.zeros(2)
+            same(gmm.gaussian_multi_distribution(x2, mu0, Sigma), oracle.gaussian_multi(x2, mu0, Sigma))
+            same(gmm.gaussian_multi_distribution_log(x2, mu0, Sigma), oracle.gaussian_multi_log(x2, mu0, Sigma))
+        x3 = np.array(g["x3"], dtype=np.float64).copy()
+        x3[3, 0], x3[9, 1], x3[20] = np.nan, np.inf, [-np.inf, np.inf]
+        same(gmm.gaussian_mixture_distribution(g["c"], x3, g["mu3"], g["Sigma3"]),
+             oracle.gaussian_mixture(g["c"], x3, g["mu3"], g["Sigma3"]))
+        same(gmm.gaussian_mixture_distribution_log(np.log(g["c"]), x3, g["mu3"], g["Sigma3"]),
+             oracle.gaussian_mixture_log(np.log(g["c"]), x3, g["mu3"], g["Sigma3"]))
+
+
+def test_lse_propagates_nan(oracle):
+    """utils.lse / lse2 (utils.py:140-204) fold with np.logaddexp: a NaN anywhere along the reduced axis is a NaN result,
+    -inf entries are neutral, an all -inf line is -inf -- along every axis form the reference accepts."""
+    from lnasr import utils
+    rng = np.random.default_rng(3)
+    x = -20.0 * rng.random((5, 7, 33))
+    x[1, 2, 5] = np.nan
+    x[3, :, 8] = -np.inf
+    x[4, 6, :] = np.nan
+    x[0, 0, :] = -np.inf
+    for axis in (0, 1, 2, (1, 2), (0, 1, 2), None):
+        with np.errstate(all="ignore"):
+            want, want2 = oracle.lse(x, axis), oracle.lse2(x, axis)
+        for got, ref in ((utils.lse(x, axis), want), (utils.lse2(x, axis), want2)):
+            got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+            assert got.shape == ref.shape, axis
+            assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.array_equal(np.isneginf(got), np.isneginf(ref)), axis
+            ok = np.isfinite(ref)
+            assert np.allclose(got[ok], ref[ok], rtol=1e-13, atol=1e-13), axis
