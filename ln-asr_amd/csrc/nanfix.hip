@@ -175,6 +175,36 @@ __global__ __launch_bounds__(256) void nan_locate_kernel(const TS* __restrict__ 
     }
 }
 
+// First and last NaN of one utterance's emissions, found by the block itself (all 256 threads call): the path of the
+// repair kernels when a hot kernel raised the flag -- then no separate scan was launched, and on clean data the repair
+// kernel is the only launch there is
+template <typename TS>
+__device__ __forceinline__ void block_nan_span(const TS* __restrict__ bu, long total, unsigned long long& first,
+                                               long long& last) {
+    __shared__ unsigned long long sf;
+    __shared__ long long sl;
+    const int tid = threadIdx.x;
+    unsigned long long mf = kNoBad;
+    long long ml = -1;
+    for (long e = tid; e < total; e += 256) {
+        const TS x = bu[e];
+        if (x != x) {
+            if (mf == kNoBad) mf = (unsigned long long)e;
+            ml = e;
+        }
+    }
+    if (tid == 0) {
+        sf = kNoBad;
+        sl = -1;
+    }
+    __syncthreads();
+    if (mf != kNoBad) atomicMin(&sf, mf);
+    if (ml >= 0) atomicMax(&sl, ml);
+    __syncthreads();
+    first = sf;
+    last = sl;
+}
+
 // Forward pass (hmm.py:97-99): np.logaddexp carries a NaN emission of frame t1 into every state of every later frame:
 // alpha[t1, j] = NaN for the NaN states, alpha[t > t1, :] = NaN, the likelihood NaN.  Backward (hmm.py:128-130):
 // beta[t] folds b[:, t + 1], so with tl the LAST frame holding a NaN, beta[t < tl, :] = NaN and the rest stands.
@@ -186,13 +216,19 @@ __global__ __launch_bounds__(256) void alpha_nan_repair_kernel(const TS* __restr
                                                                const unsigned* flag, unsigned epoch) {
     if (*flag != epoch) return;
     const int u = blockIdx.x, tid = threadIdx.x;
+    const int L = lens[u];
     unsigned long long first = kNoBad;
-    for (int c = 0; c < C; ++c) {
-        const unsigned long long s = slot[(size_t)u * C + c];
-        first = s < first ? s : first;
+    if (slot) {
+        for (int c = 0; c < C; ++c) {
+            const unsigned long long s = slot[(size_t)u * C + c];
+            first = s < first ? s : first;
+        }
+    } else {
+        long long last;
+        block_nan_span(b + (size_t)u * T * N, (long)L * N, first, last);
     }
     if (first == kNoBad) return;
-    const int L = lens[u], t1 = (int)(first / (unsigned long long)N);
+    const int t1 = (int)(first / (unsigned long long)N);
     const TS nan = quiet_nan<TS>();
     if (alpha) {
         TS* au = alpha + (size_t)u * T * N;
@@ -206,16 +242,21 @@ __global__ __launch_bounds__(256) void alpha_nan_repair_kernel(const TS* __restr
 }
 
 template <typename TS>
-__global__ __launch_bounds__(256) void beta_nan_repair_kernel(TS* __restrict__ beta, const int32_t* __restrict__ lens,
-                                                              int T, int N, int C,
+__global__ __launch_bounds__(256) void beta_nan_repair_kernel(const TS* __restrict__ b, TS* __restrict__ beta,
+                                                              const int32_t* __restrict__ lens, int T, int N, int C,
                                                               const unsigned long long* __restrict__ slot_last,
                                                               const unsigned* flag, unsigned epoch) {
     if (*flag != epoch) return;
     const int u = blockIdx.x, tid = threadIdx.x;
     long long last = -1;
-    for (int c = 0; c < C; ++c) {
-        const unsigned long long s = slot_last[(size_t)u * C + c];
-        if (s != kNoBad && (long long)s > last) last = (long long)s;
+    if (slot_last) {
+        for (int c = 0; c < C; ++c) {
+            const unsigned long long s = slot_last[(size_t)u * C + c];
+            if (s != kNoBad && (long long)s > last) last = (long long)s;
+        }
+    } else {
+        unsigned long long first;
+        block_nan_span(b + (size_t)u * T * N, (long)lens[u] * N, first, last);
     }
     if (last < 0) return;
     const long tl = last / N;                                    // beta[t] reads b[:, t + 1]: frames below tl
@@ -288,9 +329,14 @@ __global__ __launch_bounds__(256) void viterbi_nan_repair_kernel(const TS* __res
         j1 = 0;
     } else {
         unsigned long long first = kNoBad;
-        for (int c = 0; c < C; ++c) {
-            const unsigned long long s = slot[(size_t)u * C + c];
-            first = s < first ? s : first;
+        if (slot) {
+            for (int c = 0; c < C; ++c) {
+                const unsigned long long s = slot[(size_t)u * C + c];
+                first = s < first ? s : first;
+            }
+        } else {
+            long long last;
+            block_nan_span(b + (size_t)u * T * N, (long)L * N, first, last);
         }
         if (first == kNoBad) return;                             // block-uniform
         t1 = (int)(first / (unsigned long long)N);
@@ -387,29 +433,30 @@ int viterbi_nan_repair(lnasr_ctx* ctx, const void* b, int U, int T, const int32_
     const int N = ctx->model.N;
     const int C = locate_chunks(U);
     LN_REQUIRE(v, "the repair pass needs the Viterbi lattice");
-    LN_TRY(ctx->nan_slots.reserve((size_t)U * C * 8));
     unsigned* flag = ctx->nan_flag.as<unsigned>() + 1;      // the "suspect cell in v" word (backtrace_lds_kernel)
-    unsigned long long* slot = ctx->nan_slots.as<unsigned long long>();
     const double* AT = ctx->model.logAT.as<double>();
     const double* no_obs = nullptr;
+    // force: the scan is launched (grid (U, C), memory speed) and raises the word itself; otherwise the back-trace kernel
+    // has already looked, and the repair kernel -- the only launch on clean data -- finds its utterance's NaN by itself
+    unsigned long long* slot = nullptr;
+    if (force) {
+        LN_TRY(ctx->nan_slots.reserve((size_t)U * C * 8));
+        slot = ctx->nan_slots.as<unsigned long long>();
+    }
     if (dtype == LNASR_F32) {
-        LN_LAUNCH(ctx, "nan_locate_f32", nan_locate_kernel<float>, dim3(U, C), dim3(256), 0, (const float*)b, d_lens, T, N,
-                  slot, (unsigned long long*)nullptr, flag, ctx->nan_epoch, force ? 1 : 0);
+        if (force)
+            LN_LAUNCH(ctx, "nan_locate_f32", nan_locate_kernel<float>, dim3(U, C), dim3(256), 0, (const float*)b, d_lens, T,
+                      N, slot, (unsigned long long*)nullptr, flag, ctx->nan_epoch, 1);
         LN_LAUNCH(ctx, "viterbi_nan_repair_f32", viterbi_nan_repair_kernel<float>, dim3(U), dim3(256), 0, (const float*)b,
-                  (float*)v, AT, d_lens, T, N, C, slot, no_obs, 0, flag, ctx->nan_epoch, path, best);
+                  (float*)v, AT, d_lens, T, N, C, (const unsigned long long*)slot, no_obs, 0, flag, ctx->nan_epoch, path, best);
     } else {
-        LN_LAUNCH(ctx, "nan_locate", nan_locate_kernel<double>, dim3(U, C), dim3(256), 0, (const double*)b, d_lens, T, N,
-                  slot, (unsigned long long*)nullptr, flag, ctx->nan_epoch, force ? 1 : 0);
+        if (force)
+            LN_LAUNCH(ctx, "nan_locate", nan_locate_kernel<double>, dim3(U, C), dim3(256), 0, (const double*)b, d_lens, T, N,
+                      slot, (unsigned long long*)nullptr, flag, ctx->nan_epoch, 1);
         LN_LAUNCH(ctx, "viterbi_nan_repair", viterbi_nan_repair_kernel<double>, dim3(U), dim3(256), 0, (const double*)b,
-                  (double*)v, AT, d_lens, T, N, C, slot, no_obs, 0, flag, ctx->nan_epoch, path, best);
+                  (double*)v, AT, d_lens, T, N, C, (const unsigned long long*)slot, no_obs, 0, flag, ctx->nan_epoch, path, best);
     }
     return 0;
-}
-
-// force for the kernels that walk ONE utterance per block: a flat scan of the observations at memory speed raises the
-// flag first (it does not know the utterances' lengths: padding may raise it for nothing), the slow walk follows only then
-static int raise_flag_if_bad(lnasr_ctx* ctx, const double* obs, int U, int T) {
-    return nan_rows_device(ctx, obs, (long)U * T, LNASR_F64, nullptr, nullptr, true);
 }
 
 // caller-supplied emissions through the forward / backward entry points.  Word 2 of ctx->nan_flag: "a forward / backward
@@ -419,31 +466,41 @@ int trellis_nan_repair(lnasr_ctx* ctx, const void* b, int U, int T, const int32_
     if (U <= 0 || T <= 0) return 0;
     const int N = ctx->model.N;
     const int C = locate_chunks(U);
-    LN_TRY(ctx->nan_slots.reserve((size_t)U * C * 8 * 2));
     unsigned* flag = ctx->nan_flag.as<unsigned>() + 2;
-    unsigned long long* slot = ctx->nan_slots.as<unsigned long long>();
-    unsigned long long* slot_last = slot + (size_t)U * C;
-    const int f = force ? 1 : 0;
+    unsigned long long *slot = nullptr, *slot_last = nullptr;      // see viterbi_nan_repair
+    if (force) {
+        LN_TRY(ctx->nan_slots.reserve((size_t)U * C * 8 * 2));
+        slot = ctx->nan_slots.as<unsigned long long>();
+        slot_last = slot + (size_t)U * C;
+    }
     if (dtype == LNASR_F32) {
-        LN_LAUNCH(ctx, "nan_locate_f32", nan_locate_kernel<float>, dim3(U, C), dim3(256), 0, (const float*)b, d_lens, T, N,
-                  slot, beta ? slot_last : nullptr, flag, ctx->nan_epoch, f);
+        if (force)
+            LN_LAUNCH(ctx, "nan_locate_f32", nan_locate_kernel<float>, dim3(U, C), dim3(256), 0, (const float*)b, d_lens, T,
+                      N, slot, beta ? slot_last : nullptr, flag, ctx->nan_epoch, 1);
         if (alpha || loglik)
             LN_LAUNCH(ctx, "alpha_nan_repair_f32", alpha_nan_repair_kernel<float>, dim3(U), dim3(256), 0, (const float*)b,
-                      (float*)alpha, loglik, d_lens, T, N, C, slot, flag, ctx->nan_epoch);
+                      (float*)alpha, loglik, d_lens, T, N, C, (const unsigned long long*)slot, flag, ctx->nan_epoch);
         if (beta)
-            LN_LAUNCH(ctx, "beta_nan_repair_f32", beta_nan_repair_kernel<float>, dim3(U), dim3(256), 0, (float*)beta, d_lens,
-                      T, N, C, slot_last, flag, ctx->nan_epoch);
+            LN_LAUNCH(ctx, "beta_nan_repair_f32", beta_nan_repair_kernel<float>, dim3(U), dim3(256), 0, (const float*)b,
+                      (float*)beta, d_lens, T, N, C, (const unsigned long long*)slot_last, flag, ctx->nan_epoch);
     } else {
-        LN_LAUNCH(ctx, "nan_locate", nan_locate_kernel<double>, dim3(U, C), dim3(256), 0, (const double*)b, d_lens, T, N,
-                  slot, beta ? slot_last : nullptr, flag, ctx->nan_epoch, f);
+        if (force)
+            LN_LAUNCH(ctx, "nan_locate", nan_locate_kernel<double>, dim3(U, C), dim3(256), 0, (const double*)b, d_lens, T, N,
+                      slot, beta ? slot_last : nullptr, flag, ctx->nan_epoch, 1);
         if (alpha || loglik)
             LN_LAUNCH(ctx, "alpha_nan_repair", alpha_nan_repair_kernel<double>, dim3(U), dim3(256), 0, (const double*)b,
-                      (double*)alpha, loglik, d_lens, T, N, C, slot, flag, ctx->nan_epoch);
+                      (double*)alpha, loglik, d_lens, T, N, C, (const unsigned long long*)slot, flag, ctx->nan_epoch);
         if (beta)
-            LN_LAUNCH(ctx, "beta_nan_repair", beta_nan_repair_kernel<double>, dim3(U), dim3(256), 0, (double*)beta, d_lens,
-                      T, N, C, slot_last, flag, ctx->nan_epoch);
+            LN_LAUNCH(ctx, "beta_nan_repair", beta_nan_repair_kernel<double>, dim3(U), dim3(256), 0, (const double*)b,
+                      (double*)beta, d_lens, T, N, C, (const unsigned long long*)slot_last, flag, ctx->nan_epoch);
     }
     return 0;
+}
+
+// force for the kernels that walk ONE utterance per block: a flat scan of the observations at memory speed raises the
+// flag first (it does not know the utterances' lengths: padding may raise it for nothing), the slow walk follows only then
+static int raise_flag_if_bad(lnasr_ctx* ctx, const double* obs, int U, int T) {
+    return nan_rows_device(ctx, obs, (long)U * T, LNASR_F64, nullptr, nullptr, true);
 }
 
 int viterbi_nan_repair_obs(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* d_lens, double* v,
