@@ -33,7 +33,10 @@ Besides the headline the line carries
                same from pageable memory through the pinned staging ring; PCIe-inclusive, never `value`;
   baum_welch   BASELINE configs[4]: one statistics pass per rank (N=256, M=32, T=2000, 64 utterances:
                emission + forward/backward + accumulation) and the RCCL all-reduce of the packed
-               sufficient statistics (the second collective of the path), timed separately.
+               sufficient statistics (the second collective of the path), timed separately;
+  reference_api  (one rank only) the reference's own method names on ONE utterance through the mirror
+               classes -- GMMHMM.decode / calc_prob / _viterbi / _forward / train(iters=1) at the metric
+               shape with si as [N,M,D,D]: wall, device and host ms per call (tools/refapi.py).
 
     --dry-launch    CPU rehearsal of the launch path (tests): the ranks rendezvous over gloo, shard
                     a toy batch, gather toy paths through the gloo transport and rank 0 prints a
@@ -581,6 +584,17 @@ def main():
         if not ok:
             sys.stderr.write("[rank %d] Baum-Welch statistics failed their checks\n" % rank)
             rc = 1
+    refapi = None
+    if not args.no_extras and world == 1 and not use_comm and T == 1000:
+        note("reference API latency (one utterance through the mirror classes)")
+        spec = importlib.util.spec_from_file_location("lnasr_refapi", os.path.join(REPO, "tools", "refapi.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        try:
+            refapi = mod.measure(ctx, obs=obs[0], check_path=want_head[0])
+        except RuntimeError as e:
+            sys.stderr.write("[rank %d] reference API: %s\n" % (rank, e))
+            rc = 1
     rc = int(max(rk.gather(rc)))
     note("done, rc=%d" % rc)
 
@@ -625,6 +639,8 @@ def main():
         if e2e is not None:
             out["end_to_end"] = e2e
             out["baum_welch"] = bw
+        if refapi is not None:
+            out["reference_api"] = refapi
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["cpu_baseline_reference_shaped"] = cpu_ref

@@ -83,6 +83,12 @@ int lnasr_memset(lnasr_ctx* ctx, void* dst_dev, int byte, size_t bytes);
 int lnasr_host_alloc(lnasr_ctx* ctx, size_t bytes, void** out);
 int lnasr_host_free(lnasr_ctx* ctx, void* p);
 
+/* 128-bit fingerprint of a HOST buffer (no context, no device).  The reference's methods re-read self.A / self.mu /
+ * self.si on every call (hmm.py:82-99, gmmhmm.py:58-67): the mirror classes fingerprint the parameters per call and
+ * upload only what changed.  Buffers of 2 MB and more are hashed by a small pool of host threads (25 MB of `si`:
+ * ~0.2 ms instead of ~1.5 ms on one thread); the result depends on the bytes, their count and the seed only. */
+int lnasr_hash128(const void* data, size_t bytes, uint64_t seed, uint64_t* out2);
+
 /* per-kernel HIP-event timing on the context's own stream (bench.py roofline) */
 int lnasr_prof_enable(lnasr_ctx* ctx, int on);
 int lnasr_prof_reset(lnasr_ctx* ctx);

@@ -141,6 +141,7 @@ struct lnasr_ctx {
     void* ring[kRingSlots] = {nullptr, nullptr, nullptr, nullptr};
     size_t ring_cap = 0;                      // bytes per slot
     hipEvent_t ring_ev[kRingSlots] = {nullptr, nullptr, nullptr, nullptr};   // the copy that last read the slot
+    bool ring_busy[kRingSlots] = {false, false, false, false};               // ring_ev[s] was recorded and not waited for yet
     hipDeviceProp_t prop;
     lnasr::Model model;
     // workspace

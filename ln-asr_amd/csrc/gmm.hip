@@ -1336,6 +1336,15 @@ int emit_batch(lnasr_ctx* ctx, const double* obs, int U, int T, double* b, doubl
         size_t slot = 0;
         for (int c = 0; c < nch; ++c) slot = plan.len(c) > slot ? plan.len(c) : slot;
         LN_TRY(ensure_ring(ctx, slot));
+        // The previous call returned once its DMAs were ENQUEUED: with device outputs and no host-side wait (decode into
+        // a DeviceArray, statistics into device memory) its last copies may still be reading the ring.  A slot is
+        // written again only after the copy that last read it has finished.
+        for (int s = 0; s < K; ++s)
+            if (ctx->ring_busy[s]) {
+                LN_HIP(hipEventSynchronize(ctx->ring_ev[s]));
+                ctx->ring_busy[s] = false;
+            }
+        for (int c = 0; c < nch; ++c) ctx->ring_busy[c % K] = true;     // every slot used below ends with a recorded event
         for (int t = 0; t < nth; ++t) {
             workers.emplace_back([&, t] {
                 (void)hipSetDevice(ctx->device);

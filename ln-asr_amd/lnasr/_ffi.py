@@ -9,11 +9,6 @@ import threading
 
 import numpy as np
 
-try:                                   # optional: lets upload_* skip transfers of unchanged models
-    import xxhash as _xxhash
-except ImportError:                    # pragma: no cover
-    _xxhash = None
-
 F64, F32 = 0, 1
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # LNASR_LIB selects another build of the same library (the host-sanitizer build of build.py --host-asan)
@@ -46,6 +41,7 @@ SIGNATURES = {
     "lnasr_host_alloc": [_vp, _sz, _P(_vp)],
     "lnasr_host_free": [_vp, _vp],
     "lnasr_device_info": [_vp, C.c_char_p, _i, _P(_i), _P(_sz)],
+    "lnasr_hash128": [_vp, _sz, C.c_uint64, _P(C.c_uint64)],
     "lnasr_dev_alloc": [_vp, _sz, _P(_vp)],
     "lnasr_dev_free": [_vp, _vp],
     "lnasr_memcpy_h2d": [_vp, _vp, _vp, _sz],
@@ -322,50 +318,56 @@ class Context:
         return out
 
     # -- models --------------------------------------------------------------------------
-    # The reference API re-reads self.A / self.mu / ... on every call, so the mirror classes upload the model on
-    # every call too.  Hashing the parameters (xxh3: ~1.5 ms for the 25 MB of a 128-state full-covariance model)
-    # and skipping the upload when the device already holds exactly these bytes is several times cheaper than the
-    # transfer + LU inversion + coefficient packing it saves, and unlike a dirty flag it also sees in-place edits.
+    # The reference API re-reads self.A / self.mu / ... on every call, so the mirror classes hand the model over on
+    # every call too.  Fingerprinting the parameters (lnasr_hash128: ~0.2 ms for the 25 MB of a 128-state
+    # full-covariance model) and skipping the upload when the device already holds exactly these bytes is far cheaper
+    # than the transfer + LU inversion + coefficient packing it saves, and unlike a dirty flag it also sees in-place
+    # edits.  The arrays are fingerprinted AS GIVEN (dtype and strides included), so a float32 or non-contiguous
+    # parameter is converted only when it actually has to be uploaded.
     @staticmethod
     def _fingerprint(tag, arrays, *extra):
-        if _xxhash is None:
-            return None
-        h = _xxhash.xxh3_128()
-        h.update(repr((tag,) + tuple((a.shape, a.dtype.str) for a in arrays) + extra).encode())
-        for a in arrays:
-            if a.size:
-                h.update(memoryview(a.reshape(-1)).cast("B"))
-        return h.digest()
+        out = (C.c_uint64 * 2)()
+        fp = [repr((tag,) + tuple((a.shape, a.dtype.str) for a in arrays) + extra)]
+        for k, a in enumerate(arrays):
+            if not a.size:
+                continue
+            if not a.flags.c_contiguous:
+                a = np.ascontiguousarray(a)
+            check(lib().lnasr_hash128(a.ctypes.data, a.nbytes, k, out))
+            fp.append((out[0], out[1]))
+        return tuple(fp)
 
     def upload_hmm(self, A, pi):
-        A = _in(A, np.float64)
-        pi = _in(pi, np.float64)
+        A, pi = np.asarray(A), np.asarray(pi)
         N = A.shape[0]
         if A.shape != (N, N) or pi.shape != (N,):
             raise ValueError("A must be [N,N] and pi [N]; got %s, %s" % (A.shape, pi.shape))
         fp = self._fingerprint("hmm", (A, pi))
-        if fp is not None and fp == self._model_fp:
+        if fp == self._model_fp:
             return
         self._model_fp = None
+        A = _in(A, np.float64)
+        pi = _in(pi, np.float64)
         check(lib().lnasr_hmm_upload(self.handle, N, _ptr(A), _ptr(pi)))
         self.model_shape = (N,)
         self._model_fp = fp
 
     def upload_gmmhmm(self, A, pi, w, mu, sigma, diag=False, force_full=False):
         """sigma: [N,M,D,D] (diag=False) or [N,M,D] (diag=True)."""
-        A, pi, w, mu, sigma = (_in(x, np.float64) for x in (A, pi, w, mu, sigma))
+        A, pi, w, mu, sigma = (np.asarray(x) for x in (A, pi, w, mu, sigma))
         N, M, D = mu.shape
         if A.shape != (N, N) or pi.shape != (N,) or w.shape != (N, M):
             raise ValueError("inconsistent GMM-HMM shapes")
         if sigma.shape != ((N, M, D) if diag else (N, M, D, D)):
             raise ValueError("sigma shape %s does not match (N,M,D)=%s" % (sigma.shape, (N, M, D)))
+        if force_full and diag:
+            raise ValueError("force_full needs a full covariance")
         fp = self._fingerprint("gmm", (A, pi, w, mu, sigma), bool(diag), bool(force_full))
-        if fp is not None and fp == self._model_fp:
+        if fp == self._model_fp:
             return
         self._model_fp = None
+        A, pi, w, mu, sigma = (_in(x, np.float64) for x in (A, pi, w, mu, sigma))
         if force_full:
-            if diag:
-                raise ValueError("force_full needs a full covariance")
             check(lib().lnasr_model_upload_full(self.handle, N, M, D, _ptr(A), _ptr(pi), _ptr(w), _ptr(mu), _ptr(sigma)))
         else:
             check(lib().lnasr_model_upload(self.handle, N, M, D, _ptr(A), _ptr(pi), _ptr(w), _ptr(mu), _ptr(sigma),
@@ -399,7 +401,8 @@ class Context:
         return lens
 
     # -- emission ----------------------------------------------------------------------------
-    def discrete_map_b(self, logB, obs, precision=np.float64):
+    def discrete_map_b(self, logB, obs, precision=np.float64, device_out=False):
+        """device_out: leave b in HBM (a DeviceArray) although obs is a host array."""
         logB = _in(logB, np.float64)
         obs = _in(obs, np.int32)
         if obs.ndim == 1:
@@ -407,18 +410,19 @@ class Context:
         U, T = obs.shape
         N, K = logB.shape
         code = dtype_code(precision)
-        b = self._out(isinstance(obs, DeviceArray), (U, T, N), np_dtype(code))
+        b = self._out(device_out or isinstance(obs, DeviceArray), (U, T, N), np_dtype(code))
         check(lib().lnasr_discrete_map_b(self.handle, _ptr(logB), N, K, _ptr(obs), U, T, code, _ptr(b)))
         return b
 
-    def gmm_logprob(self, obs, want_bm=False, precision=np.float64, lens=None):
+    def gmm_logprob(self, obs, want_bm=False, precision=np.float64, lens=None, device_out=False):
+        """device_out: leave b / bm in HBM (DeviceArrays) although obs is a host array."""
         obs = _in(obs, np.float64)
         U, T, D = obs.shape
         N, M, D0 = self.model_shape
         if D != D0:
             raise ValueError("obs has D=%d, model has D=%d" % (D, D0))
         code = dtype_code(precision)
-        dev = isinstance(obs, DeviceArray)
+        dev = device_out or isinstance(obs, DeviceArray)
         b = self._out(dev, (U, T, N), np_dtype(code))
         bm = self._out(dev, (U, T, N, M), np_dtype(code)) if want_bm else None
         check(lib().lnasr_gmm_logprob(self.handle, _ptr(obs), U, T, _ptr(self._lens(lens, U)), code, _ptr(b), _ptr(bm)))
@@ -452,12 +456,13 @@ class Context:
         return out
 
     # -- trellises -----------------------------------------------------------------------------
-    def viterbi(self, b, want_v=True, want_bt=True, want_score=False, lens=None):
-        """b [U,T,N] -> dict(path [U,T] u32, v, bt, score)."""
+    def viterbi(self, b, want_v=True, want_bt=True, want_score=False, lens=None, host_out=False):
+        """b [U,T,N] -> dict(path [U,T] u32, v, bt, score).  Outputs live where b lives; host_out: numpy arrays
+        even for a device-resident b (the reference's methods keep b in HBM and return numpy)."""
         code = dtype_code(b.dtype)
         b = _in(b, np_dtype(code))
         U, T, N = b.shape
-        dev = isinstance(b, DeviceArray)
+        dev = isinstance(b, DeviceArray) and not host_out
         v = self._out(dev, (U, T, N), np_dtype(code)) if want_v else None
         bt = self._out(dev, (U, T, N), np.uint32) if want_bt else None
         path = self._out(dev, (U, T), np.uint32)
@@ -477,21 +482,21 @@ class Context:
         check(lib().lnasr_decode(self.handle, _ptr(obs), U, T, _ptr(self._lens(lens, U)), _ptr(path), _ptr(score)))
         return (path, score) if (want_score or score_out is not None) else path
 
-    def forward(self, b, want_alpha=True, want_loglik=True, lens=None):
+    def forward(self, b, want_alpha=True, want_loglik=True, lens=None, host_out=False):
         code = dtype_code(b.dtype)
         b = _in(b, np_dtype(code))
         U, T, N = b.shape
-        dev = isinstance(b, DeviceArray)
+        dev = isinstance(b, DeviceArray) and not host_out
         alpha = self._out(dev, (U, T, N), np_dtype(code)) if want_alpha else None
         ll = self._out(dev, (U,), np.float64) if want_loglik else None
         check(lib().lnasr_forward(self.handle, _ptr(b), U, T, _ptr(self._lens(lens, U)), code, _ptr(alpha), _ptr(ll)))
         return alpha, ll
 
-    def backward(self, b, lens=None):
+    def backward(self, b, lens=None, host_out=False):
         code = dtype_code(b.dtype)
         b = _in(b, np_dtype(code))
         U, T, N = b.shape
-        beta = self._out(isinstance(b, DeviceArray), (U, T, N), np_dtype(code))
+        beta = self._out(isinstance(b, DeviceArray) and not host_out, (U, T, N), np_dtype(code))
         check(lib().lnasr_backward(self.handle, _ptr(b), U, T, _ptr(self._lens(lens, U)), code, _ptr(beta)))
         return beta
 
@@ -505,12 +510,12 @@ class Context:
                                       _ptr(ll)))
         return ll
 
-    def baumwelch(self, b, alpha, beta, want_xi=True, lens=None):
+    def baumwelch(self, b, alpha, beta, want_xi=True, lens=None, host_out=False):
         code = dtype_code(b.dtype)
         dt = np_dtype(code)
         b, alpha, beta = _in(b, dt), _in(alpha, dt), _in(beta, dt)
         U, T, N = b.shape
-        dev = isinstance(b, DeviceArray)
+        dev = isinstance(b, DeviceArray) and not host_out
         xi = self._out(dev, (U, T, N, N), dt) if want_xi else None
         gamma = self._out(dev, (U, T, N), dt)
         check(lib().lnasr_baumwelch(self.handle, _ptr(b), _ptr(alpha), _ptr(beta), U, T, _ptr(self._lens(lens, U)),

@@ -3,7 +3,8 @@
 n states, m Gaussians per state, d-dimensional observations; `A, pi, w` are natural-log
 probabilities, `mu [N,M,D]`, `si [N,M,D,D]` linear.  Emission scoring, the trellises and the
 Baum-Welch M-step all run in HIP kernels; `_map_b` leaves `self.b [N,T]` and
-`self.bm [N,M,T]` behind exactly like the reference so that `remap=False` calls work.
+`self.bm [N,M,T]` behind exactly like the reference so that `remap=False` calls work -- in HBM, where the trellis
+methods and `_estimate` read them; they become numpy arrays when somebody reads the attributes (see lnasr/hmm.py).
 
 Covariances that are exactly diagonal take the fp64-MFMA kernel automatically; anything else
 goes through the general (LU-inverse) kernel.  `si` may also be handed over already as the
@@ -32,16 +33,16 @@ class GMMHMM(HMM):
     # ------------------------------------------------------------------ plumbing
     def _upload_gmm(self, force_full=False):
         """All parameters -> device (per call on the reference API; unchanged parameters are recognised by their
-        hash and not sent again, see _ffi.Context.upload_gmmhmm)."""
-        si = np.asarray(self.si, dtype=np.float64)
-        mu = np.asarray(self.mu, dtype=np.float64)
+        fingerprint and neither converted nor sent again, see _ffi.Context.upload_gmmhmm)."""
+        if not force_full and self._params_current():
+            return
+        si = np.asarray(self.si)
         if force_full and si.ndim == 3:
             full = np.zeros(si.shape + (si.shape[-1],))
             idx = np.arange(si.shape[-1])
             full[..., idx, idx] = si
             si = full
-        self.ctx.upload_gmmhmm(np.asarray(self.A, dtype=np.float64), np.asarray(self.pi, dtype=np.float64),
-                               np.asarray(self.w, dtype=np.float64), mu, si, diag=(si.ndim == 3 and not force_full),
+        self.ctx.upload_gmmhmm(self.A, self.pi, self.w, self.mu, si, diag=(si.ndim == 3 and not force_full),
                                force_full=force_full)
 
     def upload(self):
@@ -57,12 +58,18 @@ class GMMHMM(HMM):
     # ------------------------------------------------------------------ emission
     def _map_b(self, obs: np.ndarray):
         """bm[j,m,:] = log N(obs; mu[j,m], si[j,m]);  b[j,:] = lse_m(w[j,m] + bm[j,m,:])  (gmmhmm.py:46-67)."""
-        obs = np.asarray(obs, dtype=np.float64)
+        if isinstance(obs, _ffi.DeviceArray):                  # features already in HBM (Recognizer: MFCC -> decode)
+            batch = obs.view((1,) + obs.shape)
+        else:
+            batch = np.asarray(obs, dtype=np.float64)[None]
         self._upload_gmm()
-        b, bm = self.ctx.gmm_logprob(obs[None], want_bm=True, precision=self.precision)
-        self.b = b[0].T                              # [N,T]
-        self.bm = bm[0].transpose(1, 2, 0)           # [N,M,T]
-        self._model_fresh = True                     # see HMM._remap_or_upload
+        b, bm = self.ctx.gmm_logprob(batch, want_bm=True, precision=self.precision, device_out=True)
+        self._keep("b", b, lambda h: h[0].T)                            # [1,T,N] -> [N,T]
+        self._keep("bm", bm, lambda h: h[0].transpose(1, 2, 0))         # [1,T,N,M] -> [N,M,T]
+        self._model_fresh = True                                        # see HMM._remap_or_upload
+
+    bm = property(lambda self: self._host_get("bm"), lambda self, value: self._host_set("bm", value),
+                  doc="per-mixture log-densities [N,M,T] of the last _map_b (gmmhmm.py:58-65)")
 
     # ------------------------------------------------------------------ M-step
     def _estimate(self, obs: np.ndarray, alpha, beta, xi, gamma):
@@ -71,26 +78,22 @@ class GMMHMM(HMM):
         obs = np.asarray(obs, dtype=np.float64)
         dt = np.float32 if np.asarray(gamma).dtype == np.float32 else np.float64
         self._upload_gmm()
-        bm = np.ascontiguousarray(np.asarray(self.bm).transpose(2, 0, 1), dtype=dt)     # [T,N,M]
+        res = self.__dict__.get("_resident", {})
+        if "bm" in res and res["bm"][0].dtype == np.dtype(dt):
+            bm = res["bm"][0]                                                           # [1,T,N,M] in HBM
+        else:
+            bm = np.ascontiguousarray(np.asarray(self.bm).transpose(2, 0, 1), dtype=dt)     # [T,N,M]
         est = self.ctx.estimate_gmm(obs, bm, np.asarray(alpha, dtype=dt), np.asarray(beta, dtype=dt),
                                     np.asarray(xi, dtype=dt), np.asarray(gamma, dtype=dt), self.min_std)
         return est
 
     # ------------------------------------------------------------------ training
-    _REF_STEPS = ("_map_b", "_forward", "_backward", "_baumwelch", "_estimate", "_updatemodel", "calc_prob")
-
     def _fused_train_ok(self):
         """The on-device E+M step computes exactly what `_map_b` .. `_estimate` compute (with one
         utterance the accumulated statistics reduce to the reference's M-step), without moving xi [T,N,N] and
         bm [N,M,T] through host memory.  It is only taken when none of those steps is overridden and the model is
         float64; anything else walks the reference's sequence of calls (HMM.train)."""
-        if self.precision not in (np.double, np.float64):
-            return False
-        for name in self._REF_STEPS:
-            base = GMMHMM if name in GMMHMM.__dict__ else HMM
-            if getattr(type(self), name) is not getattr(base, name):
-                return False
-        return True
+        return self.precision in (np.double, np.float64) and self._ours(*self._REF_STEPS)
 
     def train(self, obs, iters=1, eps=0.0001, verbose: bool = True):
         """Baum-Welch on one sequence, stopping when |delta loglik| < eps  (hmm.py:285-313 with the
@@ -140,12 +143,6 @@ class GMMHMM(HMM):
         d = _load(filename, ("A", "pi", "w", "mu", "si"))
         self.A, self.pi, self.w, self.mu, self.si = d["A"], d["pi"], d["w"], d["mu"], d["si"]
         self.n, self.m, self.d = self.mu.shape
-
-    # ------------------------------------------------------------------ public API
-    def calc_prob(self, obs: np.ndarray) -> float:
-        self._map_b(obs)
-        _, ll = self.ctx.forward(self._b_dev(), want_alpha=False, want_loglik=True)
-        return np.asarray(ll, dtype=self.precision)[0]
 
     # ------------------------------------------------------------------ batch extras
     def decode_batch(self, obs_batch, lens=None, want_score=False):

@@ -6,9 +6,16 @@ csrc/estimate.hip); this class only keeps the reference's state (`self.b`), shap
 print format.  Arrays returned are fresh numpy arrays in the reference's layouts:
 `b [N,T]`, `alpha/beta/v [T,N]`, `bt [T,N] uint32`, `path [T] uint32`, `xi [T,N,N]`.
 
+State: `_map_b` leaves `self.b` behind and the `remap=False` calls read it (hmm.py:82-83,95).  Here the
+emission matrix stays in HBM after `_map_b` and the trellis methods read it there; `self.b` is a property that copies
+it to a numpy array `[N,T]` on first read.  From that moment -- or when the caller assigns an array of its own
+(`h.b = ...`) -- the host array is the authoritative one (the caller may edit it in place) and the next trellis call
+sends it to the device again.
+
 Extras (keyword-only / new methods, not in the reference): `ctx=` selects the GPU context,
 `decode_batch` / `calc_prob_batch` take `[U, T]` symbol batches.
 """
+import contextlib
 from typing import Tuple
 
 import numpy as np
@@ -37,13 +44,31 @@ class HMM:
         return self._ctx
 
     def _upload(self):
-        """Transition model -> device.  Done per call: N*N doubles, and the reference lets
-        callers mutate A / pi in place between calls."""
-        self.ctx.upload_hmm(np.asarray(self.A, dtype=np.float64), np.asarray(self.pi, dtype=np.float64))
+        """Transition model -> device.  Checked per call (the reference lets callers mutate A / pi in place between
+        calls); the device keeps what it has when the fingerprint is unchanged."""
+        if not self._params_current():
+            self.ctx.upload_hmm(self.A, self.pi)
+
+    @contextlib.contextmanager
+    def _one_check(self, enabled):
+        """Inside one outer call (a `train` iteration) whose steps are all this package's own, nothing touches the
+        parameters between the first step and `_updatemodel`: they are fingerprinted once, by the first step that
+        needs them, instead of once per inner step."""
+        self._check_state = "armed" if enabled else None
+        try:
+            yield
+        finally:
+            self._check_state = None
+
+    def _params_current(self):
+        st = self.__dict__.get("_check_state")
+        if st == "armed":
+            self._check_state = "done"
+        return st == "done"
 
     def _remap_or_upload(self, obs, remap):
         """Start of every trellis call: optionally recompute self.b, and make sure the device holds the current
-        parameters.  When `_map_b` has just uploaded (and hash-checked) the whole model inside this very call
+        parameters.  When `_map_b` has just uploaded (and fingerprinted) the whole model inside this very call
         (GMMHMM does), no user code ran in between and the second check is skipped."""
         if remap:
             self._model_fresh = False
@@ -53,35 +78,72 @@ class HMM:
                 return
         self._upload()
 
+    # `b` (and GMMHMM's `bm`): device-resident after _map_b, a numpy array once somebody looks at it or assigns one
+    def _keep(self, name, dev, to_reference_layout):
+        self.__dict__.setdefault("_resident", {})[name] = (dev, to_reference_layout)
+        self.__dict__.setdefault("_host", {}).pop(name, None)
+
+    def _host_get(self, name):
+        res = self.__dict__.get("_resident", {})
+        host = self.__dict__.setdefault("_host", {})
+        if name in res:
+            dev, layout = res.pop(name)          # handed out = the caller may write into it: the host copy rules
+            host[name] = layout(dev.to_host())
+        try:
+            return host[name]
+        except KeyError:
+            raise AttributeError("'%s' object has no attribute '%s' (call _map_b first)" % (type(self).__name__, name))
+
+    def _host_set(self, name, value):
+        self.__dict__.setdefault("_resident", {}).pop(name, None)
+        self.__dict__.setdefault("_host", {})[name] = value
+
+    b = property(lambda self: self._host_get("b"), lambda self, value: self._host_set("b", value),
+                 doc="emission log-probabilities [N,T] of the last _map_b (hmm.py:58-61)")
+
     def _b_dev(self):
-        """self.b [N,T] -> frame-major [1,T,N] of the storage dtype."""
+        """The emissions as the kernels take them, frame-major [1,T,N]: the array _map_b left in HBM, or the host
+        array (the caller's, or one already read through `self.b`) in the storage dtype."""
+        res = self.__dict__.get("_resident", {})
+        if "b" in res:
+            return res["b"][0]
         b = np.asarray(self.b)
         dt = np.float32 if b.dtype == np.float32 else np.float64
         return np.ascontiguousarray(b.T, dtype=dt)[None]
+
+    def _ours(self, *names):
+        """True when none of the named methods is replaced by a subclass: the fused routes (decode, calc_prob, the
+        on-device training step) compute exactly what the reference's sequence of calls does, and are taken only then."""
+        for name in names:
+            owner = next(c for c in type(self).__mro__ if name in c.__dict__)
+            if owner.__module__.split(".")[0] != __name__.split(".")[0]:
+                return False
+        return True
 
     # ------------------------------------------------------------------ emission
     def _map_b(self, obs: np.ndarray):
         """b[:, t] = B[:, obs[t]]  (hmm.py:47-61)."""
         obs = np.asarray(obs)
-        b = self.ctx.discrete_map_b(np.asarray(self.B, dtype=np.float64), obs.astype(np.int32), self.precision)
-        self.b = b[0].T
+        b = self.ctx.discrete_map_b(np.asarray(self.B, dtype=np.float64), obs.astype(np.int32), self.precision,
+                                    device_out=True)
+        self._keep("b", b, lambda h: h[0].T)
 
     # ------------------------------------------------------------------ trellises
     def _forward(self, obs: np.ndarray, remap: bool = False) -> np.ndarray:
         """alpha [T,N]: alpha[t,j] = lse_i(alpha[t-1,i] + A[i,j]) + b[j,t]  (hmm.py:63-100)."""
         self._remap_or_upload(obs, remap)
-        alpha, _ = self.ctx.forward(self._b_dev(), want_alpha=True, want_loglik=False)
+        alpha, _ = self.ctx.forward(self._b_dev(), want_alpha=True, want_loglik=False, host_out=True)
         return alpha[0]
 
     def _backward(self, obs: np.ndarray, remap: bool = False) -> np.ndarray:
         """beta [T,N]: beta[t,i] = lse_j(beta[t+1,j] + A[i,j] + b[j,t+1])  (hmm.py:102-131)."""
         self._remap_or_upload(obs, remap)
-        return self.ctx.backward(self._b_dev())[0]
+        return self.ctx.backward(self._b_dev(), host_out=True)[0]
 
     def _viterbi(self, obs: np.ndarray, remap: bool = False) -> Tuple[np.ndarray]:
         """(v [T,N], bt [T,N] uint32, path [T] uint32); ties -> first index  (hmm.py:133-172)."""
         self._remap_or_upload(obs, remap)
-        r = self.ctx.viterbi(self._b_dev(), want_v=True, want_bt=True)
+        r = self.ctx.viterbi(self._b_dev(), want_v=True, want_bt=True, host_out=True)
         return (r["v"][0], r["bt"][0], r["path"][0])
 
     def _baumwelch(self, obs: np.ndarray, alpha: np.ndarray, beta: np.ndarray, remap: bool = False) -> Tuple[np.ndarray]:
@@ -89,7 +151,8 @@ class HMM:
         self._remap_or_upload(obs, remap)
         b = self._b_dev()
         dt = b.dtype
-        xi, gamma = self.ctx.baumwelch(b, np.asarray(alpha, dtype=dt)[None], np.asarray(beta, dtype=dt)[None])
+        xi, gamma = self.ctx.baumwelch(b, np.asarray(alpha, dtype=dt)[None], np.asarray(beta, dtype=dt)[None],
+                                       host_out=True)
         return xi[0], gamma[0]
 
     def _estimate(self, obs: np.ndarray, alpha, beta, xi, gamma) -> dict:
@@ -127,24 +190,35 @@ class HMM:
 
     # ------------------------------------------------------------------ public API
     def calc_prob(self, obs: np.ndarray) -> float:
-        """log P(O | model) = lse(alpha[T-1])  (hmm.py:268-274)."""
+        """log P(O | model) = lse(alpha[T-1])  (hmm.py:268-274).  alpha itself is not brought back unless a subclass
+        replaced `_forward`."""
+        if not self._ours("_forward"):
+            return lse(self._forward(obs, True)[-1])
         self._remap_or_upload(obs, True)
-        _, ll = self.ctx.forward(self._b_dev(), want_alpha=False, want_loglik=True)
+        _, ll = self.ctx.forward(self._b_dev(), want_alpha=False, want_loglik=True, host_out=True)
         return np.asarray(ll, dtype=self.precision)[0]
 
     def decode(self, obs: np.ndarray) -> np.ndarray:
-        """Most likely state sequence  (hmm.py:276-283)."""
-        _, _, path = self._viterbi(obs, True)
-        return path
+        """Most likely state sequence  (hmm.py:276-283): emission, trellis and back-trace on the device, only the path
+        [T] comes back (v and bt, which the reference computes and drops here, are not copied; `self.b` -- and
+        GMMHMM's `self.bm` -- stay readable as after the reference's call)."""
+        if not self._ours("_viterbi"):
+            return self._viterbi(obs, True)[2]
+        self._remap_or_upload(obs, True)
+        return self.ctx.viterbi(self._b_dev(), want_v=False, want_bt=False, host_out=True)["path"][0]
+
+    _REF_STEPS = ("_map_b", "_forward", "_backward", "_baumwelch", "_estimate", "_updatemodel", "calc_prob")
 
     def train(self, obs, iters=1, eps=0.0001, verbose: bool = True):
         """Baum-Welch on one sequence, stopping when |delta loglik| < eps  (hmm.py:285-313).  The E and M steps go
         through the overridable methods in the reference's order, so subclasses that replace one of them keep working."""
+        ours = self._ours(*self._REF_STEPS)
         for k in range(iters):
-            self._map_b(obs)
-            alpha, beta = self._forward(obs), self._backward(obs)
-            posteriors = self._baumwelch(obs, alpha, beta)
-            new_model = self._estimate(obs, alpha, beta, *posteriors)
+            with self._one_check(ours):
+                self._map_b(obs)
+                alpha, beta = self._forward(obs), self._backward(obs)
+                posteriors = self._baumwelch(obs, alpha, beta)
+                new_model = self._estimate(obs, alpha, beta, *posteriors)
             before = lse(alpha[-1])
             self._updatemodel(new_model)
             after = self.calc_prob(obs)

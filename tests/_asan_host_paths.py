@@ -33,6 +33,22 @@ assert lib.lnasr_reload_switches() == 0
 os.environ.pop("LNASR_H2D_THREADS")
 assert lib.lnasr_reload_switches() == 0
 
+# parameter fingerprint (host only): every tail length, the threaded path (>= 2 MB), sensitivity to one bit, null checks
+import numpy as np  # noqa: E402
+rng = np.random.default_rng(0)
+o1, o2 = (C.c_uint64 * 2)(), (C.c_uint64 * 2)()
+for nbytes in (0, 1, 7, 8, 9, 31, 32, 33, 63, 64, 1000, (1 << 21) - 1, (1 << 21) + 5, 25 * (1 << 20) + 3):
+    x = rng.integers(0, 256, nbytes, dtype=np.uint8)
+    assert lib.lnasr_hash128(x.ctypes.data if nbytes else None, nbytes, 7, o1) == 0
+    assert lib.lnasr_hash128(x.ctypes.data if nbytes else None, nbytes, 7, o2) == 0 and tuple(o1) == tuple(o2)
+    assert lib.lnasr_hash128(x.ctypes.data if nbytes else None, nbytes, 8, o2) == 0 and tuple(o1) != tuple(o2)   # seed
+    for at in ({0, nbytes // 2, nbytes - 1} if nbytes else ()):
+        y = x.copy()
+        y[at] ^= 1
+        assert lib.lnasr_hash128(y.ctypes.data, nbytes, 7, o2) == 0 and tuple(o1) != tuple(o2), (nbytes, at)
+    checked += 1
+assert lib.lnasr_hash128(None, 16, 0, o1) < 0 and lib.lnasr_hash128(buf if False else None, 0, 0, None) < 0
+
 # device count / context creation without a device: an error code and a message, never a crash
 n = C.c_int(-1)
 assert lib.lnasr_device_count(C.byref(n)) == 0
@@ -86,7 +102,7 @@ calls = {
     "lnasr_allgather_paths": (null, u32, 4, 8, u32), "lnasr_allreduce_f64": (null, buf, 4),
 }
 no_ctx = {"lnasr_abi_version", "lnasr_last_error", "lnasr_device_count", "lnasr_ctx_create", "lnasr_ctx_destroy",
-          "lnasr_num_frames", "lnasr_reload_switches", "lnasr_comm_unique_id", "lnasr_comm_destroy"}
+          "lnasr_num_frames", "lnasr_reload_switches", "lnasr_comm_unique_id", "lnasr_comm_destroy", "lnasr_hash128"}
 missing = sorted(set(_ffi.SIGNATURES) - set(calls) - no_ctx)
 assert not missing, "entry points without a null-context call here: %s" % missing
 for fn, args in sorted(calls.items()):

@@ -128,6 +128,56 @@ def test_recognizer_wiring(tmp_path, synth):
     assert states.dtype == np.uint32 and states.shape == (49,) and states.max() < 4
 
 
+def _model_on_features(feats, N, M, seed):
+    """A GMM-HMM whose components sit on frames of the clip itself (means = features of chosen frames, one shared
+    per-dimension variance): states compete for real, unlike a model far away from the data."""
+    rng = np.random.default_rng(seed)
+    D = feats.shape[1]
+    pick = rng.choice(len(feats), size=N * M, replace=len(feats) < N * M)
+    mu = feats[pick].reshape(N, M, D) + 0.05 * rng.standard_normal((N, M, D))
+    var = np.broadcast_to(0.25 * feats.var(axis=0) + 1e-3, (N, M, D)).copy()
+
+    def logn(x):
+        return np.log(x / x.sum(axis=-1, keepdims=True))
+    return dict(A=logn(rng.random((N, N)) + 0.05), pi=logn(rng.random(N) + 0.05), w=logn(rng.random((N, M)) + 0.05), mu=mu, var=var)
+
+
+@pytest.mark.parametrize("clip", ["data.raw", "synthetic"])
+def test_recognize_equals_oracle_chain(tmp_path, synth, oracle, clip):
+    """Recognizer.recognize(pcm) == oracle.decode_diag(oracle.mfcc(pcm)[2], model), state for state --
+    on the reference's own speech clip (test/data.raw, read as utils.read_pcm does) and on a synthetic one; int16 PCM
+    and the same samples as float64."""
+    from lnasr.gmmhmm import GMMHMM
+    from lnasr.recognizer import Recognizer
+    from conftest import GOLDEN
+    import os
+    if clip == "data.raw":
+        pcm = np.fromfile(os.path.join(GOLDEN, "data.raw"), dtype="<i2")
+    else:
+        pcm = np.clip(synth.synth_signal(16000, seed=21) * 5, -32768, 32767).astype(np.int16)
+    with np.errstate(divide="ignore"):
+        feats = oracle.mfcc(pcm.astype(np.float64))[2]
+    N, M, D = 8, 3, 39
+    m = _model_on_features(feats, N, M, seed=5)
+    si = np.zeros((N, M, D, D))
+    si[:, :, np.arange(D), np.arange(D)] = m["var"]
+    want = oracle.decode_diag(feats, m["A"], m["pi"], m["w"], m["mu"], m["var"])
+    assert len(set(want.tolist())) >= 4                       # the path really moves between states
+    path = str(tmp_path / "am.npz")
+    GMMHMM(N, M, D, m["A"], m["pi"], m["w"], m["mu"], si).save(path)
+    rec = Recognizer({"am": path, "lm": None})
+    for samples in (pcm, pcm.astype(np.float64)):
+        got = rec.recognize(samples)
+        assert got.dtype == np.uint32 and got.shape == want.shape
+        assert np.array_equal(got, want), "%s: %d of %d states differ" % (clip, int((got != want).sum()), len(want))
+    # the two halves on their own, and the state the reference's decode() leaves behind
+    _, _, f = rec.am.mfcc.calc_mfcc(pcm)
+    assert_close(f, feats, 1e-9, 1e-9)
+    assert np.array_equal(rec.am.gmmhmm.decode(f), want)
+    ob, obm = oracle.gmm_map_b_diag(feats, m["w"], m["mu"], m["var"])
+    assert_close(rec.am.gmmhmm.b, ob, 1e-9, 1e-7), assert_close(rec.am.gmmhmm.bm, obm, 1e-9, 1e-7)
+
+
 def test_mfcc_ragged_edges(oracle):
     """Utterance lengths around every boundary of the four-frames-per-wave kernel: frames that start beyond the
     samples (n < L - S), a last frame cut anywhere, frame counts that are not multiples of four, odd sample offsets

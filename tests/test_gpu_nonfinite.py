@@ -8,7 +8,7 @@ NaN and path for path."""
 import numpy as np
 import pytest
 
-from conftest import tuned
+from conftest import env_switch, tuned
 
 pytestmark = pytest.mark.gpu
 
@@ -155,8 +155,10 @@ def test_clean_data_launches_only_the_checks(synth, ctx):
     rep = ctx.prof_report()
     ctx.prof_enable(False)
     if tuned():                                            # under fallback switches other kernels run, and some of them scan
+        # launch counts are the claim (the check read one word and returned: no scan, no locate pass); what the launch
+        # costs is a measurement, reported by tools/bench_rows.py `nanfix`, never asserted in the parity suite
         assert "viterbi_nan_repair" in rep and "nan_rows" not in rep and "nan_locate" not in rep, rep
-        assert rep["viterbi_nan_repair"][1] < 0.05, rep      # ms, event bracket included: it read one word and returned
+        assert rep["viterbi_nan_repair"][0] == 1, rep
     assert not np.isnan(ctx.calc_prob(obs).to_host()).any()
     assert p1.max() < 128
 
@@ -179,7 +181,7 @@ def test_caller_emissions_clean_or_minus_inf(synth, oracle, ctx):
     rep = ctx.prof_report()
     ctx.prof_enable(False)
     if tuned():                                            # the back-trace kernel looked: no scan, one launch that returns
-        assert "nan_locate" not in rep and rep["viterbi_nan_repair"][1] < 0.05, rep
+        assert "nan_locate" not in rep and rep["viterbi_nan_repair"][0] == 1, rep
     assert np.array_equal(r["path"].to_host()[0], oracle.viterbi(d["A"], d["pi"], b[0].T)[2])
     # left-to-right model and some impossible emissions: -inf cells everywhere, no NaN
     A = d["A"].copy()
@@ -362,3 +364,31 @@ def test_lse_propagates_nan(oracle):
             assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.array_equal(np.isneginf(got), np.isneginf(ref)), axis
             ok = np.isfinite(ref)
             assert np.allclose(got[ok], ref[ok], rtol=1e-13, atol=1e-13), axis
+
+
+def test_all_nan_row_with_the_plain_backtrace(synth, oracle, ctx):
+    """Regression for the argmax of an all-NaN row of v (fix 32a9ea1): under LNASR_NO_LDSBT the plain back-trace kernel
+    runs, whose wave arg-max started from index 0x7fffffff and never claimed one when every cell compared false -- it
+    then read A^T at that index.  An emission row of NaN makes v[t] all NaN from that frame on; path, v and bt must be
+    the oracle's (np.argmax of an all-NaN row is 0), for one utterance and inside a batch."""
+    N, U, T = 128, 5, 40
+    d = synth.synth_discrete(N, 4, 8, seed=11)
+    rng = np.random.default_rng(12)
+    b = -20.0 * rng.random((U, T, N))
+    b[0, 17, :] = np.nan                      # a whole row
+    b[2, 0, :] = np.nan                       # from the first frame
+    b[3, T - 1, 5] = np.nan                   # one cell of the last frame
+    ctx.upload_hmm(d["A"], d["pi"])
+    with np.errstate(invalid="ignore"):
+        want = [oracle.viterbi(d["A"], d["pi"], b[u].T) for u in range(U)]
+    for switches in (dict(LNASR_NO_LDSBT=1), dict(LNASR_NO_LDSBT=1, LNASR_NO_REGVIT=1), {}):
+        with env_switch(**switches):
+            for src in (b, ctx.to_device(b), b[:1]):
+                r = ctx.viterbi(src, want_v=True, want_bt=True, want_score=True)
+                r = {k: _host(x) for k, x in r.items()}
+                for u in range(len(r["path"])):
+                    ov, obt, opath = want[u]
+                    assert np.array_equal(r["path"][u], opath), (switches, u)
+                    assert np.array_equal(r["v"][u], ov, equal_nan=True), (switches, u)
+                    assert np.array_equal(r["bt"][u], obt), (switches, u)
+                    assert np.isnan(r["score"][u]) == bool(np.isnan(ov[-1]).any()), (switches, u)

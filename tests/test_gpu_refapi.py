@@ -1,0 +1,163 @@
+"""The reference's own method names as the drop-in surface (SURVEY 8b "State"; hmm.py:276-283, gmmhmm.py:46-67):
+`decode` / `calc_prob` / `_viterbi` / `_forward` keep the emissions in HBM between `_map_b` and the trellis, and
+`self.b` / `self.bm` still read as the reference leaves them -- the arrays of the golden vectors -- whenever somebody
+looks, assigns, or edits them in place."""
+import numpy as np
+import pytest
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from lnasr import _ffi
+    return _ffi.default_ctx()
+
+
+def _diag_model(g):
+    N, M, D = g["mu"].shape
+    si = np.zeros((N, M, D, D))
+    si[:, :, np.arange(D), np.arange(D)] = g["var"]
+    return N, M, D, si
+
+
+def test_b_and_bm_read_as_golden_after_decode(golden):
+    """decode() moves only the path; reading gh.b / gh.bm AFTERWARDS still yields the reference's arrays."""
+    from lnasr.gmmhmm import GMMHMM
+    for name in ("gmmhmm_d39_diag", "gmmhmm_d39_full", "gmmhmm_small"):
+        g = golden(name)
+        if "si" in g.files:
+            (N, M, D), si = g["mu"].shape, g["si"]
+        else:
+            N, M, D, si = _diag_model(g)
+        gh = GMMHMM(N, M, D, g["A"], g["pi"], g["w"], g["mu"], si)
+        assert np.array_equal(gh.decode(g["obs"]), g["path"]), name
+        assert set(gh._resident) == {"b", "bm"} and not gh._host          # nothing came back but the path
+        assert_close(gh.b, g["b"], 1e-12, 1e-12, msg=name + " b")
+        assert_close(gh.bm, g["bm"], 1e-12, 1e-12, msg=name + " bm")
+        assert gh.b.shape == g["b"].shape and gh.bm.shape == g["bm"].shape
+        assert not gh._resident                                           # read once: the host copies are the state now
+        # ... and the remap=False calls go on from them
+        v, bt, path = gh._viterbi(g["obs"])
+        assert np.array_equal(path, g["path"]) and np.array_equal(bt, g["bt"])
+        assert_close(gh.calc_prob(g["obs"]), g["loglik"][0], 1e-12)
+
+
+def test_remap_false_reads_the_resident_b(golden):
+    """_map_b, then _forward / _backward / _viterbi / _baumwelch / _estimate with remap=False: the emissions never
+    leave HBM, results as the golden ones."""
+    from lnasr.gmmhmm import GMMHMM
+    g = golden("gmmhmm_small")
+    gh = GMMHMM(5, 3, 2, g["A"], g["pi"], g["w"], g["mu"], g["si"])
+    gh._map_b(g["obs"])
+    alpha, beta = gh._forward(g["obs"]), gh._backward(g["obs"])
+    v, bt, path = gh._viterbi(g["obs"])
+    xi, gamma = gh._baumwelch(g["obs"], alpha, beta)
+    est = gh._estimate(g["obs"], alpha, beta, xi, gamma)
+    assert set(gh._resident) == {"b", "bm"} and not gh._host
+    assert_close(alpha, g["alpha"], 1e-12), assert_close(beta, g["beta"], 1e-12)
+    assert np.array_equal(path, g["path"]) and np.array_equal(bt, g["bt"])
+    assert_close(v, g["v"], 1e-12), assert_close(xi, g["xi"], 1e-11, 1e-11), assert_close(gamma, g["gamma"], 1e-11, 1e-11)
+    for k in ("A", "pi", "w", "mu", "si"):
+        assert_close(est[k], g["est_" + k], 1e-9, 1e-9, msg=k)
+
+
+def test_host_copy_is_authoritative_once_read_or_assigned(golden, oracle):
+    from lnasr.gmmhmm import GMMHMM
+    g = golden("gmmhmm_d39_diag")
+    N, M, D, si = _diag_model(g)
+    gh = GMMHMM(N, M, D, g["A"], g["pi"], g["w"], g["mu"], si)
+    gh._map_b(g["obs"])
+    b = gh.b                                           # read: from now on this array is the state
+    assert gh.b is b
+    rng = np.random.default_rng(3)
+    b += rng.normal(size=b.shape)                      # the caller edits it in place ...
+    v, bt, path = gh._viterbi(g["obs"])                # ... and remap=False must see the edit (hmm.py:155-157)
+    rv, rbt, rpath = oracle.viterbi(g["A"], g["pi"], b)
+    assert np.array_equal(v, rv) and np.array_equal(bt, rbt) and np.array_equal(path, rpath)
+    assert_close(gh._forward(g["obs"]), oracle.forward(g["A"], g["pi"], b), 1e-12)
+    gh.b = g["b"]                                      # assignment of a caller's array
+    v, bt, path = gh._viterbi(g["obs"])
+    assert np.array_equal(v, g["v"]) and np.array_equal(bt, g["bt"]) and np.array_equal(path, g["path"])
+    # remap=True replaces both again
+    assert np.array_equal(gh.decode(g["obs"]), g["path"])
+    assert_close(gh.b, g["b"], 1e-12)
+
+
+def test_in_place_parameter_edits_are_noticed_between_calls(golden, oracle):
+    """The reference re-reads self.mu / self.si / self.A on every call: an in-place edit between two decode() calls must
+    reach the device (fingerprint of the parameter bytes, lnasr_hash128), an untouched model must not be uploaded again."""
+    from lnasr.gmmhmm import GMMHMM
+    g = golden("gmmhmm_d39_diag")
+    N, M, D, si = _diag_model(g)
+    gh = GMMHMM(N, M, D, g["A"].copy(), g["pi"].copy(), g["w"].copy(), g["mu"].copy(), si)
+    assert np.array_equal(gh.decode(g["obs"]), g["path"])
+    fp = gh.ctx._model_fp
+    assert np.array_equal(gh.decode(g["obs"]), g["path"]) and gh.ctx._model_fp == fp
+    for what in ("mu", "si", "A", "w", "pi"):
+        arr = getattr(gh, what)
+        if what == "si":
+            arr[1, 0, 2, 2] *= 3.0
+        elif what in ("A", "w", "pi"):
+            arr[...] = np.roll(arr, 1, axis=-1)
+        else:
+            arr[0, 1, :] += 0.75
+        var = gh.si[:, :, np.arange(D), np.arange(D)]
+        got = gh.decode(g["obs"])
+        assert gh.ctx._model_fp != fp, what
+        fp = gh.ctx._model_fp
+        assert np.array_equal(got, oracle.decode_diag(g["obs"], gh.A, gh.pi, gh.w, gh.mu, var)), what
+        rb, _ = oracle.gmm_map_b_diag(g["obs"], gh.w, gh.mu, var)
+        assert_close(gh.calc_prob(g["obs"]), oracle.loglik(oracle.forward(gh.A, gh.pi, rb)), 1e-11, msg=what)
+
+
+def test_overridden_steps_are_walked(golden):
+    """A subclass that replaces a step keeps the reference's call sequence (decode -> _viterbi(obs, True) -> _map_b;
+    calc_prob -> _forward(obs, True)), as scripts/seg/seg.py's Seg(HMM) relies on."""
+    from lnasr.hmm import HMM
+    g = golden("toy_hmm")
+    calls = []
+
+    class Traced(HMM):
+        def _viterbi(self, obs, remap=False):
+            calls.append(("viterbi", remap))
+            return super()._viterbi(obs, remap)
+
+        def _forward(self, obs, remap=False):
+            calls.append(("forward", remap))
+            return super()._forward(obs, remap)
+
+        def _map_b(self, obs):
+            calls.append(("map_b",))
+            super()._map_b(obs)
+
+    h = Traced(2, 3, g["A"], g["B"], g["pi"])
+    assert np.array_equal(h.decode(g["obs"]), g["decode"])
+    assert_close(h.calc_prob(g["obs"]), g["calc_prob"], 1e-14)
+    assert calls == [("viterbi", True), ("map_b",), ("forward", True), ("map_b",)]
+    assert np.array_equal(h.b, g["b"])
+    plain = HMM(2, 3, g["A"], g["B"], g["pi"])
+    assert np.array_equal(plain.decode(g["obs"]), g["decode"]) and np.array_equal(plain.b, g["b"])
+    assert_close(plain.calc_prob(g["obs"]), g["calc_prob"], 1e-14)
+    with pytest.raises(AttributeError):
+        HMM(2, 3, g["A"], g["B"], g["pi"]).b              # as in the reference before any _map_b
+
+
+def test_metric_shape_single_utterance_surface(golden, synth):
+    """N=128, M=16, D=39, T=1000 with `si` as [N,M,D,D] -- the literal drop-in call (hmm.py:276-283): the golden
+    metric slice's paths, likelihood on the first 32 frames, and b read back afterwards."""
+    from lnasr.gmmhmm import GMMHMM
+    g = golden("gmmhmm_metric_slice")
+    mdl = synth.synth_model(128, 16, 39, seed=1)
+    obs = synth.synth_obs(2, 1000, 39, seed=1000)
+    gh = GMMHMM(128, 16, 39, mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["si"])
+    for u in range(2):
+        assert np.array_equal(gh.decode(obs[u]), g["path"][u])
+        b, bm = gh.b, gh.bm                                   # [N,T], [N,M,T] as the reference stores them
+        assert b.shape == (128, 1000) and bm.shape == (128, 16, 1000)
+        assert_close(b[g["sample_j"], g["sample_t"]], g["b_sample"][u], 1e-12)
+        assert_close(bm[g["sample_j"], g["sample_m"], g["sample_t"]], g["bm_sample"][u], 1e-12)
+        assert abs(b.sum() - g["b_sum"][u]) < 1e-6
+    assert_close(gh.calc_prob(obs[0][:32]), g["loglik32"][0], 1e-11)

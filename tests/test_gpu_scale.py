@@ -11,6 +11,12 @@ from conftest import assert_close, env_switch, tuned
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(scope="module")
+def ctx():
+    from lnasr import _ffi
+    return _ffi.default_ctx()
+
+
 def test_metric_config_full_size(synth, oracle):
     """N=128, M=16, D=39, T=1000, U=1024 (one GPU's shard of config 4), inputs resident in HBM."""
     from lnasr import _ffi
@@ -215,3 +221,30 @@ def test_ragged_pcm_to_paths_on_device(synth):
     assert p2.shape[1] == lens.max() + 3 and np.array_equal(p2[:, :lens.max()], host)
     with pytest.raises(_ffi.LnasrError):
         ctx.pad_rows(feat, foff, pad_rows=int(lens.max()) - 1)
+
+
+def test_back_to_back_pageable_batches_keep_their_own_observations(synth, ctx):
+    """Two decode calls in a row on DIFFERENT pageable batches with device outputs and no lens: the first call returns
+    when its last uploads are enqueued, not finished, and the second call's host threads refill the pinned staging ring
+    at once.  A ring slot must not be rewritten before the copy that last read it has completed (per-slot event), or
+    the first batch silently scores the second batch's observations.  Both results equal the resident runs."""
+    N, M, D, U, T = 128, 16, 39, 1024, 160
+    mdl = synth.synth_model(N, M, D, seed=1)
+    ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
+    batches = [synth.synth_obs(U, T, D, seed=s) for s in (41, 42, 43)]
+    want = [ctx.decode(ctx.to_device(x)).to_host() for x in batches]
+    assert not np.array_equal(want[0], want[1])
+    outs = [ctx.empty((U, T), np.uint32) for _ in batches]
+    for x, o in zip(batches, outs):                   # no host-side wait between the calls
+        ctx.decode(x, path_out=o)
+    ctx.sync()
+    for k, o in enumerate(outs):
+        assert np.array_equal(o.to_host(), want[k]), "batch %d decoded another batch's observations" % k
+    # the statistics pass takes the same upload route
+    st = [ctx.empty((ctx.bw_stats_len(),), np.float64) for _ in batches[:2]]
+    ref = [ctx.bw_accumulate(ctx.to_device(x[:256])).copy() for x in batches[:2]]
+    for x, o in zip(batches[:2], st):
+        ctx.bw_accumulate(x[:256], stats_out=o)
+    ctx.sync()
+    for k, o in enumerate(st):
+        assert_close(o.to_host(), ref[k], 1e-12, 1e-12, msg="statistics of batch %d" % k)

@@ -2,7 +2,7 @@
 """Per-row measurements of the other BASELINE.json configs on one GPU (development / DESIGN.md numbers;
 the driver-facing benchmark is bench.py).  Inputs resident in HBM, HIP-event kernel times.
 
-    python tools/bench_rows.py [mfcc] [e2e] [seg] [gmm] [fwd] [bw] [all]
+    python tools/bench_rows.py [mfcc] [e2e] [seg] [gmm] [fwd] [bw] [refapi] [all]
 """
 import os
 import sys
@@ -11,6 +11,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ln-asr_amd"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from lnasr import _ffi, synth  # noqa: E402
 from lnasr.mfcc import MFCC  # noqa: E402
 
@@ -86,6 +87,15 @@ if what & {"seg", "all"}:
     d = synth.synth_discrete(n, m, T, seed=3)
     h = HMM(n, m, d["A"], d["B"], d["pi"])
     timed("HMM.decode n=4 m=65536 T=%d" % T, lambda: h.decode(d["obs"]), T, "frames")
+
+if what & {"refapi", "all"}:
+    # the reference's own method names on one utterance, metric shape (tools/refapi.py; bench.py's reference_api block)
+    import refapi
+    r = refapi.measure(ctx)
+    for k, v in r["methods"].items():
+        print("refapi %-22s wall %8.3f ms  device %8.3f ms  host %8.3f ms   %s" % (k, v["wall_ms"], v["device_ms"], v["host_ms"], v["kernels"]))
+    print("refapi parameter fingerprint %.3f ms per call; b + bm read back afterwards %.3f ms; reference decode() %.0f ms"
+          % (r["parameter_fingerprint_ms"], r["read_b_and_bm_afterwards_ms"], r["reference_decode_ms"]))
 
 if what & {"gmm", "all"}:
     # config 3: T=1000, M=16, D=39, U=1024; single GMM (N=1) and the 128-state bank
