@@ -30,7 +30,14 @@
  *     (1 <= lens[u] <= T); rows t >= lens[u] of the outputs are left untouched.
  *   - `dtype`: storage type of b/bm/alpha/beta/v/xi/gamma buffers, LNASR_F64 or
  *     LNASR_F32.  As in the reference (`precision=`, hmm.py:38) arithmetic is
- *     fp64 either way (A, pi, w are fp64 there); F32 rounds at every store.
+ *     fp64 either way (A, pi, w are fp64 there); F32 rounds at every store and
+ *     the recursions continue from the rounded value, exactly as the reference
+ *     reads its float32 arrays back: v / bt / path (hmm.py:160-171), alpha
+ *     (hmm.py:93-99) and beta (hmm.py:124-130) equal the reference's float32
+ *     arrays bit for bit (a value whose fp64 sum lies within ~1e-15 of a float
+ *     rounding boundary may differ by one ulp).  The log-likelihood of
+ *     lnasr_forward is the fp64 log-sum-exp of the rounded alpha[T-1] (the
+ *     reference folds that one in float32: agreement to ~1e-6 relative).
  *     obs, model parameters, statistics and MFCC outputs are always fp64.
  */
 #ifndef LNASR_HIP_H
@@ -82,6 +89,11 @@ int lnasr_memset(lnasr_ctx* ctx, void* dst_dev, int byte, size_t bytes);
  * (plain numpy) goes through the context's pinned staging ring. */
 int lnasr_host_alloc(lnasr_ctx* ctx, size_t bytes, void** out);
 int lnasr_host_free(lnasr_ctx* ctx, void* p);
+
+/* The check the kernel launchers apply to every pointer they are handed when LNASR_CHECK_PTRS=1 (always in the
+ * host-sanitizer build): LNASR_E_INVALID unless p is null or device memory.  Exposed so that the CPU suite can prove
+ * the guard fires on a heap pointer (tests/test_host_asan.py). */
+int lnasr_debug_require_device_ptr(const void* p);
 
 /* 128-bit fingerprint of a HOST buffer (no context, no device).  The reference's methods re-read self.A / self.mu /
  * self.si on every call (hmm.py:82-99, gmmhmm.py:58-67): the mirror classes fingerprint the parameters per call and

@@ -34,7 +34,7 @@ def _stale(target, deps):
 
 
 ASAN_LIB = os.path.join(HERE, "lnasr", "liblnasr_hip_asan.so")
-ASAN_FLAGS = ["--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-fPIC", "-fno-omit-frame-pointer",
+ASAN_FLAGS = ["--offload-arch=gfx950", "-O1", "-g", "-DLNASR_DEBUG_GUARDS", "-std=c++17", "-fPIC", "-fno-omit-frame-pointer",
               "-fsanitize=address,undefined", "-fno-gpu-sanitize", "-fno-sanitize-recover=undefined",
               "-Wno-unused-function", "-Wno-unused-variable", "-ffp-contract=on", "-I/opt/rocm/include"]
 

@@ -1,0 +1,345 @@
+// Back-trace of the Viterbi trellis (hmm.py:168-171) and the full back-pointer matrix (hmm.py:165).
+// The pointer needed at each step, argmax_i(v[t,i] + A[i, path[t+1]]), is recomputed from the stored v with the
+// same fp64 additions as the recursion made (first index on ties, numpy.argmax's rule).
+#include "common.h"
+#include "devmath.h"
+#include "trellis.h"
+
+namespace lnasr {
+
+// ------------------------------------------------------------------------------------------
+// backtrace: one wave per utterance
+// ------------------------------------------------------------------------------------------
+template <typename TS>
+__global__ void backtrace_kernel(const TS* __restrict__ v, const double* __restrict__ AT,
+                                 const int32_t* __restrict__ lens, uint32_t* __restrict__ path,
+                                 double* __restrict__ best, int U, int T, int N) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int u = blockIdx.x * (blockDim.x >> 6) + w;
+    if (u >= U) return;
+    const int L = lens[u];
+    if (L <= 0) return;
+    const TS* vu = v + (size_t)u * T * N;
+    uint32_t* pu = path + (size_t)u * T;
+    double bv = LN_NEG_INF;
+    int bi = kNoIndex;
+    for (int j = lane; j < N; j += 64) argmax_combine(bv, bi, ld(vu, (size_t)(L - 1) * N + j), j);
+    wave_argmax(bv, bi);
+    int p = bi;
+    if (lane == 0) {
+        pu[L - 1] = (uint32_t)p;
+        if (best) best[u] = bv;
+    }
+    if (N <= 128) {
+        // two values per lane, next row prefetched while the dependent argmax chain runs
+        const int j0 = lane, j1 = lane + 64;
+        double n0 = LN_NEG_INF, n1 = LN_NEG_INF;
+        if (L >= 2) {
+            if (j0 < N) n0 = ld(vu, (size_t)(L - 2) * N + j0);
+            if (j1 < N) n1 = ld(vu, (size_t)(L - 2) * N + j1);
+        }
+        for (int t = L - 2; t >= 0; --t) {
+            const double c0 = n0, c1 = n1;
+            if (t > 0) {
+                if (j0 < N) n0 = ld(vu, (size_t)(t - 1) * N + j0);
+                if (j1 < N) n1 = ld(vu, (size_t)(t - 1) * N + j1);
+            }
+            const double* col = AT + (size_t)p * N;
+            double x = LN_NEG_INF;
+            int xi = kNoIndex;
+            if (j0 < N) { x = c0 + col[j0]; xi = j0; }
+            if (j1 < N) argmax_combine(x, xi, c1 + col[j1], j1);
+            wave_argmax(x, xi);
+            p = xi;
+            if (lane == 0) pu[t] = (uint32_t)p;
+        }
+    } else {
+        for (int t = L - 2; t >= 0; --t) {
+            const double* col = AT + (size_t)p * N;
+            double x = LN_NEG_INF;
+            int xi = kNoIndex;
+            for (int j = lane; j < N; j += 64) argmax_combine(x, xi, ld(vu, (size_t)t * N + j) + col[j], j);
+            wave_argmax(x, xi);
+            p = xi;
+            if (lane == 0) pu[t] = (uint32_t)p;
+        }
+    }
+}
+
+template <typename TS, int NMAX>
+__global__ __launch_bounds__(256) void backtrace_tiny_kernel(const TS* __restrict__ v, const uint8_t* __restrict__ bp,
+                                                             const int32_t* __restrict__ lens, uint32_t* __restrict__ path,
+                                                             double* __restrict__ best, int U, int T, int N) {
+    const int lane = threadIdx.x & 63;
+    const int u = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (u >= U) return;
+    const int L = lens[u];
+    if (L <= 0) return;
+    // last frame: first index among equal maxima
+    const double x = lane < N ? ld(v, ((size_t)u * T + (L - 1)) * N + lane) : LN_NEG_INF;
+    const double mx = wave_max_dpp(x);
+    const unsigned long long mk = __ballot(x == mx);
+    int p = __builtin_amdgcn_readfirstlane(mk ? __ffsll((long long)mk) - 1 : 0);
+    if (lane == 0 && best) best[u] = mx;
+    uint32_t* pu = path + (size_t)u * T;
+    const uint32_t* rows = reinterpret_cast<const uint32_t*>(bp + (size_t)u * T * NMAX);   // NMAX / 4 words per frame
+    constexpr int WPR = NMAX / 4;
+    uint32_t mine = 0;
+    if (lane == ((L - 1) & 63)) mine = (uint32_t)p;
+    if (((L - 1) & 63) == 0) pu[L - 1] = (uint32_t)p;
+    // frames are walked 64 at a time: lane l holds the back-pointer row of frame tb - l; path[t - 1] = row(t)[p]
+    for (int tb = L - 1; tb >= 1; tb -= 64) {
+        uint32_t w[WPR];
+        const int tl = tb - lane > 0 ? tb - lane : 0;
+#pragma unroll
+        for (int q = 0; q < WPR; ++q) w[q] = rows[(size_t)tl * WPR + q];
+        auto step = [&](int k) {
+            uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)w[0], k);
+#pragma unroll
+            for (int q = 1; q < WPR; ++q) {
+                const uint32_t wq = (uint32_t)__builtin_amdgcn_readlane((int)w[q], k);
+                word = (p >> 2) == q ? wq : word;
+            }
+            p = (int)((word >> (8 * (p & 3))) & 0xffu);
+            const int tp = tb - k - 1;
+            if (lane == (tp & 63)) mine = (uint32_t)p;
+            if ((tp & 63) == 0 && tp + lane < L) pu[tp + lane] = mine;          // frames tp .. tp + 63 are complete
+        };
+        if (tb >= 64) {                                   // a whole chunk: 64 steps, lanes known at compile time
+#pragma unroll
+            for (int k = 0; k < 64; ++k) step(k);
+        } else {
+            for (int k = 0; k < tb; ++k) step(k);         // frames tb .. 1
+        }
+    }
+}
+
+// Backtrace for N <= 128 (fp64): A^T lives in LDS so the only dependent memory access per step is
+// an LDS row read; arg-max = DPP wave max, then the first lane holding the max (ballot + ffs),
+// which is numpy.argmax's first-index rule because lane l holds states l and l+64.  Decoded
+// states are collected 64 frames at a time and written as one coalesced 256-byte row.
+template <int CPL, bool LDSAT, typename TS = double, bool FULL = false>
+__global__ __launch_bounds__(256) void backtrace_lds_kernel(const TS* __restrict__ v,
+                                                           const double* __restrict__ AT,
+                                                           const int32_t* __restrict__ lens,
+                                                           uint32_t* __restrict__ path, double* __restrict__ best,
+                                                           int U, int T, int N, unsigned* __restrict__ suspect_flag,
+                                                           unsigned epoch) {
+    // lane l holds states l, l+64, ... (CPL of them).  LDSAT: A^T [N][N] (ATs[p*N + i] = A[i][p]) lives in LDS
+    // (N <= 128); otherwise the one row a step needs is read from L2 (128 < N <= 256: 512 KB does not fit)
+    extern __shared__ double ATs[];
+    if (LDSAT) {
+        for (int e = threadIdx.x; e < N * N; e += blockDim.x) ATs[e] = AT[e];
+        __syncthreads();
+    }
+    const double* ATb = LDSAT ? ATs : AT;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int u = blockIdx.x * (blockDim.x >> 6) + w;
+    if (u >= U) return;
+    const int L = lens[u];
+    if (L <= 0) return;
+    const TS* vu = v + (size_t)u * T * N;
+    uint32_t* pu = path + (size_t)u * T;
+    bool ok[CPL];                                            // FULL: N = 64 CPL, every lane owns CPL real states and the
+    int jj[CPL];                                             // selects below fold away; else clamped: every load is a valid address
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        ok[c] = FULL || lane + 64 * c < N;
+        jj[c] = ok[c] ? lane + 64 * c : 0;
+    }
+    // first index among equal maxima (numpy.argmax): lowest column block first, lowest lane within it
+    auto pick = [&](const double (&x)[CPL], double& mx) -> int {
+        double m = x[0];
+#pragma unroll
+        for (int c = 1; c < CPL; ++c) m = vmax_f64(m, x[c]);
+        mx = wave_max_dpp(m);
+        int r = 0;                                            // scalar selects, highest block first: the lowest wins
+#pragma unroll
+        for (int c = CPL - 1; c >= 0; --c) {
+            const unsigned long long mk = __ballot(x[c] == mx);
+            r = mk ? 64 * c + __ffsll((long long)mk) - 1 : r;
+        }
+        return r;
+    };
+    // A NaN emission leaves NaN or -inf in its cell of v (the Viterbi kernels' maximum drops a NaN operand) where numpy
+    // would have turned every later frame into NaN.  This kernel reads every cell anyway and has issue slots to spare:
+    // it raises a flag when it meets such a cell, and only then is b scanned for NaNs (nanfix.hip) -- a model with -inf
+    // transitions pays that scan for nothing, a dense one never pays it
+    unsigned long long suspect = 0;
+    double x[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        const double v0 = ld(vu, (size_t)(L - 1) * N + jj[c]);
+        suspect |= __ballot(!(v0 > LN_NEG_INF));
+        x[c] = ok[c] ? v0 : LN_NEG_INF;
+    }
+    double bestv;
+    int p = pick(x, bestv);
+    if (lane == 0 && best) best[u] = bestv;
+    uint32_t mine = 0;
+    if (lane == ((L - 1) & 63)) mine = (uint32_t)p;
+    if (((L - 1) & 63) == 0) pu[L - 1] = (uint32_t)p;      // single-entry top block
+    // v rows are streamed from HBM: keep PF frames in flight per wave (register ring) so that the
+    // dependent chain below only ever waits on the A^T row
+    constexpr int PF = CPL <= 2 ? 8 : (CPL <= 4 ? 4 : (CPL <= 8 ? 2 : 1));
+    double cur[PF][CPL], nxt[PF][CPL];
+    auto load_rows = [&](int tstart, double (&r)[PF][CPL]) {     // frames tstart, tstart-1, ... (clamped at 0)
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const int tt = tstart - k > 0 ? tstart - k : 0;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) r[k][c] = ld(vu, (size_t)tt * N + jj[c]);
+        }
+    };
+    load_rows(L - 2 > 0 ? L - 2 : 0, cur);
+    for (int tb = L - 2; tb >= 0; tb -= PF) {
+        load_rows(tb - PF > 0 ? tb - PF : 0, nxt);
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const int t = tb - k;
+            if (t >= 0) {                                   // wave-uniform
+                const double* col = ATb + (size_t)p * N;
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) {
+                    const double sum = cur[k][c] + col[jj[c]];          // unconditional (clamped index), then a select
+                    suspect |= __ballot(!(cur[k][c] > LN_NEG_INF));
+                    x[c] = ok[c] ? sum : LN_NEG_INF;
+                }
+                double mx;
+                p = pick(x, mx);
+                if (lane == (t & 63)) mine = (uint32_t)p;
+                if ((t & 63) == 0) {
+                    // frames t .. min(t+63, L-1) are complete: lane l holds frame t + l
+                    if (t + lane < L) pu[t + lane] = mine;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PF; ++k)
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) cur[k][c] = nxt[k][c];
+    }
+    if (suspect != 0 && lane == 0) *suspect_flag = epoch;
+}
+
+// full back-pointer matrix (hmm.py:165): bt[u,t,j] = argmax_i(v[u,t-1,i] + A[i,j]); bt[u,0,:] = 0
+template <typename TS>
+__global__ void bt_kernel(const TS* __restrict__ v, const double* __restrict__ A, const int32_t* __restrict__ lens,
+                          uint32_t* __restrict__ bt, int T, int N) {
+    extern __shared__ double vs[];            // [N]
+    const int u = blockIdx.y, t = blockIdx.x;
+    if (t >= lens[u]) return;
+    uint32_t* out = bt + ((size_t)u * T + t) * N;
+    if (t == 0) {
+        for (int j = threadIdx.x; j < N; j += blockDim.x) out[j] = 0;
+        return;
+    }
+    const TS* vp = v + ((size_t)u * T + (t - 1)) * N;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) vs[i] = ld(vp, i);
+    __syncthreads();
+    for (int j = threadIdx.x; j < N; j += blockDim.x) {
+        double best = vs[0] + A[j];
+        int bi = 0;
+        for (int i = 1; i < N; ++i) {
+            double val = vs[i] + A[(size_t)i * N + j];
+            // numpy.argmax: the first NaN wins over everything (v repaired by viterbi_nan_repair holds the reference's NaNs)
+            if (val > best || (val != val && best == best)) { best = val; bi = i; }
+        }
+        out[j] = (uint32_t)bi;
+    }
+}
+
+
+int backtrace_device(lnasr_ctx* ctx, const void* v, int U, int T, const int32_t* d_lens, int dtype, uint32_t* path,
+                     double* best, bool* v_tested) {
+    LN_DEVPTR(v); LN_DEVPTR(d_lens); LN_DEVPTR(path); LN_DEVPTR(best);
+    // *v_tested: the kernel looked at every cell of v and raised the context's "suspect" word on NaN / -inf (nanfix.hip)
+    Model& md = ctx->model;
+    const int wpb = dispatch::kBacktraceWavesPerBlock;
+    unsigned* const sflag = ctx->nan_flag.as<unsigned>() + 1;
+    const unsigned epoch = ctx->nan_epoch;
+    if (v_tested) *v_tested = false;
+    if (ctx->bp_v == v && ctx->bp_U == U && ctx->bp_T == T && v != nullptr) {
+        // v came from viterbi_tiny_kernel: its byte back-pointers are in ws_bp
+        const uint8_t* bp = ctx->ws_bp.as<uint8_t>();
+        const int nmax = ctx->bp_nmax;
+        ctx->bp_v = nullptr;
+        const dim3 grid((U + wpb - 1) / wpb), block(64 * wpb);
+#define LN_TINY(TS, NM)                                                                                        \
+    LN_LAUNCH(ctx, "backtrace_tiny", (backtrace_tiny_kernel<TS, NM>), grid, block, 0, (const TS*)v, bp, d_lens, path, best, \
+              U, T, md.N)
+        if (dtype == LNASR_F32) {
+            if (nmax == 4) LN_TINY(float, 4);
+            else if (nmax == 8) LN_TINY(float, 8);
+            else LN_TINY(float, 16);
+        } else {
+            if (nmax == 4) LN_TINY(double, 4);
+            else if (nmax == 8) LN_TINY(double, 8);
+            else LN_TINY(double, 16);
+        }
+#undef LN_TINY
+        return 0;
+    }
+    if (dtype == LNASR_F64 && md.N <= 128 && !sw().no_ldsbt) {
+        if (v_tested) *v_tested = true;
+        if (md.N == 128)
+            LN_LAUNCH(ctx, "backtrace_lds", (backtrace_lds_kernel<2, true, double, true>), dim3((U + wpb - 1) / wpb),
+                      dim3(64 * wpb), (size_t)md.N * md.N * 8, (const double*)v, md.logAT.as<double>(), d_lens, path, best, U,
+                      T, md.N, sflag, epoch);
+        else
+            LN_LAUNCH(ctx, "backtrace_lds", (backtrace_lds_kernel<2, true>), dim3((U + wpb - 1) / wpb), dim3(64 * wpb),
+                      (size_t)md.N * md.N * 8, (const double*)v, md.logAT.as<double>(), d_lens, path, best, U, T, md.N, sflag, epoch);
+        return 0;
+    }
+    if (dtype == LNASR_F64 && md.N <= 1024 && !sw().no_ldsbt) {
+        if (v_tested) *v_tested = true;
+        // one wave per block (with few utterances the waves should sit on different CUs), N / 64 states per lane
+        if (md.N <= 256)
+            LN_LAUNCH(ctx, "backtrace_wave256", (backtrace_lds_kernel<4, false>), dim3(U), dim3(64), 0, (const double*)v,
+                      md.logAT.as<double>(), d_lens, path, best, U, T, md.N, sflag, epoch);
+        else if (md.N <= 512)
+            LN_LAUNCH(ctx, "backtrace_wave512", (backtrace_lds_kernel<8, false>), dim3(U), dim3(64), 0, (const double*)v,
+                      md.logAT.as<double>(), d_lens, path, best, U, T, md.N, sflag, epoch);
+        else
+            LN_LAUNCH(ctx, "backtrace_wave1024", (backtrace_lds_kernel<16, false>), dim3(U), dim3(64), 0, (const double*)v,
+                      md.logAT.as<double>(), d_lens, path, best, U, T, md.N, sflag, epoch);
+        return 0;
+    }
+    if (dtype == LNASR_F32 && md.N <= 128 && !sw().no_ldsbt && !sw().f32_generic) {
+        if (v_tested) *v_tested = true;
+        LN_LAUNCH(ctx, "backtrace_lds_f32", (backtrace_lds_kernel<2, true, float>), dim3((U + wpb - 1) / wpb), dim3(64 * wpb),
+                  (size_t)md.N * md.N * 8, (const float*)v, md.logAT.as<double>(), d_lens, path, best, U, T, md.N, sflag, epoch);
+        return 0;
+    }
+    if (dtype == LNASR_F32 && md.N <= 256 && !sw().no_ldsbt && !sw().f32_generic) {
+        if (v_tested) *v_tested = true;
+        LN_LAUNCH(ctx, "backtrace_wave256_f32", (backtrace_lds_kernel<4, false, float>), dim3(U), dim3(64), 0, (const float*)v,
+                  md.logAT.as<double>(), d_lens, path, best, U, T, md.N, sflag, epoch);
+        return 0;
+    }
+    if (dtype == LNASR_F32)
+        LN_LAUNCH(ctx, "backtrace_f32", backtrace_kernel<float>, dim3((U + wpb - 1) / wpb), dim3(64 * wpb), 0,
+                  (const float*)v, md.logAT.as<double>(), d_lens, path, best, U, T, md.N);
+    else
+        LN_LAUNCH(ctx, "backtrace", backtrace_kernel<double>, dim3((U + wpb - 1) / wpb), dim3(64 * wpb), 0,
+                  (const double*)v, md.logAT.as<double>(), d_lens, path, best, U, T, md.N);
+    return 0;
+}
+
+// full back-pointer matrix bt [U,T,N] from the stored v (only when the caller asks for it: HMM._viterbi returns it)
+int bt_matrix_device(lnasr_ctx* ctx, const void* v, int U, int T, const int32_t* d_lens, int dtype, uint32_t* bt) {
+    LN_DEVPTR(v); LN_DEVPTR(d_lens); LN_DEVPTR(bt);
+    const int N = ctx->model.N;
+    LN_REQUIRE(U <= 65535, "U=%d too large for the bt kernel", U);
+    int nt = ((N + 63) / 64) * 64;
+    if (nt > 256) nt = 256;
+    if (dtype == LNASR_F32)
+        LN_LAUNCH(ctx, "viterbi_bt_f32", bt_kernel<float>, dim3(T, U), dim3(nt), (size_t)N * 8, (const float*)v,
+                  ctx->model.logA.as<double>(), d_lens, bt, T, N);
+    else
+        LN_LAUNCH(ctx, "viterbi_bt", bt_kernel<double>, dim3(T, U), dim3(nt), (size_t)N * 8, (const double*)v,
+                  ctx->model.logA.as<double>(), d_lens, bt, T, N);
+    return 0;
+}
+
+}  // namespace lnasr

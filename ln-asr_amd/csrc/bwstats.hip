@@ -181,6 +181,7 @@ __global__ __launch_bounds__(256) void xi_gemm_kernel(const double* __restrict__
 
 int xi_sum_device(lnasr_ctx* ctx, const double* alpha, const double* beta, const double* b, const double* loglik,
                   const int32_t* d_lens, int U, int T, double* xi_sum) {
+    LN_DEVPTR(alpha); LN_DEVPTR(beta); LN_DEVPTR(b); LN_DEVPTR(loglik); LN_DEVPTR(d_lens); LN_DEVPTR(xi_sum);
     Model& md = ctx->model;
     const int N = md.N, NP = (N + 15) / 16 * 16;
     const long F = (long)U * T, FP = (F + 3) / 4 * 4;
@@ -619,6 +620,7 @@ bool full_stats_mfma_ok(const Model& md) {
 int full_stats_device(lnasr_ctx* ctx, const double* obs, const double* alpha, const double* beta, const double* b,
                       const double* bm, const double* c1, const int32_t* d_lens, int U, int T, double* mix, double* mix_x,
                       double* mix_xx) {
+    LN_DEVPTR(obs); LN_DEVPTR(alpha); LN_DEVPTR(beta); LN_DEVPTR(b); LN_DEVPTR(bm); LN_DEVPTR(c1); LN_DEVPTR(d_lens); LN_DEVPTR(mix); LN_DEVPTR(mix_x); LN_DEVPTR(mix_xx);
     Model& md = ctx->model;
     const int N = md.N, M = md.M, D = md.D, NCH = md.wfull_NCH;
     const int MG = (M + 31) / 32, MT = MG > 1 ? 2 : (M + 15) / 16, MP = MG > 1 ? 32 * MG : 16 * MT, KF = NCH * 80;
@@ -696,6 +698,7 @@ static int mix_launch(lnasr_ctx* ctx, int CT, dim3 grid, const double* obs, cons
 int mix_stats_device(lnasr_ctx* ctx, const double* obs, const double* alpha, const double* beta, const double* b,
                      const double* bm, const double* c1, const int32_t* d_lens, int U, int T, double* mix, double* mix_x,
                      double* mix_xx, int phase) {
+    LN_DEVPTR(obs); LN_DEVPTR(alpha); LN_DEVPTR(beta); LN_DEVPTR(b); LN_DEVPTR(bm); LN_DEVPTR(c1); LN_DEVPTR(d_lens); LN_DEVPTR(mix); LN_DEVPTR(mix_x); LN_DEVPTR(mix_xx);
     Model& md = ctx->model;
     const int N = md.N, M = md.M, D = md.D;
     // M > 32: MG groups of 32 mixtures per state, one wave each

@@ -119,6 +119,7 @@ struct Switches {
     int framepar_maxu = -1;       // LNASR_FRAMEPAR_MAXU, -1 = unset (measured rule)
     double kappa_max = kKappaMax; // LNASR_KAPPA_MAX
     int h2d_threads = 4;          // LNASR_H2D_THREADS: host threads filling the pinned staging ring
+    bool check_ptrs = false;      // LNASR_CHECK_PTRS: LN_DEVPTR verifies every pointer a launch helper is handed
     char emit = 0;                // LNASR_EMIT (ablation builds only)
 };
 const Switches& sw();
@@ -207,6 +208,16 @@ void prof_end(lnasr_ctx* ctx, int rec);
 
 // Is `p` device memory?  (host pointers from numpy are unregistered)
 bool is_device_ptr(const void* p);
+// Guard of the launch helpers (`*_device`, `*_nan_repair`, emit_*): they take DEVICE pointers only -- the entry points
+// stage host buffers first (stage_in / stage_out).  A host pointer that slips through (round 3: a side-stream
+// experiment handed the caller's numpy `obs` to the moments kernel instead of its staged copy) is a GPU memory fault
+// at best.  Under LNASR_CHECK_PTRS=1 -- always in the --host-asan build -- every such pointer is verified with
+// hipPointerGetAttributes before anything is launched and the call fails with LNASR_E_INVALID instead.
+int require_device_ptr(const void* p, const char* what, const char* where);
+#define LN_DEVPTR(p)                                                                    \
+    do {                                                                                \
+        if (lnasr::sw().check_ptrs) LN_TRY(lnasr::require_device_ptr((p), #p, __func__)); \
+    } while (0)
 // Is `p` page-locked host memory (lnasr_host_alloc / hipHostMalloc / hipHostRegister)?  Such buffers are copied
 // asynchronously at PCIe rate without a staging copy.
 bool is_pinned_host_ptr(const void* p);
@@ -255,9 +266,11 @@ int full_stats_device(lnasr_ctx* ctx, const double* obs, const double* alpha, co
 int emit_batch(lnasr_ctx* ctx, const double* obs, int U, int T, double* b, double* bm, const double** d_obs_out,
                bool* scanned_or_null = nullptr);
 
-// float32 storage (`precision=np.float32`): the tuned kernels are f64-only, so f32 inputs are widened, the f64
-// kernels run, and results are rounded to f32 on the way out (more accurate than rounding every stored
-// intermediate, and ~12x faster than the storage-templated scalar kernels; LNASR_F32_GENERIC=1 selects those)
+// float32 storage (`precision=np.float32`) of the EMISSION kernels: f32 outputs are produced by the f64 kernels and
+// rounded on the way out (gmm.hip; bm first, b from the rounded bm as the reference does, gmmhmm.py:64-67).
+// LNASR_F32_GENERIC=1 selects the storage-templated scalar kernels instead.  The trellises do not take this route:
+// their float-storage kernels round at every store and continue from the rounded value (viterbi.hip, fwdbwd.hip,
+// trellis256.hip), which is what the reference's float32 arrays do.
 bool f32_via_f64();
 int widen_f32(lnasr_ctx* ctx, const void* src, size_t n, DevBuf& ws, double** out);
 int narrow_f64(lnasr_ctx* ctx, const double* src, size_t n, void* dst);

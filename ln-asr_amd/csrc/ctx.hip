@@ -76,6 +76,10 @@ static void load_switches(Switches& s) {
     s.f32_generic = on("LNASR_F32_GENERIC");
     s.no_f32_stats = on("LNASR_NO_F32_STATS");
     s.no_pinned_ring = on("LNASR_NO_PINNED_RING");
+#ifdef LNASR_DEBUG_GUARDS
+    s.check_ptrs = true;                                   // the --host-asan build: always
+#endif
+    if (const char* e = getenv("LNASR_CHECK_PTRS")) s.check_ptrs = e[0] != '0';
     if (const char* e = getenv("LNASR_VIT")) s.vit = e[0];
     if (const char* e = getenv("LNASR_FWD")) s.fwd = e[0];
     if (const char* e = getenv("LNASR_EMIT")) s.emit = e[0];
@@ -119,6 +123,12 @@ bool is_device_ptr(const void* p) {
         return false;
     }
     return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+int require_device_ptr(const void* p, const char* what, const char* where) {
+    if (!p || is_device_ptr(p)) return 0;             // optional outputs may be null
+    return fail(LNASR_E_INVALID, "%s: `%s` (%p) is not device memory -- an unstaged host pointer reached a kernel launcher",
+                where, what, p);
 }
 
 int stage_in(lnasr_ctx* ctx, const void* p, size_t bytes, DevBuf& ws, const void** out) {
@@ -321,6 +331,8 @@ int lnasr_reload_switches(void) {
     g_sw_loaded = true;
     return 0;
 }
+
+int lnasr_debug_require_device_ptr(const void* p) { return require_device_ptr(p, "p", "lnasr_debug_require_device_ptr"); }
 
 int lnasr_host_alloc(lnasr_ctx* ctx, size_t bytes, void** out) {
     LN_ENTER(ctx);

@@ -411,6 +411,7 @@ static int launch_emit32(lnasr_ctx* ctx, const double* obs, long F, double* bv, 
 
 // emission of the fp32 pass: b [F, N] double, q32 [F, N, M] float (weighted component log-densities)
 int emit_device_f32(lnasr_ctx* ctx, const double* obs, long F, double* b, float* q32) {
+    LN_DEVPTR(obs); LN_DEVPTR(b); LN_DEVPTR(q32);
     Model& md = ctx->model;
     LN_TRY(pack32(ctx));
     const int Q = md.wpack_Q, KS = md.wpack_KS, virt = md.wpack_virt;
@@ -437,6 +438,7 @@ int emit_device_f32(lnasr_ctx* ctx, const double* obs, long F, double* b, float*
 int mix_stats_device_f32(lnasr_ctx* ctx, const double* obs, const double* alpha, const double* beta, const double* b,
                          const float* q32, const double* c1, const int32_t* d_lens, int U, int T, double* mix,
                          double* mix_x, double* mix_xx, int phase) {
+    LN_DEVPTR(obs); LN_DEVPTR(alpha); LN_DEVPTR(beta); LN_DEVPTR(b); LN_DEVPTR(q32); LN_DEVPTR(c1); LN_DEVPTR(d_lens); LN_DEVPTR(mix); LN_DEVPTR(mix_x); LN_DEVPTR(mix_xx);
     Model& md = ctx->model;
     const int N = md.N, M = md.M, D = md.D;
     const int MT = (M + 15) / 16, CT = (2 * D + 1 + 15) / 16;

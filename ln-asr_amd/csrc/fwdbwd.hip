@@ -1,0 +1,829 @@
+// Forward / backward recursions (hmm.py:63-131), kernels for N <= 128 and the dispatch over every family.
+// 128 < N <= 256: trellis256.hip; N > 256: bign.hip.
+#include "common.h"
+#include "devmath.h"
+#include "trellis.h"
+
+namespace lnasr {
+
+// ------------------------------------------------------------------------------------------
+// forward / backward (log domain)
+// ------------------------------------------------------------------------------------------
+// alpha[t,j] = lse_i(alpha[t-1,i] + A[i,j]) + b[t,j]                       (hmm.py:97-99)
+// Evaluated as s + log(sum_i exp(alpha[t-1,i] - s) * expA[i,j]) with s = max_i alpha[t-1,i]:
+// one exp per state per frame and an FMA per (i,j) instead of a transcendental per (i,j).
+// Columns whose linear-domain sum falls below kSafeSum (every contributor underflowed, or the
+// column is unreachable) are redone with the exact max-shifted log-domain sum, so the result
+// equals the reference's logaddexp fold to rounding for every input, including -inf entries.
+
+template <typename TS, bool BACKWARD>
+__global__ void fwdbwd_generic(const TS* __restrict__ b, const double* __restrict__ Alog,
+                               const double* __restrict__ Aexp, const double* __restrict__ pi,
+                               const int32_t* __restrict__ lens, TS* __restrict__ out, double* __restrict__ loglik,
+                               int U, int T, int N) {
+    // FORWARD : Alog = logA [i][j] (row i, col j), Aexp = expA;  thread j sums over i: Aexp[i*N+j]
+    // BACKWARD: Alog = logA^T [j][i], Aexp = expA^T;             thread i sums over j: Aexp[j*N+i]
+    extern __shared__ double sm[];
+    double* prev = sm;                 // [N]  previous row (forward: alpha[t-1]; backward: beta[t+1]+b[t+1])
+    double* ex = sm + N;               // [N]  exp(prev - s)
+    double* scratch = sm + 2 * N;      // [32]
+    const int u = blockIdx.x;
+    const int L = lens[u];
+    if (L <= 0) return;
+    const TS* bu = b + (size_t)u * T * N;
+    TS* ou = out ? out + (size_t)u * T * N : nullptr;
+
+    if (!BACKWARD) {
+        for (int j = threadIdx.x; j < N; j += blockDim.x) {
+            double val = rnd<TS>(pi[j] + ld(bu, j));
+            if (ou) st(ou, j, val);
+            prev[j] = val;
+        }
+    } else {
+        for (int j = threadIdx.x; j < N; j += blockDim.x) {
+            if (ou) st(ou, (size_t)(L - 1) * N + j, 0.0);
+            if (L >= 2) prev[j] = 0.0 + ld(bu, (size_t)(L - 1) * N + j);
+        }
+    }
+    __syncthreads();
+    const int steps = L - 1;
+    for (int sidx = 0; sidx < steps; ++sidx) {
+        const int t = BACKWARD ? (L - 2 - sidx) : (1 + sidx);
+        double lm = LN_NEG_INF;
+        for (int i = threadIdx.x; i < N; i += blockDim.x) lm = fmax(lm, prev[i]);
+        const double s = block_max(lm, scratch);
+        for (int i = threadIdx.x; i < N; i += blockDim.x) ex[i] = (s == LN_NEG_INF) ? 0.0 : exp(prev[i] - s);
+        __syncthreads();
+        double newv[4];                // up to 4 states per thread (N <= 4 * blockDim)
+        int cnt = 0;
+        for (int j = threadIdx.x; j < N; j += blockDim.x, ++cnt) {
+            double sum = 0.0;
+            for (int i = 0; i < N; ++i) sum += ex[i] * Aexp[(size_t)i * N + j];
+            double val;
+            if (sum >= kSafeSum && s != LN_NEG_INF) {
+                val = s + log(sum);
+            } else {
+                double mx = LN_NEG_INF;
+                for (int i = 0; i < N; ++i) mx = fmax(mx, prev[i] + Alog[(size_t)i * N + j]);
+                if (mx == LN_NEG_INF) {
+                    val = mx;
+                } else {
+                    double s2 = 0.0;
+                    for (int i = 0; i < N; ++i) s2 += exp(prev[i] + Alog[(size_t)i * N + j] - mx);
+                    val = mx + log(s2);
+                }
+            }
+            if (!BACKWARD) {
+                val = rnd<TS>(val + ld(bu, (size_t)t * N + j));
+                if (ou) st(ou, (size_t)t * N + j, val);
+                newv[cnt] = val;
+            } else {
+                val = rnd<TS>(val);
+                if (ou) st(ou, (size_t)t * N + j, val);
+                newv[cnt] = val + ld(bu, (size_t)t * N + j);     // feeds step t-1: beta[t] + b[t]
+            }
+        }
+        __syncthreads();
+        cnt = 0;
+        for (int j = threadIdx.x; j < N; j += blockDim.x, ++cnt) prev[j] = newv[cnt];
+        __syncthreads();
+    }
+    if (!BACKWARD && loglik) {
+        // calc_prob: lse(alpha[L-1])  (hmm.py:274)
+        double lm = LN_NEG_INF;
+        for (int i = threadIdx.x; i < N; i += blockDim.x) lm = fmax(lm, prev[i]);
+        const double s = block_max(lm, scratch);
+        double ls = 0.0;
+        for (int i = threadIdx.x; i < N; i += blockDim.x) ls += (s == LN_NEG_INF) ? 0.0 : exp(prev[i] - s);
+        const double tot = block_sum(ls, scratch);
+        if (threadIdx.x == 0) loglik[u] = (s == LN_NEG_INF) ? s : s + log(tot);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward / backward, register-resident exp(A) (N <= 64*CPT, N <= NW*RPT; fp64 storage)
+// ------------------------------------------------------------------------------------------
+// Same blocking as viterbi_reg: thread (wave w, lane l) keeps expA[w*RPT + r][l + 64c] (forward) or
+// expA^T (backward) in registers, UB utterances walk in lock-step, row slices are combined through
+// LDS and the CPT*UB (utterance, column-block) jobs are finalised by one wave each:
+//     prev_t[j] = S + log(sum_i e[i] * expA[i,j])  (+ b[t,j] for forward)
+//     e_t[j]    = exp(prev_t[j] - S'),   S' = max_j prev_{t-1}[j]
+// The shift S' lags one frame (the max of the frame just consumed), so no extra block-wide
+// reduction sits on the critical path: any shift is exact in floating point as long as nothing
+// over/underflows, and sums outside [1e-290, 1e290] (or NaN) fall back to the exact max-shifted
+// log-domain evaluation of that column, as in fwdbwd_generic.
+template <bool BACKWARD, int CPT, int NW, int RPT, int UB, int WPE>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void fwdbwd_reg(
+    const double* __restrict__ b, const double* __restrict__ Aexp, const double* __restrict__ Alog,
+    const double* __restrict__ pi, const int32_t* __restrict__ lens, double* __restrict__ out,
+    double* __restrict__ loglik, int U, int T, int N) {
+    constexpr int NP = 64 * CPT;
+    constexpr int NJOB = CPT * UB;
+    constexpr int JPW = (NJOB + NW - 1) / NW;
+    __shared__ double Es[2][UB][NP];      // exp(prev - shift) of the frame being consumed
+    __shared__ double Cs[2][UB][NP];      // prev itself (log domain) for the exact fallback
+    __shared__ double Ps[NW > 1 ? NW : 1][UB][NP];
+    __shared__ double Ms[2][UB][CPT];     // per column-block max of prev
+    __shared__ double Ss[2][UB];          // shift the e values of this buffer were computed with
+    __shared__ double etab[kExpTab];      // table-driven exp / log (devmath.h)
+    __shared__ double ltab[2 * kLogTab];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    exp_table_init(etab, threadIdx.x, 64 * NW);
+    log_table_init(ltab, threadIdx.x, 64 * NW);   // visible after the first __syncthreads below
+    const int u0 = blockIdx.x * UB;
+
+    double areg[CPT][RPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c)
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const int i = w * RPT + r, j = lane + 64 * c;
+            areg[c][r] = (i < N && j < N) ? Aexp[(size_t)i * N + j] : 0.0;
+        }
+
+    int len[UB], maxlen = 0;
+#pragma unroll
+    for (int k = 0; k < UB; ++k) {
+        len[k] = (u0 + k < U) ? lens[u0 + k] : 0;
+        maxlen = len[k] > maxlen ? len[k] : maxlen;
+    }
+    // jobs of this wave
+    int jk[JPW], jc[JPW], jlen[JPW];
+    const double* bp[JPW];
+    double* op[JPW];
+    bool jvalid[JPW];
+#pragma unroll
+    for (int jj = 0; jj < JPW; ++jj) {
+        const int q = w + jj * NW;
+        jvalid[jj] = q < NJOB;
+        jk[jj] = jvalid[jj] ? q / CPT : 0;
+        jc[jj] = q % CPT;
+        const int uu = (u0 + jk[jj] < U) ? u0 + jk[jj] : U - 1;
+        const int j = lane + 64 * jc[jj];
+        bp[jj] = b + (size_t)uu * T * N + (j < N ? j : N - 1);
+        op[jj] = out ? out + (size_t)uu * T * N + (j < N ? j : N - 1) : nullptr;
+        jlen[jj] = 0;
+#pragma unroll
+        for (int k = 0; k < UB; ++k)
+            if (k == jk[jj]) jlen[jj] = len[k];
+    }
+    // frame of utterance-job jj at step s:  forward t = s;  backward t = L-1-s
+    auto frame_of = [&](int jj, int step) { return BACKWARD ? jlen[jj] - 1 - step : step; };
+
+    // step 0: prev_0 and its per-block max
+#pragma unroll
+    for (int jj = 0; jj < JPW; ++jj) {
+        if (jvalid[jj]) {
+            const int k = jk[jj], c = jc[jj], j = lane + 64 * c;
+            double prev = LN_NEG_INF;
+            if (j < N && jlen[jj] > 0) {
+                const int t0 = frame_of(jj, 0);
+                const double bv = bp[jj][(size_t)t0 * N];
+                if (BACKWARD) {
+                    if (op[jj]) op[jj][(size_t)t0 * N] = 0.0;
+                    prev = 0.0 + bv;
+                } else {
+                    prev = pi[j] + bv;
+                    if (op[jj]) op[jj][0] = prev;
+                }
+            }
+            Cs[0][k][j] = prev;
+            const double m = wave_max_dpp(prev);
+            if (lane == 0) Ms[0][k][c] = m;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int jj = 0; jj < JPW; ++jj) {
+        if (jvalid[jj]) {
+            const int k = jk[jj], c = jc[jj], j = lane + 64 * c;
+            double S = Ms[0][k][0];
+#pragma unroll
+            for (int cc = 1; cc < CPT; ++cc) S = fmax(S, Ms[0][k][cc]);
+            const double prev = Cs[0][k][j];
+            Es[0][k][j] = (S == LN_NEG_INF || prev == LN_NEG_INF) ? 0.0 : exp_clamped(prev - S, etab);
+            if (c == 0 && lane == 0) Ss[0][k] = S;
+        }
+    }
+    double bnext[JPW];
+#pragma unroll
+    for (int jj = 0; jj < JPW; ++jj) {
+        int t1 = frame_of(jj, 1);
+        t1 = t1 < 0 ? 0 : (t1 > T - 1 ? T - 1 : t1);
+        bnext[jj] = jvalid[jj] ? bp[jj][(size_t)t1 * N] : 0.0;
+    }
+    __syncthreads();
+
+    for (int step = 1; step < maxlen; ++step) {
+        const int cur = (step - 1) & 1, nxt = step & 1;
+        double bcur[JPW];
+#pragma unroll
+        for (int jj = 0; jj < JPW; ++jj) {
+            bcur[jj] = bnext[jj];
+            int tn = frame_of(jj, step + 1);
+            tn = tn < 0 ? 0 : (tn > T - 1 ? T - 1 : tn);
+            if (jvalid[jj]) bnext[jj] = bp[jj][(size_t)tn * N];
+        }
+        // the wave's RPT e-values of an utterance sit in RPT/16 VGPR pairs, 16 per DPP row (lane l holds
+        // e[16 g + (l & 15)]); v_fmac_f64_dpp row_newbcast:n feeds value n to every lane, so a transition is
+        // ONE vector instruction and the LDS sees one read per utterance instead of one per row (the broadcast
+        // reads made this kernel LDS-bound: 64 of them per frame against 128 FMAs)
+        static_assert(RPT % 16 == 0, "row slices are whole DPP rows");
+        double ek[UB][RPT / 16];
+#pragma unroll
+        for (int k = 0; k < UB; ++k)
+#pragma unroll
+            for (int g = 0; g < RPT / 16; ++g) ek[k][g] = Es[cur][k][w * RPT + 16 * g + (lane & 15)];
+        double acc[UB][CPT];
+#pragma unroll
+        for (int k = 0; k < UB; ++k)
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) acc[k][c] = 0.0;
+        static_for<0, RPT>([&](auto r) {
+#pragma unroll
+            for (int k = 0; k < UB; ++k)
+#pragma unroll
+                for (int c = 0; c < CPT; ++c) fmac_bcast<(r.value & 15)>(acc[k][c], ek[k][r.value >> 4], areg[c][r.value]);
+        });
+        if (NW > 1) {
+#pragma unroll
+            for (int k = 0; k < UB; ++k)
+#pragma unroll
+                for (int c = 0; c < CPT; ++c) Ps[w][k][lane + 64 * c] = acc[k][c];
+            __syncthreads();
+        }
+#pragma unroll
+        for (int jj = 0; jj < JPW; ++jj) {
+            if (jvalid[jj]) {
+                const int k = jk[jj], c = jc[jj], j = lane + 64 * c;
+                if (step < jlen[jj]) {
+                    double sum;
+                    if (NW > 1) {
+                        sum = Ps[0][k][j];
+#pragma unroll
+                        for (int ww = 1; ww < NW; ++ww) sum += Ps[ww][k][j];
+                    } else {
+                        sum = acc[k][c];
+                    }
+                    const double Sc = Ss[cur][k];
+                    double val;
+                    if (sum >= kSafeSum && sum <= 1e290 && Sc != LN_NEG_INF) {
+                        val = Sc + log_sum(sum, ltab);
+                    } else {                       // exact log-domain column (rare)
+                        val = exact_column_lse(&Cs[cur][k][0], Alog + (j < N ? j : N - 1), N);
+                    }
+                    const int t = frame_of(jj, step);
+                    double prev;
+                    if (BACKWARD) {
+                        if (j < N && op[jj]) op[jj][(size_t)t * N] = val;
+                        prev = val + bcur[jj];
+                    } else {
+                        prev = val + bcur[jj];
+                        if (j < N && op[jj]) op[jj][(size_t)t * N] = prev;
+                    }
+                    if (j >= N) prev = LN_NEG_INF;
+                    double S = Ms[cur][k][0];
+#pragma unroll
+                    for (int cc = 1; cc < CPT; ++cc) S = fmax(S, Ms[cur][k][cc]);
+                    Cs[nxt][k][j] = prev;
+                    Es[nxt][k][j] = (S == LN_NEG_INF || prev == LN_NEG_INF) ? 0.0 : exp_clamped(prev - S, etab);
+                    const double m = wave_max_dpp(prev);
+                    if (lane == 0) Ms[nxt][k][c] = m;
+                    if (c == 0 && lane == 0) Ss[nxt][k] = S;
+                } else {                           // this utterance has ended: carry its state
+                    Cs[nxt][k][j] = Cs[cur][k][j];
+                    Es[nxt][k][j] = Es[cur][k][j];
+                    if (lane == 0) Ms[nxt][k][c] = Ms[cur][k][c];
+                    if (c == 0 && lane == 0) Ss[nxt][k] = Ss[cur][k];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // calc_prob: lse_j alpha[L-1, j]  (hmm.py:274)
+    if (!BACKWARD && loglik && w == 0) {
+        const int fin = (maxlen > 0 ? maxlen - 1 : 0) & 1;
+#pragma unroll
+        for (int k = 0; k < UB; ++k) {
+            if (u0 + k < U && len[k] > 0) {
+                double mx = Ms[fin][k][0];
+#pragma unroll
+                for (int cc = 1; cc < CPT; ++cc) mx = fmax(mx, Ms[fin][k][cc]);
+                double sacc = 0.0;
+#pragma unroll
+                for (int c = 0; c < CPT; ++c) {
+                    const double pv = Cs[fin][k][lane + 64 * c];
+                    sacc += (mx == LN_NEG_INF || pv == LN_NEG_INF) ? 0.0 : exp(pv - mx);
+                }
+                sacc = wave_sum(sacc);
+                if (lane == 0) loglik[u0 + k] = (mx == LN_NEG_INF) ? mx : mx + log(sacc);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward / backward, 64 < N <= 128, four utterances per block: COLUMN-owned blocking.
+// Wave w owns the 16 columns j = 16 w + (lane & 15); the four 16-lane DPP rows of the wave split the
+// 128 source states into groups of 32, so lane (g, c) keeps expA[32 g + r][16 w + c], r < 32, in
+// registers.  A transition is still one v_fmac_f64_dpp (the e value comes from lane n of the row), but
+// the row-group partial sums of a column now sit in the SAME wave: two v_permlane32_swap and one
+// v_permlane16_swap (gfx950) turn the four utterances' partials into "row k holds utterance k's sum",
+// so the whole finalisation (log, emission, store, exp) of 4 utterances x 16 columns runs on all 64
+// lanes of the wave that produced the sums -- no partial sums through the LDS, ONE barrier per frame
+// (fwdbwd_reg: partials through the LDS, two barriers).  Same shift rule, same exact fallback.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void swap32_f64(double& a, double& b) {     // a[63:32] <-> b[31:0]
+    auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)hi[0], (int)lo[0]);
+    b = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ void swap16_f64(double& a, double& b) {     // odd rows of a <-> even rows of b
+    auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)hi[0], (int)lo[0]);
+    b = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ double row_max_dpp(double x) {             // max over the 16 lanes of a DPP row
+    x = vmax_f64(x, dpp_f64<0xB1>(x));
+    x = vmax_f64(x, dpp_f64<0x4E>(x));
+    x = vmax_f64(x, dpp_f64<0x141>(x));
+    return vmax_f64(x, dpp_f64<0x140>(x));
+}
+
+template <bool BACKWARD>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void fwdbwd_cols(
+    const double* __restrict__ b, const double* __restrict__ Aexp, const double* __restrict__ Alog,
+    const double* __restrict__ pi, const int32_t* __restrict__ lens, double* __restrict__ out,
+    double* __restrict__ loglik, int U, int T, int N) {
+    constexpr int NP = 128, UB = 4, NW = 8;
+    __shared__ double Es[2][UB][NP];      // exp(prev - shift) of the frame being consumed
+    __shared__ double Cs[2][UB][NP];      // prev itself (log domain) for the exact fallback
+    __shared__ double Ms[2][UB][NW];      // per wave (16 columns) max of prev
+    __shared__ double Ss[2][UB];          // shift the e values of this buffer were computed with
+    __shared__ double etab[kExpTab];
+    __shared__ double ltab[2 * kLogTab];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    exp_table_init(etab, threadIdx.x, 64 * NW);
+    log_table_init(ltab, threadIdx.x, 64 * NW);   // visible after the first __syncthreads below
+    const int u0 = blockIdx.x * UB;
+    const int g = lane >> 4, c = lane & 15;
+    const int j = 16 * w + c;                      // the lane's column, products and finalisation alike
+    const int jc = j < N ? j : N - 1;
+
+    double areg[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+        const int i = 32 * g + r;
+        areg[r] = (i < N && j < N) ? Aexp[(size_t)i * N + j] : 0.0;
+    }
+    int maxlen = 0;
+#pragma unroll
+    for (int k = 0; k < UB; ++k) {
+        const int l = (u0 + k < U) ? lens[u0 + k] : 0;
+        maxlen = l > maxlen ? l : maxlen;
+    }
+    // finalisation role: row g of the wave is utterance k = g
+    const int k = g;
+    const int uu = (u0 + k < U) ? u0 + k : U - 1;
+    const int klen = (u0 + k < U) ? lens[u0 + k] : 0;
+    const double* bp = b + (size_t)uu * T * N + jc;
+    double* op = out ? out + (size_t)uu * T * N + jc : nullptr;
+    auto frame_of = [&](int step) { return BACKWARD ? klen - 1 - step : step; };
+    auto clampt = [&](int t) { return t < 0 ? 0 : (t > T - 1 ? T - 1 : t); };
+
+    // step 0
+    {
+        double prev = LN_NEG_INF;
+        if (j < N && klen > 0) {
+            const int t0 = frame_of(0);
+            const double bv = bp[(size_t)t0 * N];
+            if (BACKWARD) {
+                if (op) op[(size_t)t0 * N] = 0.0;
+                prev = 0.0 + bv;
+            } else {
+                prev = pi[j] + bv;
+                if (op) op[0] = prev;
+            }
+        }
+        Cs[0][k][j] = prev;
+        const double m = row_max_dpp(prev);
+        if (c == 0) Ms[0][k][w] = m;
+    }
+    __syncthreads();
+    {
+        double S = Ms[0][k][0];
+#pragma unroll
+        for (int ww = 1; ww < NW; ++ww) S = fmax(S, Ms[0][k][ww]);
+        const double prev = Cs[0][k][j];
+        Es[0][k][j] = (S == LN_NEG_INF || prev == LN_NEG_INF) ? 0.0 : exp_clamped(prev - S, etab);
+        if (w == 0 && c == 0) Ss[0][k] = S;
+    }
+    double bnext = bp[(size_t)clampt(frame_of(1)) * N];
+    drain_vmem();                                  // areg resident: no vmcnt guards in the loop
+    __syncthreads();
+
+    for (int step = 1; step < maxlen; ++step) {
+        const int cur = (step - 1) & 1, nxt = step & 1;
+        const double bcur = bnext;
+        bnext = bp[(size_t)clampt(frame_of(step + 1)) * N];
+        // e values of the four utterances for this lane's row group: lane (g, c) holds e[32 g + 16 q + c]
+        double ek[UB][2];
+#pragma unroll
+        for (int kk = 0; kk < UB; ++kk)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) ek[kk][q] = Es[cur][kk][32 * g + 16 * q + c];
+        double acc[UB];
+#pragma unroll
+        for (int kk = 0; kk < UB; ++kk) acc[kk] = 0.0;
+        static_for<0, 32>([&](auto r) {
+#pragma unroll
+            for (int kk = 0; kk < UB; ++kk) fmac_bcast<(r.value & 15)>(acc[kk], ek[kk][r.value >> 4], areg[r.value]);
+        });
+        // row groups -> utterances: after the swaps row k of `sum` holds utterance k's total,
+        // ((g0 + g2) + (g1 + g3)) in every lane
+        swap32_f64(acc[0], acc[2]);
+        swap32_f64(acc[1], acc[3]);
+        double s02 = acc[0] + acc[2], s13 = acc[1] + acc[3];
+        swap16_f64(s02, s13);
+        const double sum = s02 + s13;
+
+        if (step < klen) {
+            const double Sc = Ss[cur][k];
+            double val;
+            if (sum >= kSafeSum && sum <= 1e290 && Sc != LN_NEG_INF) {
+                val = Sc + log_sum(sum, ltab);
+            } else {                               // exact log-domain column (rare)
+                val = exact_column_lse(&Cs[cur][k][0], Alog + jc, N);
+            }
+            const int t = frame_of(step);
+            double prev;
+            if (BACKWARD) {
+                if (j < N && op) op[(size_t)t * N] = val;
+                prev = val + bcur;
+            } else {
+                prev = val + bcur;
+                if (j < N && op) op[(size_t)t * N] = prev;
+            }
+            if (j >= N) prev = LN_NEG_INF;
+            double S = Ms[cur][k][0];
+#pragma unroll
+            for (int ww = 1; ww < NW; ++ww) S = fmax(S, Ms[cur][k][ww]);
+            Cs[nxt][k][j] = prev;
+            Es[nxt][k][j] = (S == LN_NEG_INF || prev == LN_NEG_INF) ? 0.0 : exp_clamped(prev - S, etab);
+            const double m = row_max_dpp(prev);
+            if (c == 0) Ms[nxt][k][w] = m;
+            if (w == 0 && c == 0) Ss[nxt][k] = S;
+        } else {                                   // this utterance has ended: carry its state
+            Cs[nxt][k][j] = Cs[cur][k][j];
+            Es[nxt][k][j] = Es[cur][k][j];
+            if (c == 0) Ms[nxt][k][w] = Ms[cur][k][w];
+            if (w == 0 && c == 0) Ss[nxt][k] = Ss[cur][k];
+        }
+        __syncthreads();
+    }
+    // calc_prob: lse_j alpha[L-1, j]  (hmm.py:274)
+    if (!BACKWARD && loglik && w == 0) {
+        const int fin = (maxlen > 0 ? maxlen - 1 : 0) & 1;
+#pragma unroll
+        for (int kk = 0; kk < UB; ++kk) {
+            if (u0 + kk < U && lens[u0 + kk] > 0) {
+                double mx = Ms[fin][kk][0];
+#pragma unroll
+                for (int ww = 1; ww < NW; ++ww) mx = fmax(mx, Ms[fin][kk][ww]);
+                double sacc = 0.0;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const double pv = Cs[fin][kk][lane + 64 * h];
+                    sacc += (mx == LN_NEG_INF || pv == LN_NEG_INF) ? 0.0 : exp(pv - mx);
+                }
+                sacc = wave_sum(sacc);
+                if (lane == 0) loglik[u0 + kk] = (mx == LN_NEG_INF) ? mx : mx + log(sacc);
+            }
+        }
+    }
+}
+
+// The same column-owned scheme with TWO utterances per block of FOUR waves (round 3).  A wave owns 32 columns (two per
+// lane: 64 transition entries = 128 registers), so a block is one wave per SIMD and two blocks share a CU: two waves per SIMD
+// as before, but from blocks that do not share a barrier.  With four utterances behind one barrier all eight waves were in
+// the same phase -- SQ counters of fwdbwd_cols: vector issue 63 % of the kernel, 40 % of every wave's time in s_waitcnt (the e
+// vector right after the barrier, the log / exp table look-ups of the finalisation) with its SIMD partner waiting on the
+// same thing.  Independent blocks drift apart and one's product phase runs under the other's waits (what merging the two
+// Viterbi blocks of a CU behind one barrier had shown from the other side: 1.37 -> 2.68 ms).  The four accumulators of a
+// lane are now (utterance, column half) instead of four utterances; the swap network is unchanged and leaves combination
+// m = 2 k + h in row m: row g of a wave finalises utterance g >> 1, column 32 w + 16 (g & 1) + c.
+// TS = storage type of b and alpha / beta.  float (`precision=np.float32`): the arithmetic stays fp64 -- A and pi are
+// float64 arrays in the reference, so alpha[t-1] + A[:, j] is a float64 sum there too -- and every alpha[t, j] / beta[t, i]
+// is rounded to float where the reference's float32 array rounds it, at the store (hmm.py:93-99, 124-130); the next
+// frame continues from the ROUNDED value, as the reference reads its array back.
+template <bool BACKWARD, typename TS = double>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void fwdbwd_cols2(
+    const TS* __restrict__ b, const double* __restrict__ Aexp, const double* __restrict__ Alog,
+    const double* __restrict__ pi, const int32_t* __restrict__ lens, TS* __restrict__ out,
+    double* __restrict__ loglik, int U, int T, int N, unsigned* __restrict__ nan_flag, unsigned nan_epoch) {
+    constexpr int NP = 128, UB = 2, NW = 4, NM = 2 * NW;   // NM: partial maxima per utterance (wave x column half)
+    // a NaN emission: np.logaddexp carries it into every later (earlier) frame, the maxima here drop it.  The value the
+    // lanes finalise is NaN exactly then; one compare into the scalar unit per frame raises the flag for nanfix.hip
+    unsigned long long saw_nan = 0;
+    __shared__ double Es[2][UB][NP];      // exp(prev - shift) of the frame being consumed
+    __shared__ double Cs[2][UB][NP];      // prev itself (log domain) for the exact fallback
+    __shared__ double Ms[2][UB][NM];      // per DPP row (16 columns) max of prev
+    __shared__ double Ss[2][UB];          // shift the e values of this buffer were computed with
+    __shared__ double etab[kExpTab];
+    __shared__ double ltab[2 * kLogTab];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    exp_table_init(etab, threadIdx.x, 64 * NW);
+    log_table_init(ltab, threadIdx.x, 64 * NW);   // visible after the first __syncthreads below
+    const int u0 = blockIdx.x * UB;
+    const unsigned cls = blockIdx.x >= (gridDim.x + 1) / 2 ? 1u : 0u;      // the two blocks of a CU: alternate_priority
+    const int g = lane >> 4, c = lane & 15;
+
+    double areg[2][32];                            // product role: columns 32 w + 16 q + c, source rows 32 g + r
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            const int i = 32 * g + r, jq = 32 * w + 16 * q + c;
+            areg[q][r] = (i < N && jq < N) ? Aexp[(size_t)i * N + jq] : 0.0;
+        }
+    int maxlen = 0;
+#pragma unroll
+    for (int kk = 0; kk < UB; ++kk) {
+        const int l = (u0 + kk < U) ? lens[u0 + kk] : 0;
+        maxlen = l > maxlen ? l : maxlen;
+    }
+    // finalisation role: row g of the wave is utterance k, column half h
+    const int k = g >> 1, h = g & 1;
+    const int j = 32 * w + 16 * h + c;
+    const int jc = j < N ? j : N - 1;
+    const int uu = (u0 + k < U) ? u0 + k : U - 1;
+    const int klen = (u0 + k < U) ? lens[u0 + k] : 0;
+    const TS* bp = b + (size_t)uu * T * N + jc;
+    TS* op = out ? out + (size_t)uu * T * N + jc : nullptr;
+    auto frame_of = [&](int step) { return BACKWARD ? klen - 1 - step : step; };
+    auto clampt = [&](int t) { return t < 0 ? 0 : (t > T - 1 ? T - 1 : t); };
+
+    // step 0
+    {
+        double prev = LN_NEG_INF;
+        if (j < N && klen > 0) {
+            const int t0 = frame_of(0);
+            const double bv = (double)bp[(size_t)t0 * N];
+            if (BACKWARD) {
+                if (op) op[(size_t)t0 * N] = (TS)0.0;
+                prev = 0.0 + bv;
+            } else {
+                prev = rnd<TS>(pi[j] + bv);
+                if (op) op[0] = (TS)prev;
+            }
+        }
+        saw_nan |= __ballot(prev != prev);
+        Cs[0][k][j] = prev;
+        const double m = row_max_dpp(prev);
+        if (c == 0) Ms[0][k][2 * w + h] = m;
+    }
+    __syncthreads();
+    {
+        double S = Ms[0][k][0];
+#pragma unroll
+        for (int e = 1; e < NM; ++e) S = fmax(S, Ms[0][k][e]);
+        const double prev = Cs[0][k][j];
+        Es[0][k][j] = (S == LN_NEG_INF || prev == LN_NEG_INF) ? 0.0 : exp_clamped(prev - S, etab);
+        if (w == 0 && h == 0 && c == 0) Ss[0][k] = S;
+    }
+    double bnext = (double)bp[(size_t)clampt(frame_of(1)) * N];
+    drain_vmem();                                  // areg resident: no vmcnt guards in the loop
+    __syncthreads();
+
+    for (int step = 1; step < maxlen; ++step) {
+        if ((step & 7) == 0) alternate_priority(cls);
+        const int cur = (step - 1) & 1, nxt = step & 1;
+        const double bcur = bnext;
+        bnext = (double)bp[(size_t)clampt(frame_of(step + 1)) * N];
+        // e values of both utterances for this lane's row group: lane (g, c) holds e[32 g + 16 q + c]
+        double ek[UB][2];
+#pragma unroll
+        for (int kk = 0; kk < UB; ++kk)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) ek[kk][q] = Es[cur][kk][32 * g + 16 * q + c];
+        double acc[UB][2];                         // [utterance][column half]
+#pragma unroll
+        for (int kk = 0; kk < UB; ++kk)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) acc[kk][q] = 0.0;
+        static_for<0, 32>([&](auto r) {
+#pragma unroll
+            for (int kk = 0; kk < UB; ++kk)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) fmac_bcast<(r.value & 15)>(acc[kk][q], ek[kk][r.value >> 4], areg[q][r.value]);
+        });
+        // row groups -> (utterance, column half): after the swaps row m of `sum` holds combination m = 2 k + h,
+        // ((g0 + g2) + (g1 + g3)) in every lane
+        swap32_f64(acc[0][0], acc[1][0]);
+        swap32_f64(acc[0][1], acc[1][1]);
+        double s02 = acc[0][0] + acc[1][0], s13 = acc[0][1] + acc[1][1];
+        swap16_f64(s02, s13);
+        const double sum = s02 + s13;
+
+        bool prev_nan = false;
+        if (step < klen) {
+            const double Sc = Ss[cur][k];
+            double val;
+            if (sum >= kSafeSum && sum <= 1e290 && Sc != LN_NEG_INF) {
+                val = Sc + log_sum(sum, ltab);
+            } else {                               // exact log-domain column (rare)
+                val = exact_column_lse(&Cs[cur][k][0], Alog + jc, N);
+            }
+            const int t = frame_of(step);
+            double prev;
+            if (BACKWARD) {
+                val = rnd<TS>(val);
+                if (j < N && op) op[(size_t)t * N] = (TS)val;
+                prev = val + bcur;
+            } else {
+                prev = rnd<TS>(val + bcur);
+                if (j < N && op) op[(size_t)t * N] = (TS)prev;
+            }
+            if (j >= N) prev = LN_NEG_INF;
+            prev_nan = prev != prev;
+            double S = Ms[cur][k][0];
+#pragma unroll
+            for (int e = 1; e < NM; ++e) S = fmax(S, Ms[cur][k][e]);
+            Cs[nxt][k][j] = prev;
+            Es[nxt][k][j] = (S == LN_NEG_INF || prev == LN_NEG_INF) ? 0.0 : exp_clamped(prev - S, etab);
+            const double m = row_max_dpp(prev);
+            if (c == 0) Ms[nxt][k][2 * w + h] = m;
+            if (w == 0 && h == 0 && c == 0) Ss[nxt][k] = S;
+        } else {                                   // this utterance has ended: carry its state
+            Cs[nxt][k][j] = Cs[cur][k][j];
+            Es[nxt][k][j] = Es[cur][k][j];
+            if (c == 0) Ms[nxt][k][2 * w + h] = Ms[cur][k][2 * w + h];
+            if (w == 0 && h == 0 && c == 0) Ss[nxt][k] = Ss[cur][k];
+        }
+        saw_nan |= __ballot(prev_nan);             // outside the branch: the rows of a wave end at different frames
+        __syncthreads();
+    }
+    if (saw_nan != 0 && lane == 0) *nan_flag = nan_epoch;
+    // calc_prob: lse_j alpha[L-1, j]  (hmm.py:274)
+    if (!BACKWARD && loglik && w == 0) {
+        const int fin = (maxlen > 0 ? maxlen - 1 : 0) & 1;
+#pragma unroll
+        for (int kk = 0; kk < UB; ++kk) {
+            if (u0 + kk < U && lens[u0 + kk] > 0) {
+                double mx = Ms[fin][kk][0];
+#pragma unroll
+                for (int e = 1; e < NM; ++e) mx = fmax(mx, Ms[fin][kk][e]);
+                double sacc = 0.0;
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const double pv = Cs[fin][kk][lane + 64 * hh];
+                    sacc += (mx == LN_NEG_INF || pv == LN_NEG_INF) ? 0.0 : exp(pv - mx);
+                }
+                sacc = wave_sum(sacc);
+                if (lane == 0) loglik[u0 + kk] = (mx == LN_NEG_INF) ? mx : mx + log(sacc);
+            }
+        }
+    }
+}
+
+
+int forward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d_lens, int dtype, void* alpha,
+                   double* loglik) {
+    LN_DEVPTR(b); LN_DEVPTR(d_lens); LN_DEVPTR(alpha); LN_DEVPTR(loglik);
+    Model& md = ctx->model;
+    const int N = md.N;
+    ctx->fwd_nan_tested = false;
+    // precision=np.float32: float storage, every alpha rounded at its store and the recursion continued from the
+    // rounded value, as the reference's float32 array does (hmm.py:93-99).  N <= 128: the column-owned kernel with float
+    // storage; 128 < N <= 256: the on-chip kernel with float storage; otherwise (and under LNASR_F32_GENERIC /
+    // LNASR_NO_REGFWD / LNASR_NO_COLFWD) the storage-templated generic kernel below -- the same rounding everywhere.
+    if (dtype == LNASR_F32 && !sw().f32_generic) {
+        if (N <= dispatch::kRegMaxN && !sw().no_regfwd && !sw().no_colfwd) {
+            LN_LAUNCH(ctx, "forward_cols2_f32", (fwdbwd_cols2<false, float>), dim3((U + 1) / 2), dim3(256), 0, (const float*)b,
+                      md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens, (float*)alpha, loglik, U, T,
+                      N, ctx->nan_flag.as<unsigned>() + 2, ctx->nan_epoch);
+            ctx->fwd_nan_tested = true;
+            return 0;
+        }
+        if (N > dispatch::kRegMaxN && N <= dispatch::kOnChipMaxN && !sw().no_t256)
+            return trellis256_device(ctx, 1, b, U, T, d_lens, LNASR_F32, alpha, loglik);
+    }
+    if (dtype == LNASR_F64 && N <= dispatch::kRegMaxN && !sw().no_regfwd) {
+        if (N <= dispatch::kReg64MaxN)
+            LN_LAUNCH(ctx, "forward_reg_n64", (fwdbwd_reg<false, 1, 2, 32, 2, 3>), dim3((U + 1) / 2), dim3(128), 0,
+                      (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
+                      (double*)alpha, loglik, U, T, N);
+        else
+            // column-owned waves, two utterances per four-wave block, two blocks per CU (fwdbwd_cols2): measured against the
+            // eight-wave kernels at every batch size -- 16 ... 512 utterances 0.83-0.87 ms against 0.96-1.02 (fwdbwd_reg, two
+            // per block), 1000 utterances 1.23 against 1.45 (fwdbwd_cols, four per block)
+            if (!sw().no_colfwd && sw().fwd != 'c')
+            {
+                LN_LAUNCH(ctx, "forward_cols2_n128", (fwdbwd_cols2<false>), dim3((U + 1) / 2), dim3(256), 0,
+                          (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
+                          (double*)alpha, loglik, U, T, N, ctx->nan_flag.as<unsigned>() + 2, ctx->nan_epoch);
+                ctx->fwd_nan_tested = true;
+            }
+            else if (!sw().no_colfwd)            // LNASR_FWD=c: four per eight-wave block
+                LN_LAUNCH(ctx, "forward_cols_n128", (fwdbwd_cols<false>), dim3((U + 3) / 4), dim3(512), 0,
+                          (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
+                          (double*)alpha, loglik, U, T, N);
+            else if (!dispatch::fwdbwd_reg_four_per_block(U, ctx->prop.multiProcessorCount))      // row-owned waves, partial sums through the LDS
+                LN_LAUNCH(ctx, "forward_reg_n128", (fwdbwd_reg<false, 2, 8, 16, 2, 4>), dim3((U + 1) / 2), dim3(512), 0,
+                          (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
+                          (double*)alpha, loglik, U, T, N);
+            else
+                LN_LAUNCH(ctx, "forward_reg_n128", (fwdbwd_reg<false, 2, 8, 16, 4, 2>), dim3((U + 3) / 4), dim3(512), 0,
+                          (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
+                          (double*)alpha, loglik, U, T, N);
+        return 0;
+    }
+    if (dtype == LNASR_F64 && N > dispatch::kRegMaxN && N <= dispatch::kOnChipMaxN && !sw().no_t256)
+        return trellis256_device(ctx, 1, b, U, T, d_lens, LNASR_F64, alpha, loglik);
+    if (dtype == LNASR_F64 && N > dispatch::kOnChipMaxN && dispatch::fwdbwd_framepar(N, U))
+        return fwdbwd_frames_device(ctx, false, (const double*)b, U, T, d_lens, (double*)alpha, loglik);
+    if (dtype == LNASR_F64 && N > dispatch::kRegMaxN && N <= dispatch::kStreamMaxN && !sw().no_stream)
+        return fwdbwd_stream_device(ctx, false, (const double*)b, U, T, d_lens, (double*)alpha, loglik);
+    int nt = ((N + 63) / 64) * 64;
+    if (nt > 1024) nt = 1024;
+    LN_REQUIRE(N <= 4 * nt, "N=%d too large for the forward kernel", N);
+    const size_t shmem = (size_t)(2 * N + 32) * 8;
+    if (dtype == LNASR_F32)
+        LN_LAUNCH(ctx, "forward_f32", (fwdbwd_generic<float, false>), dim3(U), dim3(nt), shmem, (const float*)b,
+                  md.logA.as<double>(), md.expA.as<double>(), md.logpi.as<double>(), d_lens, (float*)alpha, loglik,
+                  U, T, N);
+    else
+        LN_LAUNCH(ctx, "forward", (fwdbwd_generic<double, false>), dim3(U), dim3(nt), shmem, (const double*)b,
+                  md.logA.as<double>(), md.expA.as<double>(), md.logpi.as<double>(), d_lens, (double*)alpha, loglik,
+                  U, T, N);
+    return 0;
+}
+
+int backward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d_lens, int dtype, void* beta) {
+    LN_DEVPTR(b); LN_DEVPTR(d_lens); LN_DEVPTR(beta);
+    Model& md = ctx->model;
+    const int N = md.N;
+    ctx->fwd_nan_tested = false;
+    const double* expAT = md.expAT.as<double>();
+    if (dtype == LNASR_F32 && !sw().f32_generic) {       // float storage, rounded at every store (hmm.py:124-130); see forward_device
+        if (N <= dispatch::kRegMaxN && !sw().no_regfwd && !sw().no_colfwd) {
+            LN_LAUNCH(ctx, "backward_cols2_f32", (fwdbwd_cols2<true, float>), dim3((U + 1) / 2), dim3(256), 0, (const float*)b,
+                      expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (float*)beta, (double*)nullptr, U, T, N,
+                      ctx->nan_flag.as<unsigned>() + 2, ctx->nan_epoch);
+            ctx->fwd_nan_tested = true;
+            return 0;
+        }
+        if (N > dispatch::kRegMaxN && N <= dispatch::kOnChipMaxN && !sw().no_t256)
+            return trellis256_device(ctx, 2, b, U, T, d_lens, LNASR_F32, beta, nullptr);
+    }
+    if (dtype == LNASR_F64 && N <= dispatch::kRegMaxN && !sw().no_regfwd) {
+        if (N <= dispatch::kReg64MaxN)
+            LN_LAUNCH(ctx, "backward_reg_n64", (fwdbwd_reg<true, 1, 2, 32, 2, 3>), dim3((U + 1) / 2), dim3(128), 0,
+                      (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
+                      (double*)nullptr, U, T, N);
+        else
+            if (!sw().no_colfwd && sw().fwd != 'c')
+            {
+                LN_LAUNCH(ctx, "backward_cols2_n128", (fwdbwd_cols2<true>), dim3((U + 1) / 2), dim3(256), 0,
+                          (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
+                          (double*)nullptr, U, T, N, ctx->nan_flag.as<unsigned>() + 2, ctx->nan_epoch);
+                ctx->fwd_nan_tested = true;
+            }
+            else if (!sw().no_colfwd)
+                LN_LAUNCH(ctx, "backward_cols_n128", (fwdbwd_cols<true>), dim3((U + 3) / 4), dim3(512), 0,
+                          (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
+                          (double*)nullptr, U, T, N);
+            else if (!dispatch::fwdbwd_reg_four_per_block(U, ctx->prop.multiProcessorCount))
+                LN_LAUNCH(ctx, "backward_reg_n128", (fwdbwd_reg<true, 2, 8, 16, 2, 4>), dim3((U + 1) / 2), dim3(512), 0,
+                          (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
+                          (double*)nullptr, U, T, N);
+            else
+                LN_LAUNCH(ctx, "backward_reg_n128", (fwdbwd_reg<true, 2, 8, 16, 4, 2>), dim3((U + 3) / 4), dim3(512), 0,
+                          (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
+                          (double*)nullptr, U, T, N);
+        return 0;
+    }
+    if (dtype == LNASR_F64 && N > dispatch::kRegMaxN && N <= dispatch::kOnChipMaxN && !sw().no_t256)
+        return trellis256_device(ctx, 2, b, U, T, d_lens, LNASR_F64, beta, nullptr);
+    if (dtype == LNASR_F64 && N > dispatch::kOnChipMaxN && dispatch::fwdbwd_framepar(N, U))
+        return fwdbwd_frames_device(ctx, true, (const double*)b, U, T, d_lens, (double*)beta, nullptr);
+    if (dtype == LNASR_F64 && N > dispatch::kRegMaxN && N <= dispatch::kStreamMaxN && !sw().no_stream)
+        return fwdbwd_stream_device(ctx, true, (const double*)b, U, T, d_lens, (double*)beta, nullptr);
+    int nt = ((N + 63) / 64) * 64;
+    if (nt > 1024) nt = 1024;
+    LN_REQUIRE(N <= 4 * nt, "N=%d too large for the backward kernel", N);
+    const size_t shmem = (size_t)(2 * N + 32) * 8;
+    if (dtype == LNASR_F32)
+        LN_LAUNCH(ctx, "backward_f32", (fwdbwd_generic<float, true>), dim3(U), dim3(nt), shmem, (const float*)b,
+                  md.logAT.as<double>(), expAT, md.logpi.as<double>(), d_lens, (float*)beta, (double*)nullptr, U, T,
+                  N);
+    else
+        LN_LAUNCH(ctx, "backward", (fwdbwd_generic<double, true>), dim3(U), dim3(nt), shmem, (const double*)b,
+                  md.logAT.as<double>(), expAT, md.logpi.as<double>(), d_lens, (double*)beta, (double*)nullptr, U, T,
+                  N);
+    return 0;
+}
+
+}  // namespace lnasr

@@ -1072,6 +1072,7 @@ int emit_device(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, v
 }
 
 int emit_device_raw(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, void* bm, bool* scanned, bool* rows_done) {
+    LN_DEVPTR(obs); LN_DEVPTR(b); LN_DEVPTR(bm);
     Model& md = ctx->model;
     bool rows_dummy = false;
     if (!rows_done) rows_done = &rows_dummy;

@@ -343,6 +343,7 @@ static int launch_full(lnasr_ctx* ctx, const double* obs, long F, double* b, dou
 
 // returns 1 if the launch was issued, 0 if this model / dtype is not covered, < 0 on error
 int emit_full_mfma_device(lnasr_ctx* ctx, const double* obs, long F, double* b, double* bm) {
+    LN_DEVPTR(obs); LN_DEVPTR(b); LN_DEVPTR(bm);
     Model& md = ctx->model;
     if (md.wfull_Q == 0 || sw().no_mfma) return 0;
     const int N = md.N, M = md.M, virt = md.wfull_virt;

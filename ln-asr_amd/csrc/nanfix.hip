@@ -397,6 +397,7 @@ int locate_chunks(int U) {
 bool nan_rows_rescored(const Model& md) { return !md.diag || md.D == 1; }
 
 int nan_rows_device(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, void* bm, bool force) {
+    LN_DEVPTR(obs); LN_DEVPTR(b); LN_DEVPTR(bm);
     if (F <= 0) return 0;
     const Model& md = ctx->model;
     const long E = F * (long)md.D;
@@ -429,6 +430,7 @@ int nan_rows_device(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* 
 
 int viterbi_nan_repair(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d_lens, int dtype, void* v,
                        uint32_t* path, double* best, bool force) {
+    LN_DEVPTR(b); LN_DEVPTR(d_lens); LN_DEVPTR(v); LN_DEVPTR(path); LN_DEVPTR(best);
     if (U <= 0 || T <= 0) return 0;
     const int N = ctx->model.N;
     const int C = locate_chunks(U);
@@ -463,6 +465,7 @@ int viterbi_nan_repair(lnasr_ctx* ctx, const void* b, int U, int T, const int32_
 // kernel met a NaN" (fwdbwd_cols2 tests the value it finalises; the other kernels leave the scan to `force`)
 int trellis_nan_repair(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d_lens, int dtype, void* alpha,
                        double* loglik, void* beta, bool force) {
+    LN_DEVPTR(b); LN_DEVPTR(d_lens);
     if (U <= 0 || T <= 0) return 0;
     const int N = ctx->model.N;
     const int C = locate_chunks(U);
@@ -505,6 +508,7 @@ static int raise_flag_if_bad(lnasr_ctx* ctx, const double* obs, int U, int T) {
 
 int viterbi_nan_repair_obs(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* d_lens, double* v,
                            uint32_t* path, double* best, bool force) {
+    LN_DEVPTR(obs); LN_DEVPTR(d_lens); LN_DEVPTR(v); LN_DEVPTR(path); LN_DEVPTR(best);
     if (U <= 0 || T <= 0) return 0;
     LN_REQUIRE(obs && v, "the repair pass needs the observations and the Viterbi lattice");
     if (force) LN_TRY(raise_flag_if_bad(ctx, obs, U, T));
@@ -517,6 +521,7 @@ int viterbi_nan_repair_obs(lnasr_ctx* ctx, const double* obs, int U, int T, cons
 
 int stats_nan_repair(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* d_lens, double* stats, long n,
                      bool force) {
+    LN_DEVPTR(obs); LN_DEVPTR(d_lens); LN_DEVPTR(stats);
     if (U <= 0 || T <= 0 || n <= 0) return 0;
     if (force) LN_TRY(raise_flag_if_bad(ctx, obs, U, T));
     LN_LAUNCH(ctx, "stats_nan_repair", nan_stats_kernel, dim3(U), dim3(256), 0, obs, d_lens, T, ctx->model.D, stats, n,
@@ -525,6 +530,7 @@ int stats_nan_repair(lnasr_ctx* ctx, const double* obs, int U, int T, const int3
 }
 
 int loglik_nan_repair(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* d_lens, double* loglik, bool force) {
+    LN_DEVPTR(obs); LN_DEVPTR(d_lens); LN_DEVPTR(loglik);
     if (U <= 0 || T <= 0) return 0;
     if (force) LN_TRY(raise_flag_if_bad(ctx, obs, U, T));
     LN_LAUNCH(ctx, "loglik_nan_repair", nan_utt_obs_kernel, dim3(U), dim3(256), 0, obs, d_lens, T, ctx->model.D, loglik,

@@ -42,6 +42,7 @@ SIGNATURES = {
     "lnasr_host_free": [_vp, _vp],
     "lnasr_device_info": [_vp, C.c_char_p, _i, _P(_i), _P(_sz)],
     "lnasr_hash128": [_vp, _sz, C.c_uint64, _P(C.c_uint64)],
+    "lnasr_debug_require_device_ptr": [_vp],
     "lnasr_dev_alloc": [_vp, _sz, _P(_vp)],
     "lnasr_dev_free": [_vp, _vp],
     "lnasr_memcpy_h2d": [_vp, _vp, _vp, _sz],

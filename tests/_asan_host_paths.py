@@ -47,7 +47,17 @@ for nbytes in (0, 1, 7, 8, 9, 31, 32, 33, 63, 64, 1000, (1 << 21) - 1, (1 << 21)
         y[at] ^= 1
         assert lib.lnasr_hash128(y.ctypes.data, nbytes, 7, o2) == 0 and tuple(o1) != tuple(o2), (nbytes, at)
     checked += 1
-assert lib.lnasr_hash128(None, 16, 0, o1) < 0 and lib.lnasr_hash128(buf if False else None, 0, 0, None) < 0
+assert lib.lnasr_hash128(None, 16, 0, o1) < 0 and lib.lnasr_hash128(None, 0, 0, None) < 0
+
+# the launch helpers' pointer guard (LN_DEVPTR, always on in this build): a heap pointer -- what a numpy array hands over --
+# is refused with a message that names it; null (an optional output) passes
+heap = np.zeros(64)
+rc = lib.lnasr_debug_require_device_ptr(heap.ctypes.data)
+assert rc == -1 and b"not device memory" in lib.lnasr_last_error(), (rc, lib.lnasr_last_error())
+stack = (C.c_double * 8)()
+assert lib.lnasr_debug_require_device_ptr(C.addressof(stack)) == -1
+assert lib.lnasr_debug_require_device_ptr(None) == 0
+checked += 3
 
 # device count / context creation without a device: an error code and a message, never a crash
 n = C.c_int(-1)
@@ -102,7 +112,8 @@ calls = {
     "lnasr_allgather_paths": (null, u32, 4, 8, u32), "lnasr_allreduce_f64": (null, buf, 4),
 }
 no_ctx = {"lnasr_abi_version", "lnasr_last_error", "lnasr_device_count", "lnasr_ctx_create", "lnasr_ctx_destroy",
-          "lnasr_num_frames", "lnasr_reload_switches", "lnasr_comm_unique_id", "lnasr_comm_destroy", "lnasr_hash128"}
+          "lnasr_num_frames", "lnasr_reload_switches", "lnasr_comm_unique_id", "lnasr_comm_destroy", "lnasr_hash128",
+          "lnasr_debug_require_device_ptr"}
 missing = sorted(set(_ffi.SIGNATURES) - set(calls) - no_ctx)
 assert not missing, "entry points without a null-context call here: %s" % missing
 for fn, args in sorted(calls.items()):

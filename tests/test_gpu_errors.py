@@ -61,3 +61,45 @@ def test_two_contexts_and_reupload(synth, oracle):
     finally:
         a.close()
         b.close()
+
+
+def test_launch_helpers_get_device_pointers_only(synth):
+    """LNASR_CHECK_PTRS=1: every pointer handed to a kernel launcher (`*_device`, `*_nan_repair`, emit_*) is verified
+    with hipPointerGetAttributes first.  Host-array calls of every entry point of the path pass -- the entry points
+    stage them -- with host, pinned and device inputs and outputs mixed; and the guard does fire on a heap pointer."""
+    from conftest import env_switch
+    from lnasr import _ffi
+    from lnasr.gmmhmm import GMMHMM
+    with env_switch(LNASR_CHECK_PTRS=1):
+        ctx = _ffi.default_ctx()
+        heap = np.zeros(16)
+        assert _ffi.lib().lnasr_debug_require_device_ptr(heap.ctypes.data) == -1
+        assert _ffi.lib().lnasr_debug_require_device_ptr(ctx.empty((4,)).ptr) == 0
+        for N, M, D, U, T in ((128, 16, 39, 130, 24), (256, 32, 39, 3, 24), (5, 3, 2, 2, 9), (320, 2, 4, 2, 6)):
+            mdl = synth.synth_model(N, M, D, seed=2)
+            obs = synth.synth_obs(U, T, D, seed=3)
+            ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
+            lens = np.full(U, T, dtype=np.int32)
+            lens[-1] = T - 2
+            for src in (obs, ctx.pinned_copy(obs), ctx.to_device(obs)):
+                p = ctx.decode(src, lens=lens)
+                ll = ctx.calc_prob(src, lens=lens)
+                st = ctx.bw_accumulate(src, lens=lens)
+                st32 = ctx.bw_accumulate(src, lens=lens, precision=np.float32)
+                b, bm = ctx.gmm_logprob(src, want_bm=True)
+                r = ctx.viterbi(b, want_score=True, lens=lens)
+                al, l2 = ctx.forward(b, lens=lens)
+                be = ctx.backward(b, lens=lens)
+                xi, ga = ctx.baumwelch(b, al, be, lens=lens)
+            ctx.sync()
+            # mixed placement: device emissions, host outputs (the mirror classes' route)
+            db = ctx.to_device(np.asarray(b.to_host() if hasattr(b, "to_host") else b))
+            r = ctx.viterbi(db, host_out=True)
+            assert isinstance(r["path"], np.ndarray)
+        mdl = synth.synth_model(5, 3, 2, seed=4)
+        g = GMMHMM(5, 3, 2, mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["si"])
+        o = synth.synth_obs(1, 30, 2, seed=5)[0]
+        g.train(o, iters=2, verbose=False)
+        g32 = GMMHMM(5, 3, 2, mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["si"], precision=np.float32)
+        g32.train(o, iters=2, verbose=False)
+        assert g.decode(o).shape == (30,)

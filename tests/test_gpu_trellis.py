@@ -517,3 +517,65 @@ def test_onchip256_hard_inputs(synth, oracle, ctx):
                 ra, rb = oracle.forward(A, d["pi"], b[u, :L].T), oracle.backward(A, b[u, :L].T)
             assert_close(a0[u, :L], ra, 1e-11, 1e-11), assert_close(be0[u, :L], rb, 1e-11, 1e-11)
             assert_close(l0[u], oracle.loglik(ra), 1e-12)
+
+
+def _ulps32(a, b):
+    """Distance in float32 units in the last place (equal infinities: 0)."""
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    ia, ib = a.view(np.int32).astype(np.int64), b.view(np.int32).astype(np.int64)
+    ia = np.where(ia < 0, -(ia & 0x7fffffff), ia)
+    ib = np.where(ib < 0, -(ib & 0x7fffffff), ib)
+    return np.abs(ia - ib)
+
+
+def test_float32_forward_backward_round_at_every_store(golden, synth, oracle):
+    """precision=np.float32 (hmm.py:93-99, 124-130): the reference stores every alpha[t] / beta[t] into a float32 array
+    and reads it back for the next frame.  The float-storage kernels do the same -- fp64 sum, one rounding at the store,
+    recursion continued from the rounded value -- so alpha and beta equal the reference's float32 arrays bit for bit up
+    to the rare value whose fp64 sum lies within ~1e-15 of a float rounding boundary (then one ulp, never more, and
+    never the drift of a recursion that rounds only once at the end).  Checked against the reference's own arrays
+    (goldens gmmhmm_f32_mid N=32 T=512, gmmhmm_small_f32) and, for the other kernel families, against the oracle run
+    with precision=np.float32: N=128 (column-owned kernel), N=200 (on-chip kernel), N=300 (generic kernel)."""
+    from lnasr import _ffi
+    from lnasr.gmmhmm import GMMHMM
+    ctx = _ffi.default_ctx()
+
+    def check(got, want, what, max_off=2):
+        assert got.dtype == np.float32 and got.shape == want.shape, what
+        d = _ulps32(got, want)
+        assert d.max() <= 1 and int((d > 0).sum()) <= max_off, (what, int(d.max()), int((d > 0).sum()), d.size)
+
+    g = golden("gmmhmm_f32_mid")
+    N, M, D, T = (int(x) for x in g["shape"])
+    mdl = synth.synth_model(N, M, D, seed=int(g["seeds"][0]))
+    obs = synth.synth_obs(1, T, D, seed=int(g["seeds"][1]))[0]
+    gh = GMMHMM(N, M, D, mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["si"], precision=np.float32, ctx=ctx)
+    gh.b = g["b"]                                            # the reference's own float32 emissions
+    check(gh._forward(obs), g["alpha"], "f32_mid alpha")
+    check(gh._backward(obs), g["beta"], "f32_mid beta")
+    ll = gh.ctx.forward(gh._b_dev(), want_alpha=False)[1][0]
+    assert abs(ll - float(g["loglik"][0])) <= 2e-6 * abs(float(g["loglik"][0]))      # the reference folds this one in float32
+    gs = golden("gmmhmm_small_f32")
+    g2 = GMMHMM(5, 3, 2, gs["A"], gs["pi"], gs["w"], gs["mu"], gs["si"], precision=np.float32, ctx=ctx)
+    g2.b = gs["b"]
+    check(g2._forward(gs["obs"]), gs["alpha"], "small_f32 alpha", 0)
+    check(g2._backward(gs["obs"]), gs["beta"], "small_f32 beta", 0)
+    # the other families, against the oracle's float32 recursion; ragged batch, an unreachable state, a -inf emission
+    for N, T, U in ((128, 300, 3), (64, 90, 2), (200, 260, 3), (256, 120, 2), (300, 40, 2)):
+        d = synth.synth_discrete(N, 4, 8, seed=N)
+        A = d["A"].copy()
+        A[:, 3] = -np.inf
+        rng = np.random.default_rng(N + 1)
+        b = (-25.0 * rng.random((U, T, N))).astype(np.float32)
+        b[0, T // 2, 5] = -np.inf
+        lens = np.array([T, T - 7, T - 1][:U], dtype=np.int32)
+        ctx.upload_hmm(A, d["pi"])
+        al, _ = ctx.forward(b, lens=lens)
+        be = ctx.backward(b, lens=lens)
+        for u in range(U):
+            L = int(lens[u])
+            with np.errstate(divide="ignore", invalid="ignore"):
+                oa = oracle.forward(A, d["pi"], b[u, :L].T, precision=np.float32)
+                ob = oracle.backward(A, b[u, :L].T, precision=np.float32)
+            check(al[u, :L], oa, "N=%d alpha u=%d" % (N, u), max_off=max(2, oa.size // 20000))
+            check(be[u, :L], ob, "N=%d beta u=%d" % (N, u), max_off=max(2, ob.size // 20000))

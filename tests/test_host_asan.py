@@ -1,7 +1,8 @@
 """SURVEY.md section 5 (race detection / sanitizers): the host side of the C-ABI under AddressSanitizer + UBSan in the
 CPU suite.  `build.py --host-asan` instruments the host code of every translation unit (device code is compiled as
 usual); the library is then loaded into a python that has the ASan runtime preloaded and driven through its
-no-device paths: symbol table, error plumbing, argument checks of EVERY entry point, the switch table."""
+no-device paths: symbol table, error plumbing, argument checks of EVERY entry point, the switch table, the parameter
+fingerprint (threaded), and the launch helpers' device-pointer guard firing on a heap pointer."""
 import importlib.util
 import os
 import subprocess
