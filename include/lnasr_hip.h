@@ -74,7 +74,8 @@ void lnasr_ctx_destroy(lnasr_ctx* ctx);
 int lnasr_sync(lnasr_ctx* ctx);
 /* every stream of the context's device has drained (hipDeviceSynchronize): the bracket of a timed region */
 int lnasr_device_sync(lnasr_ctx* ctx);
-/* LNASR_* test / ablation switches are read once per process; this re-reads them from the environment */
+/* LNASR_* test / ablation switches are read once per process; this re-reads them from the environment.  Test-only:
+ * not to be called while another thread is inside the library. */
 int lnasr_reload_switches(void);
 int lnasr_device_info(lnasr_ctx* ctx, char* name, int name_cap, int* cu_count, size_t* hbm_bytes);
 
@@ -86,7 +87,11 @@ int lnasr_memcpy_d2h(lnasr_ctx* ctx, void* dst_host, const void* src_dev, size_t
 int lnasr_memset(lnasr_ctx* ctx, void* dst_dev, int byte, size_t bytes);
 /* Page-locked host memory (hipHostMalloc).  The reference hands host arrays to decode() (hmm.py:276-283); a host
  * buffer from here is recognised by every entry point and moves at PCIe rate with no staging copy, a pageable one
- * (plain numpy) goes through the context's pinned staging ring. */
+ * (plain numpy) goes through the context's pinned staging ring.
+ * A page-locked INPUT is read by asynchronous copies: when every output of a call is a device pointer the call
+ * returns with those copies possibly still in flight, so the buffer must stay unchanged until lnasr_sync() (a
+ * pageable input has been consumed when the call returns; a call with a host output always has).
+ * lnasr_host_free: ctx may be NULL for a block that outlives its context (device-wide wait, then freed). */
 int lnasr_host_alloc(lnasr_ctx* ctx, size_t bytes, void** out);
 int lnasr_host_free(lnasr_ctx* ctx, void* p);
 

@@ -1,5 +1,6 @@
 // Runtime: context, device memory, staging, per-kernel HIP-event profiling, errors.
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 
 #include "common.h"
@@ -54,7 +55,7 @@ void Model::release() {
 }
 
 static Switches g_sw;
-static bool g_sw_loaded = false;
+static std::atomic<bool> g_sw_loaded{false};      // release after g_sw is filled, acquire before it is read
 static std::mutex g_sw_mu;
 
 static void load_switches(Switches& s) {
@@ -93,11 +94,11 @@ static void load_switches(Switches& s) {
 }
 
 const Switches& sw() {
-    if (!g_sw_loaded) {
+    if (!g_sw_loaded.load(std::memory_order_acquire)) {
         std::lock_guard<std::mutex> lk(g_sw_mu);
-        if (!g_sw_loaded) {
+        if (!g_sw_loaded.load(std::memory_order_relaxed)) {
             load_switches(g_sw);
-            g_sw_loaded = true;
+            g_sw_loaded.store(true, std::memory_order_release);
         }
     }
     return g_sw;
@@ -325,10 +326,12 @@ int lnasr_device_sync(lnasr_ctx* ctx) {
     return 0;
 }
 
+// TEST-ONLY: rewrites the switch table in place.  Must not run while another thread is inside the library (readers
+// hold a reference to the table without the lock); the test-suite is single-threaded around it.
 int lnasr_reload_switches(void) {
     std::lock_guard<std::mutex> lk(g_sw_mu);
     load_switches(g_sw);
-    g_sw_loaded = true;
+    g_sw_loaded.store(true, std::memory_order_release);
     return 0;
 }
 
@@ -344,9 +347,15 @@ int lnasr_host_alloc(lnasr_ctx* ctx, size_t bytes, void** out) {
 
 int lnasr_host_free(lnasr_ctx* ctx, void* p) {
     LN_ENTER(ctx);
-    LN_REQUIRE(ctx, "null ctx");
     if (!p) return 0;
-    LN_HIP(hipStreamSynchronize(ctx->stream));
+    // the context is only needed to wait for copies that may still read the block; a block that outlives its context
+    // (ctx == NULL) is freed after a device-wide wait instead of being leaked
+    if (ctx) {
+        LN_HIP(hipStreamSynchronize(ctx->stream));
+        LN_HIP(hipStreamSynchronize(ctx->stream2));
+    } else {
+        LN_HIP(hipDeviceSynchronize());
+    }
     LN_HIP(hipHostFree(p));
     return 0;
 }

@@ -199,7 +199,7 @@ class _PinnedBlock:
 
     def __del__(self):
         try:
-            if self.ptr and self.ctx.handle:
+            if self.ptr:                       # a block that outlives its (closed) context is still freed: null ctx
                 lib().lnasr_host_free(self.ctx.handle, self.ptr)
         except Exception:
             pass
@@ -402,8 +402,16 @@ class Context:
         return lens
 
     # -- emission ----------------------------------------------------------------------------
-    def discrete_map_b(self, logB, obs, precision=np.float64, device_out=False):
-        """device_out: leave b in HBM (a DeviceArray) although obs is a host array."""
+    @staticmethod
+    def _reuse(buf, shape, dtype):
+        """`buf` if it is a DeviceArray of exactly this shape and dtype (an output buffer offered for reuse), else None."""
+        if isinstance(buf, DeviceArray) and buf.ptr and buf.shape == tuple(shape) and buf.dtype == np.dtype(dtype):
+            return buf
+        return None
+
+    def discrete_map_b(self, logB, obs, precision=np.float64, device_out=False, b_out=None):
+        """device_out: leave b in HBM (a DeviceArray) although obs is a host array; b_out: a DeviceArray to write into
+        when its shape and dtype fit (saves an allocation per call)."""
         logB = _in(logB, np.float64)
         obs = _in(obs, np.int32)
         if obs.ndim == 1:
@@ -411,12 +419,15 @@ class Context:
         U, T = obs.shape
         N, K = logB.shape
         code = dtype_code(precision)
-        b = self._out(device_out or isinstance(obs, DeviceArray), (U, T, N), np_dtype(code))
+        b = self._reuse(b_out, (U, T, N), np_dtype(code))
+        if b is None:
+            b = self._out(device_out or isinstance(obs, DeviceArray), (U, T, N), np_dtype(code))
         check(lib().lnasr_discrete_map_b(self.handle, _ptr(logB), N, K, _ptr(obs), U, T, code, _ptr(b)))
         return b
 
-    def gmm_logprob(self, obs, want_bm=False, precision=np.float64, lens=None, device_out=False):
-        """device_out: leave b / bm in HBM (DeviceArrays) although obs is a host array."""
+    def gmm_logprob(self, obs, want_bm=False, precision=np.float64, lens=None, device_out=False, b_out=None, bm_out=None):
+        """device_out: leave b / bm in HBM (DeviceArrays) although obs is a host array; b_out / bm_out: DeviceArrays to
+        write into when their shapes and dtypes fit (saves two allocations per call)."""
         obs = _in(obs, np.float64)
         U, T, D = obs.shape
         N, M, D0 = self.model_shape
@@ -424,8 +435,14 @@ class Context:
             raise ValueError("obs has D=%d, model has D=%d" % (D, D0))
         code = dtype_code(precision)
         dev = device_out or isinstance(obs, DeviceArray)
-        b = self._out(dev, (U, T, N), np_dtype(code))
-        bm = self._out(dev, (U, T, N, M), np_dtype(code)) if want_bm else None
+        b = self._reuse(b_out, (U, T, N), np_dtype(code))
+        if b is None:
+            b = self._out(dev, (U, T, N), np_dtype(code))
+        bm = None
+        if want_bm:
+            bm = self._reuse(bm_out, (U, T, N, M), np_dtype(code))
+            if bm is None:
+                bm = self._out(dev, (U, T, N, M), np_dtype(code))
         check(lib().lnasr_gmm_logprob(self.handle, _ptr(obs), U, T, _ptr(self._lens(lens, U)), code, _ptr(b), _ptr(bm)))
         return (b, bm) if want_bm else b
 

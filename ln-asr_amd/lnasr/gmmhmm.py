@@ -63,7 +63,8 @@ class GMMHMM(HMM):
         else:
             batch = np.asarray(obs, dtype=np.float64)[None]
         self._upload_gmm()
-        b, bm = self.ctx.gmm_logprob(batch, want_bm=True, precision=self.precision, device_out=True)
+        b, bm = self.ctx.gmm_logprob(batch, want_bm=True, precision=self.precision, device_out=True,
+                                     b_out=self._device_buffer("b"), bm_out=self._device_buffer("bm"))
         self._keep("b", b, lambda h: h[0].T)                            # [1,T,N] -> [N,T]
         self._keep("bm", bm, lambda h: h[0].transpose(1, 2, 0))         # [1,T,N,M] -> [N,M,T]
         self._model_fresh = True                                        # see HMM._remap_or_upload

@@ -82,6 +82,13 @@ class HMM:
     def _keep(self, name, dev, to_reference_layout):
         self.__dict__.setdefault("_resident", {})[name] = (dev, to_reference_layout)
         self.__dict__.setdefault("_host", {}).pop(name, None)
+        self.__dict__.setdefault("_spare", {}).pop(name, None)
+
+    def _device_buffer(self, name):
+        """The device array the previous _map_b wrote `name` into, offered to the next one as its output buffer (same
+        utterance length: no allocation per call).  Nobody outside holds it: readers get host copies."""
+        res = self.__dict__.get("_resident", {})
+        return res[name][0] if name in res else self.__dict__.get("_spare", {}).get(name)
 
     def _host_get(self, name):
         res = self.__dict__.get("_resident", {})
@@ -89,6 +96,7 @@ class HMM:
         if name in res:
             dev, layout = res.pop(name)          # handed out = the caller may write into it: the host copy rules
             host[name] = layout(dev.to_host())
+            self.__dict__.setdefault("_spare", {})[name] = dev
         try:
             return host[name]
         except KeyError:
@@ -125,7 +133,7 @@ class HMM:
         """b[:, t] = B[:, obs[t]]  (hmm.py:47-61)."""
         obs = np.asarray(obs)
         b = self.ctx.discrete_map_b(np.asarray(self.B, dtype=np.float64), obs.astype(np.int32), self.precision,
-                                    device_out=True)
+                                    device_out=True, b_out=self._device_buffer("b"))
         self._keep("b", b, lambda h: h[0].T)
 
     # ------------------------------------------------------------------ trellises

@@ -87,7 +87,7 @@ off = (C.c_int64 * 2)(0, 16)
 calls = {
     "lnasr_sync": (null,), "lnasr_device_sync": (null,), "lnasr_device_info": (null, name, 32, C.byref(ci), C.byref(szt)),
     "lnasr_dev_alloc": (null, 16, C.byref(h)), "lnasr_dev_free": (null, null), "lnasr_host_alloc": (null, 16, C.byref(h)),
-    "lnasr_host_free": (null, null), "lnasr_memcpy_h2d": (null, buf, buf, 8), "lnasr_memcpy_d2h": (null, buf, buf, 8),
+"lnasr_memcpy_h2d": (null, buf, buf, 8), "lnasr_memcpy_d2h": (null, buf, buf, 8),
     "lnasr_memset": (null, buf, 0, 8), "lnasr_prof_enable": (null, 1), "lnasr_prof_reset": (null,),
     "lnasr_prof_count": (null, C.byref(ci)), "lnasr_prof_get": (null, 0, name, 32, C.byref(i64), C.byref(dbl)),
     "lnasr_model_upload": (null, 2, 2, 2, buf, buf, buf, buf, buf, 1),
@@ -113,7 +113,7 @@ calls = {
 }
 no_ctx = {"lnasr_abi_version", "lnasr_last_error", "lnasr_device_count", "lnasr_ctx_create", "lnasr_ctx_destroy",
           "lnasr_num_frames", "lnasr_reload_switches", "lnasr_comm_unique_id", "lnasr_comm_destroy", "lnasr_hash128",
-          "lnasr_debug_require_device_ptr"}
+          "lnasr_debug_require_device_ptr", "lnasr_host_free"}
 missing = sorted(set(_ffi.SIGNATURES) - set(calls) - no_ctx)
 assert not missing, "entry points without a null-context call here: %s" % missing
 for fn, args in sorted(calls.items()):
@@ -122,6 +122,7 @@ for fn, args in sorted(calls.items()):
     assert lib.lnasr_last_error(), fn
     checked += 1
 assert lib.lnasr_comm_destroy(None) == 0                         # documented no-op
+assert lib.lnasr_host_free(None, None) == 0                      # null block: no-op whatever the context
 assert lib.lnasr_comm_unique_id(None) < 0
 
 # the Python layer turns the codes into exceptions that carry the message

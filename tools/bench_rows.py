@@ -2,7 +2,7 @@
 """Per-row measurements of the other BASELINE.json configs on one GPU (development / DESIGN.md numbers;
 the driver-facing benchmark is bench.py).  Inputs resident in HBM, HIP-event kernel times.
 
-    python tools/bench_rows.py [mfcc] [e2e] [seg] [gmm] [fwd] [bw] [refapi] [all]
+    python tools/bench_rows.py [mfcc] [e2e] [seg] [gmm] [fwd] [bw] [refapi] [nanfix] [all]
 """
 import os
 import sys
@@ -96,6 +96,28 @@ if what & {"refapi", "all"}:
         print("refapi %-22s wall %8.3f ms  device %8.3f ms  host %8.3f ms   %s" % (k, v["wall_ms"], v["device_ms"], v["host_ms"], v["kernels"]))
     print("refapi parameter fingerprint %.3f ms per call; b + bm read back afterwards %.3f ms; reference decode() %.0f ms"
           % (r["parameter_fingerprint_ms"], r["read_b_and_bm_afterwards_ms"], r["reference_decode_ms"]))
+
+if what & {"nanfix", "all"}:
+    # What the non-finite-data checks cost on CLEAN data (the parity suite asserts launch counts only):
+    # decode (the emission kernel tested the features it staged: one launch that reads a word), lnasr_viterbi on a dense
+    # model (the back-trace kernel looked at v), and lnasr_viterbi on a LEFT-TO-RIGHT model, whose -inf transitions put
+    # -inf cells into v on perfectly clean data: the suspect word is raised and the repair kernel scans b for nothing.
+    U, T, N, M, D = 64, 1000, 128, 16, 39
+    mdl = synth.synth_model(N, M, D, seed=1)
+    ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
+    obs = ctx.to_device(synth.synth_obs(U, T, D, seed=5))
+    timed("nanfix: decode, clean data (U=%d)" % U, lambda: ctx.decode(obs), U * T, "frames")
+    b = ctx.gmm_logprob(obs)
+    timed("nanfix: viterbi, dense model", lambda: ctx.viterbi(b, want_v=False, want_bt=False), U * T, "frames")
+    A = mdl["A"].copy()
+    A[np.tril_indices(N, -1)] = -np.inf                  # left-to-right: no way back
+    ctx.upload_hmm(A, mdl["pi"])
+    timed("nanfix: viterbi, left-to-right model", lambda: ctx.viterbi(b, want_v=False, want_bt=False), U * T, "frames")
+    b1 = ctx.to_device(b.to_host()[:1])
+    timed("nanfix: viterbi, left-to-right, U=1", lambda: ctx.viterbi(b1, want_v=False, want_bt=False), T, "frames")
+    ctx.upload_hmm(mdl["A"], mdl["pi"])
+    timed("nanfix: viterbi, dense, U=1", lambda: ctx.viterbi(b1, want_v=False, want_bt=False), T, "frames")
+    del b, b1, obs
 
 if what & {"gmm", "all"}:
     # config 3: T=1000, M=16, D=39, U=1024; single GMM (N=1) and the 128-state bank
