@@ -1,7 +1,7 @@
 """Discrete-observation HMM with the reference's call surface (lnasr/hmm.py:16-313).
 
 All probabilities (A, B, pi, b, alpha, beta, v, xi, gamma) are natural-log values; `A[i, j]`
-is the transition i -> j.  Every trellis below runs in HIP kernels (csrc/trellis.hip,
+is the transition i -> j.  Every trellis below runs in HIP kernels (csrc/viterbi.hip, backtrace.hip, fwdbwd.hip,
 csrc/estimate.hip); this class only keeps the reference's state (`self.b`), shapes, dtypes and
 print format.  Arrays returned are fresh numpy arrays in the reference's layouts:
 `b [N,T]`, `alpha/beta/v [T,N]`, `bt [T,N] uint32`, `path [T] uint32`, `xi [T,N,N]`.
