@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Builds liblnasr_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
 
-    python ln-asr_amd/build.py [--force] [--keep-temps] [--host-asan]
+    python ln-asr_amd/build.py [--force] [--keep-temps] [--host-asan] [--variant NAME -DMACRO[=v] ...]
 
 One object per csrc/*.hip (compiled in parallel, rebuilt only when stale), linked with RCCL
 into ln-asr_amd/lnasr/liblnasr_hip.so -- in-tree, so the library travels with the snapshot.
@@ -10,6 +10,9 @@ into ln-asr_amd/lnasr/liblnasr_hip.so -- in-tree, so the library travels with th
 checks, staging, the upload pipeline's threads) is instrumented with AddressSanitizer + UBSan; the device code is
 compiled as usual (-fno-gpu-sanitize: GPU ASan needs xnack+, which this pool does not run).  Load it with
 LNASR_LIB=<path> and LD_PRELOAD=<asan_runtime()> (tests/test_host_asan.py).
+
+--variant NAME with -D macros builds liblnasr_hip_NAME.so in its own object directory: experiment builds that are
+measured against the shipped library in the same gpurun call (LNASR_LIB=<path> selects one); never the default.
 """
 import concurrent.futures as cf
 import glob
@@ -45,10 +48,14 @@ def asan_runtime():
     return hits[-1] if hits else None
 
 
-def build(force=False, keep_temps=False, verbose=True, host_asan=False):
+def build(force=False, keep_temps=False, verbose=True, host_asan=False, variant=None, defines=()):
     obj_dir = OBJ + "_asan" if host_asan else OBJ
     lib = ASAN_LIB if host_asan else LIB
     flags = ASAN_FLAGS if host_asan else FLAGS
+    if variant:
+        obj_dir = OBJ + "_" + variant
+        lib = os.path.join(HERE, "lnasr", "liblnasr_hip_%s.so" % variant)
+        flags = FLAGS + list(defines)
     os.makedirs(obj_dir, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
@@ -90,4 +97,6 @@ def build(force=False, keep_temps=False, verbose=True, host_asan=False):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, keep_temps="--keep-temps" in sys.argv, host_asan="--host-asan" in sys.argv)
+    _variant = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else None
+    build(force="--force" in sys.argv, keep_temps="--keep-temps" in sys.argv, host_asan="--host-asan" in sys.argv,
+          variant=_variant, defines=[a for a in sys.argv[1:] if a.startswith("-D")])

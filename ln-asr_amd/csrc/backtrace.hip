@@ -124,7 +124,8 @@ __global__ __launch_bounds__(256) void backtrace_lds_kernel(const TS* __restrict
                                                            const int32_t* __restrict__ lens,
                                                            uint32_t* __restrict__ path, double* __restrict__ best,
                                                            int U, int T, int N, unsigned* __restrict__ suspect_flag,
-                                                           unsigned epoch) {
+                                                           unsigned epoch, int suspect_inf) {
+    // suspect_inf = 0: the Viterbi kernel has tested the emissions itself (viterbi_reg1b<.., CHKB>): only a NaN cell is a suspect
     // lane l holds states l, l+64, ... (CPL of them).  LDSAT: A^T [N][N] (ATs[p*N + i] = A[i][p]) lives in LDS
     // (N <= 128); otherwise the one row a step needs is read from L2 (128 < N <= 256: 512 KB does not fit)
     extern __shared__ double ATs[];
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(256) void backtrace_lds_kernel(const TS* __restrict
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
         const double v0 = ld(vu, (size_t)(L - 1) * N + jj[c]);
-        suspect |= __ballot(!(v0 > LN_NEG_INF));
+        suspect |= __ballot(suspect_inf ? !(v0 > LN_NEG_INF) : v0 != v0);
         x[c] = ok[c] ? v0 : LN_NEG_INF;
     }
     double bestv;
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(256) void backtrace_lds_kernel(const TS* __restrict
 #pragma unroll
                 for (int c = 0; c < CPL; ++c) {
                     const double sum = cur[k][c] + col[jj[c]];          // unconditional (clamped index), then a select
-                    suspect |= __ballot(!(cur[k][c] > LN_NEG_INF));
+                    suspect |= __ballot(suspect_inf ? !(cur[k][c] > LN_NEG_INF) : cur[k][c] != cur[k][c]);
                     x[c] = ok[c] ? sum : LN_NEG_INF;
                 }
                 double mx;
@@ -251,7 +252,7 @@ __global__ void bt_kernel(const TS* __restrict__ v, const double* __restrict__ A
 
 
 int backtrace_device(lnasr_ctx* ctx, const void* v, int U, int T, const int32_t* d_lens, int dtype, uint32_t* path,
-                     double* best, bool* v_tested) {
+                     double* best, bool* v_tested, bool suspect_inf) {
     LN_DEVPTR(v); LN_DEVPTR(d_lens); LN_DEVPTR(path); LN_DEVPTR(best);
     // *v_tested: the kernel looked at every cell of v and raised the context's "suspect" word on NaN / -inf (nanfix.hip)
     Model& md = ctx->model;
@@ -285,10 +286,10 @@ int backtrace_device(lnasr_ctx* ctx, const void* v, int U, int T, const int32_t*
         if (md.N == 128)
             LN_LAUNCH(ctx, "backtrace_lds", (backtrace_lds_kernel<2, true, double, true>), dim3((U + wpb - 1) / wpb),
                       dim3(64 * wpb), (size_t)md.N * md.N * 8, (const double*)v, md.logAT.as<double>(), d_lens, path, best, U,
-                      T, md.N, sflag, epoch);
+                      T, md.N, sflag, epoch, suspect_inf ? 1 : 0);
         else
             LN_LAUNCH(ctx, "backtrace_lds", (backtrace_lds_kernel<2, true>), dim3((U + wpb - 1) / wpb), dim3(64 * wpb),
-                      (size_t)md.N * md.N * 8, (const double*)v, md.logAT.as<double>(), d_lens, path, best, U, T, md.N, sflag, epoch);
+                      (size_t)md.N * md.N * 8, (const double*)v, md.logAT.as<double>(), d_lens, path, best, U, T, md.N, sflag, epoch, suspect_inf ? 1 : 0);
         return 0;
     }
     if (dtype == LNASR_F64 && md.N <= 1024 && !sw().no_ldsbt) {
@@ -296,25 +297,25 @@ int backtrace_device(lnasr_ctx* ctx, const void* v, int U, int T, const int32_t*
         // one wave per block (with few utterances the waves should sit on different CUs), N / 64 states per lane
         if (md.N <= 256)
             LN_LAUNCH(ctx, "backtrace_wave256", (backtrace_lds_kernel<4, false>), dim3(U), dim3(64), 0, (const double*)v,
-                      md.logAT.as<double>(), d_lens, path, best, U, T, md.N, sflag, epoch);
+                      md.logAT.as<double>(), d_lens, path, best, U, T, md.N, sflag, epoch, suspect_inf ? 1 : 0);
         else if (md.N <= 512)
             LN_LAUNCH(ctx, "backtrace_wave512", (backtrace_lds_kernel<8, false>), dim3(U), dim3(64), 0, (const double*)v,
-                      md.logAT.as<double>(), d_lens, path, best, U, T, md.N, sflag, epoch);
+                      md.logAT.as<double>(), d_lens, path, best, U, T, md.N, sflag, epoch, suspect_inf ? 1 : 0);
         else
             LN_LAUNCH(ctx, "backtrace_wave1024", (backtrace_lds_kernel<16, false>), dim3(U), dim3(64), 0, (const double*)v,
-                      md.logAT.as<double>(), d_lens, path, best, U, T, md.N, sflag, epoch);
+                      md.logAT.as<double>(), d_lens, path, best, U, T, md.N, sflag, epoch, suspect_inf ? 1 : 0);
         return 0;
     }
     if (dtype == LNASR_F32 && md.N <= 128 && !sw().no_ldsbt && !sw().f32_generic) {
         if (v_tested) *v_tested = true;
         LN_LAUNCH(ctx, "backtrace_lds_f32", (backtrace_lds_kernel<2, true, float>), dim3((U + wpb - 1) / wpb), dim3(64 * wpb),
-                  (size_t)md.N * md.N * 8, (const float*)v, md.logAT.as<double>(), d_lens, path, best, U, T, md.N, sflag, epoch);
+                  (size_t)md.N * md.N * 8, (const float*)v, md.logAT.as<double>(), d_lens, path, best, U, T, md.N, sflag, epoch, suspect_inf ? 1 : 0);
         return 0;
     }
     if (dtype == LNASR_F32 && md.N <= 256 && !sw().no_ldsbt && !sw().f32_generic) {
         if (v_tested) *v_tested = true;
         LN_LAUNCH(ctx, "backtrace_wave256_f32", (backtrace_lds_kernel<4, false, float>), dim3(U), dim3(64), 0, (const float*)v,
-                  md.logAT.as<double>(), d_lens, path, best, U, T, md.N, sflag, epoch);
+                  md.logAT.as<double>(), d_lens, path, best, U, T, md.N, sflag, epoch, suspect_inf ? 1 : 0);
         return 0;
     }
     if (dtype == LNASR_F32)

@@ -801,6 +801,13 @@ __global__ __launch_bounds__(64 * NW) void mfcc_frame512x4_kernel(
         const bool more = g < bend;
         if (more) place(g, false);                 // the next group's whereabouts, ahead of its loads
         LN_STAMP(1);
+        // Wave priority by PHASE (round 4).  The two waves of a SIMD are in different phases most of the time; the arbiter
+        // favours the older one whatever it is doing.  Everything except the two register FFTs is a chain of LDS / DPP / memory
+        // round trips with few instructions between them: those phases run at priority 1, so their instructions issue the
+        // moment their operands arrive and the partner's dense FFT work fills the gaps, instead of the reverse.  Measured on
+        // one box, ms per 256 k frames (f64 / int16): 0.291 / 0.281 without, 0.279 / 0.267 with only the exchange and the mel / DCT
+        // tail raised, 0.270 / 0.265 as here; priority 3 instead of 1: the same (profiles/r04c_prio_experiment.log, r04d).
+        __builtin_amdgcn_s_setprio(0);                       // dense vector work: window, first FFT, twiddles
 #pragma unroll
         for (int n2 = 0; n2 < NR; ++n2) {
             const int k0 = 2 * (n1 + 16 * n2);
@@ -818,6 +825,7 @@ __global__ __launch_bounds__(64 * NW) void mfcc_frame512x4_kernel(
             v[k2] = cmul(v[k2], tw);
         }
         LN_STAMP(2);
+        __builtin_amdgcn_s_setprio(1);
         // exchange: tile [k2][n1] with rows of 17 (both sides free of bank conflicts)
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) X[k2 * 17 + n1] = v[k2].re;
@@ -832,8 +840,10 @@ __global__ __launch_bounds__(64 * NW) void mfcc_frame512x4_kernel(
         for (int j = 0; j < 16; ++j) v[j].im = X[n1 * 17 + j];
         __builtin_amdgcn_wave_barrier();
         LN_STAMP(3);
+        __builtin_amdgcn_s_setprio(0);
         fft16(v);                                  // over n1: v[k1] = Z[16 k1 + k2]
         LN_STAMP(4);
+        __builtin_amdgcn_s_setprio(1);                       // split, power, the next group's requests, mel / log / DCT, pre-emphasis
         // mirror lane's upper half
         // lane k2 needs lane (16 - k2) mod 16 of its row: row_mirror (l <- 15 - l) then row_ror:1 (l <- l - 1), two DPP
         // moves per word and no trip through the LDS crossbar (ds_bpermute: one more latency-bound step, tools/mfcc_stamps.py)

@@ -82,10 +82,14 @@ constexpr int kBacktraceWavesPerBlock = 4;
 // ---- launchers -------------------------------------------------------------------------------------------------------
 // b, v, alpha, beta [U,T,N] and d_lens [U] are DEVICE pointers (LN_DEVPTR checks them under LNASR_CHECK_PTRS=1).
 int device_lens(lnasr_ctx* ctx, const int32_t* lens, int U, int T, const int32_t** out);
-int viterbi_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d_lens, int dtype, void* v);
-// *v_tested: the kernel looked at every cell of v and raised the context's "suspect" word on NaN / -inf (nanfix.hip)
+// b_tested (optional): ask the kernel to look for NaN emissions itself; *b_tested = it did (word 1 of ctx->nan_flag raised
+// with the call's epoch when it met one) -- then the back-trace need not treat -inf cells of v as suspects
+int viterbi_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d_lens, int dtype, void* v,
+                   bool* b_tested = nullptr);
+// *v_tested: the kernel looked at every cell of v and raised the context's "suspect" word on NaN / -inf (nanfix.hip);
+// suspect_inf = false: the Viterbi kernel tested its emissions (b_tested), a -inf cell is then just a forbidden state
 int backtrace_device(lnasr_ctx* ctx, const void* v, int U, int T, const int32_t* d_lens, int dtype, uint32_t* path,
-                     double* best, bool* v_tested = nullptr);
+                     double* best, bool* v_tested = nullptr, bool suspect_inf = true);
 int bt_matrix_device(lnasr_ctx* ctx, const void* v, int U, int T, const int32_t* d_lens, int dtype, uint32_t* bt);
 int forward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d_lens, int dtype, void* alpha,
                    double* loglik);

@@ -189,12 +189,14 @@ int lnasr_viterbi(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* le
     // float32 storage stays on the storage-templated kernels here: rounding v to f32 after every frame is what
     // makes v, bt and path bit-identical to the reference run with precision=np.float32 (golden gmmhmm_small_f32);
     // forward / backward / emission are tolerance-checked and take the widened f64 route (common.h)
-    bool nan_tested = false;
-    LN_TRY(viterbi_device(ctx, d_b, U, T, d_lens, dtype, d_v));
-    LN_TRY(backtrace_device(ctx, d_v, U, T, d_lens, dtype, (uint32_t*)d_path, (double*)d_best, &nan_tested));
-    // emissions handed in by the caller: a NaN among them propagates as numpy's max / argmax do (nanfix.hip); kernels
-    // that did not look for one themselves cost a scan of b here
-    LN_TRY(viterbi_nan_repair(ctx, d_b, U, T, d_lens, dtype, d_v, (uint32_t*)d_path, (double*)d_best, !nan_tested));
+    // emissions handed in by the caller: a NaN among them propagates as numpy's max / argmax do (nanfix.hip).  The
+    // register-resident Viterbi kernels test the emissions they load (b_tested) and raise the flag themselves -- a -inf cell of v is
+    // then just a forbidden state (left-to-right models) and no suspect; otherwise the back-trace kernel flags NaN and -inf cells of
+    // v, and kernels that did not look at all cost a scan of b here
+    bool b_tested = false, v_tested = false;
+    LN_TRY(viterbi_device(ctx, d_b, U, T, d_lens, dtype, d_v, &b_tested));
+    LN_TRY(backtrace_device(ctx, d_v, U, T, d_lens, dtype, (uint32_t*)d_path, (double*)d_best, &v_tested, !b_tested));
+    LN_TRY(viterbi_nan_repair(ctx, d_b, U, T, d_lens, dtype, d_v, (uint32_t*)d_path, (double*)d_best, !(b_tested || v_tested)));
     if (bt_or_null) {
         LN_TRY(stage_out(ctx, bt_or_null, cells * 4, ctx->ws_out3, &d_bt));
         LN_TRY(bt_matrix_device(ctx, d_v, U, T, d_lens, dtype, (uint32_t*)d_bt));
@@ -225,13 +227,15 @@ int lnasr_decode(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t*
     // three launches in series on one stream (cutting the batch into chunks whose trellis work runs on a side stream
     // beside the next chunk's emission was measured slower, DESIGN 4.8, and removed in round 3)
     const double* d_x = nullptr;
-    bool scanned = false, v_tested = false;
+    bool scanned = false, v_tested = false, b_tested = false;
     // (full covariance: the emission pass re-scores frames with a non-finite feature itself -- an infinity gives -inf or
     // NaN per component there -- and the trellis is repaired from the emissions, as for lnasr_viterbi)
     const bool by_obs = !nan_rows_rescored(md);
     LN_TRY(emit_batch(ctx, obs, U, T, ctx->ws_b.as<double>(), nullptr, &d_x, by_obs ? &scanned : nullptr));
-    LN_TRY(viterbi_device(ctx, ctx->ws_b.p, U, T, d_lens, LNASR_F64, ctx->ws_v.p));
-    LN_TRY(backtrace_device(ctx, ctx->ws_v.p, U, T, d_lens, LNASR_F64, (uint32_t*)d_path, (double*)d_best, &v_tested));
+    // (diagonal models: the emission kernel tested the features, the Viterbi kernel runs without its own test of b)
+    LN_TRY(viterbi_device(ctx, ctx->ws_b.p, U, T, d_lens, LNASR_F64, ctx->ws_v.p, by_obs ? nullptr : &b_tested));
+    LN_TRY(backtrace_device(ctx, ctx->ws_v.p, U, T, d_lens, LNASR_F64, (uint32_t*)d_path, (double*)d_best, &v_tested,
+                            !b_tested));
     // a NaN or an infinite feature makes its frame's emissions NaN in the reference, and np.max carries that through every
     // later frame: one launch that returns at once unless the emission kernel raised the flag (nanfix.hip)
     if (by_obs)
@@ -239,7 +243,7 @@ int lnasr_decode(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t*
                                       !scanned));
     else
         LN_TRY(viterbi_nan_repair(ctx, ctx->ws_b.p, U, T, d_lens, LNASR_F64, ctx->ws_v.p, (uint32_t*)d_path, (double*)d_best,
-                                  !v_tested));
+                                  !(b_tested || v_tested)));
     LN_TRY(finish_out(ctx, path, d_path, (size_t)U * T * 4));
     if (best_score_or_null) LN_TRY(finish_out(ctx, best_score_or_null, d_best, (size_t)U * 8));
     return 0;

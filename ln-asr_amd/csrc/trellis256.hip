@@ -48,6 +48,10 @@ __device__ __forceinline__ void trellis256_role(double* sm, const TS* __restrict
     constexpr int NREG = FIN ? kT256FinReg : kT256CmpReg, NLDS = 64 - NREG;
     const int tid = threadIdx.x, lane = tid & 63;
     const int jc = tid & (NP - 1), rs = tid >> 8;
+    // the four finalising waves (one per SIMD) are the frame's critical path: they multiply AND finalise while the other twelve
+    // wait at the barrier -- favoured at the arbiter (round 4: forward 2.764 -> 2.732 ms, backward 2.797 -> 2.781 at config 5;
+    // small, because the frame is a dependent chain rather than an issue contest: profiles/r04c_prio_experiment.log)
+    if (FIN) __builtin_amdgcn_s_setprio(1);
     double* Al = FIN ? sm + kT256Al0 + jc : sm + kT256Al1 + (rs - 1) * NP + jc;
     constexpr int ALS = FIN ? NP : 3 * NP;                               // stride between LDS rows of A
     double* Vs = sm + kT256Vs;

@@ -211,12 +211,19 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
 // The opposite direction, after four-wave blocks had paid in fwdbwd_cols2: <2, 4, 32, 2, 2> -- two utterances per FOUR-wave
 // block, 230 registers, two waves per SIMD -- 1.29 ms against 1.27; <2, 4, 32, 1, 3> -- one utterance, three blocks per CU,
 // 168 registers and six of them spilled -- 1.99 ms.  This kernel is 76 % vector issue (SQ counters), not waits.)
-template <int CPT, int NW, int RPT, int UB, int WPE, typename TS = double, bool ALT = false>
+// CHKB (lnasr_viterbi: emissions handed in by the caller): wave 0 tests the emissions it loads anyway for NaN -- the LDS atomic
+// maximum drops a NaN candidate, so a NaN emission would otherwise surface only as a -inf cell of v, which a model with
+// forbidden transitions (left-to-right: the normal ASR topology) has on perfectly clean data -- and raises word 1 of the
+// context's flag itself; the back-trace then need not treat -inf cells as suspects.  Two compares per
+// frame and column block in one of eight waves; the decode path (features tested by the emission kernel) runs CHKB = false.
+template <int CPT, int NW, int RPT, int UB, int WPE, typename TS = double, bool ALT = false, bool CHKB = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void viterbi_reg1b(
     const TS* __restrict__ b, const double* __restrict__ A, const double* __restrict__ pi,
-    const int32_t* __restrict__ lens, TS* __restrict__ v, int U, int T, int N) {
+    const int32_t* __restrict__ lens, TS* __restrict__ v, int U, int T, int N, unsigned* __restrict__ nan_flag,
+    unsigned nan_epoch) {
     constexpr int NP = 64 * CPT;
     __shared__ double Vs[3][UB][NP];
+    unsigned long long saw_nan = 0;
     LN_BLOCK_T0;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int u0 = blockIdx.x * UB;
@@ -242,7 +249,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
             double val = LN_NEG_INF;
             if (j < N && len[k] > 0) {
                 size_t o = ((size_t)(u0 + k) * T) * N + j;
-                val = rnd<TS>(pi[j] + ld(b, o));
+                const double b0 = ld(b, o);
+                if (CHKB && b0 != b0) saw_nan = 1;             // frame 0 (per-lane: merged into the ballot word below)
+                val = rnd<TS>(pi[j] + b0);
                 st(v, o, val);
             }
             Vs[0][k][j] = val;
@@ -272,6 +281,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
 
     int cur = 0;                                   // buffer holding v[t-1]
     for (int t = 1; t < maxlen; ++t) {
+        // (priority by PHASE instead -- loads, atomics and the barrier at 1, the add / max runs at 0, the scheme that pays in the
+        // MFCC kernel -- was measured in round 4: 2.06 ms against 1.27; this kernel is issue-bound, its waves must not yield)
         if (ALT && (t & 7) == 0) alternate_priority(cls);     // devmath.h
         const int nxt = cur == 2 ? 0 : cur + 1, rst = nxt == 2 ? 0 : nxt + 1;
         double bcur[UB][CPT];
@@ -283,6 +294,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
                 bcur[k][c] = bnext[k][c];
                 bnext[k][c] = ld(pl[c], (uoff[k] + tn) * N);
             }
+        if (CHKB && w == 0) {                      // wave-uniform: one wave looks at the frame's emissions for the block
+#pragma unroll
+            for (int k = 0; k < UB; ++k)
+#pragma unroll
+                for (int c = 0; c < CPT; ++c)
+                    saw_nan |= __ballot(bcur[k][c] != bcur[k][c] && t < len[k] && lane + 64 * c < N);
+        }
         // v[t-1] of the columns this wave stores to global (complete since the last barrier)
         if (t > 1 && w < NJOB) {
             const int k = w / CPT, c = w % CPT, j = lane + 64 * c;
@@ -328,6 +346,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
         const int k = w / CPT, c = w % CPT, j = lane + 64 * c;
         if (j < N && maxlen - 1 < len[k]) st(v, ((size_t)(u0 + k) * T + (maxlen - 1)) * N + j, Vs[cur][k][j]);
     }
+    if (CHKB && __ballot(saw_nan != 0) != 0 && lane == 0) *nan_flag = nan_epoch;
     LN_BLOCK_T1;
 }
 LN_BLOCK_TIMES_EXPORT(lnasr_dbg_block_times_trellis)
@@ -450,8 +469,14 @@ __global__ __launch_bounds__(256) void viterbi_tiny_kernel(const TS* __restrict_
 }
 
 
-int viterbi_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d_lens, int dtype, void* v) {
+int viterbi_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d_lens, int dtype, void* v, bool* b_tested) {
     LN_DEVPTR(b); LN_DEVPTR(d_lens); LN_DEVPTR(v);
+    // b_tested given: the caller wants the kernel to look for NaN emissions itself when it can (*b_tested = it did, and
+    // raised word 1 of ctx->nan_flag with the call's epoch if it met one)
+    const bool chk = b_tested != nullptr;
+    if (b_tested) *b_tested = false;
+    unsigned* const nflag = ctx->nan_flag.as<unsigned>() + 1;
+    const unsigned epoch = ctx->nan_epoch;
     Model& md = ctx->model;
     const int N = md.N;
     const double* A = md.logA.as<double>();
@@ -495,12 +520,21 @@ int viterbi_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
             // default: single-barrier kernel (LDS atomic max); LNASR_VIT=a selects the two-barrier one
             if (vsel == 'a' && U < dispatch::kViterbiPairFromU) LN_VIT("viterbi_reg_n128_u1", 2, 8, 16, 1, 4);
             if (vsel == 'a') LN_VIT("viterbi_reg_n128", 2, 8, 16, 2, 4);
+            if (chk) *b_tested = true;
             if (U < dispatch::kViterbiPairFromU) {
-                LN_LAUNCH(ctx, "viterbi_reg1b_n128_u1", (viterbi_reg1b<2, 8, 16, 1, 4>), dim3(U), dim3(512), 0,
-                          (const double*)b, A, pi, d_lens, (double*)v, U, T, N);
+                if (chk)
+                    LN_LAUNCH(ctx, "viterbi_reg1b_n128_u1", (viterbi_reg1b<2, 8, 16, 1, 4, double, false, true>), dim3(U), dim3(512),
+                              0, (const double*)b, A, pi, d_lens, (double*)v, U, T, N, nflag, epoch);
+                else
+                    LN_LAUNCH(ctx, "viterbi_reg1b_n128_u1", (viterbi_reg1b<2, 8, 16, 1, 4>), dim3(U), dim3(512), 0,
+                              (const double*)b, A, pi, d_lens, (double*)v, U, T, N, nflag, epoch);
             } else {
-                LN_LAUNCH(ctx, "viterbi_reg1b_n128", (viterbi_reg1b<2, 8, 16, 2, 4, double, true>), dim3((U + 1) / 2), dim3(512), 0,
-                          (const double*)b, A, pi, d_lens, (double*)v, U, T, N);
+                if (chk)
+                    LN_LAUNCH(ctx, "viterbi_reg1b_n128", (viterbi_reg1b<2, 8, 16, 2, 4, double, true, true>), dim3((U + 1) / 2),
+                              dim3(512), 0, (const double*)b, A, pi, d_lens, (double*)v, U, T, N, nflag, epoch);
+                else
+                    LN_LAUNCH(ctx, "viterbi_reg1b_n128", (viterbi_reg1b<2, 8, 16, 2, 4, double, true>), dim3((U + 1) / 2), dim3(512), 0,
+                              (const double*)b, A, pi, d_lens, (double*)v, U, T, N, nflag, epoch);
             }
             return 0;
         }
@@ -508,12 +542,22 @@ int viterbi_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
     }
     if (dtype == LNASR_F32 && N <= dispatch::kRegMaxN && !sw().no_regvit && !sw().f32_generic) {
         // precision=np.float32: the same register-resident kernel, fp64 arithmetic, float storage and rounding
-        if (U < dispatch::kViterbiPairFromU)
-            LN_LAUNCH(ctx, "viterbi_reg1b_n128_u1_f32", (viterbi_reg1b<2, 8, 16, 1, 4, float>), dim3(U), dim3(512), 0,
-                      (const float*)b, A, pi, d_lens, (float*)v, U, T, N);
-        else
-            LN_LAUNCH(ctx, "viterbi_reg1b_n128_f32", (viterbi_reg1b<2, 8, 16, 2, 4, float, true>), dim3((U + 1) / 2), dim3(512), 0,
-                      (const float*)b, A, pi, d_lens, (float*)v, U, T, N);
+        if (chk) *b_tested = true;
+        if (U < dispatch::kViterbiPairFromU) {
+            if (chk)
+                LN_LAUNCH(ctx, "viterbi_reg1b_n128_u1_f32", (viterbi_reg1b<2, 8, 16, 1, 4, float, false, true>), dim3(U), dim3(512),
+                          0, (const float*)b, A, pi, d_lens, (float*)v, U, T, N, nflag, epoch);
+            else
+                LN_LAUNCH(ctx, "viterbi_reg1b_n128_u1_f32", (viterbi_reg1b<2, 8, 16, 1, 4, float>), dim3(U), dim3(512), 0,
+                          (const float*)b, A, pi, d_lens, (float*)v, U, T, N, nflag, epoch);
+        } else {
+            if (chk)
+                LN_LAUNCH(ctx, "viterbi_reg1b_n128_f32", (viterbi_reg1b<2, 8, 16, 2, 4, float, true, true>), dim3((U + 1) / 2),
+                          dim3(512), 0, (const float*)b, A, pi, d_lens, (float*)v, U, T, N, nflag, epoch);
+            else
+                LN_LAUNCH(ctx, "viterbi_reg1b_n128_f32", (viterbi_reg1b<2, 8, 16, 2, 4, float, true>), dim3((U + 1) / 2), dim3(512), 0,
+                          (const float*)b, A, pi, d_lens, (float*)v, U, T, N, nflag, epoch);
+        }
         return 0;
     }
     constexpr int UB = 4;

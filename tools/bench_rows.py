@@ -110,8 +110,10 @@ if what & {"nanfix", "all"}:
     b = ctx.gmm_logprob(obs)
     timed("nanfix: viterbi, dense model", lambda: ctx.viterbi(b, want_v=False, want_bt=False), U * T, "frames")
     A = mdl["A"].copy()
-    A[np.tril_indices(N, -1)] = -np.inf                  # left-to-right: no way back
-    ctx.upload_hmm(A, mdl["pi"])
+    A[np.tril_indices(N, -1)] = -np.inf                  # left-to-right: no way back, every path starts in state 0
+    pi0 = np.full(N, -np.inf)
+    pi0[0] = 0.0
+    ctx.upload_hmm(A, pi0)
     timed("nanfix: viterbi, left-to-right model", lambda: ctx.viterbi(b, want_v=False, want_bt=False), U * T, "frames")
     b1 = ctx.to_device(b.to_host()[:1])
     timed("nanfix: viterbi, left-to-right, U=1", lambda: ctx.viterbi(b1, want_v=False, want_bt=False), T, "frames")
