@@ -75,6 +75,26 @@ def test_random_shape(seed, synth, oracle, ctx):
         assert_close(beta[u, :L], rb, 1e-10, 1e-10, msg="beta " + tag)
         assert abs(ll[u] - oracle.loglik(ra)) <= 1e-10 * max(1.0, abs(ll[u])), "loglik " + tag
 
+    # precision=np.float32 storage on the same dispatch branch: v / bt / path bit-identical to the oracle's float32 run, alpha and
+    # beta rounded at every store like the reference's float32 arrays (at most one ulp where an fp64 sum straddles a boundary)
+    b32 = np.asarray(b).astype(np.float32)
+    r32 = ctx.viterbi(b32, lens=lens)
+    a32, _ = ctx.forward(b32, lens=lens)
+    be32 = ctx.backward(b32, lens=lens)
+    for u in range(U):
+        L = int(lens[u])
+        gb = np.ascontiguousarray(b32[u, :L].T)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            v, bt, path = oracle.viterbi(A, mdl["pi"], gb, precision=np.float32)
+            ra, rb = oracle.forward(A, mdl["pi"], gb, precision=np.float32), oracle.backward(A, gb, precision=np.float32)
+        assert r32["v"].dtype == np.float32 and np.array_equal(r32["v"][u, :L], v), "v f32 " + tag
+        assert np.array_equal(r32["bt"][u, :L], bt) and np.array_equal(r32["path"][u, :L], path), "path f32 " + tag
+        for got, want, what in ((a32[u, :L], ra, "alpha"), (be32[u, :L], rb, "beta")):
+            assert got.dtype == np.float32
+            assert_close(got, want, 1.3e-7, 0.0, msg="%s f32 %s" % (what, tag))
+            off = int((got != want).sum()) - int((np.isnan(got) & np.isnan(want)).sum())
+            assert off <= max(2, want.size // 5000), "%s f32 %s: %d of %d values off by an ulp" % (what, tag, off, want.size)
+
     if N * N * T <= 400000 and N * M * D * T <= 200000:         # statistics: the oracle materialises xi [T,N,N]
         st = ctx.bw_accumulate(obs, lens=lens)
         with np.errstate(divide="ignore", invalid="ignore", under="ignore"):
