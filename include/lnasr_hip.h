@@ -105,6 +105,12 @@ int lnasr_debug_require_device_ptr(const void* p);
  * upload only what changed.  Buffers of 2 MB and more are hashed by a small pool of host threads (25 MB of `si`:
  * ~0.2 ms instead of ~1.5 ms on one thread); the result depends on the bytes, their count and the seed only. */
 int lnasr_hash128(const void* data, size_t bytes, uint64_t seed, uint64_t* out2);
+/* The same fingerprint of n buffers (buffer k with seed + k) in the background: _begin returns at once, _end waits and
+ * writes two words per buffer (out may be NULL to discard).  Lets a caller enqueue work on the model the device already
+ * holds while the check that it is still current runs beside it.  The buffers must stay alive and unchanged until _end;
+ * every job begun must be ended. */
+int lnasr_hash128_begin(const void* const* ptrs, const size_t* bytes, int n, uint64_t seed, void** job_out);
+int lnasr_hash128_end(void* job, uint64_t* out);
 
 /* per-kernel HIP-event timing on the context's own stream (bench.py roofline) */
 int lnasr_prof_enable(lnasr_ctx* ctx, int on);

@@ -137,6 +137,18 @@ class Pool {
 
 using namespace lnasr;
 
+namespace {
+// one background fingerprint of several buffers (lnasr_hash128_begin / _end)
+struct HashJob {
+    std::vector<const void*> ptr;
+    std::vector<size_t> bytes;
+    std::vector<uint64_t> out;           // two words per buffer
+    uint64_t seed = 0;
+    int rc = 0;
+    std::thread th;
+};
+}  // namespace
+
 extern "C" {
 
 int lnasr_hash128(const void* data, size_t bytes, uint64_t seed, uint64_t* out2) {
@@ -160,6 +172,45 @@ int lnasr_hash128(const void* data, size_t bytes, uint64_t seed, uint64_t* out2)
     });
     hash_segment(reinterpret_cast<const unsigned char*>(dig.data()), dig.size() * 8, seed ^ (uint64_t)bytes, out2);
     return 0;
+}
+
+// The same fingerprint of n buffers (buffer k hashed with seed + k) computed in the BACKGROUND: _begin returns at once,
+// _end waits and writes two words per buffer.  The mirror classes start it on the model parameters, enqueue the call's
+// kernels on the model the device already holds while it runs, and keep the result only if the fingerprint confirms
+// that nothing changed (lnasr/gmmhmm.py: the 0.2 ms check of a 25 MB model then costs the call nothing).  The buffers
+// must stay alive and unchanged until _end; every job begun must be ended (it owns a thread).
+int lnasr_hash128_begin(const void* const* ptrs, const size_t* bytes, int n, uint64_t seed, void** job_out) {
+    LN_REQUIRE(job_out, "null job_out");
+    *job_out = nullptr;
+    LN_REQUIRE(n >= 0 && (n == 0 || (ptrs && bytes)), "bad buffer list");
+    for (int k = 0; k < n; ++k) LN_REQUIRE(ptrs[k] || bytes[k] == 0, "null buffer %d", k);
+    HashJob* j = new HashJob();
+    j->ptr.assign(ptrs, ptrs + n);
+    j->bytes.assign(bytes, bytes + n);
+    j->out.assign((size_t)2 * n, 0);
+    j->seed = seed;
+    try {
+        j->th = std::thread([j] {
+            for (size_t k = 0; k < j->ptr.size() && j->rc == 0; ++k)
+                j->rc = lnasr_hash128(j->ptr[k], j->bytes[k], j->seed + k, &j->out[2 * k]);
+        });
+    } catch (...) {
+        delete j;
+        return fail(LNASR_E_INVALID, "could not start the fingerprint thread");
+    }
+    *job_out = j;
+    return 0;
+}
+
+int lnasr_hash128_end(void* job, uint64_t* out) {
+    LN_REQUIRE(job, "null job");
+    HashJob* j = static_cast<HashJob*>(job);
+    if (j->th.joinable()) j->th.join();
+    const int rc = j->rc;
+    if (rc == 0 && out)
+        for (size_t k = 0; k < j->out.size(); ++k) out[k] = j->out[k];
+    delete j;
+    return rc;
 }
 
 }  // extern "C"

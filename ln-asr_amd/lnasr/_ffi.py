@@ -42,6 +42,8 @@ SIGNATURES = {
     "lnasr_host_free": [_vp, _vp],
     "lnasr_device_info": [_vp, C.c_char_p, _i, _P(_i), _P(_sz)],
     "lnasr_hash128": [_vp, _sz, C.c_uint64, _P(C.c_uint64)],
+    "lnasr_hash128_begin": [_P(_vp), _P(_sz), _i, C.c_uint64, _P(_vp)],
+    "lnasr_hash128_end": [_vp, _P(C.c_uint64)],
     "lnasr_debug_require_device_ptr": [_vp],
     "lnasr_dev_alloc": [_vp, _sz, _P(_vp)],
     "lnasr_dev_free": [_vp, _vp],
@@ -206,6 +208,36 @@ class _PinnedBlock:
         self.ptr = None
 
 
+class _FingerprintJob:
+    """A parameter fingerprint computed in the background (lnasr_hash128_begin / _end): started before a call's kernels are
+    enqueued, collected with result() when the call is about to hand its answer back.  result() equals what
+    Context._fingerprint returns for the same arrays."""
+
+    def __init__(self, head, arrays):
+        self._arrays = [a if a.flags.c_contiguous else np.ascontiguousarray(a) for a in arrays]   # kept alive until result()
+        n = len(self._arrays)
+        ptrs = (C.c_void_p * n)(*[a.ctypes.data if a.size else None for a in self._arrays])
+        sizes = (C.c_size_t * n)(*[a.nbytes for a in self._arrays])
+        job = C.c_void_p()
+        check(lib().lnasr_hash128_begin(ptrs, sizes, n, 0, C.byref(job)))
+        self._job, self._head = job, head
+
+    def result(self):
+        job, self._job = self._job, None
+        out = (C.c_uint64 * (2 * len(self._arrays)))()
+        check(lib().lnasr_hash128_end(job, out))
+        fp = [self._head] + [(out[2 * k], out[2 * k + 1]) for k, a in enumerate(self._arrays) if a.size]
+        self._arrays = None
+        return tuple(fp)
+
+    def __del__(self):
+        try:
+            if self._job:
+                lib().lnasr_hash128_end(self._job, None)
+        except Exception:
+            pass
+
+
 def _ptr(x):
     """void* of a numpy array / DeviceArray / None."""
     if x is None:
@@ -326,9 +358,13 @@ class Context:
     # edits.  The arrays are fingerprinted AS GIVEN (dtype and strides included), so a float32 or non-contiguous
     # parameter is converted only when it actually has to be uploaded.
     @staticmethod
+    def _fp_head(tag, arrays, extra):
+        return repr((tag,) + tuple((a.shape, a.dtype.str) for a in arrays) + tuple(extra))
+
+    @staticmethod
     def _fingerprint(tag, arrays, *extra):
         out = (C.c_uint64 * 2)()
-        fp = [repr((tag,) + tuple((a.shape, a.dtype.str) for a in arrays) + extra)]
+        fp = [Context._fp_head(tag, arrays, extra)]
         for k, a in enumerate(arrays):
             if not a.size:
                 continue
@@ -338,7 +374,13 @@ class Context:
             fp.append((out[0], out[1]))
         return tuple(fp)
 
+    def gmm_fingerprint_job(self, A, pi, w, mu, sigma, diag=False, force_full=False):
+        """The fingerprint upload_gmmhmm would compute for these parameters, started in the background."""
+        arrays = tuple(np.asarray(x) for x in (A, pi, w, mu, sigma))
+        return _FingerprintJob(self._fp_head("gmm", arrays, (bool(diag), bool(force_full))), arrays)
+
     def upload_hmm(self, A, pi):
+        self.model_owner = None
         A, pi = np.asarray(A), np.asarray(pi)
         N = A.shape[0]
         if A.shape != (N, N) or pi.shape != (N,):
@@ -353,8 +395,10 @@ class Context:
         self.model_shape = (N,)
         self._model_fp = fp
 
-    def upload_gmmhmm(self, A, pi, w, mu, sigma, diag=False, force_full=False):
-        """sigma: [N,M,D,D] (diag=False) or [N,M,D] (diag=True)."""
+    def upload_gmmhmm(self, A, pi, w, mu, sigma, diag=False, force_full=False, owner=None):
+        """sigma: [N,M,D,D] (diag=False) or [N,M,D] (diag=True).  owner: id of the model object these parameters
+        belong to (recorded as self.model_owner: the mirror classes speculate only on a model they uploaded themselves)."""
+        self.model_owner = owner
         A, pi, w, mu, sigma = (np.asarray(x) for x in (A, pi, w, mu, sigma))
         N, M, D = mu.shape
         if A.shape != (N, N) or pi.shape != (N,) or w.shape != (N, M):

@@ -139,20 +139,25 @@ class HMM:
     # ------------------------------------------------------------------ trellises
     def _forward(self, obs: np.ndarray, remap: bool = False) -> np.ndarray:
         """alpha [T,N]: alpha[t,j] = lse_i(alpha[t-1,i] + A[i,j]) + b[j,t]  (hmm.py:63-100)."""
-        self._remap_or_upload(obs, remap)
-        alpha, _ = self.ctx.forward(self._b_dev(), want_alpha=True, want_loglik=False, host_out=True)
-        return alpha[0]
+        def run():
+            self._remap_or_upload(obs, remap)
+            return self.ctx.forward(self._b_dev(), want_alpha=True, want_loglik=False, host_out=True)[0][0]
+        return self._outer(run)
 
     def _backward(self, obs: np.ndarray, remap: bool = False) -> np.ndarray:
         """beta [T,N]: beta[t,i] = lse_j(beta[t+1,j] + A[i,j] + b[j,t+1])  (hmm.py:102-131)."""
-        self._remap_or_upload(obs, remap)
-        return self.ctx.backward(self._b_dev(), host_out=True)[0]
+        def run():
+            self._remap_or_upload(obs, remap)
+            return self.ctx.backward(self._b_dev(), host_out=True)[0]
+        return self._outer(run)
 
     def _viterbi(self, obs: np.ndarray, remap: bool = False) -> Tuple[np.ndarray]:
         """(v [T,N], bt [T,N] uint32, path [T] uint32); ties -> first index  (hmm.py:133-172)."""
-        self._remap_or_upload(obs, remap)
-        r = self.ctx.viterbi(self._b_dev(), want_v=True, want_bt=True, host_out=True)
-        return (r["v"][0], r["bt"][0], r["path"][0])
+        def run():
+            self._remap_or_upload(obs, remap)
+            r = self.ctx.viterbi(self._b_dev(), want_v=True, want_bt=True, host_out=True)
+            return (r["v"][0], r["bt"][0], r["path"][0])
+        return self._outer(run)
 
     def _baumwelch(self, obs: np.ndarray, alpha: np.ndarray, beta: np.ndarray, remap: bool = False) -> Tuple[np.ndarray]:
         """(xi [T,N,N], gamma [T,N]); the last frame is -inf  (hmm.py:174-200)."""
@@ -197,14 +202,40 @@ class HMM:
         self.n, self.m = self.B.shape
 
     # ------------------------------------------------------------------ public API
+    def _confirmed(self):
+        """End of a speculative attempt (GMMHMM._upload_gmm): True when no background check is pending or it confirms that
+        the device held exactly the current parameters."""
+        job = self.__dict__.pop("_spec_job", None)
+        return job is None or job.result() == self.ctx._model_fp
+
+    def _outer(self, fn):
+        """Run `fn` (emission + one trellis, the answer only) first on the model the device already holds, with the
+        parameter check beside it, and again the checked way if the check says the parameters have changed."""
+        self._speculating = True
+        try:
+            out = fn()
+        except Exception:
+            self._speculating = False
+            if self._confirmed():
+                raise                                   # not a stale-model artefact: the caller's error
+            out = None
+        finally:
+            self._speculating = False
+        if out is not None and self._confirmed():
+            return out
+        return fn()
+
     def calc_prob(self, obs: np.ndarray) -> float:
         """log P(O | model) = lse(alpha[T-1])  (hmm.py:268-274).  alpha itself is not brought back unless a subclass
         replaced `_forward`."""
         if not self._ours("_forward"):
             return lse(self._forward(obs, True)[-1])
-        self._remap_or_upload(obs, True)
-        _, ll = self.ctx.forward(self._b_dev(), want_alpha=False, want_loglik=True, host_out=True)
-        return np.asarray(ll, dtype=self.precision)[0]
+
+        def run():
+            self._remap_or_upload(obs, True)
+            _, ll = self.ctx.forward(self._b_dev(), want_alpha=False, want_loglik=True, host_out=True)
+            return np.asarray(ll, dtype=self.precision)[0]
+        return self._outer(run)
 
     def decode(self, obs: np.ndarray) -> np.ndarray:
         """Most likely state sequence  (hmm.py:276-283): emission, trellis and back-trace on the device, only the path
@@ -212,8 +243,11 @@ class HMM:
         GMMHMM's `self.bm` -- stay readable as after the reference's call)."""
         if not self._ours("_viterbi"):
             return self._viterbi(obs, True)[2]
-        self._remap_or_upload(obs, True)
-        return self.ctx.viterbi(self._b_dev(), want_v=False, want_bt=False, host_out=True)["path"][0]
+
+        def run():
+            self._remap_or_upload(obs, True)
+            return self.ctx.viterbi(self._b_dev(), want_v=False, want_bt=False, host_out=True)["path"][0]
+        return self._outer(run)
 
     _REF_STEPS = ("_map_b", "_forward", "_backward", "_baumwelch", "_estimate", "_updatemodel", "calc_prob")
 

@@ -48,6 +48,23 @@ for nbytes in (0, 1, 7, 8, 9, 31, 32, 33, 63, 64, 1000, (1 << 21) - 1, (1 << 21)
         assert lib.lnasr_hash128(y.ctypes.data, nbytes, 7, o2) == 0 and tuple(o1) != tuple(o2), (nbytes, at)
     checked += 1
 assert lib.lnasr_hash128(None, 16, 0, o1) < 0 and lib.lnasr_hash128(None, 0, 0, None) < 0
+# the background job: same digests as the synchronous calls (buffer k with seed + k), empty buffers, discarded results
+bufs = [rng.integers(0, 256, n, dtype=np.uint8) for n in (3 << 20, 0, 17, (5 << 20) + 1)]
+job = _ffi._FingerprintJob("head", bufs)
+want = ["head"]
+for k, x in enumerate(bufs):
+    if x.size:
+        assert lib.lnasr_hash128(x.ctypes.data, x.nbytes, k, o1) == 0
+        want.append((o1[0], o1[1]))
+assert job.result() == tuple(want)
+for _ in range(20):
+    del job
+    job = _ffi._FingerprintJob("head", bufs)                      # never collected: ended by the destructor
+del job
+h2 = C.c_void_p()
+assert lib.lnasr_hash128_begin(None, None, 2, 0, C.byref(h2)) < 0 and not h2.value
+assert lib.lnasr_hash128_begin(None, None, 0, 0, None) < 0 and lib.lnasr_hash128_end(None, None) < 0
+checked += 3
 
 # the launch helpers' pointer guard (LN_DEVPTR, always on in this build): a heap pointer -- what a numpy array hands over --
 # is refused with a message that names it; null (an optional output) passes
@@ -113,7 +130,7 @@ calls = {
 }
 no_ctx = {"lnasr_abi_version", "lnasr_last_error", "lnasr_device_count", "lnasr_ctx_create", "lnasr_ctx_destroy",
           "lnasr_num_frames", "lnasr_reload_switches", "lnasr_comm_unique_id", "lnasr_comm_destroy", "lnasr_hash128",
-          "lnasr_debug_require_device_ptr", "lnasr_host_free"}
+          "lnasr_debug_require_device_ptr", "lnasr_host_free", "lnasr_hash128_begin", "lnasr_hash128_end"}
 missing = sorted(set(_ffi.SIGNATURES) - set(calls) - no_ctx)
 assert not missing, "entry points without a null-context call here: %s" % missing
 for fn, args in sorted(calls.items()):

@@ -161,3 +161,40 @@ def test_metric_shape_single_utterance_surface(golden, synth):
         assert_close(bm[g["sample_j"], g["sample_m"], g["sample_t"]], g["bm_sample"][u], 1e-12)
         assert abs(b.sum() - g["b_sum"][u]) < 1e-6
     assert_close(gh.calc_prob(obs[0][:32]), g["loglik32"][0], 1e-11)
+
+
+def test_parameter_check_runs_beside_the_kernels(golden, oracle, monkeypatch):
+    """decode() / calc_prob() on a context whose model this object uploaded last: the fingerprint of the parameters is
+    computed in the background (lnasr_hash128_begin) while the kernels run on the model the device holds, and the answer
+    is kept only if it confirms.  Second call: no synchronous check, no upload; after an in-place edit: the
+    speculative answer is dropped and the call repeated on the new parameters; another object using the context in
+    between: no speculation at all."""
+    from lnasr.gmmhmm import GMMHMM
+    g = golden("gmmhmm_d39_diag")
+    N, M, D, si = _diag_model(g)
+    gh = GMMHMM(N, M, D, g["A"].copy(), g["pi"].copy(), g["w"].copy(), g["mu"].copy(), si)
+    ctx = gh.ctx
+    calls = {"upload": 0, "job": 0}
+    up, job = ctx.upload_gmmhmm, ctx.gmm_fingerprint_job
+    monkeypatch.setattr(ctx, "upload_gmmhmm", lambda *a, **k: (calls.__setitem__("upload", calls["upload"] + 1), up(*a, **k))[1])
+    monkeypatch.setattr(ctx, "gmm_fingerprint_job", lambda *a, **k: (calls.__setitem__("job", calls["job"] + 1), job(*a, **k))[1])
+    assert np.array_equal(gh.decode(g["obs"]), g["path"])
+    assert calls == {"upload": 1, "job": 0} and ctx.model_owner == id(gh)
+    assert np.array_equal(gh.decode(g["obs"]), g["path"])
+    assert_close(gh.calc_prob(g["obs"]), g["loglik"][0], 1e-12)
+    assert calls == {"upload": 1, "job": 2}                      # both answers came from speculative runs that were confirmed
+    gh.mu[3, 1, :] -= 0.5                                        # in place: the next speculative answer must be thrown away
+    var = gh.si[:, :, np.arange(D), np.arange(D)]
+    want = oracle.decode_diag(g["obs"], gh.A, gh.pi, gh.w, gh.mu, var)
+    assert not np.array_equal(want, g["path"])
+    assert np.array_equal(gh.decode(g["obs"]), want)
+    assert calls == {"upload": 2, "job": 3}
+    rb, _ = oracle.gmm_map_b_diag(g["obs"], gh.w, gh.mu, var)
+    assert_close(gh.b, rb, 1e-12)                                # the state left behind is the repeated call's, not the stale one
+    other = GMMHMM(N, M, D, g["A"], g["pi"], g["w"], g["mu"], si, ctx=ctx)
+    assert np.array_equal(other.decode(g["obs"]), g["path"])     # uploads its own model: gh no longer owns the device copy
+    assert np.array_equal(gh.decode(g["obs"]), want)
+    assert calls == {"upload": 4, "job": 3}
+    # a call that fails for the caller's own reasons still fails, speculating or not
+    with pytest.raises(ValueError, match="D="):
+        gh.decode(g["obs"][:, :5])
