@@ -118,14 +118,15 @@ __global__ __launch_bounds__(256) void backtrace_tiny_kernel(const TS* __restric
 // an LDS row read; arg-max = DPP wave max, then the first lane holding the max (ballot + ffs),
 // which is numpy.argmax's first-index rule because lane l holds states l and l+64.  Decoded
 // states are collected 64 frames at a time and written as one coalesced 256-byte row.
-template <int CPL, bool LDSAT, typename TS = double, bool FULL = false>
+// SUSPECT = false: nobody will read the suspect word (decode on a diagonal model: the emission kernel tested the features;
+// lnasr_viterbi when the Viterbi kernel tested the emissions itself) -- no cell of v is tested at all.
+template <int CPL, bool LDSAT, typename TS = double, bool FULL = false, bool SUSPECT = true>
 __global__ __launch_bounds__(256) void backtrace_lds_kernel(const TS* __restrict__ v,
                                                            const double* __restrict__ AT,
                                                            const int32_t* __restrict__ lens,
                                                            uint32_t* __restrict__ path, double* __restrict__ best,
                                                            int U, int T, int N, unsigned* __restrict__ suspect_flag,
-                                                           unsigned epoch, int suspect_inf) {
-    // suspect_inf = 0: the Viterbi kernel has tested the emissions itself (viterbi_reg1b<.., CHKB>): only a NaN cell is a suspect
+                                                           unsigned epoch) {
     // lane l holds states l, l+64, ... (CPL of them).  LDSAT: A^T [N][N] (ATs[p*N + i] = A[i][p]) lives in LDS
     // (N <= 128); otherwise the one row a step needs is read from L2 (128 < N <= 256: 512 KB does not fit)
     extern __shared__ double ATs[];
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(256) void backtrace_lds_kernel(const TS* __restrict
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
         const double v0 = ld(vu, (size_t)(L - 1) * N + jj[c]);
-        suspect |= __ballot(suspect_inf ? !(v0 > LN_NEG_INF) : v0 != v0);
+        if (SUSPECT) suspect |= __ballot(!(v0 > LN_NEG_INF));
         x[c] = ok[c] ? v0 : LN_NEG_INF;
     }
     double bestv;
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(256) void backtrace_lds_kernel(const TS* __restrict
 #pragma unroll
                 for (int c = 0; c < CPL; ++c) {
                     const double sum = cur[k][c] + col[jj[c]];          // unconditional (clamped index), then a select
-                    suspect |= __ballot(suspect_inf ? !(cur[k][c] > LN_NEG_INF) : cur[k][c] != cur[k][c]);
+                    if (SUSPECT) suspect |= __ballot(!(cur[k][c] > LN_NEG_INF));
                     x[c] = ok[c] ? sum : LN_NEG_INF;
                 }
                 double mx;
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(256) void backtrace_lds_kernel(const TS* __restrict
 #pragma unroll
             for (int c = 0; c < CPL; ++c) cur[k][c] = nxt[k][c];
     }
-    if (suspect != 0 && lane == 0) *suspect_flag = epoch;
+    if (SUSPECT && suspect != 0 && lane == 0) *suspect_flag = epoch;
 }
 
 // full back-pointer matrix (hmm.py:165): bt[u,t,j] = argmax_i(v[u,t-1,i] + A[i,j]); bt[u,0,:] = 0
@@ -252,7 +253,7 @@ __global__ void bt_kernel(const TS* __restrict__ v, const double* __restrict__ A
 
 
 int backtrace_device(lnasr_ctx* ctx, const void* v, int U, int T, const int32_t* d_lens, int dtype, uint32_t* path,
-                     double* best, bool* v_tested, bool suspect_inf) {
+                     double* best, bool* v_tested, bool want_suspect) {
     LN_DEVPTR(v); LN_DEVPTR(d_lens); LN_DEVPTR(path); LN_DEVPTR(best);
     // *v_tested: the kernel looked at every cell of v and raised the context's "suspect" word on NaN / -inf (nanfix.hip)
     Model& md = ctx->model;
@@ -281,43 +282,35 @@ int backtrace_device(lnasr_ctx* ctx, const void* v, int U, int T, const int32_t*
 #undef LN_TINY
         return 0;
     }
+    // SUSPECT variant only when somebody will read the word (want_suspect: the caller's emissions were not tested upstream)
+#define LN_BT(name, CPLv, LDSv, TSv, FULLv, grid, block, shm)                                                          \
+    do {                                                                                                               \
+        if (want_suspect)                                                                                               \
+            LN_LAUNCH(ctx, name, (backtrace_lds_kernel<CPLv, LDSv, TSv, FULLv, true>), grid, block, shm, (const TSv*)v,  \
+                      md.logAT.as<double>(), d_lens, path, best, U, T, md.N, sflag, epoch);                            \
+        else                                                                                                           \
+            LN_LAUNCH(ctx, name, (backtrace_lds_kernel<CPLv, LDSv, TSv, FULLv, false>), grid, block, shm, (const TSv*)v, \
+                      md.logAT.as<double>(), d_lens, path, best, U, T, md.N, sflag, epoch);                            \
+        if (v_tested) *v_tested = want_suspect;                                                                         \
+        return 0;                                                                                                      \
+    } while (0)
+    const dim3 g4((U + wpb - 1) / wpb), b4(64 * wpb), g1(U), b1(64);
+    const size_t at_lds = (size_t)md.N * md.N * 8;
     if (dtype == LNASR_F64 && md.N <= 128 && !sw().no_ldsbt) {
-        if (v_tested) *v_tested = true;
-        if (md.N == 128)
-            LN_LAUNCH(ctx, "backtrace_lds", (backtrace_lds_kernel<2, true, double, true>), dim3((U + wpb - 1) / wpb),
-                      dim3(64 * wpb), (size_t)md.N * md.N * 8, (const double*)v, md.logAT.as<double>(), d_lens, path, best, U,
-                      T, md.N, sflag, epoch, suspect_inf ? 1 : 0);
-        else
-            LN_LAUNCH(ctx, "backtrace_lds", (backtrace_lds_kernel<2, true>), dim3((U + wpb - 1) / wpb), dim3(64 * wpb),
-                      (size_t)md.N * md.N * 8, (const double*)v, md.logAT.as<double>(), d_lens, path, best, U, T, md.N, sflag, epoch, suspect_inf ? 1 : 0);
-        return 0;
+        if (md.N == 128) LN_BT("backtrace_lds", 2, true, double, true, g4, b4, at_lds);
+        LN_BT("backtrace_lds", 2, true, double, false, g4, b4, at_lds);
     }
     if (dtype == LNASR_F64 && md.N <= 1024 && !sw().no_ldsbt) {
-        if (v_tested) *v_tested = true;
         // one wave per block (with few utterances the waves should sit on different CUs), N / 64 states per lane
-        if (md.N <= 256)
-            LN_LAUNCH(ctx, "backtrace_wave256", (backtrace_lds_kernel<4, false>), dim3(U), dim3(64), 0, (const double*)v,
-                      md.logAT.as<double>(), d_lens, path, best, U, T, md.N, sflag, epoch, suspect_inf ? 1 : 0);
-        else if (md.N <= 512)
-            LN_LAUNCH(ctx, "backtrace_wave512", (backtrace_lds_kernel<8, false>), dim3(U), dim3(64), 0, (const double*)v,
-                      md.logAT.as<double>(), d_lens, path, best, U, T, md.N, sflag, epoch, suspect_inf ? 1 : 0);
-        else
-            LN_LAUNCH(ctx, "backtrace_wave1024", (backtrace_lds_kernel<16, false>), dim3(U), dim3(64), 0, (const double*)v,
-                      md.logAT.as<double>(), d_lens, path, best, U, T, md.N, sflag, epoch, suspect_inf ? 1 : 0);
-        return 0;
+        if (md.N <= 256) LN_BT("backtrace_wave256", 4, false, double, false, g1, b1, 0);
+        if (md.N <= 512) LN_BT("backtrace_wave512", 8, false, double, false, g1, b1, 0);
+        LN_BT("backtrace_wave1024", 16, false, double, false, g1, b1, 0);
     }
-    if (dtype == LNASR_F32 && md.N <= 128 && !sw().no_ldsbt && !sw().f32_generic) {
-        if (v_tested) *v_tested = true;
-        LN_LAUNCH(ctx, "backtrace_lds_f32", (backtrace_lds_kernel<2, true, float>), dim3((U + wpb - 1) / wpb), dim3(64 * wpb),
-                  (size_t)md.N * md.N * 8, (const float*)v, md.logAT.as<double>(), d_lens, path, best, U, T, md.N, sflag, epoch, suspect_inf ? 1 : 0);
-        return 0;
-    }
-    if (dtype == LNASR_F32 && md.N <= 256 && !sw().no_ldsbt && !sw().f32_generic) {
-        if (v_tested) *v_tested = true;
-        LN_LAUNCH(ctx, "backtrace_wave256_f32", (backtrace_lds_kernel<4, false, float>), dim3(U), dim3(64), 0, (const float*)v,
-                  md.logAT.as<double>(), d_lens, path, best, U, T, md.N, sflag, epoch, suspect_inf ? 1 : 0);
-        return 0;
-    }
+    if (dtype == LNASR_F32 && md.N <= 128 && !sw().no_ldsbt && !sw().f32_generic)
+        LN_BT("backtrace_lds_f32", 2, true, float, false, g4, b4, at_lds);
+    if (dtype == LNASR_F32 && md.N <= 256 && !sw().no_ldsbt && !sw().f32_generic)
+        LN_BT("backtrace_wave256_f32", 4, false, float, false, g1, b1, 0);
+#undef LN_BT
     if (dtype == LNASR_F32)
         LN_LAUNCH(ctx, "backtrace_f32", backtrace_kernel<float>, dim3((U + wpb - 1) / wpb), dim3(64 * wpb), 0,
                   (const float*)v, md.logAT.as<double>(), d_lens, path, best, U, T, md.N);

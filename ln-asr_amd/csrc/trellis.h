@@ -86,10 +86,11 @@ int device_lens(lnasr_ctx* ctx, const int32_t* lens, int U, int T, const int32_t
 // with the call's epoch when it met one) -- then the back-trace need not treat -inf cells of v as suspects
 int viterbi_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d_lens, int dtype, void* v,
                    bool* b_tested = nullptr);
-// *v_tested: the kernel looked at every cell of v and raised the context's "suspect" word on NaN / -inf (nanfix.hip);
-// suspect_inf = false: the Viterbi kernel tested its emissions (b_tested), a -inf cell is then just a forbidden state
+// want_suspect: the kernel looks at every cell of v it reads and raises the context's "suspect" word on NaN / -inf (nanfix.hip;
+// *v_tested = it did).  false when nobody will read the word: the emissions were tested upstream (b_tested, or the features
+// by the emission kernel in lnasr_decode) -- a -inf cell is then just a forbidden state, and the kernel tests nothing
 int backtrace_device(lnasr_ctx* ctx, const void* v, int U, int T, const int32_t* d_lens, int dtype, uint32_t* path,
-                     double* best, bool* v_tested = nullptr, bool suspect_inf = true);
+                     double* best, bool* v_tested = nullptr, bool want_suspect = true);
 int bt_matrix_device(lnasr_ctx* ctx, const void* v, int U, int T, const int32_t* d_lens, int dtype, uint32_t* bt);
 int forward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d_lens, int dtype, void* alpha,
                    double* loglik);

@@ -235,7 +235,7 @@ int lnasr_decode(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t*
     // (diagonal models: the emission kernel tested the features, the Viterbi kernel runs without its own test of b)
     LN_TRY(viterbi_device(ctx, ctx->ws_b.p, U, T, d_lens, LNASR_F64, ctx->ws_v.p, by_obs ? nullptr : &b_tested));
     LN_TRY(backtrace_device(ctx, ctx->ws_v.p, U, T, d_lens, LNASR_F64, (uint32_t*)d_path, (double*)d_best, &v_tested,
-                            !b_tested));
+                            !by_obs && !b_tested));
     // a NaN or an infinite feature makes its frame's emissions NaN in the reference, and np.max carries that through every
     // later frame: one launch that returns at once unless the emission kernel raised the flag (nanfix.hip)
     if (by_obs)
