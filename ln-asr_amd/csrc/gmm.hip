@@ -40,13 +40,18 @@ __global__ void transpose_exp_kernel(const double* __restrict__ A, double* __res
     ET[(size_t)j * N + i] = e;
 }
 
-// flag[0] = 1 if any off-diagonal entry of any Sigma is not exactly zero
+// flag[0] = 1 if any off-diagonal entry of any Sigma is not exactly zero.  One atomic per WAVE that found one, and none once
+// the flag is up (a genuinely full model used to issue three million atomics on one address here: 1.1 ms of every upload)
 __global__ void detect_offdiag_kernel(const double* __restrict__ S, size_t total, int D, int* flag) {
+    if (*reinterpret_cast<volatile int*>(flag) != 0) return;
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    size_t e = idx % ((size_t)D * D);
-    int r = (int)(e / D), c = (int)(e % D);
-    if (r != c && !(S[idx] == 0.0)) atomicOr(flag, 1);
+    bool hit = false;
+    if (idx < total) {
+        size_t e = idx % ((size_t)D * D);
+        int r = (int)(e / D), c = (int)(e % D);
+        hit = r != c && !(S[idx] == 0.0);
+    }
+    if (__any(hit) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 
 __global__ void extract_diag_kernel(const double* __restrict__ S, double* __restrict__ var, size_t NMD, int D) {
@@ -103,28 +108,34 @@ __global__ void centre_kernel(const double* __restrict__ mu, int NM, int D, doub
 }
 
 // mu_c = mu - centre, and kappa = max_c (mu_c)^T P_c (mu_c): the size of the terms the expanded quadratic cancels.
-// One thread per component; prec == nullptr: diagonal model (ivar).  A non-finite value counts as +inf.
+// One WAVE per component (rows of P read coalesced; a thread per component walked its own 12 KB matrix with a stride of
+// D doubles: 1.3 ms per pass at the metric shape); prec == nullptr: diagonal model (ivar).  A non-finite value counts as +inf.
 __global__ void centre_mu_kernel(const double* __restrict__ mu, const double* __restrict__ centre,
                                  const double* __restrict__ ivar, const double* __restrict__ prec, int NM, int D,
                                  double* __restrict__ mu_c, unsigned long long* __restrict__ kappa_bits) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (c >= NM) return;
     const double* m = mu + (size_t)c * D;
     double* mc = mu_c + (size_t)c * D;
-    for (int d = 0; d < D; ++d) mc[d] = m[d] - centre[d];
-    double k = 0.0;
-    if (prec) {
-        const double* P = prec + (size_t)c * D * D;
-        for (int i = 0; i < D; ++i) {
-            double t = 0.0;
-            for (int j = 0; j < D; ++j) t += fabs(P[(size_t)i * D + j] * mc[j]);
-            k += fabs(mc[i]) * t;
+    double k = 0.0;                                    // lane-partial; summed over the wave at the end (all terms >= 0)
+    for (int j0 = 0; j0 < D; j0 += 64) {
+        const int j = j0 + lane;
+        const double mj = j < D ? m[j] - centre[j] : 0.0;
+        if (j < D) mc[j] = mj;
+        if (prec) {
+            const double* P = prec + (size_t)c * D * D;
+            for (int i = 0; i < D; ++i) {              // k += |mc_i| * sum_j |P_ij mc_j|
+                const double mi = m[i] - centre[i];
+                if (j < D) k += fabs(mi) * fabs(P[(size_t)i * D + j] * mj);
+            }
+        } else if (j < D) {
+            k += mj * mj * fabs(ivar[(size_t)c * D + j]);
         }
-    } else {
-        for (int d = 0; d < D; ++d) k += mc[d] * mc[d] * fabs(ivar[(size_t)c * D + d]);
     }
+    k = wave_sum(k);
     if (!(k - k == 0.0)) k = __builtin_huge_val();
-    atomicMax(kappa_bits, (unsigned long long)__double_as_longlong(k));   // k >= 0: the bit patterns order like the values
+    if (lane == 0) atomicMax(kappa_bits, (unsigned long long)__double_as_longlong(k));   // k >= 0: the bit patterns order like the values
 }
 
 // One block (64 threads) per component: Gauss-Jordan elimination with partial pivoting on
@@ -647,7 +658,11 @@ __global__ void emit_diag_generic(const double* __restrict__ obs, const double* 
     __syncthreads();
     const double* xs = xs_all + (size_t)(w % fw) * D * 64;
     const long frame = fb + (long)(w % fw) * 64 + lane;
-    for (int n = w / fw; n < N; n += 4 / fw) {
+    // blockIdx.y: a slab of states (the grid is frame tiles x state slabs -- with frame tiles alone a 1000-frame utterance
+    // gave 16 blocks to 256 CUs: round 4, `train` at the metric shape spent 62 ms here)
+    const int slab = (N + gridDim.y - 1) / gridDim.y;
+    const int n_lo = blockIdx.y * slab, n_hi = n_lo + slab < N ? n_lo + slab : N;
+    for (int n = n_lo + w / fw; n < n_hi; n += 4 / fw) {
         Lse acc;
         for (int m = 0; m < M; ++m) {
             const size_t c = (size_t)n * M + m;
@@ -684,7 +699,11 @@ __global__ void emit_full_generic(const double* __restrict__ obs, const double* 
     __syncthreads();
     const double* xs = xs_all + (size_t)(w % fw) * D * 64;
     const long frame = fb + (long)(w % fw) * 64 + lane;
-    for (int n = w / fw; n < N; n += 4 / fw) {
+    // blockIdx.y: a slab of states (the grid is frame tiles x state slabs -- with frame tiles alone a 1000-frame utterance
+    // gave 16 blocks to 256 CUs: round 4, `train` at the metric shape spent 62 ms here)
+    const int slab = (N + gridDim.y - 1) / gridDim.y;
+    const int n_lo = blockIdx.y * slab, n_hi = n_lo + slab < N ? n_lo + slab : N;
+    for (int n = n_lo + w / fw; n < n_hi; n += 4 / fw) {
         Lse acc;
         for (int m = 0; m < M; ++m) {
             const size_t c = (size_t)n * M + m;
@@ -861,7 +880,7 @@ static int centre_and_kappa(lnasr_ctx* ctx, const double* prec) {
             LN_HIP(hipMemsetAsync(md.centre.p, 0, (size_t)D * 8, ctx->stream));
         else
             LN_LAUNCH(ctx, "centre", centre_kernel, dim3(D), dim3(256), 0, md.mu.as<double>(), NM, D, md.centre.as<double>());
-        LN_LAUNCH(ctx, "centre_mu", centre_mu_kernel, dim3((NM + 63) / 64), dim3(64), 0, md.mu.as<double>(),
+        LN_LAUNCH(ctx, "centre_mu", centre_mu_kernel, dim3((NM + 3) / 4), dim3(256), 0, md.mu.as<double>(),
                   (const double*)md.centre.as<double>(), prec ? nullptr : (const double*)md.ivar.as<double>(), prec, NM, D,
                   md.mu_c.as<double>(), kbits);
         unsigned long long kb = 0;
@@ -1164,25 +1183,33 @@ int emit_device_raw(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* 
         if (rc != 0) return rc < 0 ? rc : 0;
     }
     const int fw = N >= 4 ? 1 : 4;
-    const unsigned grid = (unsigned)((F + 64 * fw - 1) / (64 * fw));
+    const unsigned gx = (unsigned)((F + 64 * fw - 1) / (64 * fw));
+    // state slabs: enough blocks to fill the chip when the frame tiles alone do not, never fewer than one state per wave
+    unsigned gy = 1;
+    if (fw == 1) {
+        const unsigned want = (4u * (unsigned)(ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256) + gx - 1) / gx;
+        const unsigned most = (unsigned)(N / 4 > 0 ? N / 4 : 1);
+        gy = want < 1 ? 1 : (want > most ? most : want);
+    }
+    const dim3 grid(gx, gy);
     const size_t shmem = (size_t)D * 64 * 8 * fw;
     LN_REQUIRE(shmem <= 160 * 1024, "D=%d too large for the generic emission kernel", D);
     if (md.diag) {
         if (dtype == LNASR_F32)
-            LN_LAUNCH(ctx, "emit_diag_generic_f32", emit_diag_generic<float>, dim3(grid), dim3(256), shmem, obs,
+            LN_LAUNCH(ctx, "emit_diag_generic_f32", emit_diag_generic<float>, grid, dim3(256), shmem, obs,
                       md.mu.as<double>(), md.ivar.as<double>(), md.gconst.as<double>(), md.logw.as<double>(),
                       (float*)b, (float*)bm, F, N, M, D, fw);
         else
-            LN_LAUNCH(ctx, "emit_diag_generic", emit_diag_generic<double>, dim3(grid), dim3(256), shmem, obs,
+            LN_LAUNCH(ctx, "emit_diag_generic", emit_diag_generic<double>, grid, dim3(256), shmem, obs,
                       md.mu.as<double>(), md.ivar.as<double>(), md.gconst.as<double>(), md.logw.as<double>(),
                       (double*)b, (double*)bm, F, N, M, D, fw);
     } else {
         if (dtype == LNASR_F32)
-            LN_LAUNCH(ctx, "emit_full_generic_f32", emit_full_generic<float>, dim3(grid), dim3(256), shmem, obs,
+            LN_LAUNCH(ctx, "emit_full_generic_f32", emit_full_generic<float>, grid, dim3(256), shmem, obs,
                       md.mu.as<double>(), md.prec.as<double>(), md.gconst.as<double>(), md.logw.as<double>(),
                       (float*)b, (float*)bm, F, N, M, D, fw);
         else
-            LN_LAUNCH(ctx, "emit_full_generic", emit_full_generic<double>, dim3(grid), dim3(256), shmem, obs,
+            LN_LAUNCH(ctx, "emit_full_generic", emit_full_generic<double>, grid, dim3(256), shmem, obs,
                       md.mu.as<double>(), md.prec.as<double>(), md.gconst.as<double>(), md.logw.as<double>(),
                       (double*)b, (double*)bm, F, N, M, D, fw);
     }

@@ -43,7 +43,10 @@ class GMMHMM(HMM):
             return
         si = np.asarray(self.si)
         ctx = self.ctx
-        if not force_full and self.__dict__.get("_speculating") and ctx.model_owner == id(self) and ctx._model_fp is not None:
+        # (not after this object itself replaced its parameters -- _updatemodel, reset, load, apply_stats: the speculative run
+        # would be thrown away for certain)
+        if not force_full and self.__dict__.get("_speculating") and not self.__dict__.get("_replaced") \
+                and ctx.model_owner == id(self) and ctx._model_fp is not None:
             self._spec_job = ctx.gmm_fingerprint_job(self.A, self.pi, self.w, self.mu, si, diag=(si.ndim == 3))
             return
         if force_full and si.ndim == 3:
@@ -53,6 +56,7 @@ class GMMHMM(HMM):
             si = full
         ctx.upload_gmmhmm(self.A, self.pi, self.w, self.mu, si, diag=(si.ndim == 3 and not force_full),
                           force_full=force_full, owner=id(self))
+        self._replaced = False
 
     def upload(self):
         """Upload once before a series of *_batch calls (parameters must not change in between)."""
@@ -124,6 +128,7 @@ class GMMHMM(HMM):
                 break
 
     def _updatemodel(self, model):
+        self._replaced = True
         self.A = model["A"]
         self.pi = model["pi"]
         self.mu = model["mu"]
@@ -142,6 +147,7 @@ class GMMHMM(HMM):
             self.mu = (0.6 * np.random.random_sample((n, m, d)) - 0.3).astype(self.precision)
         else:
             return
+        self._replaced = True
         self.si = np.broadcast_to(np.eye(d, dtype=self.precision), (n, m, d, d)).copy()
 
     def save(self, filename):
@@ -153,6 +159,7 @@ class GMMHMM(HMM):
         d = _load(filename, ("A", "pi", "w", "mu", "si"))
         self.A, self.pi, self.w, self.mu, self.si = d["A"], d["pi"], d["w"], d["mu"], d["si"]
         self.n, self.m, self.d = self.mu.shape
+        self._replaced = True
 
     # ------------------------------------------------------------------ batch extras
     def decode_batch(self, obs_batch, lens=None, want_score=False):
@@ -210,6 +217,7 @@ class GMMHMM(HMM):
     def apply_stats(self, stats):
         """M-step from accumulated statistics; updates the parameters in place."""
         m = self.ctx.bw_mstep(stats, self.min_std)
+        self._replaced = True
         self.A, self.pi, self.w, self.mu = m["A"], m["pi"], m["w"], m["mu"]
         self.si = m["var"] if "var" in m else m["si"]
         return m
