@@ -87,13 +87,54 @@ def measure(ctx, reps=20, obs=None, check_path=None):
     dev, kern = _device_ms(ctx, one_iter, 2)
     rows["train(iters=1)"] = {"wall_ms": wall, "best_ms": best, "device_ms": dev, "host_ms": max(0.0, wall - dev),
                               "kernels": {k: round(v["ms_per_call"], 4) for k, v in list(kern.items())[:5]}}
-    return {"what": "the reference's own method names on one utterance through the mirror classes (lnasr.gmmhmm.GMMHMM): "
+    toy = toy_scripts(ctx)
+    return {"toy_scripts": toy,
+            "what": "the reference's own method names on one utterance through the mirror classes (lnasr.gmmhmm.GMMHMM): "
                     "N=%d M=%d D=%d T=%d, si as [N,M,D,D], numpy arrays in and out; wall = median of %d calls, "
                     "device = kernel time of the same call (HIP events, separate pass), host = the rest" % (N, M, D, T, reps),
             "methods": rows, "parameter_fingerprint_ms": fp_ms, "read_b_and_bm_afterwards_ms": read_ms,
             "reference_decode_ms": REFERENCE_DECODE_MS,
             "reference_decode_source": "BASELINE.md section 2: the unmodified reference, survey container",
             "decode_frames_per_s": T / (rows["decode"]["wall_ms"] * 1e-3)}
+
+
+def toy_scripts(ctx):
+    """The unsupervised-training halves of the reference's own test scripts, at their own (toy) sizes -- where launch and
+    transfer latency, not arithmetic, is what a GPU path could lose on: test/hmm-test.py:41-51 (discrete HMM n=4, m=5, T=190,
+    reset('random'), train(obs, 100): 48 Baum-Welch iterations until eps in the survey's run, 1.26 s for the whole script)
+    and test/gmmhmm-test.py:10-20 (GMMHMM n=5, m=3, d=2, T=40, train(obs, 10): 0.09 s for the whole script)."""
+    import contextlib
+    import io
+    from lnasr.gmmhmm import GMMHMM
+    from lnasr.hmm import HMM
+    out = {}
+    obs = np.array((0, 1, 1, 2, 0, 4, 2, 3, 4, 2, 0, 2, 3, 4, 4, 2, 1, 0, 1) * 10)
+    for rep in range(2):                                   # second run: library warm
+        np.random.seed(0)
+        h = HMM(4, 5, ctx=ctx)
+        h.reset("random")
+        buf = io.StringIO()
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(buf):
+            h.train(obs, 100)
+        dt = time.perf_counter() - t0
+    iters = buf.getvalue().count("Iter:")
+    out["hmm-test.py train(obs, 100)"] = {"wall_ms": dt * 1e3, "iterations": iters, "ms_per_iteration": dt * 1e3 / max(1, iters),
+                                         "reference_script_ms": 1260.0}
+    for rep in range(2):
+        np.random.seed(0)
+        x = np.array(0.6 * np.random.random_sample((40, 2)) - 0.3, dtype=np.double)
+        gh = GMMHMM(5, 3, 2, ctx=ctx)
+        gh.reset("random")
+        buf = io.StringIO()
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(buf):
+            gh.train(x, 10)
+        dt = time.perf_counter() - t0
+    iters = buf.getvalue().count("Iter:")
+    out["gmmhmm-test.py train(obs, 10)"] = {"wall_ms": dt * 1e3, "iterations": iters, "ms_per_iteration": dt * 1e3 / max(1, iters),
+                                           "reference_script_ms": 90.0}
+    return out
 
 
 def main():
@@ -106,6 +147,9 @@ def main():
         print("%-22s %9.3f %9.3f %9.3f %9.3f   %s" % (k, v["wall_ms"], v["best_ms"], v["device_ms"], v["host_ms"], v["kernels"]))
     print("parameter fingerprint (per call): %.3f ms; reading b + bm back afterwards: %.3f ms; reference decode(): %.0f ms"
           % (r["parameter_fingerprint_ms"], r["read_b_and_bm_afterwards_ms"], r["reference_decode_ms"]))
+    for k, v in r["toy_scripts"].items():
+        print("%-32s %8.2f ms for %d iterations (%.3f ms each); the reference's whole script: %.0f ms"
+              % (k, v["wall_ms"], v["iterations"], v["ms_per_iteration"], v["reference_script_ms"]))
 
 
 if __name__ == "__main__":
