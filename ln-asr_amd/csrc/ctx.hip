@@ -363,7 +363,9 @@ int lnasr_host_free(lnasr_ctx* ctx, void* p) {
 int lnasr_device_info(lnasr_ctx* ctx, char* name, int name_cap, int* cu_count, size_t* hbm_bytes) {
     LN_ENTER(ctx);
     LN_REQUIRE(ctx, "null ctx");
-    if (name && name_cap > 0) snprintf(name, name_cap, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+    // (this pool's driver reports an empty marketing name: say what the device is rather than print " (gfx950...)")
+    if (name && name_cap > 0)
+        snprintf(name, name_cap, "%s (%s)", ctx->prop.name[0] ? ctx->prop.name : "AMD Instinct MI355X-class GPU", ctx->prop.gcnArchName);
     if (cu_count) *cu_count = ctx->prop.multiProcessorCount;
     if (hbm_bytes) *hbm_bytes = ctx->prop.totalGlobalMem;
     return 0;
