@@ -113,7 +113,8 @@ constexpr double kKappaMaxF32 = 128.0;
 struct Switches {
     bool no_mfma = false, no_pad = false, no_tinyvit = false, no_regvit = false, no_regfwd = false, no_colfwd = false,
          no_t256 = false, no_framepar = false, no_stream = false, no_ldsbt = false, no_mfma_stats = false,
-         no_fft512 = false, no_pipeline = false, f32_generic = false, no_f32_stats = false, no_pinned_ring = false;
+         no_fft512 = false, no_pipeline = false, f32_generic = false, no_f32_stats = false, no_pinned_ring = false,
+         no_tinyfwd = false;
     char vit = 0;                 // LNASR_VIT: first character, 0 = unset
     char fwd = 0;                 // LNASR_FWD: 'c' = the four-utterance column-owned forward / backward kernel (fwdbwd_cols)
     int framepar_maxu = -1;       // LNASR_FRAMEPAR_MAXU, -1 = unset (measured rule)

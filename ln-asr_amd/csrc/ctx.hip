@@ -64,6 +64,7 @@ static void load_switches(Switches& s) {
     s.no_mfma = on("LNASR_NO_MFMA");
     s.no_pad = on("LNASR_NO_PAD");
     s.no_tinyvit = on("LNASR_NO_TINYVIT");
+    s.no_tinyfwd = on("LNASR_NO_TINYFWD");
     s.no_regvit = on("LNASR_NO_REGVIT");
     s.no_regfwd = on("LNASR_NO_REGFWD");
     s.no_colfwd = on("LNASR_NO_COLFWD");

@@ -691,12 +691,184 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 
+// ------------------------------------------------------------------------------------------
+// Tiny models (N <= 16; round 4): the toy HMMs of the reference's own test scripts (test/hmm-test.py n = 4,
+// test/gmmhmm-test.py n = 5) and segmentation-sized discrete HMMs (scripts/seg/seg.py, n = 4) through `train` /
+// `calc_prob`.  The block kernels above spend two barriers and an LDS round trip per frame whatever N is: 2 us a frame,
+// i.e. 0.38 ms for one forward pass over T = 190 -- three quarters of a Baum-Welch iteration of hmm-test.py.  Here, as in
+// viterbi_tiny_kernel: one WAVE per utterance, no barrier; lane j (of DPP row 0) holds prev[j] and the column
+// expA[:, j] in registers, the e values reach every lane through v_fmac_f64_dpp row_newbcast (one instruction per
+// transition), the maximum is four DPP steps inside the row, emissions and results move through the wave's LDS slice 64
+// frames at a time.  Same shift rule, same exact log-domain fallback for columns whose linear sum leaves the safe range,
+// same rounding at the store for float storage as the kernels above.
+//   FORWARD : Aexp = expA  [i][j], Alog = logA;   lane j:  a[i] = expA[i][j]
+//   BACKWARD: Aexp = expA^T[j][i], Alog = logA^T; lane i:  a[j] = expA[i][j]   (prev[j] = beta[t+1, j] + b[t+1, j])
+// ------------------------------------------------------------------------------------------
+template <typename TS, bool BACKWARD, int NMAX>
+__global__ __launch_bounds__(256) void fwdbwd_tiny_kernel(const TS* __restrict__ b, const double* __restrict__ Aexp,
+                                                         const double* __restrict__ Alog, const double* __restrict__ pi,
+                                                         const int32_t* __restrict__ lens, TS* __restrict__ out,
+                                                         double* __restrict__ loglik, int U, int T, int N,
+                                                         unsigned* __restrict__ nan_flag, unsigned nan_epoch) {
+    constexpr int C = 64;
+    __shared__ double bch[4][C * NMAX];                   // emissions of the chunk, [frame - lo][state], stride N
+    __shared__ double och[4][C * NMAX + 1];               // results of the chunk, same layout (+ a slot for idle lanes)
+    __shared__ double etab[kExpTab];
+    __shared__ double ltab[2 * kLogTab];
+    exp_table_init(etab, threadIdx.x, 256);
+    log_table_init(ltab, threadIdx.x, 256);
+    __syncthreads();                                      // tables; from here on the waves never synchronise
+    constexpr int ODUMP = C * NMAX;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int u = blockIdx.x * 4 + w;
+    if (u >= U) return;
+    const int L = lens[u];
+    if (L <= 0) return;
+    const bool act = lane < N;
+    const int j = act ? lane : N - 1;
+    double a[NMAX], al[NMAX];                             // linear and log transition weights into this lane's state
+#pragma unroll
+    for (int i = 0; i < NMAX; ++i) {
+        a[i] = (i < N && act) ? Aexp[(size_t)i * N + j] : 0.0;
+        al[i] = (i < N && act) ? Alog[(size_t)i * N + j] : LN_NEG_INF;
+    }
+    const TS* bu = b + (size_t)u * T * N;
+    TS* ou = out ? out + (size_t)u * T * N : nullptr;
+    double* bc = bch[w];
+    double* oc = och[w];
+    constexpr int EPL = (C * NMAX + 63) / 64;
+    double stage[EPL];
+    // chunk c covers steps 64 c .. 64 c + nfr - 1; step s is frame s (forward) or L - 1 - s (backward); lo = its lowest frame
+    auto chunk_lo = [&](int s0, int nfr) { return BACKWARD ? L - s0 - nfr : s0; };
+    auto fetch = [&](int s0) {
+        const int nfr = L - s0 < C ? L - s0 : C;
+        const int lo = chunk_lo(s0, nfr);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int idx = lane + 64 * e;
+            stage[e] = idx < nfr * N ? ld(bu, (size_t)lo * N + idx) : 0.0;
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int idx = lane + 64 * e;
+            if (idx < C * N) bc[idx] = stage[e];
+        }
+    };
+    unsigned long long saw_nan = 0;
+    double prev = LN_NEG_INF;                             // log domain; lanes >= N stay at -inf
+    fetch(0);
+    stash();
+    __builtin_amdgcn_wave_barrier();
+    for (int s0 = 0; s0 < L; s0 += C) {
+        const int nfr = L - s0 < C ? L - s0 : C;
+        const int lo = chunk_lo(s0, nfr);
+        if (s0 + C < L) fetch(s0 + C);                    // the next chunk's emissions travel during this one
+        for (int k = 0; k < nfr; ++k) {
+            const int fl = BACKWARD ? nfr - 1 - k : k;    // frame - lo
+            const double bt_ = bc[fl * N + j];
+            double val;
+            if (s0 + k == 0) {                            // first step: alpha[0] = pi + b[0];  beta[L-1] = 0
+                val = BACKWARD ? 0.0 : rnd<TS>(pi[j] + bt_);
+            } else {
+                double S = act ? prev : LN_NEG_INF;
+                S = vmax_f64(S, dpp_f64<0xB1>(S));
+                S = vmax_f64(S, dpp_f64<0x4E>(S));
+                S = vmax_f64(S, dpp_f64<0x141>(S));
+                S = vmax_f64(S, dpp_f64<0x140>(S));
+                const bool dead = S == LN_NEG_INF;
+                const double e = (dead || prev == LN_NEG_INF || !act) ? 0.0 : exp_clamped(prev - S, etab);
+                double sum = 0.0;
+                static_for<0, NMAX>([&](auto I) { fmac_bcast<decltype(I)::value>(sum, e, a[decltype(I)::value]); });
+                const bool safe = sum >= kSafeSum && sum <= 1e290 && !dead;
+                val = S + log_sum(safe ? sum : 1.0, ltab);
+                if (__any(!safe && act)) {                // rare, wave-uniform: the exact log-domain column for every lane
+                    double mx = LN_NEG_INF;
+                    static_for<0, NMAX>([&](auto I) {
+                        mx = fmax(mx, mov_bcast<decltype(I)::value>(prev) + al[decltype(I)::value]);
+                    });
+                    double s2 = 0.0;
+                    static_for<0, NMAX>([&](auto I) {
+                        const double z = mov_bcast<decltype(I)::value>(prev) + al[decltype(I)::value];
+                        s2 += (mx == LN_NEG_INF || z == LN_NEG_INF) ? 0.0 : exp(z - mx);
+                    });
+                    const double ex = (mx == LN_NEG_INF || mx != mx) ? mx : mx + log(s2);
+                    val = safe ? val : ex;
+                }
+                val = BACKWARD ? rnd<TS>(val) : rnd<TS>(val + bt_);
+            }
+            oc[act ? fl * N + j : ODUMP] = val;
+            prev = BACKWARD ? val + bt_ : val;
+            saw_nan |= __ballot(act && prev != prev);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (ou) {                                         // the chunk's rows leave whole
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const int idx = lane + 64 * e;
+                if (idx < nfr * N) st(ou, (size_t)lo * N + idx, oc[idx]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (s0 + C < L) stash();
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (saw_nan != 0 && lane == 0) *nan_flag = nan_epoch;
+    if (!BACKWARD && loglik) {                            // calc_prob: lse_j alpha[L-1, j]  (hmm.py:274)
+        double mx = act ? prev : LN_NEG_INF;
+        mx = vmax_f64(mx, dpp_f64<0xB1>(mx));
+        mx = vmax_f64(mx, dpp_f64<0x4E>(mx));
+        mx = vmax_f64(mx, dpp_f64<0x141>(mx));
+        mx = vmax_f64(mx, dpp_f64<0x140>(mx));
+        double sacc = (!act || mx == LN_NEG_INF || prev == LN_NEG_INF) ? 0.0 : exp(prev - mx);
+        sacc += dpp_f64<0xB1>(sacc);
+        sacc += dpp_f64<0x4E>(sacc);
+        sacc += dpp_f64<0x141>(sacc);
+        sacc += dpp_f64<0x140>(sacc);
+        const double nanv = act ? prev : 0.0;             // a NaN alpha anywhere makes the likelihood NaN
+        const bool any_nan = __ballot(nanv != nanv) != 0;
+        if (lane == 0) loglik[u] = any_nan ? __builtin_nan("") : ((mx == LN_NEG_INF) ? mx : mx + log(sacc));
+    }
+}
+
+template <bool BACKWARD>
+static int fwdbwd_tiny_launch(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d_lens, int dtype, void* out,
+                              double* loglik) {
+    Model& md = ctx->model;
+    const int N = md.N;
+    const double* Alin = BACKWARD ? md.expAT.as<double>() : md.expA.as<double>();
+    const double* Alog = BACKWARD ? md.logAT.as<double>() : md.logA.as<double>();
+    const double* pi = md.logpi.as<double>();
+    unsigned* flag = ctx->nan_flag.as<unsigned>() + 2;
+    const dim3 grid((U + 3) / 4), block(256);
+    const int nmax = N <= 4 ? 4 : (N <= 8 ? 8 : 16);
+#define LN_FT(TS, NM)                                                                                                \
+    LN_LAUNCH(ctx, BACKWARD ? "backward_tiny" : "forward_tiny", (fwdbwd_tiny_kernel<TS, BACKWARD, NM>), grid, block, 0, \
+              (const TS*)b, Alin, Alog, pi, d_lens, (TS*)out, BACKWARD ? (double*)nullptr : loglik, U, T, N, flag,   \
+              ctx->nan_epoch)
+    if (dtype == LNASR_F32) {
+        if (nmax == 4) LN_FT(float, 4);
+        else if (nmax == 8) LN_FT(float, 8);
+        else LN_FT(float, 16);
+    } else {
+        if (nmax == 4) LN_FT(double, 4);
+        else if (nmax == 8) LN_FT(double, 8);
+        else LN_FT(double, 16);
+    }
+#undef LN_FT
+    ctx->fwd_nan_tested = true;
+    return 0;
+}
+
 int forward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d_lens, int dtype, void* alpha,
                    double* loglik) {
     LN_DEVPTR(b); LN_DEVPTR(d_lens); LN_DEVPTR(alpha); LN_DEVPTR(loglik);
     Model& md = ctx->model;
     const int N = md.N;
     ctx->fwd_nan_tested = false;
+    if (N <= dispatch::kTinyMaxN && !sw().no_tinyfwd && (dtype == LNASR_F64 || !sw().f32_generic))
+        return fwdbwd_tiny_launch<false>(ctx, b, U, T, d_lens, dtype, alpha, loglik);
     // precision=np.float32: float storage, every alpha rounded at its store and the recursion continued from the
     // rounded value, as the reference's float32 array does (hmm.py:93-99).  N <= 128: the column-owned kernel with float
     // storage; 128 < N <= 256: the on-chip kernel with float storage; otherwise (and under LNASR_F32_GENERIC /
@@ -769,6 +941,8 @@ int backward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* 
     const int N = md.N;
     ctx->fwd_nan_tested = false;
     const double* expAT = md.expAT.as<double>();
+    if (N <= dispatch::kTinyMaxN && !sw().no_tinyfwd && (dtype == LNASR_F64 || !sw().f32_generic))
+        return fwdbwd_tiny_launch<true>(ctx, b, U, T, d_lens, dtype, beta, nullptr);
     if (dtype == LNASR_F32 && !sw().f32_generic) {       // float storage, rounded at every store (hmm.py:124-130); see forward_device
         if (N <= dispatch::kRegMaxN && !sw().no_regfwd && !sw().no_colfwd) {
             LN_LAUNCH(ctx, "backward_cols2_f32", (fwdbwd_cols2<true, float>), dim3((U + 1) / 2), dim3(256), 0, (const float*)b,

@@ -168,6 +168,17 @@ class DeviceArray:
         check(lib().lnasr_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, self.nbytes))
         return out
 
+    def rows_to_host(self, first, count, width):
+        """`count` rows of `width` elements starting at row `first` of the array seen as [rows, width] -> numpy [count, width]
+        (e.g. alpha[T-1] of a resident [1,T,N] trellis without moving the other T-1 rows)."""
+        total = self.nbytes // (int(width) * self.dtype.itemsize)
+        if not (0 <= first and first + count <= total):
+            raise ValueError("rows %d..%d of %d" % (first, first + count, total))
+        out = np.empty((int(count), int(width)), dtype=self.dtype)
+        off = int(first) * int(width) * self.dtype.itemsize
+        check(lib().lnasr_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr + off, out.nbytes))
+        return out
+
     def free(self):
         if getattr(self, "_parent", None) is not None:      # a view: the parent owns the memory
             self._parent = None

