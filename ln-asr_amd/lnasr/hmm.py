@@ -132,9 +132,20 @@ class HMM:
     def _map_b(self, obs: np.ndarray):
         """b[:, t] = B[:, obs[t]]  (hmm.py:47-61)."""
         obs = np.asarray(obs)
-        b = self.ctx.discrete_map_b(np.asarray(self.B, dtype=np.float64), obs.astype(np.int32), self.precision,
+        b = self.ctx.discrete_map_b(self._B_resident(), obs.astype(np.int32), self.precision,
                                     device_out=True, b_out=self._device_buffer("b"))
         self._keep("b", b, lambda h: h[0].T)
+
+    def _B_resident(self):
+        """The emission table in HBM, sent again only when its bytes changed (scripts/seg/seg.py's B is [4, 65536]: 2 MB per
+        `decode` otherwise; the check is the same fingerprint the transition model gets)."""
+        B = np.asarray(self.B)
+        fp = self.ctx._fingerprint("B", (B,))
+        held = self.__dict__.get("_B_dev")
+        if held is None or held[0] != fp or held[1].ctx is not self.ctx or not held[1].ptr:
+            held = (fp, self.ctx.to_device(B, dtype=np.float64))
+            self._B_dev = held
+        return held[1]
 
     # ------------------------------------------------------------------ trellises
     def _forward(self, obs: np.ndarray, remap: bool = False) -> np.ndarray:
