@@ -358,3 +358,61 @@ def test_viterbi_tiny_models_chunk_boundaries(N, dtype, synth, oracle, ctx):
         assert np.array_equal(r["bt"][u, :L], bt), "bt N=%d u=%d" % (N, u)
         assert np.array_equal(r["path"][u, :L], path), "path N=%d u=%d" % (N, u)
         assert r["score"][u] == v[-1].max()
+
+
+def test_full_covariance_direct_form_on_the_matrix_cores(golden, synth, oracle, ctx):
+    """Full-covariance models the expanded quadratic is refused for (kappa beyond the gate) are scored in the reference's
+    direct form (x - mu)^T P (x - mu) by `emit_full_direct_mfma` (Y P as fp64 MFMAs per component, then a row-wise dot):
+    the reference's own d39 golden forced onto it, a model with means 15 units apart and a real full Sigma (the case the
+    gate exists for), and odd shapes -- D from 1 to 64, N not a multiple of four, M beyond one mixture group, frame counts
+    off the 64-frame tile, with and without bm -- against the oracle's reference-shaped arithmetic."""
+    g = golden("gmmhmm_d39_full")
+    N, M, D = g["mu"].shape
+    with env_switch(LNASR_KAPPA_MAX="0"):
+        ctx._model_fp = None
+        ctx.upload_gmmhmm(g["A"], g["pi"], g["w"], g["mu"], g["si"])
+        assert ctx.model_conditioning()[1] and not ctx.model_is_diag()
+        (b, bm), names = _kernels_of(ctx, lambda: ctx.gmm_logprob(g["obs"][None], want_bm=True))
+        assert "emit_full_direct_mfma_bm" in names or not tuned()
+        assert_close(b[0].T, g["b"], 1e-12), assert_close(bm[0].transpose(1, 2, 0), g["bm"], 1e-12)
+        b_only, names = _kernels_of(ctx, lambda: ctx.gmm_logprob(g["obs"][None]))
+        assert "emit_full_direct_mfma" in names or not tuned()
+        assert np.array_equal(b_only, b)
+        assert np.array_equal(ctx.decode(g["obs"][None])[0], g["path"])
+    ctx._model_fp = None
+    # the gate's own case with a genuinely full Sigma: wide means, small variances, correlated dimensions
+    w = golden("gmmhmm_offset_means")
+    Nw, Mw, Dw = w["wide_mu"].shape
+    rng = np.random.default_rng(17)
+    si = np.zeros((Nw, Mw, Dw, Dw))
+    for n in range(Nw):
+        for m in range(Mw):
+            R = 0.2 * rng.standard_normal((Dw, Dw))
+            sd = np.sqrt(w["wide_var"][n, m])
+            si[n, m] = (np.eye(Dw) + R @ R.T) * np.outer(sd, sd)
+    ctx.upload_gmmhmm(w["A"], w["pi"], w["w"], w["wide_mu"], si)
+    kappa, direct = ctx.model_conditioning()
+    assert direct and kappa > 1e4
+    (b, bm), names = _kernels_of(ctx, lambda: ctx.gmm_logprob(w["wide_obs"][None], want_bm=True))
+    assert "emit_full_direct_mfma_bm" in names or not tuned()
+    ob, obm = oracle.gmm_map_b(w["wide_obs"], w["w"], w["wide_mu"], si)
+    assert_close(b[0].T, ob, 1e-11, 1e-9), assert_close(bm[0].transpose(1, 2, 0), obm, 1e-11, 1e-9)
+    # shapes around every edge of the kernel's tiling
+    with env_switch(LNASR_KAPPA_MAX="0"):
+        for N, M, D, U, T in ((5, 3, 1, 2, 7), (3, 17, 2, 1, 70), (6, 1, 16, 3, 33), (9, 7, 17, 2, 64), (4, 4, 33, 1, 129),
+                              (2, 2, 48, 2, 20), (3, 5, 64, 1, 65), (130, 2, 5, 1, 10)):
+            mdl = synth.synth_model(N, M, D, seed=N + M + D, full_cov=True)
+            obs = synth.synth_obs(U, T, D, seed=D)
+            ctx._model_fp = None
+            ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["si"])
+            if D > 1:
+                assert ctx.model_conditioning()[1]
+            b, bm = ctx.gmm_logprob(obs, want_bm=True)
+            b2 = ctx.gmm_logprob(obs)
+            for u in range(U):
+                ob, obm = oracle.gmm_map_b(obs[u], mdl["w"], mdl["mu"], mdl["si"])
+                tag = "N=%d M=%d D=%d T=%d" % (N, M, D, T)
+                assert_close(b[u].T, ob, 1e-11, 1e-10, msg="b " + tag)
+                assert_close(bm[u].transpose(1, 2, 0), obm, 1e-11, 1e-10, msg="bm " + tag)
+                assert_close(b2[u].T, ob, 1e-11, 1e-10, msg="b (no bm) " + tag)
+    ctx._model_fp = None
