@@ -150,6 +150,7 @@ struct lnasr_ctx {
     lnasr::DevBuf ws_in, ws_in2, ws_in3, ws_in4, ws_in5;   // staged host inputs
     lnasr::DevBuf ws_out, ws_out2, ws_out3;                // staged outputs
     lnasr::DevBuf ws_b, ws_bm, ws_v, ws_alpha, ws_beta, ws_misc, ws_misc2, ws_lens, ws_stats;
+    int lens_fill_U = 0, lens_fill_T = -1;                 // ws_lens holds "every utterance is T frames long" for this many utterances
     lnasr::DevBuf ws_p, ws_q, ws_raw;                      // Baum-Welch statistics: xi factors, raw mixture moments
     lnasr::DevBuf ws_w1, ws_w2, ws_w3;                     // float32 storage: widened inputs / outputs of the f64 kernels
     lnasr::DevBuf ws_pad;                                  // bm of a padded model before compaction
