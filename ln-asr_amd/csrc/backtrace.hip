@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void backtrace_tiny_kernel(const TS* __restric
 // SUSPECT = false: nobody will read the suspect word (decode on a diagonal model: the emission kernel tested the features;
 // lnasr_viterbi when the Viterbi kernel tested the emissions itself) -- no cell of v is tested at all.
 template <int CPL, bool LDSAT, typename TS = double, bool FULL = false, bool SUSPECT = true>
-__global__ __launch_bounds__(256) void backtrace_lds_kernel(const TS* __restrict__ v,
+__global__ __launch_bounds__(1024) void backtrace_lds_kernel(const TS* __restrict__ v,
                                                            const double* __restrict__ AT,
                                                            const int32_t* __restrict__ lens,
                                                            uint32_t* __restrict__ path, double* __restrict__ best,
@@ -257,7 +257,10 @@ int backtrace_device(lnasr_ctx* ctx, const void* v, int U, int T, const int32_t*
     LN_DEVPTR(v); LN_DEVPTR(d_lens); LN_DEVPTR(path); LN_DEVPTR(best);
     // *v_tested: the kernel looked at every cell of v and raised the context's "suspect" word on NaN / -inf (nanfix.hip)
     Model& md = ctx->model;
-    const int wpb = dispatch::kBacktraceWavesPerBlock;
+    // waves (= utterances) per block of the LDS kernels: four while the batch fits one round of blocks (one per CU: A^T takes
+    // 128 KB of its LDS), more -- up to sixteen, four chains per SIMD -- when it does not: the chains are latency-bound and
+    // interleave, so 8192 utterances on one GPU take two rounds instead of eight (2.17 -> 1.51 ms; 2048: 0.52 -> 0.43)
+    const int wpb = dispatch::backtrace_waves_per_block(U, ctx->prop.multiProcessorCount);
     unsigned* const sflag = ctx->nan_flag.as<unsigned>() + 1;
     const unsigned epoch = ctx->nan_epoch;
     if (v_tested) *v_tested = false;
@@ -266,7 +269,7 @@ int backtrace_device(lnasr_ctx* ctx, const void* v, int U, int T, const int32_t*
         const uint8_t* bp = ctx->ws_bp.as<uint8_t>();
         const int nmax = ctx->bp_nmax;
         ctx->bp_v = nullptr;
-        const dim3 grid((U + wpb - 1) / wpb), block(64 * wpb);
+        const dim3 grid((U + 3) / 4), block(256);           // four waves per block: the kernel's LDS slices are [4]
 #define LN_TINY(TS, NM)                                                                                        \
     LN_LAUNCH(ctx, "backtrace_tiny", (backtrace_tiny_kernel<TS, NM>), grid, block, 0, (const TS*)v, bp, d_lens, path, best, \
               U, T, md.N)
@@ -312,10 +315,10 @@ int backtrace_device(lnasr_ctx* ctx, const void* v, int U, int T, const int32_t*
         LN_BT("backtrace_wave256_f32", 4, false, float, false, g1, b1, 0);
 #undef LN_BT
     if (dtype == LNASR_F32)
-        LN_LAUNCH(ctx, "backtrace_f32", backtrace_kernel<float>, dim3((U + wpb - 1) / wpb), dim3(64 * wpb), 0,
+        LN_LAUNCH(ctx, "backtrace_f32", backtrace_kernel<float>, dim3((U + 3) / 4), dim3(256), 0,
                   (const float*)v, md.logAT.as<double>(), d_lens, path, best, U, T, md.N);
     else
-        LN_LAUNCH(ctx, "backtrace", backtrace_kernel<double>, dim3((U + wpb - 1) / wpb), dim3(64 * wpb), 0,
+        LN_LAUNCH(ctx, "backtrace", backtrace_kernel<double>, dim3((U + 3) / 4), dim3(256), 0,
                   (const double*)v, md.logAT.as<double>(), d_lens, path, best, U, T, md.N);
     return 0;
 }

@@ -74,8 +74,14 @@ inline int fwdbwd_stream_ub(int N, int U, int n_cu) {
     return 4;
 }
 
-// Back-trace: waves (= utterances) per block of the LDS kernels.  Round 1.
-constexpr int kBacktraceWavesPerBlock = 4;
+// Back-trace: waves (= utterances) per block of the LDS kernels: four (round 1) while U <= 4 x CUs, i.e. while one round of
+// blocks -- one per CU, A^T fills its LDS -- covers the batch; beyond that as many as keep it to one round, at most sixteen
+// (round 4, bench.py --utts 8192: the latency-bound chains of a SIMD's four waves interleave for free).
+inline int backtrace_waves_per_block(int U, int n_cu) {
+    if (n_cu <= 0) n_cu = 256;
+    const int w = (U + n_cu - 1) / n_cu;
+    return w < 4 ? 4 : (w > 16 ? 16 : w);
+}
 
 }  // namespace dispatch
 
