@@ -707,7 +707,9 @@ __global__ __launch_bounds__(64 * NW) void mfcc_frame512x4_kernel(
     // the younger fills the gaps), so waves 0-3 of every block finished after 194 us and waves 4-7 after 252 us, alone
     // on their SIMDs for the difference (per-wave lifetimes: tools/mfcc_stamps.py); and ceil(G / waves) groups per wave
     // left the last six blocks without work.  With tickets the fast waves simply take more chunks.
-    constexpr int kChunk = 2;
+    // (chunks of 1 / 2 / 4 / 8 / 16 groups with the phase priorities in place, ms per 256 k frames f64 / int16: 0.263 / 0.256,
+    // 0.268 / 0.258, 0.259 / 0.249, 0.260 / 0.258, 0.261 / 0.259: round 4)
+    constexpr int kChunk = 4;
     const int64_t G = (F + 3) / 4, per_block = (G + gridDim.x - 1) / gridDim.x;
     const int64_t bbeg = (int64_t)blockIdx.x * per_block, bend = bbeg + per_block < G ? bbeg + per_block : G;
     if (tid == 0) ticket = 0;
