@@ -523,7 +523,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                                                           double* __restrict__ bm, long F, int M, int D, long ntiles,
                                                           unsigned* __restrict__ nan_flag, unsigned nan_epoch) {
     constexpr int NL = KS / 2;                 // loads per lane and tile
-    constexpr unsigned kTick = 2;              // tiles per draw (1: 0.079 ms, the draw then sits in front of every prefetch; 2: 0.074)
+    constexpr unsigned kTick = 2;              // tiles per draw (1: 0.079 ms, the draw then sits in front of every prefetch; 2: 0.074;
+                                               // round 4, another box: 2: 0.078, 4: 0.082, 8: 0.081)
     __shared__ double etab[kExpTab];
     __shared__ double ltab[2 * kLogTab];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
