@@ -403,6 +403,31 @@ def gen_discrete_mid():
          calc_prob=np.array([h.calc_prob(obs)]))
 
 
+def gen_f32_families():
+    """precision=np.float32 on the sizes of the other trellis kernel families (round 4): the reference's own float32 alpha /
+    beta / v / bt / path for N = 12 (one-wave kernels), N = 128 (register / column-owned kernels) and N = 200 (on-chip
+    kernel) -- every value rounded at its store and read back for the next frame (hmm.py:93-99, 124-130, 160-165)."""
+    out = {}
+    for N, T in ((12, 80), (128, 48), (200, 24)):
+        d = synth.synth_discrete(N, 8, T, seed=40 + N)
+        A = d["A"].copy()
+        A[2, :] = -np.inf                                  # a state that can only be left towards state 5 ...
+        A[2, 5] = 0.0
+        A[:, 7] = -np.inf                                  # ... and an unreachable one
+        h = HMM(N, 8, A, d["B"], d["pi"], precision=np.float32)
+        obs = d["obs"]
+        alpha = h._forward(obs, True)
+        beta = h._backward(obs)
+        v, bt, path = h._viterbi(obs)
+        assert alpha.dtype == np.float32 and v.dtype == np.float32 and h.b.dtype == np.float32
+        tag = "n%d_" % N
+        # (A, B, pi, obs are regenerated by the tests from the same seed with the repo's own synth module: only checksums here)
+        out.update({tag + "A_sum": np.array([np.where(np.isfinite(A), A, 0.0).sum()]), tag + "obs": obs,
+                    tag + "b_sum": np.array([h.b.astype(np.float64).sum()]),
+                    tag + "alpha": alpha, tag + "beta": beta, tag + "v": v, tag + "bt": bt.astype(np.uint8), tag + "path": path})
+    save("hmm_f32_families", shapes=np.array([[12, 80], [128, 48], [200, 24]]), **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:                       # python gen_golden.py gen_gmmhmm_f32_mid ...: only these fixtures
         with np.errstate(divide="ignore"):
@@ -423,3 +448,4 @@ if __name__ == "__main__":
         gen_offset_means()
         gen_gmmhmm_f32_mid()
         gen_nonfinite()
+        gen_f32_families()

@@ -579,3 +579,31 @@ def test_float32_forward_backward_round_at_every_store(golden, synth, oracle):
                 ob = oracle.backward(A, b[u, :L].T, precision=np.float32)
             check(al[u, :L], oa, "N=%d alpha u=%d" % (N, u), max_off=max(2, oa.size // 20000))
             check(be[u, :L], ob, "N=%d beta u=%d" % (N, u), max_off=max(2, ob.size // 20000))
+
+
+def test_float32_reference_arrays_on_every_kernel_family(golden, synth):
+    """The reference itself run with precision=np.float32 at N = 12 (one-wave kernels), N = 128 (register-resident Viterbi,
+    column-owned forward / backward) and N = 200 (on-chip kernel), golden hmm_f32_families: v, bt and path bit for bit; alpha
+    and beta bit for bit up to the rare value whose fp64 sum straddles a float rounding boundary (one ulp, at most two values).
+    Through the mirror class, i.e. HMM(precision=np.float32)._forward / _backward / _viterbi on the resident float32 b."""
+    from lnasr.hmm import HMM
+    g = golden("hmm_f32_families")
+    for N, T in g["shapes"]:
+        N, T = int(N), int(T)
+        d = synth.synth_discrete(N, 8, T, seed=40 + N)
+        A = d["A"].copy()
+        A[2, :] = -np.inf
+        A[2, 5] = 0.0
+        A[:, 7] = -np.inf
+        tag = "n%d_" % N
+        assert np.array_equal(d["obs"], g[tag + "obs"])
+        h = HMM(N, 8, A, d["B"], d["pi"], precision=np.float32)
+        alpha = h._forward(d["obs"], True)
+        beta = h._backward(d["obs"])
+        v, bt, path = h._viterbi(d["obs"])
+        assert alpha.dtype == np.float32 and beta.dtype == np.float32 and v.dtype == np.float32 and h.b.dtype == np.float32
+        assert np.array_equal(v, g[tag + "v"]) and np.array_equal(bt, g[tag + "bt"]) and np.array_equal(path, g[tag + "path"]), N
+        for got, want, what in ((alpha, g[tag + "alpha"], "alpha"), (beta, g[tag + "beta"], "beta")):
+            dd = _ulps32(got, want)
+            assert dd.max() <= 1 and int((dd > 0).sum()) <= 2, (N, what, int(dd.max()), int((dd > 0).sum()))
+        assert np.array_equal(h.decode(d["obs"]), g[tag + "path"])

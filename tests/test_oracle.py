@@ -356,3 +356,34 @@ def test_mfcc_synth(oracle, golden, synth):
     assert np.array_equal(oracle.filter_bank(cfg), g["fbank"])
     p, c, f = oracle.mfcc(g["signal"], cfg)
     assert_close(c, g["cepstrum"], 1e-10, 1e-10), assert_close(f, g["features"], 1e-10, 1e-10)
+
+
+def _f32_family_model(synth, N, T):
+    """The model gen_golden.gen_f32_families built for N states (same seed, same two edits)."""
+    d = synth.synth_discrete(N, 8, T, seed=40 + N)
+    A = d["A"].copy()
+    A[2, :] = -np.inf
+    A[2, 5] = 0.0
+    A[:, 7] = -np.inf
+    return A, d["B"], d["pi"], d["obs"]
+
+
+def test_float32_recursions_match_the_reference_on_every_family_size(oracle, golden, synth):
+    """precision=np.float32 at N = 12 / 128 / 200 (golden hmm_f32_families, the imported reference): the oracle's float32 forward,
+    backward and Viterbi -- fp64 sums, one rounding at the store, the next frame reads the rounded value -- are the reference's
+    arrays bit for bit.  (These are the sizes of the one-wave, register-resident and on-chip GPU kernel families.)"""
+    g = golden("hmm_f32_families")
+    for N, T in g["shapes"]:
+        N, T = int(N), int(T)
+        A, B, pi, obs = _f32_family_model(synth, N, T)
+        tag = "n%d_" % N
+        assert np.array_equal(obs, g[tag + "obs"])
+        assert abs(np.where(np.isfinite(A), A, 0.0).sum() - g[tag + "A_sum"][0]) < 1e-9
+        b = oracle.map_b(B, obs, np.float32)
+        assert abs(b.astype(np.float64).sum() - g[tag + "b_sum"][0]) < 1e-6
+        with np.errstate(divide="ignore", invalid="ignore"):
+            alpha = oracle.forward(A, pi, b, np.float32)
+            beta = oracle.backward(A, b, np.float32)
+            v, bt, path = oracle.viterbi(A, pi, b, np.float32)
+        assert np.array_equal(alpha, g[tag + "alpha"]) and np.array_equal(beta, g[tag + "beta"]), N
+        assert np.array_equal(v, g[tag + "v"]) and np.array_equal(bt, g[tag + "bt"]) and np.array_equal(path, g[tag + "path"]), N
