@@ -607,3 +607,29 @@ def test_float32_reference_arrays_on_every_kernel_family(golden, synth):
             dd = _ulps32(got, want)
             assert dd.max() <= 1 and int((dd > 0).sum()) <= 2, (N, what, int(dd.max()), int((dd > 0).sum()))
         assert np.array_equal(h.decode(d["obs"]), g[tag + "path"])
+
+
+def test_float32_train_tracks_the_reference(golden):
+    """GMMHMM(precision=np.float32).train, three iterations (golden gmmhmm_small_f32, the imported reference): the float32 model
+    walks the reference's call sequence (the fused step is float64 only); every printed likelihood agrees to float32 accuracy (the
+    reference folds lse(alpha[-1]) in float32 arithmetic, np.logaddexp on float32 scalars: not reproducible bit for bit), the
+    re-estimated parameters to 1e-5, the decoded path exactly."""
+    import re
+    from lnasr.gmmhmm import GMMHMM
+    g = golden("gmmhmm_small_f32")
+    gh = GMMHMM(5, 3, 2, g["A"], g["pi"], g["w"], g["mu"], g["si"], precision=np.float32)
+    assert not gh._fused_train_ok()
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        gh.train(g["obs"], 3, 0.0, True)
+    num = r"[-+]?\\d\\.\\d+e[-+]\\d+"
+    got = [[float(x) for x in re.findall(num, line)] for line in buf.getvalue().splitlines()]
+    want = [[float(x) for x in re.findall(num, line)] for line in str(g["train_log"]).splitlines()]
+    assert len(got) == len(want) == 3
+    for a, b in zip(got, want):
+        assert_close(np.array(a), np.array(b), 3e-6)
+    for k in ("A", "pi", "w", "mu", "si"):
+        assert np.asarray(getattr(gh, k)).dtype == g["train3_" + k].dtype, k
+        assert_close(getattr(gh, k), g["train3_" + k], 1e-5, 1e-5, msg=k)
+    assert abs(gh.calc_prob(g["obs"]) - g["train3_loglik"][0]) < 1e-5 * abs(g["train3_loglik"][0])
+    assert np.array_equal(gh.decode(g["obs"]), g["train3_decode"])
