@@ -799,8 +799,8 @@ __global__ __launch_bounds__(256) void fwdbwd_tiny_kernel(const TS* __restrict__
                 val = BACKWARD ? rnd<TS>(val) : rnd<TS>(val + bt_);
             }
             oc[act ? fl * N + j : ODUMP] = val;
-            prev = BACKWARD ? val + bt_ : val;
-            saw_nan |= __ballot(act && prev != prev);
+            prev = act ? (BACKWARD ? val + bt_ : val) : LN_NEG_INF;   // idle lanes stay at -inf: they are broadcast too
+            saw_nan |= __ballot(prev != prev);
         }
         __builtin_amdgcn_wave_barrier();
         if (ou) {                                         // the chunk's rows leave whole
