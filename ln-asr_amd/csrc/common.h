@@ -74,6 +74,7 @@ struct Model {
     DevBuf prec;                 // full: Sigma^-1 [N,M,D,D]
     DevBuf gconst;               // [N,M]: -0.5 (D ln 2pi + ln det Sigma)
     DevBuf sigma_raw;            // full upload staging [N,M,D,D]
+    DevBuf lu_bad;               // [N,M] int: components the register LU declined (redone by the LDS kernel)
     DevBuf wpack, wpack_nw;      // MFMA-packed coefficient fragments (diag): with / without log w folded in
     int wpack_Q = 0, wpack_KS = 0, wpack_NG = 0;
     DevBuf wdirect;              // N = 1: coefficient fragments of the single mixture (gmm.hip: emit_single_direct)
@@ -114,10 +115,11 @@ struct Switches {
     bool no_mfma = false, no_pad = false, no_tinyvit = false, no_regvit = false, no_regfwd = false, no_colfwd = false,
          no_t256 = false, no_framepar = false, no_stream = false, no_ldsbt = false, no_mfma_stats = false,
          no_fft512 = false, no_pipeline = false, f32_generic = false, no_f32_stats = false, no_pinned_ring = false,
-         no_tinyfwd = false;
+         no_tinyfwd = false, no_reglu = false, no_tilepack = false;
     char vit = 0;                 // LNASR_VIT: first character, 0 = unset
     char fwd = 0;                 // LNASR_FWD: 'c' = the four-utterance column-owned forward / backward kernel (fwdbwd_cols)
     int framepar_maxu = -1;       // LNASR_FRAMEPAR_MAXU, -1 = unset (measured rule)
+    int fwd_one_maxu = -1;        // LNASR_FWD_ONE_MAXU: one utterance per block in the column-owned forward / backward up to this batch size
     double kappa_max = kKappaMax; // LNASR_KAPPA_MAX
     int h2d_threads = 4;          // LNASR_H2D_THREADS: host threads filling the pinned staging ring
     bool check_ptrs = false;      // LNASR_CHECK_PTRS: LN_DEVPTR verifies every pointer a launch helper is handed

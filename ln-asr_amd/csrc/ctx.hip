@@ -49,7 +49,7 @@ void DevBuf::release() {
 }
 
 void Model::release() {
-    DevBuf* all[] = {&logA, &logAT, &logpi, &expA, &expAT, &logw, &mu, &ivar, &var, &prec, &gconst, &sigma_raw, &wpack, &wpack_nw, &wdirect, &pad_mu, &pad_ivar, &pad_gconst, &pad_logw, &pad_prec, &wfull, &wfull_nw, &pairtab, &flags, &centre, &mu_c, &wpack32};
+    DevBuf* all[] = {&logA, &logAT, &logpi, &expA, &expAT, &logw, &mu, &ivar, &var, &prec, &gconst, &sigma_raw, &wpack, &wpack_nw, &wdirect, &pad_mu, &pad_ivar, &pad_gconst, &pad_logw, &pad_prec, &wfull, &wfull_nw, &pairtab, &flags, &centre, &mu_c, &wpack32, &lu_bad};
     for (DevBuf* b : all) b->release();
     has_hmm = has_gmm = false;
 }
@@ -65,6 +65,8 @@ static void load_switches(Switches& s) {
     s.no_pad = on("LNASR_NO_PAD");
     s.no_tinyvit = on("LNASR_NO_TINYVIT");
     s.no_tinyfwd = on("LNASR_NO_TINYFWD");
+    s.no_reglu = on("LNASR_NO_REGLU");
+    s.no_tilepack = on("LNASR_NO_TILEPACK");
     s.no_regvit = on("LNASR_NO_REGVIT");
     s.no_regfwd = on("LNASR_NO_REGFWD");
     s.no_colfwd = on("LNASR_NO_COLFWD");
@@ -86,6 +88,7 @@ static void load_switches(Switches& s) {
     if (const char* e = getenv("LNASR_FWD")) s.fwd = e[0];
     if (const char* e = getenv("LNASR_EMIT")) s.emit = e[0];
     if (const char* e = getenv("LNASR_FRAMEPAR_MAXU")) s.framepar_maxu = atoi(e);
+    if (const char* e = getenv("LNASR_FWD_ONE_MAXU")) s.fwd_one_maxu = atoi(e);
     if (const char* e = getenv("LNASR_KAPPA_MAX")) s.kappa_max = atof(e);
     if (const char* e = getenv("LNASR_H2D_THREADS")) {
         s.h2d_threads = atoi(e);

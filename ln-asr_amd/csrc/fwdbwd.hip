@@ -518,12 +518,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // float64 arrays in the reference, so alpha[t-1] + A[:, j] is a float64 sum there too -- and every alpha[t, j] / beta[t, i]
 // is rounded to float where the reference's float32 array rounds it, at the store (hmm.py:93-99, 124-130); the next
 // frame continues from the ROUNDED value, as the reference reads its array back.
-template <bool BACKWARD, typename TS = double>
+// UB = 1 (round 5): ONE utterance per block, for batches that leave CUs idle anyway (a single utterance through the reference's
+// calc_prob / _forward / train, hmm.py:268-313).  The frame is a chain of dependent instructions walked by a lone wave per
+// SIMD, so its duration is its instruction count: without the second utterance's 64 products per lane and its half of the
+// swap network a frame is ~150 instructions instead of ~230.  Rows 0-1 of a wave then hold column half 0, rows 2-3 half 1
+// (the odd rows repeat the even ones and store nothing); sums are associated as with two utterances: the same bits.
+template <bool BACKWARD, typename TS = double, int UB = 2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void fwdbwd_cols2(
     const TS* __restrict__ b, const double* __restrict__ Aexp, const double* __restrict__ Alog,
     const double* __restrict__ pi, const int32_t* __restrict__ lens, TS* __restrict__ out,
     double* __restrict__ loglik, int U, int T, int N, unsigned* __restrict__ nan_flag, unsigned nan_epoch) {
-    constexpr int NP = 128, UB = 2, NW = 4, NM = 2 * NW;   // NM: partial maxima per utterance (wave x column half)
+    constexpr int NP = 128, NW = 4, NM = 2 * NW;   // NM: partial maxima per utterance (wave x column half)
     // a NaN emission: np.logaddexp carries it into every later (earlier) frame, the maxima here drop it.  The value the
     // lanes finalise is NaN exactly then; one compare into the scalar unit per frame raises the flag for nanfix.hip
     unsigned long long saw_nan = 0;
@@ -555,7 +560,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         maxlen = l > maxlen ? l : maxlen;
     }
     // finalisation role: row g of the wave is utterance k, column half h
-    const int k = g >> 1, h = g & 1;
+    const int k = UB == 2 ? g >> 1 : 0, h = UB == 2 ? g & 1 : g >> 1;
+    const bool primary = UB == 2 || (g & 1) == 0;             // UB = 1: the odd rows duplicate the even ones
     const int j = 32 * w + 16 * h + c;
     const int jc = j < N ? j : N - 1;
     const int uu = (u0 + k < U) ? u0 + k : U - 1;
@@ -572,11 +578,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int t0 = frame_of(0);
             const double bv = (double)bp[(size_t)t0 * N];
             if (BACKWARD) {
-                if (op) op[(size_t)t0 * N] = (TS)0.0;
+                if (op && primary) op[(size_t)t0 * N] = (TS)0.0;
                 prev = 0.0 + bv;
             } else {
                 prev = rnd<TS>(pi[j] + bv);
-                if (op) op[0] = (TS)prev;
+                if (op && primary) op[0] = (TS)prev;
             }
         }
         saw_nan |= __ballot(prev != prev);
@@ -623,9 +629,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         });
         // row groups -> (utterance, column half): after the swaps row m of `sum` holds combination m = 2 k + h,
         // ((g0 + g2) + (g1 + g3)) in every lane
-        swap32_f64(acc[0][0], acc[1][0]);
-        swap32_f64(acc[0][1], acc[1][1]);
-        double s02 = acc[0][0] + acc[1][0], s13 = acc[0][1] + acc[1][1];
+        double s02, s13;
+        if constexpr (UB == 2) {
+            swap32_f64(acc[0][0], acc[1][0]);
+            swap32_f64(acc[0][1], acc[1][1]);
+            s02 = acc[0][0] + acc[1][0];
+            s13 = acc[0][1] + acc[1][1];
+        } else {                                   // rows 0-1: half 0 (g0 + g2, g1 + g3), rows 2-3: half 1
+            swap32_f64(acc[0][0], acc[0][1]);
+            s02 = acc[0][0] + acc[0][1];
+            s13 = s02;
+        }
         swap16_f64(s02, s13);
         const double sum = s02 + s13;
 
@@ -642,11 +656,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             double prev;
             if (BACKWARD) {
                 val = rnd<TS>(val);
-                if (j < N && op) op[(size_t)t * N] = (TS)val;
+                if (j < N && op && primary) op[(size_t)t * N] = (TS)val;
                 prev = val + bcur;
             } else {
                 prev = rnd<TS>(val + bcur);
-                if (j < N && op) op[(size_t)t * N] = (TS)prev;
+                if (j < N && op && primary) op[(size_t)t * N] = (TS)prev;
             }
             if (j >= N) prev = LN_NEG_INF;
             prev_nan = prev != prev;
@@ -875,9 +889,14 @@ int forward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
     // LNASR_NO_REGFWD / LNASR_NO_COLFWD) the storage-templated generic kernel below -- the same rounding everywhere.
     if (dtype == LNASR_F32 && !sw().f32_generic) {
         if (N <= dispatch::kRegMaxN && !sw().no_regfwd && !sw().no_colfwd) {
-            LN_LAUNCH(ctx, "forward_cols2_f32", (fwdbwd_cols2<false, float>), dim3((U + 1) / 2), dim3(256), 0, (const float*)b,
-                      md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens, (float*)alpha, loglik, U, T,
-                      N, ctx->nan_flag.as<unsigned>() + 2, ctx->nan_epoch);
+            if (dispatch::fwdbwd_one_per_block(U, ctx->prop.multiProcessorCount))
+                LN_LAUNCH(ctx, "forward_cols1_f32", (fwdbwd_cols2<false, float, 1>), dim3(U), dim3(256), 0, (const float*)b,
+                          md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens, (float*)alpha, loglik, U,
+                          T, N, ctx->nan_flag.as<unsigned>() + 2, ctx->nan_epoch);
+            else
+                LN_LAUNCH(ctx, "forward_cols2_f32", (fwdbwd_cols2<false, float>), dim3((U + 1) / 2), dim3(256), 0,
+                          (const float*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
+                          (float*)alpha, loglik, U, T, N, ctx->nan_flag.as<unsigned>() + 2, ctx->nan_epoch);
             ctx->fwd_nan_tested = true;
             return 0;
         }
@@ -895,9 +914,14 @@ int forward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
             // per block), 1000 utterances 1.23 against 1.45 (fwdbwd_cols, four per block)
             if (!sw().no_colfwd && sw().fwd != 'c')
             {
-                LN_LAUNCH(ctx, "forward_cols2_n128", (fwdbwd_cols2<false>), dim3((U + 1) / 2), dim3(256), 0,
-                          (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
-                          (double*)alpha, loglik, U, T, N, ctx->nan_flag.as<unsigned>() + 2, ctx->nan_epoch);
+                if (dispatch::fwdbwd_one_per_block(U, ctx->prop.multiProcessorCount))
+                    LN_LAUNCH(ctx, "forward_cols1_n128", (fwdbwd_cols2<false, double, 1>), dim3(U), dim3(256), 0,
+                              (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
+                              (double*)alpha, loglik, U, T, N, ctx->nan_flag.as<unsigned>() + 2, ctx->nan_epoch);
+                else
+                    LN_LAUNCH(ctx, "forward_cols2_n128", (fwdbwd_cols2<false>), dim3((U + 1) / 2), dim3(256), 0,
+                              (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
+                              (double*)alpha, loglik, U, T, N, ctx->nan_flag.as<unsigned>() + 2, ctx->nan_epoch);
                 ctx->fwd_nan_tested = true;
             }
             else if (!sw().no_colfwd)            // LNASR_FWD=c: four per eight-wave block
@@ -945,9 +969,14 @@ int backward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* 
         return fwdbwd_tiny_launch<true>(ctx, b, U, T, d_lens, dtype, beta, nullptr);
     if (dtype == LNASR_F32 && !sw().f32_generic) {       // float storage, rounded at every store (hmm.py:124-130); see forward_device
         if (N <= dispatch::kRegMaxN && !sw().no_regfwd && !sw().no_colfwd) {
-            LN_LAUNCH(ctx, "backward_cols2_f32", (fwdbwd_cols2<true, float>), dim3((U + 1) / 2), dim3(256), 0, (const float*)b,
-                      expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (float*)beta, (double*)nullptr, U, T, N,
-                      ctx->nan_flag.as<unsigned>() + 2, ctx->nan_epoch);
+            if (dispatch::fwdbwd_one_per_block(U, ctx->prop.multiProcessorCount))
+                LN_LAUNCH(ctx, "backward_cols1_f32", (fwdbwd_cols2<true, float, 1>), dim3(U), dim3(256), 0, (const float*)b,
+                          expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (float*)beta, (double*)nullptr, U, T, N,
+                          ctx->nan_flag.as<unsigned>() + 2, ctx->nan_epoch);
+            else
+                LN_LAUNCH(ctx, "backward_cols2_f32", (fwdbwd_cols2<true, float>), dim3((U + 1) / 2), dim3(256), 0,
+                          (const float*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (float*)beta,
+                          (double*)nullptr, U, T, N, ctx->nan_flag.as<unsigned>() + 2, ctx->nan_epoch);
             ctx->fwd_nan_tested = true;
             return 0;
         }
@@ -962,9 +991,14 @@ int backward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* 
         else
             if (!sw().no_colfwd && sw().fwd != 'c')
             {
-                LN_LAUNCH(ctx, "backward_cols2_n128", (fwdbwd_cols2<true>), dim3((U + 1) / 2), dim3(256), 0,
-                          (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
-                          (double*)nullptr, U, T, N, ctx->nan_flag.as<unsigned>() + 2, ctx->nan_epoch);
+                if (dispatch::fwdbwd_one_per_block(U, ctx->prop.multiProcessorCount))
+                    LN_LAUNCH(ctx, "backward_cols1_n128", (fwdbwd_cols2<true, double, 1>), dim3(U), dim3(256), 0,
+                              (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
+                              (double*)nullptr, U, T, N, ctx->nan_flag.as<unsigned>() + 2, ctx->nan_epoch);
+                else
+                    LN_LAUNCH(ctx, "backward_cols2_n128", (fwdbwd_cols2<true>), dim3((U + 1) / 2), dim3(256), 0,
+                              (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
+                              (double*)nullptr, U, T, N, ctx->nan_flag.as<unsigned>() + 2, ctx->nan_epoch);
                 ctx->fwd_nan_tested = true;
             }
             else if (!sw().no_colfwd)

@@ -41,18 +41,27 @@ __global__ void transpose_exp_kernel(const double* __restrict__ A, double* __res
     ET[(size_t)j * N + i] = e;
 }
 
-// flag[0] = 1 if any off-diagonal entry of any Sigma is not exactly zero.  One atomic per WAVE that found one, and none once
-// the flag is up (a genuinely full model used to issue three million atomics on one address here: 1.1 ms of every upload)
-__global__ void detect_offdiag_kernel(const double* __restrict__ S, size_t total, int D, int* flag) {
-    if (*reinterpret_cast<volatile int*>(flag) != 0) return;
-    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool hit = false;
-    if (idx < total) {
-        size_t e = idx % ((size_t)D * D);
-        int r = (int)(e / D), c = (int)(e % D);
-        hit = r != c && !(S[idx] == 0.0);
+// flag[0] = 1 if any off-diagonal entry of any Sigma is not exactly zero.  A few hundred blocks walk the components and stop
+// at the first hit anybody has reported; a hit is reported with a plain (idempotent) store.  History: one atomicOr per non-zero
+// entry was three million atomics on one address (1.1 ms of every upload of a genuinely full model); one per wave still let
+// every RESIDENT wave of a one-thread-per-entry grid -- 8,000 of them, all started before the first report landed -- queue
+// its atomic at the same L2 line (0.12 ms per launch; round 5).  A diagonal model (the case that reads everything) streams
+// its 25 MB once.
+__global__ void detect_offdiag_kernel(const double* __restrict__ S, int NM, int D, int* flag) {
+    const int DD = D * D;
+    for (int c = blockIdx.x; c < NM; c += gridDim.x) {
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+        const double* Sc = S + (size_t)c * DD;
+        bool hit = false;
+        for (int e = threadIdx.x; e < DD; e += blockDim.x) {
+            const int r = e / D, col = e - r * D;
+            hit |= r != col && !(Sc[e] == 0.0);
+        }
+        if (__any(hit)) {
+            if ((threadIdx.x & 63) == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
     }
-    if (__any(hit) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 
 __global__ void extract_diag_kernel(const double* __restrict__ S, double* __restrict__ var, size_t NMD, int D) {
@@ -147,12 +156,13 @@ __global__ void centre_mu_kernel(const double* __restrict__ mu, const double* __
 // pivots, same factors, same subtractions as before: the inverse is bit for bit the one the old kernel produced.
 // 1.78 -> 1.19 ms for the 2048 components of the metric shape (what is left is the column walk through the LDS).
 __global__ void lu_invert_kernel(const double* __restrict__ S, double* __restrict__ P,
-                                 double* __restrict__ gconst, int D) {
+                                 double* __restrict__ gconst, int D, const int* __restrict__ only) {
     extern __shared__ double lds[];
     const int W = 2 * D;
     double* a = lds;                          // [D][2D]
     double* fac = lds + (size_t)D * W;        // [D] row factors of the current step
     const int c = blockIdx.x, lane = threadIdx.x;            // blockDim.x == 64
+    if (only && !only[c]) return;             // second pass behind lu_invert_reg_kernel: the components it declined
     const double* Sc = S + (size_t)c * D * D;
     for (int e = lane; e < D * W; e += 64) {
         int r = e / W, col = e % W;
@@ -206,6 +216,111 @@ __global__ void lu_invert_kernel(const double* __restrict__ S, double* __restric
         P[(size_t)c * D * D + e] = a[r * W + D + col];
     }
     if (lane == 0) gconst[c] = -0.5 * ((double)D * kLog2Pi + log_of_det(logabs, sign));
+}
+
+// Round 5: the same elimination with the matrix in REGISTERS (D <= 40): one wave per component, lane r holds row r of the
+// augmented system [Sigma | I] -- but only the DP columns that are not yet (left part) or no longer (right part) unit
+// vectors, in a window that slides one column to the left per step: x[0] is always the pivot column, step k consumes it and
+// appends the right-part column that the pivot row's unit entry turns into.  The step loop is a real loop, the column loop is
+// unrolled over fixed registers.  Rows are never moved: a lane remembers which logical row it holds (`pos`), the pivot search
+// runs over the lanes whose logical row is >= k with the old kernel's rule (largest |a|, lowest logical row among equals), and
+// the row / column permutation is undone when the result is written.  The pivot row reaches the other lanes through the LDS
+// (one broadcast read per column).  Per step ~DP fused multiply-adds and ~2 DP LDS / move instructions per lane against five
+// block barriers and a column walk through the LDS: 0.60 ms -> see DESIGN 4.10 for the 2048 components of the metric shape.
+// Same pivots; factors are formed with the pivot's reciprocal (one division per step instead of one per row).
+// A component with a zero / non-finite pivot or a non-finite entry is left to lu_invert_kernel (`bad[c]` = 1), whose way of
+// spreading the infinities and NaNs is the pinned one.
+template <int DP>
+__global__ __launch_bounds__(64) void lu_invert_reg_kernel(const double* __restrict__ S, double* __restrict__ P,
+                                                           double* __restrict__ gconst, int D, int* __restrict__ bad) {
+    __shared__ double st[DP * DP];            // Sigma on the way in, the inverse on the way out (coalesced both ways)
+    __shared__ double bc[DP];                 // the pivot row of the step
+    __shared__ double lg[DP];                 // log |pivot| per step
+    __shared__ int colmap[DP];                // slot j of the final window <-> original column colmap[j]
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const double* Sc = S + (size_t)c * D * D;
+    bool nonfinite = false;
+    for (int e = lane; e < D * D; e += 64) {
+        const double v = Sc[e];
+        nonfinite |= !(v - v == 0.0);
+        st[e] = v;
+    }
+    if (__any(nonfinite)) {
+        if (lane == 0) bad[c] = 1;
+        return;
+    }
+    __syncthreads();
+    double x[DP];
+#pragma unroll
+    for (int j = 0; j < DP; ++j) {
+        double v = (lane == j) ? 1.0 : 0.0;                       // padding rows / columns: identity
+        if (lane < D && j < D) v = st[lane * D + j];
+        x[j] = lane < DP ? v : 0.0;
+    }
+    int pos = lane;                           // logical row held by this lane
+    double mypv = 1.0;                        // lane k keeps the pivot of step k
+    int nswap = 0;
+    for (int k = 0; k < DP; ++k) {
+        double av = (lane < DP && pos >= k) ? fabs(x[0]) : -1.0;
+        av = av >= 0.0 ? av : -1.0;                               // a NaN never wins
+        const double mx = wave_max_dpp(av);
+        if (!(mx > 0.0) || mx == __builtin_huge_val()) {          // singular / overflowed: the LDS kernel's business
+            if (lane == 0) bad[c] = 1;
+            return;
+        }
+        unsigned long long cand = __ballot(av == mx);
+        int p = __ffsll((long long)cand) - 1;
+        if (cand & (cand - 1)) {                                  // equal magnitudes: the lowest logical row
+            int best = 1 << 30;
+            while (cand) {
+                const int l = __ffsll((long long)cand) - 1;
+                cand &= cand - 1;
+                const int pl = __builtin_amdgcn_readlane(pos, l);
+                if (pl < best) { best = pl; p = l; }
+            }
+        }
+        const int q = __builtin_amdgcn_readlane(pos, p);
+        if (pos == k) pos = q;                                    // the swap of rows k and q, on the labels only
+        if (lane == p) pos = k;
+        nswap += q != k;
+        const double pv = readlane_f64(x[0], p);
+        const double rp = 1.0 / pv;
+        if (lane == k) mypv = pv;
+        const bool isp = lane == p;
+        if (isp) {
+#pragma unroll
+            for (int j = 1; j < DP; ++j) {
+                bc[j] = x[j];
+                x[j] = 0.0;                                       // so that the update below leaves row_p * rp here
+            }
+        }
+        __syncthreads();
+        const double fac = isp ? -rp : x[0] * rp;
+#pragma unroll
+        for (int j = 1; j < DP; ++j) x[j - 1] = fma(-fac, bc[j], x[j]);
+        x[DP - 1] = -fac;                                         // the entering right-part column: unit entry in the pivot row
+        __syncthreads();
+    }
+    // lane l holds logical row pos; slot j belongs to the original column of the lane that was pivot at step j
+    if (lane < DP) colmap[pos] = lane;
+    if (lane < DP) lg[lane] = log(fabs(mypv));
+    __syncthreads();
+    if (lane < DP && pos < D) {
+#pragma unroll
+        for (int j = 0; j < DP; ++j) {
+            const int col = colmap[j];
+            if (col < D) st[pos * D + col] = x[j];
+        }
+    }
+    const unsigned long long negs = __ballot(lane < D && mypv < 0.0);
+    __syncthreads();
+    for (int e = lane; e < D * D; e += 64) P[(size_t)c * D * D + e] = st[e];
+    if (lane == 0) {
+        double logabs = 0.0;
+        for (int k = 0; k < D; ++k) logabs += lg[k];
+        const int sign = ((__popcll(negs) + nswap) & 1) ? -1 : 1;
+        gconst[c] = -0.5 * ((double)D * kLog2Pi + log_of_det(logabs, sign));
+    }
 }
 
 // Coefficients of the expanded quadratic, laid out as MFMA A-operand fragments:
@@ -924,9 +1039,8 @@ static int model_upload_impl(lnasr_ctx* ctx, int N, int M, int D, const double* 
         if (allow_diag_detect) {
             LN_TRY(md.flags.reserve(256));
             LN_HIP(hipMemsetAsync(md.flags.p, 0, 4, ctx->stream));
-            size_t total = NMD * D;
-            LN_LAUNCH(ctx, "detect_offdiag", detect_offdiag_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256),
-                      0, md.sigma_raw.as<double>(), total, D, md.flags.as<int>());
+            LN_LAUNCH(ctx, "detect_offdiag", detect_offdiag_kernel, dim3((unsigned)(NM < 512 ? NM : 512)), dim3(256), 0,
+                      md.sigma_raw.as<double>(), (int)NM, D, md.flags.as<int>());
             int flag = 0;
             LN_HIP(hipMemcpyAsync(&flag, md.flags.p, 4, hipMemcpyDeviceToHost, ctx->stream));
             LN_HIP(hipStreamSynchronize(ctx->stream));
@@ -1017,8 +1131,24 @@ static int model_upload_impl(lnasr_ctx* ctx, int N, int M, int D, const double* 
     } else {
         LN_TRY(md.prec.reserve(NMD * D * 8));
         size_t shmem = (size_t)(D * 2 * D + D) * 8;
+        const int* only = nullptr;
+        if (D <= 40 && !sw().no_reglu) {
+            // matrices in registers; a component with a zero / non-finite pivot is flagged and redone by the LDS kernel
+            LN_TRY(md.lu_bad.reserve(NM * 4));
+            LN_HIP(hipMemsetAsync(md.lu_bad.p, 0, NM * 4, ctx->stream));
+#define LN_LUREG(DPv)                                                                                             \
+    LN_LAUNCH(ctx, "lu_invert_reg", lu_invert_reg_kernel<DPv>, dim3((unsigned)NM), dim3(64), 0,                     \
+              md.sigma_raw.as<double>(), md.prec.as<double>(), md.gconst.as<double>(), D, md.lu_bad.as<int>())
+            if (D <= 8) LN_LUREG(8);
+            else if (D <= 16) LN_LUREG(16);
+            else if (D <= 24) LN_LUREG(24);
+            else if (D <= 32) LN_LUREG(32);
+            else LN_LUREG(40);
+#undef LN_LUREG
+            only = md.lu_bad.as<int>();
+        }
         LN_LAUNCH(ctx, "lu_invert", lu_invert_kernel, dim3((unsigned)NM), dim3(64), shmem, md.sigma_raw.as<double>(),
-                  md.prec.as<double>(), md.gconst.as<double>(), D);
+                  md.prec.as<double>(), md.gconst.as<double>(), D, only);
         LN_TRY(centre_and_kappa(ctx, md.prec.as<double>()));
         md.wfull_Q = 0;
         md.pad_N = md.pad_M = 0;
@@ -1510,7 +1640,7 @@ static int gauss_components(lnasr_ctx* ctx, int M, const double* x, size_t L, in
     double* d_P = ctx->ws_misc.as<double>();
     double* d_g = d_P + (size_t)M * D * D;
     LN_LAUNCH(ctx, "lu_invert", lu_invert_kernel, dim3((unsigned)M), dim3(64), (size_t)(D * 2 * D + D) * 8,
-              (const double*)d_S, d_P, d_g, D);
+              (const double*)d_S, d_P, d_g, D, (const int*)nullptr);
     LN_TRY(ctx->ws_misc2.reserve((size_t)M * L * 8));
     LN_LAUNCH(ctx, "gauss_multi", gauss_multi_kernel, dim3((unsigned)((L + 127) / 128)), dim3(128), 0,
               (const double*)d_x, L, D, M, (const double*)d_mu, d_P, d_g, want_log, ctx->ws_misc2.as<double>());

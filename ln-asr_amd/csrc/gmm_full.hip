@@ -90,6 +90,75 @@ __global__ void pack_wfull_kernel(const double* __restrict__ mu, const double* _
     wfull[idx] = val;
 }
 
+// Round 5: the same coefficients, one BLOCK per MFMA tile row group -- the 16 components (state group sg, mixture tile q) whose
+// values interleave in every 512-byte fragment of wfull.  pack_wfull_kernel (one thread per output value) gathered its inputs:
+// a wave read 16 different 12 KB precision matrices at two transposed positions each, and did so again for every k-step and
+// for both variants (0.37 ms per launch at the metric shape, 0.74 ms per upload).  Here each component's matrix is read ONCE,
+// coalesced, into the LDS, its K coefficients are formed there (same expressions, same summation order: the same bits),
+// parked in a [K][16] tile, and the block writes the tile out as whole fragments -- both variants (with / without log w
+// folded into the constant) from the one tile.
+__global__ __launch_bounds__(256) void pack_wfull_tile_kernel(const double* __restrict__ mu, const double* __restrict__ prec,
+                                                              const double* __restrict__ gconst,
+                                                              const double* __restrict__ logw, const int* __restrict__ pairtab,
+                                                              double* __restrict__ wfull, double* __restrict__ wfull_nw,
+                                                              int N, int M, int D, int Q, int NCH) {
+    extern __shared__ double lds[];
+    const int K80 = NCH * kFC;
+    double* coef = lds;                            // [K80][16]
+    double* Pl = coef + (size_t)K80 * 16;          // [D][D]: the component in hand
+    double* ml = Pl + D * D;                       // [D]
+    double* tl = ml + D;                           // [D]: sum_j P_ij m_j
+    __shared__ double c_lw[16], c_g[16], c_hs[16]; // constant term: (log w + gconst) - 0.5 m^T P m, kept in its parts
+    const int tid = threadIdx.x;
+    const int sg = blockIdx.x / Q, q = blockIdx.x % Q;
+    const int kconst = D * (D + 1) / 2 + D;
+    for (int row = 0; row < 16; ++row) {
+        const int state = 4 * sg + (row & 3), mix = 4 * q + (row >> 2);
+        const size_t c = (size_t)state * M + mix;
+        __syncthreads();                           // the previous component's readers are done with Pl / ml / tl
+        for (int e = tid; e < D * D; e += 256) Pl[e] = prec[c * D * D + e];
+        if (tid < D) ml[tid] = mu[c * D + tid];
+        __syncthreads();
+        for (int i = tid; i < D; i += 256) {
+            double t = 0.0;
+            for (int j = 0; j < D; ++j) t += Pl[i * D + j] * ml[j];
+            tl[i] = t;
+        }
+        __syncthreads();
+        for (int k = tid; k < K80; k += 256) {
+            const int code = pairtab[k], d = code & 0xFF, e = (code >> 8) & 0xFF;
+            double val = 0.0;
+            if (d < 0xFE && e < 0xFE) {
+                val = d == e ? -0.5 * Pl[d * D + d] : -0.5 * (Pl[d * D + e] + Pl[e * D + d]);
+            } else if (d < 0xFE && e == 0xFF) {
+                double s = 0.0;
+                for (int j = 0; j < D; ++j) s += (Pl[d * D + j] + Pl[j * D + d]) * ml[j];
+                val = 0.5 * s;
+            } else if (d == 0xFF) {
+                double s = 0.0;
+                for (int i = 0; i < D; ++i) s += ml[i] * tl[i];
+                c_lw[row] = logw[c];
+                c_g[row] = gconst[c];
+                c_hs[row] = 0.5 * s;
+            }
+            coef[k * 16 + row] = val;
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < NCH * kFKS * 64; idx += 256) {
+        const int lane = idx & 63, r1 = idx >> 6, ks = r1 % kFKS, ch = r1 / kFKS;
+        const int k = kFC * ch + 4 * ks + (lane >> 4), row = lane & 15;
+        const size_t out = ((((size_t)sg * NCH + ch) * Q + q) * kFKS + ks) * 64 + lane;
+        double v = coef[k * 16 + row], vn = v;
+        if (k == kconst) {
+            v = (c_lw[row] + c_g[row]) - c_hs[row];
+            vn = (0.0 + c_g[row]) - c_hs[row];
+        }
+        wfull[out] = v;
+        wfull_nw[out] = vn;
+    }
+}
+
 template <int Q, bool WRITE_BM>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void emit_full_mfma(
     const double* __restrict__ obs, const double* __restrict__ wfull, const int* __restrict__ pairtab,
@@ -426,9 +495,15 @@ int pack_full_model(lnasr_ctx* ctx) {
     const size_t total = (size_t)(Nv / 4) * NCH * Q * kFKS * 64;
     LN_TRY(md.wfull.reserve(total * 8));
     LN_TRY(md.wfull_nw.reserve(total * 8));
-    for (int fold = 1; fold >= 0; --fold)
-        LN_LAUNCH(ctx, "pack_wfull", pack_wfull_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, mu_s, pr_s, gc_s,
-                  lw_s, md.pairtab.as<int>(), (fold ? md.wfull : md.wfull_nw).as<double>(), Nv, Mv, D, Q, NCH, fold);
+    const size_t tile_lds = ((size_t)NCH * kFC * 16 + (size_t)D * D + 2 * D) * 8;
+    if (tile_lds <= 150 * 1024 && !sw().no_tilepack) {
+        LN_LAUNCH(ctx, "pack_wfull_tile", pack_wfull_tile_kernel, dim3((unsigned)((Nv / 4) * Q)), dim3(256), tile_lds, mu_s, pr_s,
+                  gc_s, lw_s, md.pairtab.as<int>(), md.wfull.as<double>(), md.wfull_nw.as<double>(), Nv, Mv, D, Q, NCH);
+    } else {
+        for (int fold = 1; fold >= 0; --fold)
+            LN_LAUNCH(ctx, "pack_wfull", pack_wfull_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, mu_s, pr_s,
+                      gc_s, lw_s, md.pairtab.as<int>(), (fold ? md.wfull : md.wfull_nw).as<double>(), Nv, Mv, D, Q, NCH, fold);
+    }
     md.wfull_Q = Q;
     md.wfull_NCH = NCH;
     md.wfull_virt = virt;

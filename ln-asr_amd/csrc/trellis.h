@@ -39,6 +39,15 @@ constexpr int kViterbiPairFromU = 512;
 // the batch holds four per CU.  Round 1 (profiles/r01k_rows.log).
 inline bool fwdbwd_reg_four_per_block(int U, int n_cu) { return U >= 4 * n_cu; }
 
+// Forward / backward, 64 < N <= 128, column-owned kernels: ONE utterance per four-wave block (fwdbwd_cols2<.., 1>) up to two
+// blocks per CU, two utterances per block beyond.  tools/bench_rows.py fwdsweep, round 5 (profiles/r05e_fwdsweep.log), ms for
+// T = 1000, forward, two per block / one per block: U=1 0.96 / 0.75, 64 0.88 / 0.77, 256 0.91 / 0.78, 512 0.95 / 0.89,
+// 768 1.19 / 1.65, 1024 1.33 / 1.87 (backward alike).  LNASR_FWD_ONE_MAXU overrides (tests, sweeps).
+inline bool fwdbwd_one_per_block(int U, int n_cu) {
+    if (sw().fwd_one_maxu >= 0) return U <= sw().fwd_one_maxu;
+    return U <= 2 * (n_cu > 0 ? n_cu : 256);
+}
+
 // N > 256: frame-parallel kernels (ONE launch per frame over the whole batch) against per-utterance streaming
 // kernels.  tools/bign.py, T = 100, ms, frame-parallel / streaming, round 2:
 //   Viterbi  N=320: U=64 1.2/2.1  U=512 2.2/2.2  U=1024 3.0/2.4    N=512: 1.1/4.5  3.0/4.6  4.2/5.1

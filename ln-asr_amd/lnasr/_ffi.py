@@ -431,6 +431,30 @@ class Context:
         self.model_shape = (N, M, D)
         self._model_fp = fp
 
+    def upload_gmmhmm_device(self, A, pi, w, mu, sigma, diag=False, force_full=False, owner=None, token=None):
+        """The same upload from DeviceArrays (the parameters an on-device M-step left in HBM: lnasr.gmmhmm.GMMHMM.train):
+        device-to-device copies, no fingerprint -- nobody outside can have edited these arrays.  `token` becomes the
+        context's record of what it holds; it never equals a fingerprint of host arrays, so a later host upload is
+        checked as usual."""
+        for x in (A, pi, w, mu, sigma):
+            if not isinstance(x, DeviceArray) or x.ctx is not self or not x.ptr or x.dtype != np.float64:
+                raise LnasrError("upload_gmmhmm_device takes float64 DeviceArrays of this context")
+        N, M, D = mu.shape
+        if A.shape != (N, N) or pi.shape != (N,) or w.shape != (N, M):
+            raise ValueError("inconsistent GMM-HMM shapes")
+        if sigma.shape != ((N, M, D) if diag else (N, M, D, D)):
+            raise ValueError("sigma shape %s does not match (N,M,D)=%s" % (sigma.shape, (N, M, D)))
+        if force_full and diag:
+            raise ValueError("force_full needs a full covariance")
+        self.model_owner = owner
+        self._model_fp = None
+        if force_full:
+            check(lib().lnasr_model_upload_full(self.handle, N, M, D, A.ptr, pi.ptr, w.ptr, mu.ptr, sigma.ptr))
+        else:
+            check(lib().lnasr_model_upload(self.handle, N, M, D, A.ptr, pi.ptr, w.ptr, mu.ptr, sigma.ptr, 1 if diag else 0))
+        self.model_shape = (N, M, D)
+        self._model_fp = token
+
     def model_is_diag(self):
         v = C.c_int(0)
         check(lib().lnasr_model_is_diag(self.handle, C.byref(v)))
@@ -640,17 +664,21 @@ class Context:
                                           _ptr(stats)))
         return stats
 
-    def bw_mstep(self, stats, min_std=0.01):
+    def bw_mstep(self, stats, min_std=0.01, device_out=False, out=None):
+        """M-step on packed statistics (host array or DeviceArray).  device_out: the new parameters stay in HBM as
+        DeviceArrays (`out`: a dict of DeviceArrays to write into where shape and dtype fit -- no allocation per call)."""
         N, M, D = self.model_shape
         diag = self.model_is_diag()
-        A = np.empty((N, N))
-        pi = np.empty(N)
-        w = np.empty((N, M))
-        mu = np.empty((N, M, D))
-        sg = np.empty((N, M, D) if diag else (N, M, D, D))
+        sig = "var" if diag else "si"
+        shapes = {"A": (N, N), "pi": (N,), "w": (N, M), "mu": (N, M, D), sig: (N, M, D) if diag else (N, M, D, D)}
+        res = {}
+        for k, shp in shapes.items():
+            buf = self._reuse((out or {}).get("si" if k == "var" else k), shp, np.float64) if device_out else None
+            res[k] = buf if buf is not None else self._out(device_out, shp, np.float64)
         stats = _in(stats, np.float64)
-        check(lib().lnasr_bw_mstep(self.handle, _ptr(stats), float(min_std), _ptr(A), _ptr(pi), _ptr(w), _ptr(mu), _ptr(sg)))
-        return {"A": A, "pi": pi, "w": w, "mu": mu, ("var" if diag else "si"): sg}
+        check(lib().lnasr_bw_mstep(self.handle, _ptr(stats), float(min_std), _ptr(res["A"]), _ptr(res["pi"]), _ptr(res["w"]),
+                                   _ptr(res["mu"]), _ptr(res[sig])))
+        return res
 
     # -- numeric utils -------------------------------------------------------------------------
     def lse3(self, x, base2=False):

@@ -13,10 +13,19 @@ diagonal `[N,M,D]` (extension).
 Batch extras (not in the reference): `upload()`, `decode_batch`, `calc_prob_batch`,
 `accumulate` / `apply_stats` (multi-utterance Baum-Welch, statistics all-reducible over RCCL).
 """
+import itertools
+
 import numpy as np
 
 from . import _ffi
 from .hmm import HMM, _save, _load, _log_normalised, _log_uniform, _report_iteration
+
+
+def _same(x):
+    return x
+
+
+_SERIAL = itertools.count(1)          # one number per device-resident parameter set, process-wide (never reused)
 
 
 class GMMHMM(HMM):
@@ -31,6 +40,31 @@ class GMMHMM(HMM):
         self.min_std = 0.01
 
     # ------------------------------------------------------------------ plumbing
+    # A, pi, w, mu, si are numpy arrays as in the reference -- except right after an on-device M-step (`train`), which
+    # leaves the NEW parameters in HBM (25 MB of Sigma at 128 states x 16 mixtures x 39 x 39 need not visit the host between
+    # two iterations).  The attributes are properties over the same mechanism as `b` / `bm` (lnasr/hmm.py): reading one copies
+    # it to a numpy array, and from then on -- or when the caller assigns an array -- the host array is the parameter (it may
+    # be edited in place) and goes through the fingerprinted upload again.
+    _PARAMS = ("A", "pi", "w", "mu", "si")
+    A = property(lambda self: self._host_get("A"), lambda self, value: self._host_set("A", value))
+    pi = property(lambda self: self._host_get("pi"), lambda self, value: self._host_set("pi", value))
+    w = property(lambda self: self._host_get("w"), lambda self, value: self._host_set("w", value))
+    mu = property(lambda self: self._host_get("mu"), lambda self, value: self._host_set("mu", value))
+    si = property(lambda self: self._host_get("si"), lambda self, value: self._host_set("si", value))
+
+    def _keep_param(self, name, dev):
+        """A parameter the device produced: resident until somebody reads the attribute; the array it replaces is kept as
+        the output buffer of the next M-step (two buffers per parameter, no allocation per iteration)."""
+        res = self.__dict__.setdefault("_resident", {})
+        spare = self.__dict__.setdefault("_spare", {})
+        old = res.pop(name, None)
+        if old is not None and old[0] is not dev:
+            spare[name] = old[0]
+        elif spare.get(name) is dev:
+            spare.pop(name)
+        res[name] = (dev, _same)
+        self.__dict__.setdefault("_host", {}).pop(name, None)
+
     def _upload_gmm(self, force_full=False):
         """All parameters -> device (per call on the reference API; unchanged parameters are recognised by their
         fingerprint and neither converted nor sent again, see _ffi.Context.upload_gmmhmm).
@@ -38,11 +72,26 @@ class GMMHMM(HMM):
         Inside decode() / calc_prob() (`_speculating`) on a context whose model this object uploaded last, the check
         runs in the BACKGROUND (lnasr_hash128_begin) while the call's kernels are enqueued on the model the device
         holds; `HMM._confirmed` collects it before the answer is handed back, and a mismatch repeats the call the checked
-        way.  The 0.2 ms fingerprint of a 25 MB model then overlaps the 0.8 ms the device needs anyway."""
+        way.  The 0.2 ms fingerprint of a 25 MB model then overlaps the 0.8 ms the device needs anyway.
+
+        Parameters an on-device M-step left in HBM are installed device to device, unchecked: nobody outside this object
+        has seen them (reading an attribute turns it into a host array and sends the object down the checked road)."""
         if not force_full and self._params_current():
             return
-        si = np.asarray(self.si)
         ctx = self.ctx
+        res = self.__dict__.get("_resident", {})
+        if any(k in res for k in self._PARAMS):
+            if all(k in res and res[k][0].ctx is ctx and res[k][0].ptr for k in self._PARAMS):
+                token = ("dev", self._dev_serial, bool(force_full))
+                if ctx._model_fp != token:
+                    d = {k: res[k][0] for k in self._PARAMS}
+                    ctx.upload_gmmhmm_device(d["A"], d["pi"], d["w"], d["mu"], d["si"], diag=(len(d["si"].shape) == 3),
+                                             force_full=force_full, owner=id(self), token=token)
+                self._replaced = False
+                return
+            for k in self._PARAMS:                    # some read, some not: all of them to the host, the checked road below
+                getattr(self, k)
+        si = np.asarray(self.si)
         # (not after this object itself replaced its parameters -- _updatemodel, reset, load, apply_stats: the speculative run
         # would be thrown away for certain)
         if not force_full and self.__dict__.get("_speculating") and not self.__dict__.get("_replaced") \
@@ -111,29 +160,63 @@ class GMMHMM(HMM):
 
     def train(self, obs, iters=1, eps=0.0001, verbose: bool = True):
         """Baum-Welch on one sequence, stopping when |delta loglik| < eps  (hmm.py:285-313 with the
-        gmmhmm.py:69-156 M-step): same iterates, same printed line."""
+        gmmhmm.py:69-156 M-step): same iterates, same printed line.
+
+        On the fused route everything between the observations going up and the likelihoods coming back stays in HBM: the
+        packed statistics, the M-step's new A, pi, w, mu, Sigma (installed as the next model device to device; they become
+        numpy arrays when somebody reads the attributes) -- per iteration two numbers cross PCIe.  And while another
+        iteration may follow, L(lambda_new | O) is taken from the E-step that iteration needs anyway (the reference computes
+        it twice: `calc_prob` at the end of iteration k and `lse(alpha[-1])` at the start of k + 1 are the same forward pass
+        over the same model, hmm.py:301-304); the last iteration scores with `calc_prob` as the reference does, and when the
+        loop stops on `eps` after an E-step, `_map_b` leaves `self.b` / `self.bm` as that `calc_prob` would have."""
         if not self._fused_train_ok():
             return super().train(obs, iters, eps, verbose)
+        ctx = self.ctx
         obs = np.ascontiguousarray(obs, dtype=np.float64)
+        d_obs = ctx.to_device(obs[None])
         N, M, D = self.n, self.m, self.d
         ll_at = N * N + 2 * N + N * M + N * M * D + N * M * D * D
-        for k in range(iters):
+
+        def e_step():
             self._upload_gmm()
-            if self.ctx.model_is_diag():               # the reference's M-step returns a FULL Sigma even then
+            if ctx.model_is_diag():                    # the reference's M-step returns a FULL Sigma even then
                 self._upload_gmm(force_full=True)
-            stats = self.ctx.bw_accumulate(obs[None])
-            before = self.precision(stats[ll_at])
-            self._updatemodel(self.ctx.bw_mstep(stats, self.min_std))
-            if _report_iteration(k, before, self.calc_prob(obs), verbose) < eps:
+            st = self._reuse_buffer("_stats_dev", (ctx.bw_stats_len(),))
+            ctx.bw_accumulate(d_obs, stats_out=st)
+            return st, self.precision(st.rows_to_host(ll_at, 1, 1)[0, 0])
+
+        stats = None
+        for k in range(iters):
+            if stats is None:
+                stats, before = e_step()
+            spare = self.__dict__.get("_spare", {})
+            self._updatemodel(ctx.bw_mstep(stats, self.min_std, device_out=True, out={p: spare.get(p) for p in self._PARAMS}))
+            if k + 1 < iters:
+                stats, after = e_step()                # = the `before` of iteration k + 1
+            else:
+                stats, after = None, self.calc_prob(obs)
+            if _report_iteration(k, before, after, verbose) < eps:
                 break
+            before = after
+        if stats is not None:                          # stopped on eps right after an E-step: the state calc_prob leaves
+            self._map_b(d_obs.view(obs.shape))
+        d_obs.free()
+
+    def _reuse_buffer(self, name, shape, dtype=np.float64):
+        buf = self.__dict__.get(name)
+        if buf is None or buf.ctx is not self.ctx or not buf.ptr or buf.shape != tuple(shape) or buf.dtype != np.dtype(dtype):
+            buf = self.ctx.empty(shape, dtype)
+            self.__dict__[name] = buf
+        return buf
 
     def _updatemodel(self, model):
         self._replaced = True
-        self.A = model["A"]
-        self.pi = model["pi"]
-        self.mu = model["mu"]
-        self.si = model["si"]
-        self.w = model["w"]
+        for k in ("A", "pi", "mu", "si", "w"):
+            if isinstance(model[k], _ffi.DeviceArray):
+                self._keep_param(k, model[k])
+            else:
+                setattr(self, k, model[k])
+        self._dev_serial = next(_SERIAL)
 
     def reset(self, init_type):
         """'uniform': zero means, identity Sigma; 'random': A, pi, w from the global numpy RNG (in that order, float64

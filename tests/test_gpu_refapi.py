@@ -34,7 +34,8 @@ def test_b_and_bm_read_as_golden_after_decode(golden):
             N, M, D, si = _diag_model(g)
         gh = GMMHMM(N, M, D, g["A"], g["pi"], g["w"], g["mu"], si)
         assert np.array_equal(gh.decode(g["obs"]), g["path"]), name
-        assert set(gh._resident) == {"b", "bm"} and not gh._host          # nothing came back but the path
+        # nothing came back but the path (the parameters the caller handed over are host arrays, as given)
+        assert set(gh._resident) == {"b", "bm"} and set(gh._host) == set(GMMHMM._PARAMS)
         assert_close(gh.b, g["b"], 1e-12, 1e-12, msg=name + " b")
         assert_close(gh.bm, g["bm"], 1e-12, 1e-12, msg=name + " bm")
         assert gh.b.shape == g["b"].shape and gh.bm.shape == g["bm"].shape
@@ -56,7 +57,7 @@ def test_remap_false_reads_the_resident_b(golden):
     v, bt, path = gh._viterbi(g["obs"])
     xi, gamma = gh._baumwelch(g["obs"], alpha, beta)
     est = gh._estimate(g["obs"], alpha, beta, xi, gamma)
-    assert set(gh._resident) == {"b", "bm"} and not gh._host
+    assert set(gh._resident) == {"b", "bm"} and set(gh._host) == set(GMMHMM._PARAMS)    # (the parameters: host arrays as given)
     assert_close(alpha, g["alpha"], 1e-12), assert_close(beta, g["beta"], 1e-12)
     assert np.array_equal(path, g["path"]) and np.array_equal(bt, g["bt"])
     assert_close(v, g["v"], 1e-12), assert_close(xi, g["xi"], 1e-11, 1e-11), assert_close(gamma, g["gamma"], 1e-11, 1e-11)
@@ -198,3 +199,65 @@ def test_parameter_check_runs_beside_the_kernels(golden, oracle, monkeypatch):
     # a call that fails for the caller's own reasons still fails, speculating or not
     with pytest.raises(ValueError, match="D="):
         gh.decode(g["obs"][:, :5])
+
+
+def test_train_leaves_the_new_parameters_in_hbm_until_somebody_reads_them(golden):
+    """GMMHMM.train on the fused route (round 5): the M-step's A, pi, w, mu, Sigma stay in HBM and are installed as the next
+    model device to device; the attributes are numpy arrays the moment they are read -- the golden ones (gmmhmm_small: the
+    imported reference after three iterations) -- and from then on host arrays rule again: an in-place edit reaches the device."""
+    import contextlib
+    import io
+    from lnasr.gmmhmm import GMMHMM
+    from lnasr import _ffi
+    g = golden("gmmhmm_small")
+    gh = GMMHMM(5, 3, 2, g["A"].copy(), g["pi"].copy(), g["w"].copy(), g["mu"].copy(), g["si"].copy())    # the model before training
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        gh.train(g["obs"], 3, 0.0, True)
+    assert buf.getvalue() == str(g["train_log"])
+    assert set(GMMHMM._PARAMS) <= set(gh._resident)                       # nothing but likelihoods came back
+    assert all(isinstance(gh._resident[k][0], _ffi.DeviceArray) for k in GMMHMM._PARAMS)
+    # scoring and decoding go on from the resident model (no host copy appears)
+    assert abs(gh.calc_prob(g["obs"]) - g["train3_loglik"][0]) < 1e-9
+    assert np.array_equal(gh.decode(g["obs"]), g["train3_decode"])
+    assert set(GMMHMM._PARAMS) <= set(gh._resident)
+    # reading makes them numpy arrays: the reference's values
+    for k in GMMHMM._PARAMS:
+        assert_close(getattr(gh, k), g["train3_" + k], 1e-8, 1e-10, msg=k)
+        assert isinstance(getattr(gh, k), np.ndarray) and k not in gh._resident
+    assert abs(gh.calc_prob(g["obs"]) - g["train3_loglik"][0]) < 1e-9       # the checked (host) road gives the same
+    # an in-place edit of a parameter that was read reaches the device
+    before = gh.calc_prob(g["obs"])
+    gh.mu[...] += 0.05
+    assert gh.calc_prob(g["obs"]) != before
+    # a second training run starts from the edited host arrays and ends resident again, in the spare buffers
+    with contextlib.redirect_stdout(io.StringIO()):
+        gh.train(g["obs"], 2, 0.0, True)
+    assert set(GMMHMM._PARAMS) <= set(gh._resident)
+
+
+def test_train_stops_on_eps_with_the_state_calc_prob_leaves(synth):
+    """The fused loop takes L(lambda_new | O) from the next iteration's E-step; when it stops on eps right after one, self.b /
+    self.bm are those of the final model, as after the reference's closing calc_prob (hmm.py:304)."""
+    from lnasr.gmmhmm import GMMHMM
+    N, M, D, T = 6, 2, 3, 200
+    mdl = synth.synth_model(N, M, D, seed=11)
+    obs = synth.synth_obs(1, T, D, seed=12)[0]
+
+    class Stepwise(GMMHMM):                          # an overridden step: the reference's call sequence, calc_prob included
+        def _estimate(self, *a):
+            return super()._estimate(*a)
+    runs = []
+    for cls in (GMMHMM, Stepwise):
+        gh = cls(N, M, D, mdl["A"].copy(), mdl["pi"].copy(), mdl["w"].copy(), mdl["mu"].copy(), mdl["si"].copy())
+        import contextlib, io
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            gh.train(obs, 60, 0.5, True)
+        runs.append((buf.getvalue(), gh))
+    (log_a, a), (log_b, b) = runs
+    assert a._fused_train_ok() and not b._fused_train_ok()
+    assert log_a == log_b and 1 < log_a.count("Iter:") < 60                 # stopped on eps, same iteration, same lines
+    assert_close(a.b, b.b, 1e-12, 1e-12), assert_close(a.bm, b.bm, 1e-12, 1e-12)
+    for k in GMMHMM._PARAMS:
+        assert_close(getattr(a, k), getattr(b, k), 1e-9, 1e-11, msg=k)

@@ -406,12 +406,22 @@ def test_forward_backward_column_owned_kernel(N, synth, oracle, ctx):
     with env_switch(LNASR_FWD="c"):
         alpha3, ll3 = ctx.forward(b, lens=lens)
         beta3 = ctx.backward(b, lens=lens)
+    with env_switch(LNASR_FWD_ONE_MAXU=1 << 20):           # ONE utterance per block: the tier of batches up to 2 x CUs (round 5)
+        alpha4, ll4 = ctx.forward(b, lens=lens)
+        beta4 = ctx.backward(b, lens=lens)
+    with env_switch(LNASR_FWD_ONE_MAXU=0):                 # ... and two per block for a batch that would take one
+        alpha5, ll5 = ctx.forward(b[:9], lens=lens[:9])
+        beta5 = ctx.backward(b[:9], lens=lens[:9])
     assert np.array_equal(ll_only, ll)
-    # same products, same swap network, same order of additions: the two column-owned kernels agree to the bit
+    # same products, same swap network, same order of additions: the column-owned kernels agree to the bit
     for u in range(U):
         L = lens[u]
         assert np.array_equal(alpha[u, :L], alpha3[u, :L]) and np.array_equal(beta[u, :L], beta3[u, :L]), u
-    assert np.array_equal(ll, ll3)
+        assert np.array_equal(alpha[u, :L], alpha4[u, :L]) and np.array_equal(beta[u, :L], beta4[u, :L]), u
+    for u in range(9):
+        L = lens[u]
+        assert np.array_equal(alpha[u, :L], alpha5[u, :L]) and np.array_equal(beta[u, :L], beta5[u, :L]), u
+    assert np.array_equal(ll, ll3) and np.array_equal(ll, ll4) and np.array_equal(ll[:9], ll5)
     for u in range(U):
         L = lens[u]
         assert_close(alpha[u, :L], alpha2[u, :L], 1e-12, msg="alpha vs row-sliced kernel u=%d" % u)

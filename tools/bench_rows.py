@@ -2,7 +2,7 @@
 """Per-row measurements of the other BASELINE.json configs on one GPU (development / DESIGN.md numbers;
 the driver-facing benchmark is bench.py).  Inputs resident in HBM, HIP-event kernel times.
 
-    python tools/bench_rows.py [mfcc] [e2e] [seg] [gmm] [fwd] [bw] [refapi] [nanfix] [all]
+    python tools/bench_rows.py [mfcc] [e2e] [seg] [gmm] [fwd] [fwdsweep] [bw] [refapi] [nanfix] [all]
 """
 import os
 import sys
@@ -149,6 +149,29 @@ if what & {"fwd", "all"}:
           algo_flop=U * T * 3.0 * N * N)
     timed("calc_prob (emission + forward)", lambda: _ffi.check(lib.lnasr_calc_prob(ctx.handle, obs.ptr, U, T, None, ll.ptr)),
           U * T, "frames")
+
+if what & {"fwdsweep"}:
+    # dispatch::fwdbwd_one_per_block (csrc/trellis.h): one utterance per four-wave block against two, N = 128, by batch size
+    import contextlib
+    T, N, M, D = 1000, 128, 16, 39
+    mdl = synth.synth_model(N, M, D, seed=1)
+    ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
+    lib = _ffi.lib()
+    for U in (1, 16, 64, 128, 256, 384, 512, 768, 1024):
+        obs = ctx.to_device(synth.synth_obs(U, T, D, seed=1000))
+        b = ctx.gmm_logprob(obs)
+        al = ctx.empty((U, T, N), np.float64)
+        ll = ctx.empty((U,), np.float64)
+        for maxu, tag in ((0, "two per block"), (1 << 20, "one per block")):
+            os.environ["LNASR_FWD_ONE_MAXU"] = str(maxu)
+            _ffi.reload_switches()
+            timed("forward U=%d, %s" % (U, tag), lambda: _ffi.check(lib.lnasr_forward(ctx.handle, b.ptr, U, T, None, 0, al.ptr, ll.ptr)),
+                  U * T, "frames")
+            timed("backward U=%d, %s" % (U, tag), lambda: _ffi.check(lib.lnasr_backward(ctx.handle, b.ptr, U, T, None, 0, al.ptr)),
+                  U * T, "frames")
+        del obs, b, al, ll
+    os.environ.pop("LNASR_FWD_ONE_MAXU", None)
+    _ffi.reload_switches()
 
 if what & {"bw", "all"}:
     # config 5: N=256, M=32, T=2000, D=39, 64 utterances per GPU
