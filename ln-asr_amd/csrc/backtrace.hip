@@ -224,14 +224,16 @@ __global__ __launch_bounds__(1024) void backtrace_lds_kernel(const TS* __restric
     if (SUSPECT && suspect != 0 && lane == 0) *suspect_flag = epoch;
 }
 
-// full back-pointer matrix (hmm.py:165): bt[u,t,j] = argmax_i(v[u,t-1,i] + A[i,j]); bt[u,0,:] = 0
-template <typename TS>
+// full back-pointer matrix (hmm.py:165): bt[u,t,j] = argmax_i(v[u,t-1,i] + A[i,j]); bt[u,0,:] = 0.
+// OUT = uint32_t, pitch N: the array HMM._viterbi returns.  OUT = uint8_t (N <= 256), pitch a multiple of 16: the rows the
+// small-batch back-trace chases through (backtrace_chase_kernel below).
+template <typename TS, typename OUT>
 __global__ void bt_kernel(const TS* __restrict__ v, const double* __restrict__ A, const int32_t* __restrict__ lens,
-                          uint32_t* __restrict__ bt, int T, int N) {
+                          OUT* __restrict__ bt, int T, int N, int pitch) {
     extern __shared__ double vs[];            // [N]
     const int u = blockIdx.y, t = blockIdx.x;
     if (t >= lens[u]) return;
-    uint32_t* out = bt + ((size_t)u * T + t) * N;
+    OUT* out = bt + ((size_t)u * T + t) * pitch;
     if (t == 0) {
         for (int j = threadIdx.x; j < N; j += blockDim.x) out[j] = 0;
         return;
@@ -247,10 +249,82 @@ __global__ void bt_kernel(const TS* __restrict__ v, const double* __restrict__ A
             // numpy.argmax: the first NaN wins over everything (v repaired by viterbi_nan_repair holds the reference's NaNs)
             if (val > best || (val != val && best == best)) { best = val; bi = i; }
         }
-        out[j] = (uint32_t)bi;
+        out[j] = (OUT)bi;
     }
 }
 
+// Small batches (round 5; the reference's decode(obs) is ONE utterance, hmm.py:276-283): the arg-max chain of
+// backtrace_lds_kernel costs ~550 cycles a frame and nothing shortens a dependent chain -- but with a handful of utterances
+// the chip is idle, so the back-pointers of EVERY state are formed first, all frames at once (bt_kernel above, bytes), and
+// the chain that is left is one LDS byte read per frame: path[t-1] = bt[t][path[t]].  One wave per utterance; the rows
+// travel HBM -> registers -> LDS FR frames at a time, the next chunk in flight while the current one is walked.
+// Same additions, same first-index rule as the recomputing kernels: the same path.  (Batches: the N^2 work per frame is the
+// Viterbi kernel's all over again -- from ~32 utterances on the recomputing kernel is cheaper, dispatch::backtrace_chase.)
+template <typename TS, int NPV>   // NPV: 16-byte pieces per lane and chunk
+__global__ __launch_bounds__(64) void backtrace_chase_kernel(const TS* __restrict__ v, const uint8_t* __restrict__ btb,
+                                                             const int32_t* __restrict__ lens, uint32_t* __restrict__ path,
+                                                             double* __restrict__ best, int U, int T, int N, int NP, int FR) {
+    extern __shared__ uint8_t rows[];                         // [2][NPV * 1024] (>= FR * NP)
+    const int lane = threadIdx.x, u = blockIdx.x;
+    const int L = lens[u];
+    if (L <= 0) return;
+    const TS* vu = v + (size_t)u * T * N;
+    uint32_t* pu = path + (size_t)u * T;
+    const uint8_t* bu = btb + (size_t)u * T * NP;
+    // last frame: first index among equal maxima (lane l holds states l, l + 64, ...), as backtrace_lds_kernel picks it
+    int p;
+    {
+        double x[4], m = LN_NEG_INF;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int j = lane + 64 * c;
+            x[c] = j < N ? ld(vu, (size_t)(L - 1) * N + j) : LN_NEG_INF;
+            m = vmax_f64(m, x[c]);
+        }
+        const double mx = wave_max_dpp(m);
+        p = 0;
+#pragma unroll
+        for (int c = 3; c >= 0; --c) {
+            const unsigned long long mk = __ballot(x[c] == mx);
+            p = mk ? 64 * c + __ffsll((long long)mk) - 1 : p;
+        }
+        if (lane == 0 && best) best[u] = mx;
+    }
+    uint32_t mine = 0;
+    if (lane == ((L - 1) & 63)) mine = (uint32_t)p;
+    if (((L - 1) & 63) == 0) pu[L - 1] = (uint32_t)p;
+    if (L == 1) return;
+    // rows 1 .. L-1 are walked downwards in chunks of FR: chunk k = rows hi_k - FR + 1 .. hi_k (clipped at 1)
+    constexpr int chunk_bytes = NPV * 1024;                   // >= FR * NP: 16 bytes x 64 lanes x NPV pieces
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 stage[NPV];
+    auto fetch = [&](int hi) {
+        const int lo = hi - FR + 1 > 1 ? hi - FR + 1 : 1;
+        const uint8_t* src = bu + (size_t)lo * NP;
+        const int nbytes = (hi - lo + 1) * NP;
+#pragma unroll
+        for (int q = 0; q < NPV; ++q) {
+            const int off = (q * 64 + lane) * 16;
+            stage[q] = off < nbytes ? *reinterpret_cast<const u32x4*>(src + off) : u32x4{0, 0, 0, 0};
+        }
+    };
+    fetch(L - 1);
+    int buf = 0;
+    for (int hi = L - 1; hi >= 1; hi -= FR, buf ^= 1) {
+        const int lo = hi - FR + 1 > 1 ? hi - FR + 1 : 1;
+        uint8_t* dst = rows + (size_t)buf * chunk_bytes;
+#pragma unroll
+        for (int q = 0; q < NPV; ++q) *reinterpret_cast<u32x4*>(dst + (q * 64 + lane) * 16) = stage[q];
+        __syncthreads();                                      // one wave: orders the LDS writes before the reads below
+        if (lo > 1) fetch(lo - 1);                            // the next chunk travels while this one is walked
+        for (int t = hi; t >= lo; --t) {
+            p = dst[(t - lo) * NP + p];                       // path[t-1] = bt[t][path[t]]
+            const int tp = t - 1;
+            if (lane == (tp & 63)) mine = (uint32_t)p;
+            if ((tp & 63) == 0 && tp + lane < L) pu[tp + lane] = mine;      // frames tp .. tp + 63 are complete
+        }
+    }
+}
 
 int backtrace_device(lnasr_ctx* ctx, const void* v, int U, int T, const int32_t* d_lens, int dtype, uint32_t* path,
                      double* best, bool* v_tested, bool want_suspect) {
@@ -283,6 +357,29 @@ int backtrace_device(lnasr_ctx* ctx, const void* v, int U, int T, const int32_t*
             else LN_TINY(double, 16);
         }
 #undef LN_TINY
+        return 0;
+    }
+    // a handful of utterances whose cells nobody has to test: all back-pointers at once, then a chain of LDS byte reads
+    if (!want_suspect && md.N <= 256 && dispatch::backtrace_chase(U) && !sw().no_ldsbt) {
+        const int NP = (md.N + 15) / 16 * 16;
+        const int FR = NP <= 128 ? 128 : 64;                  // 16 KB (NP = 128) ... 16 KB (NP = 256) per chunk
+        const int npv = FR * NP / 1024;                       // 16-byte pieces per lane: 2 ... 16
+        LN_TRY(ctx->ws_btb.reserve((size_t)U * T * NP + 1024));
+        uint8_t* btb = ctx->ws_btb.as<uint8_t>();
+        int nt = ((md.N + 63) / 64) * 64;
+        if (nt > 256) nt = 256;
+#define LN_CHASE(TSv, tag)                                                                                          \
+    do {                                                                                                            \
+        LN_LAUNCH(ctx, "viterbi_bt_bytes" tag, (bt_kernel<TSv, uint8_t>), dim3(T, U), dim3(nt), (size_t)md.N * 8,    \
+                  (const TSv*)v, md.logA.as<double>(), d_lens, btb, T, md.N, NP);                                   \
+        if (npv <= 2) LN_LAUNCH(ctx, "backtrace_chase" tag, (backtrace_chase_kernel<TSv, 2>), dim3(U), dim3(64), 2 * 2 * 1024, (const TSv*)v, btb, d_lens, path, best, U, T, md.N, NP, FR); \
+        else if (npv <= 4) LN_LAUNCH(ctx, "backtrace_chase" tag, (backtrace_chase_kernel<TSv, 4>), dim3(U), dim3(64), 2 * 4 * 1024, (const TSv*)v, btb, d_lens, path, best, U, T, md.N, NP, FR); \
+        else if (npv <= 8) LN_LAUNCH(ctx, "backtrace_chase" tag, (backtrace_chase_kernel<TSv, 8>), dim3(U), dim3(64), 2 * 8 * 1024, (const TSv*)v, btb, d_lens, path, best, U, T, md.N, NP, FR); \
+        else LN_LAUNCH(ctx, "backtrace_chase" tag, (backtrace_chase_kernel<TSv, 16>), dim3(U), dim3(64), 2 * 16 * 1024, (const TSv*)v, btb, d_lens, path, best, U, T, md.N, NP, FR); \
+    } while (0)
+        if (dtype == LNASR_F32) LN_CHASE(float, "_f32");
+        else LN_CHASE(double, "");
+#undef LN_CHASE
         return 0;
     }
     // SUSPECT variant only when somebody will read the word (want_suspect: the caller's emissions were not tested upstream)
@@ -331,11 +428,11 @@ int bt_matrix_device(lnasr_ctx* ctx, const void* v, int U, int T, const int32_t*
     int nt = ((N + 63) / 64) * 64;
     if (nt > 256) nt = 256;
     if (dtype == LNASR_F32)
-        LN_LAUNCH(ctx, "viterbi_bt_f32", bt_kernel<float>, dim3(T, U), dim3(nt), (size_t)N * 8, (const float*)v,
-                  ctx->model.logA.as<double>(), d_lens, bt, T, N);
+        LN_LAUNCH(ctx, "viterbi_bt_f32", (bt_kernel<float, uint32_t>), dim3(T, U), dim3(nt), (size_t)N * 8, (const float*)v,
+                  ctx->model.logA.as<double>(), d_lens, bt, T, N, N);
     else
-        LN_LAUNCH(ctx, "viterbi_bt", bt_kernel<double>, dim3(T, U), dim3(nt), (size_t)N * 8, (const double*)v,
-                  ctx->model.logA.as<double>(), d_lens, bt, T, N);
+        LN_LAUNCH(ctx, "viterbi_bt", (bt_kernel<double, uint32_t>), dim3(T, U), dim3(nt), (size_t)N * 8, (const double*)v,
+                  ctx->model.logA.as<double>(), d_lens, bt, T, N, N);
     return 0;
 }
 

@@ -119,6 +119,7 @@ struct Switches {
     char vit = 0;                 // LNASR_VIT: first character, 0 = unset
     char fwd = 0;                 // LNASR_FWD: 'c' = the four-utterance column-owned forward / backward kernel (fwdbwd_cols)
     int framepar_maxu = -1;       // LNASR_FRAMEPAR_MAXU, -1 = unset (measured rule)
+    int chase_maxu = -1;          // LNASR_CHASE_MAXU: back-pointer chase instead of the arg-max back-trace up to this batch size
     int fwd_one_maxu = -1;        // LNASR_FWD_ONE_MAXU: one utterance per block in the column-owned forward / backward up to this batch size
     double kappa_max = kKappaMax; // LNASR_KAPPA_MAX
     int h2d_threads = 4;          // LNASR_H2D_THREADS: host threads filling the pinned staging ring
@@ -157,6 +158,7 @@ struct lnasr_ctx {
     lnasr::DevBuf ws_w1, ws_w2, ws_w3;                     // float32 storage: widened inputs / outputs of the f64 kernels
     lnasr::DevBuf ws_pad;                                  // bm of a padded model before compaction
     lnasr::DevBuf ws_bp;                                   // byte back-pointers of the tiny-model Viterbi (N <= 16)
+    lnasr::DevBuf ws_btb;                                  // byte back-pointer rows of the small-batch back-trace (backtrace.hip)
     // non-finite data (nanfix.hip): a device word the hot kernels set to the running call's epoch when they meet a NaN or
     // an infinity, and the per-utterance slots of the scan that follows
     lnasr::DevBuf nan_flag, nan_slots;

@@ -89,6 +89,7 @@ static void load_switches(Switches& s) {
     if (const char* e = getenv("LNASR_EMIT")) s.emit = e[0];
     if (const char* e = getenv("LNASR_FRAMEPAR_MAXU")) s.framepar_maxu = atoi(e);
     if (const char* e = getenv("LNASR_FWD_ONE_MAXU")) s.fwd_one_maxu = atoi(e);
+    if (const char* e = getenv("LNASR_CHASE_MAXU")) s.chase_maxu = atoi(e);
     if (const char* e = getenv("LNASR_KAPPA_MAX")) s.kappa_max = atof(e);
     if (const char* e = getenv("LNASR_H2D_THREADS")) {
         s.h2d_threads = atoi(e);
@@ -295,7 +296,7 @@ void lnasr_ctx_destroy(lnasr_ctx* ctx) {
     ctx->model.release();
     DevBuf* all[] = {&ctx->ws_in, &ctx->ws_in2, &ctx->ws_in3, &ctx->ws_in4, &ctx->ws_in5, &ctx->ws_out, &ctx->ws_out2,
                      &ctx->ws_out3, &ctx->ws_b, &ctx->ws_bm, &ctx->ws_v, &ctx->ws_alpha, &ctx->ws_beta,
-                     &ctx->ws_misc, &ctx->ws_misc2, &ctx->ws_lens, &ctx->ws_stats, &ctx->ws_p, &ctx->ws_q, &ctx->ws_raw, &ctx->ws_w1, &ctx->ws_w2, &ctx->ws_w3, &ctx->ws_pad, &ctx->ws_bp, &ctx->mfcc_const, &ctx->nan_flag, &ctx->nan_slots};
+                     &ctx->ws_misc, &ctx->ws_misc2, &ctx->ws_lens, &ctx->ws_stats, &ctx->ws_p, &ctx->ws_q, &ctx->ws_raw, &ctx->ws_w1, &ctx->ws_w2, &ctx->ws_w3, &ctx->ws_pad, &ctx->ws_bp, &ctx->ws_btb, &ctx->mfcc_const, &ctx->nan_flag, &ctx->nan_slots};
     for (DevBuf* b : all) b->release();
     for (auto& r : ctx->prof_recs) {
         (void)hipEventDestroy(r.e0);

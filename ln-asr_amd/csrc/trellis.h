@@ -92,6 +92,16 @@ inline int backtrace_waves_per_block(int U, int n_cu) {
     return w < 4 ? 4 : (w > 16 ? 16 : w);
 }
 
+// Back-trace of a handful of utterances: every back-pointer first (all frames in parallel, bytes), then a chain of LDS byte
+// reads (backtrace_chase_kernel) instead of an arg-max per frame.  The N^2 work per frame pays while the chip is idle.
+// tools/bench_rows.py btsweep, round 5 (profiles/r05g_btsweep.log), decode at N = 128, T = 1000, ms, arg-max
+// back-trace / chase: U=1 0.80 / 0.68, 4 0.83 / 0.71, 8 0.87 / 0.78, 16 0.93 / 0.88, 32 1.04 / 1.10, 64 1.24 / 1.52.
+// LNASR_CHASE_MAXU overrides (tests, sweeps).
+inline bool backtrace_chase(int U) {
+    if (sw().chase_maxu >= 0) return U <= sw().chase_maxu;
+    return U <= 16;
+}
+
 }  // namespace dispatch
 
 // ---- launchers -------------------------------------------------------------------------------------------------------

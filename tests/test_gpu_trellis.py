@@ -643,3 +643,40 @@ def test_float32_train_tracks_the_reference(golden):
         assert_close(getattr(gh, k), g["train3_" + k], 1e-5, 1e-5, msg=k)
     assert abs(gh.calc_prob(g["obs"]) - g["train3_loglik"][0]) < 1e-5 * abs(g["train3_loglik"][0])
     assert np.array_equal(gh.decode(g["obs"]), g["train3_decode"])
+
+
+@pytest.mark.parametrize("N", [17, 64, 65, 100, 128, 129, 200, 256])
+def test_back_pointer_chase_equals_the_argmax_backtrace(N, synth, oracle, ctx):
+    """Small batches (round 5): every back-pointer first (bytes), then path[t-1] = bt[t][path[t]] as a chain of LDS reads
+    (backtrace_chase_kernel) -- against the recomputing back-trace kernels (LNASR_CHASE_MAXU=0) on ragged batches (lengths 1, 2,
+    a multiple of the chunk, one past it), ties, forbidden transitions and an unreachable state, both storages; and against the
+    oracle."""
+    rng = np.random.default_rng(N)
+    d = synth.synth_discrete(N, 4, 8, seed=N)
+    A = d["A"].copy()
+    A[3, :] = -np.inf
+    A[3, 5] = 0.0
+    A[:, 7] = -np.inf
+    A[1, :] = A[0, :]                                     # equal rows: ties between source states 0 and 1
+    ctx.upload_hmm(A, d["pi"])
+    U, T = 9, 300
+    b = np.ascontiguousarray(-30.0 * rng.random((U, T, N)))
+    b[:, :, 1] = b[:, :, 0]
+    lens = np.array([T, 1, 2, 64, 65, 128, 129, 257, T - 1], dtype=np.int32)
+    for dt in (np.float64, np.float32):
+        bb = b.astype(dt)
+        with env_switch(LNASR_CHASE_MAXU=1 << 20):
+            r1 = ctx.viterbi(bb, want_v=True, want_bt=False, want_score=True, lens=lens)
+        with env_switch(LNASR_CHASE_MAXU=0):
+            r0 = ctx.viterbi(bb, want_v=True, want_bt=False, want_score=True, lens=lens)
+        for u in range(U):
+            L = lens[u]
+            assert np.array_equal(r1["path"][u, :L], r0["path"][u, :L]), (N, dt, u)
+            assert np.array_equal(r1["v"][u, :L], r0["v"][u, :L])
+        assert np.array_equal(r1["score"], r0["score"])
+        if dt == np.float64:
+            for u in (0, 3, 7):
+                L = lens[u]
+                with np.errstate(invalid="ignore", divide="ignore"):
+                    _, _, want = oracle.viterbi(A, d["pi"], np.ascontiguousarray(b[u, :L].T))
+                assert np.array_equal(r1["path"][u, :L], want), (N, u)

@@ -2,7 +2,7 @@
 """Per-row measurements of the other BASELINE.json configs on one GPU (development / DESIGN.md numbers;
 the driver-facing benchmark is bench.py).  Inputs resident in HBM, HIP-event kernel times.
 
-    python tools/bench_rows.py [mfcc] [e2e] [seg] [gmm] [fwd] [fwdsweep] [bw] [refapi] [nanfix] [all]
+    python tools/bench_rows.py [mfcc] [e2e] [seg] [gmm] [fwd] [fwdsweep] [btsweep] [bw] [refapi] [nanfix] [all]
 """
 import os
 import sys
@@ -171,6 +171,25 @@ if what & {"fwdsweep"}:
                   U * T, "frames")
         del obs, b, al, ll
     os.environ.pop("LNASR_FWD_ONE_MAXU", None)
+    _ffi.reload_switches()
+
+if what & {"btsweep"}:
+    # dispatch::backtrace_chase (csrc/trellis.h): back-pointer chase against the arg-max back-trace, N = 128, by batch size
+    T, N, M, D = 1000, 128, 16, 39
+    mdl = synth.synth_model(N, M, D, seed=1)
+    ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
+    for U in (1, 4, 8, 16, 32, 64, 128):
+        obs = ctx.to_device(synth.synth_obs(U, T, D, seed=1000))
+        ref = None
+        for maxu, tag in ((0, "arg-max back-trace"), (1 << 20, "back-pointer chase")):
+            os.environ["LNASR_CHASE_MAXU"] = str(maxu)
+            _ffi.reload_switches()
+            timed("decode U=%d, %s" % (U, tag), lambda: ctx.decode(obs), U * T, "frames")
+            p = ctx.decode(obs).to_host()
+            assert ref is None or np.array_equal(ref, p)
+            ref = p
+        del obs
+    os.environ.pop("LNASR_CHASE_MAXU", None)
     _ffi.reload_switches()
 
 if what & {"bw", "all"}:
