@@ -115,11 +115,12 @@ struct Switches {
     bool no_mfma = false, no_pad = false, no_tinyvit = false, no_regvit = false, no_regfwd = false, no_colfwd = false,
          no_t256 = false, no_framepar = false, no_stream = false, no_ldsbt = false, no_mfma_stats = false,
          no_fft512 = false, no_pipeline = false, f32_generic = false, no_f32_stats = false, no_pinned_ring = false,
-         no_tinyfwd = false, no_reglu = false, no_tilepack = false;
+         no_tinyfwd = false, no_reglu = false, no_tilepack = false, no_latfwd = false;
     char vit = 0;                 // LNASR_VIT: first character, 0 = unset
     char fwd = 0;                 // LNASR_FWD: 'c' = the four-utterance column-owned forward / backward kernel (fwdbwd_cols)
     int framepar_maxu = -1;       // LNASR_FRAMEPAR_MAXU, -1 = unset (measured rule)
     int chase_maxu = -1;          // LNASR_CHASE_MAXU: back-pointer chase instead of the arg-max back-trace up to this batch size
+    int fwd_lat_maxu = -1;        // LNASR_FWD_LAT_MAXU: the chain-shortened one-utterance forward / backward (fwdbwd_lat4) up to this batch size
     int fwd_one_maxu = -1;        // LNASR_FWD_ONE_MAXU: one utterance per block in the column-owned forward / backward up to this batch size
     double kappa_max = kKappaMax; // LNASR_KAPPA_MAX
     int h2d_threads = 4;          // LNASR_H2D_THREADS: host threads filling the pinned staging ring

@@ -67,6 +67,7 @@ static void load_switches(Switches& s) {
     s.no_tinyfwd = on("LNASR_NO_TINYFWD");
     s.no_reglu = on("LNASR_NO_REGLU");
     s.no_tilepack = on("LNASR_NO_TILEPACK");
+    s.no_latfwd = on("LNASR_NO_LATFWD");
     s.no_regvit = on("LNASR_NO_REGVIT");
     s.no_regfwd = on("LNASR_NO_REGFWD");
     s.no_colfwd = on("LNASR_NO_COLFWD");
@@ -90,6 +91,7 @@ static void load_switches(Switches& s) {
     if (const char* e = getenv("LNASR_FRAMEPAR_MAXU")) s.framepar_maxu = atoi(e);
     if (const char* e = getenv("LNASR_FWD_ONE_MAXU")) s.fwd_one_maxu = atoi(e);
     if (const char* e = getenv("LNASR_CHASE_MAXU")) s.chase_maxu = atoi(e);
+    if (const char* e = getenv("LNASR_FWD_LAT_MAXU")) s.fwd_lat_maxu = atoi(e);
     if (const char* e = getenv("LNASR_KAPPA_MAX")) s.kappa_max = atof(e);
     if (const char* e = getenv("LNASR_H2D_THREADS")) {
         s.h2d_threads = atoi(e);

@@ -705,6 +705,260 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 
+// One utterance per FOUR-wave block with the logarithm and the exponential taken OFF the frame's dependent chain (fp64
+// storage; round 5).  SQ counters of fwdbwd_cols2<.., 1> on one utterance (profiles/r05k_*): 164 vector instructions per wave
+// and frame, 657 per CU -- 656 cycles of issue -- in a frame of 1,758 cycles: a lone wave per SIMD walking
+//     e row from the LDS -> products -> swaps -> log (table) -> + b -> exp (table) -> LDS -> barrier
+// issues 37 % of the time.  (Eight waves of 16 columns -- built, measured, removed -- shorten each wave's chain but finalise every column
+// four times over: 1,050 instructions per CU, 0.72 ms against 0.75.)  Here the chain loses its log / exp half:
+//     e[t, j] = sum[t, j] * G[t, j],   G[t, j] = exp((Sh[t-1] - Sh[t]) + b[t, j]),
+// where Sh[t] -- the shift the row e[t, :] is expressed in -- is extrapolated from the maxima of the log-domain rows of frames
+// t - 2 and t - 3: known when the frame starts, so G is formed beside the products and the chain is  LDS -> products -> swaps -> one multiply -> LDS ->
+// barrier.  The log-domain value  Sh[t-1] + log(sum[t, j]) + b[t, j]  (the result, the input of the exact fallback and of the
+// shift two frames on) is evaluated one iteration LATER, in the same straight-line block as the next frame's products, where
+// it fills the issue slots their dependences leave.  A sum outside [1e-290, 1e290] (or a non-finite one) is redone from the
+// log-domain row of the frame before, exactly as in the other kernels -- that row is complete by then, a barrier lies in
+// between -- so whatever a degenerate e did to later sums is caught by the same test; results agree with the log-round-trip
+// kernels to the rounding of one multiplication.  (Round 2 measured the idea at 1024 utterances and dropped it: with the
+// chip full the chain's instructions still have to issue.  With one utterance per CU only the chain's LENGTH counts.)
+template <bool BACKWARD>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void fwdbwd_lat4(
+    const double* __restrict__ b, const double* __restrict__ Aexp, const double* __restrict__ Alog,
+    const double* __restrict__ pi, const int32_t* __restrict__ lens, double* __restrict__ out,
+    double* __restrict__ loglik, int U, int T, int N, unsigned* __restrict__ nan_flag, unsigned nan_epoch) {
+    constexpr int NP = 128, NW = 4, NM = 2 * NW;
+    unsigned long long saw_nan = 0;
+    __shared__ double Es[2][NP];          // e row (linear domain) of the frame being consumed / produced
+    __shared__ double Cs[2][NP];          // log-domain row by frame parity (exact fallback, likelihood)
+    __shared__ double Ms[2][NM];          // per DPP row (16 columns) maximum of the log-domain row, by frame parity
+    __shared__ double etab[kExpTab];
+    __shared__ double ltab[2 * kLogTab];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    exp_table_init(etab, threadIdx.x, 64 * NW);
+    log_table_init(ltab, threadIdx.x, 64 * NW);   // visible after the first __syncthreads below
+    const int u = blockIdx.x;
+    const int g = lane >> 4, c = lane & 15;
+    const int h = g >> 1;                          // finalisation role: rows 0-1 column half 0, rows 2-3 half 1
+    const bool primary = (g & 1) == 0;             // the odd rows repeat the even ones and store nothing
+    const int j = 32 * w + 16 * h + c;
+    const int jc = j < N ? j : N - 1;
+
+    double areg[2][32];                            // product role: columns 32 w + 16 q + c, source rows 32 g + r
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            const int i = 32 * g + r, jq = 32 * w + 16 * q + c;
+            areg[q][r] = (i < N && jq < N) ? Aexp[(size_t)i * N + jq] : 0.0;
+        }
+    const int klen = lens[u];
+    if (klen <= 0) return;
+    const double* bp = b + (size_t)u * T * N + jc;
+    double* op = (out && j < N && primary) ? out + (size_t)u * T * N + jc : nullptr;
+    auto frame_of = [&](int step) { return BACKWARD ? klen - 1 - step : step; };
+    auto clampt = [&](int t) { return t < 0 ? 0 : (t > T - 1 ? T - 1 : t); };
+    auto row_maxima = [&](int buf) {
+        double S = Ms[buf][0];
+#pragma unroll
+        for (int e = 1; e < NM; ++e) S = fmax(S, Ms[buf][e]);
+        return S;
+    };
+
+    // step 0: the log-domain row, its maximum, e in that shift
+    {
+        double prev = LN_NEG_INF;
+        if (j < N) {
+            const int t0 = frame_of(0);
+            const double bv = bp[(size_t)t0 * N];
+            if (BACKWARD) {
+                if (op) op[(size_t)t0 * N] = 0.0;
+                prev = 0.0 + bv;
+            } else {
+                prev = pi[j] + bv;
+                if (op) op[0] = prev;
+            }
+        }
+        saw_nan |= __ballot(prev != prev);
+        Cs[0][j] = prev;
+        const double m = row_max_dpp(prev);
+        if (c == 0 && primary) Ms[0][2 * w + h] = m;
+    }
+    __syncthreads();
+    double sh_e;                                   // Sh[step - 1]: the shift of the e row an iteration consumes
+    {
+        sh_e = row_maxima(0);
+        const double prev = Cs[0][j];
+        Es[0][j] = (sh_e == LN_NEG_INF || prev == LN_NEG_INF) ? 0.0 : exp_clamped(prev - sh_e, etab);
+    }
+    double bnext = bp[(size_t)clampt(frame_of(1)) * N];
+    drain_vmem();                                  // areg resident: no vmcnt guards in the loop
+    __syncthreads();
+
+    // One straight-line block per iteration: the e row of frame `step` (the chain) and, beside it, the log-domain evaluation
+    // of frame step - 1.  `eval` = 0 in the first turn (frame 0 is complete): the evaluation runs on a harmless sum and its
+    // stores are masked.  The last turn (step == klen) only evaluates frame klen - 1.
+    // A wave issues in order and is alone on its SIMD, so what overlaps is what the instruction stream interleaves -- and left
+    // to itself the scheduler put the whole evaluation between the products and the swaps and the exponential of G after them
+    // (0.62 ms: the chain as long as before).  The stream is therefore laid out by hand: sixteen groups of four products, a
+    // slice of the other work (table exp and log spelled out: devmath.h's exp_nonpos / log_sum step by step) after each,
+    // pinned with sched_barrier.
+#define LN_PROD(R)                                                        \
+    fmac_bcast<R>(acc[0][0], ek[0], areg[0][R]);                         \
+    fmac_bcast<R>(acc[0][1], ek[1], areg[0][16 + R]);                    \
+    fmac_bcast<R>(acc[1][0], ek[0], areg[1][R]);                         \
+    fmac_bcast<R>(acc[1][1], ek[1], areg[1][16 + R])
+#define LN_PIN __builtin_amdgcn_sched_barrier(0)
+    constexpr double kInvStep = 369.32993046757463, kStepHi = 2.7076061740622863e-03, kStepLo = 9.058776616587108e-20;
+    constexpr double kMagic = 6755399441055744.0, kLn2 = 0.69314718055994530942;
+    double sum_prev = 1.0, b_prev = 0.0, sh_pp = 0.0, m3 = LN_NEG_INF;
+    for (int step = 1; step <= klen; ++step) {
+        const int cur = (step - 1) & 1, nxt = step & 1;
+        const bool eval = step >= 2;
+        const double bcur = bnext;
+        bnext = bp[(size_t)clampt(frame_of(step + 1)) * N];
+        double ek[2];
+        ek[0] = Es[cur][32 * g + c];
+        ek[1] = Es[cur][32 * g + 16 + c];
+        // the shift of the row this iteration produces: the maximum of the log-domain row two frames back (frame 0 for step 1)
+        double mrow[NM];
+#pragma unroll
+        for (int e = 0; e < NM; ++e) mrow[e] = Ms[eval ? nxt : 0][e];
+        // ---- evaluation of frame f = step - 1, part 1 (registers only): range test, mantissa, table address
+        const int fb = cur, pb = nxt;              // parity buffers of frame f and of frame f - 1
+        const bool safe = sum_prev >= kSafeSum && sum_prev <= 1e290 && sh_pp != LN_NEG_INF;
+        const double ls = safe ? sum_prev : 1.0;
+        const int lhi = __double2hiint(ls);
+        const int le = (lhi >> 20) - 1023;
+        const int lj = (lhi >> 13) & (kLogTab - 1);
+        const double lm = __hiloint2double((lhi & 0x000FFFFF) | 0x3FF00000, __double2loint(ls));
+        const double lt0 = ltab[2 * lj], lt1 = ltab[2 * lj + 1];
+        LN_PIN;
+        double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+        LN_PROD(0);
+        double m01 = vmax_f64(mrow[0], mrow[1]), m23 = vmax_f64(mrow[2], mrow[3]);     // (a NaN row surfaces through prev != prev)
+        LN_PIN;
+        LN_PROD(1);
+        double m45 = vmax_f64(mrow[4], mrow[5]), m67 = vmax_f64(mrow[6], mrow[7]);
+        LN_PIN;
+        LN_PROD(2);
+        m01 = vmax_f64(m01, m23);
+        m45 = vmax_f64(m45, m67);
+        LN_PIN;
+        LN_PROD(3);
+        // ... carried forward by the last step the maxima took, twice (the row produced now is two frames further on): whatever
+        // the per-frame size of the emissions (-60 or -600), e stays near 1 and the whole exponent range is left for the spread
+        // WITHIN a row.  Any value works as a shift as long as every lane computes the same one -- these all read the same words.
+        const double m2 = vmax_f64(m01, m45);
+        const double trend = (m2 != LN_NEG_INF && m3 != LN_NEG_INF && eval) ? m2 - m3 : 0.0;
+        const double sh_new = fma(2.0, trend, m2);
+        m3 = m2;
+        // ---- G = exp((Sh[t-1] - Sh[t]) + b[t, j]) (0 where a shift is -inf: the exact fallback takes over), part 1
+        const bool sh_ok = sh_new != LN_NEG_INF && sh_e != LN_NEG_INF && j < N;
+        const double gx0 = sh_ok ? (sh_e - sh_new) + bcur : 0.0;
+        LN_PIN;
+        LN_PROD(4);
+        double gx = gx0;
+        asm("v_min_f64 %0, %1, %2" : "=v"(gx) : "v"(gx0), "v"(690.0));
+        gx = vmax_f64(gx, -700.0);
+        const double gkp = fma(gx, kInvStep, kMagic);
+        LN_PIN;
+        LN_PROD(5);
+        const int gk = __double2loint(gkp);
+        const double gt0 = etab[gk & (kExpTab - 1)];
+        const double gkd = gkp - kMagic;
+        LN_PIN;
+        LN_PROD(6);
+        // ---- evaluation, part 2: the logarithm (log_sum), the log-domain value, its store
+        const double lr = fma(lm, lt0, -1.0);
+        double gr = fma(-gkd, kStepHi, gx);
+        LN_PIN;
+        LN_PROD(7);
+        double lq = fma(lr, -1.0 / 6.0, 0.2);
+        gr = fma(-gkd, kStepLo, gr);
+        LN_PIN;
+        LN_PROD(8);
+        lq = fma(lq, lr, -0.25);
+        double gq = fma(gr, 1.0 / 24.0, 1.0 / 6.0);
+        LN_PIN;
+        LN_PROD(9);
+        lq = fma(lq, lr, 1.0 / 3.0);
+        gq = fma(gq, gr, 0.5);
+        const double grr = gr * gr;
+        LN_PIN;
+        LN_PROD(10);
+        lq = fma(lq, lr, -0.5);
+        const double gp = fma(gq, grr, gr);
+        LN_PIN;
+        LN_PROD(11);
+        lq = fma(lq, lr, 1.0);
+        const double gt = __hiloint2double(__double2hiint(gt0) + ((gk >> 8) << 20), __double2loint(gt0));
+        double Gv = fma(gt, gp, gt);
+        LN_PIN;
+        LN_PROD(12);
+        double val = sh_pp + fma((double)le, kLn2, fma(lq, lr, lt1));
+        Gv = gx0 > 690.0 ? __builtin_huge_val() : Gv;
+        const double G = sh_ok ? Gv : 0.0;
+        LN_PIN;
+        LN_PROD(13);
+        double prev = j < N ? val + b_prev : LN_NEG_INF;
+        double* const opf = eval ? op : nullptr;
+        const size_t oidx = (size_t)frame_of(eval ? step - 1 : 0) * N;
+        if (opf) opf[oidx] = BACKWARD ? val : prev;
+        if (eval) Cs[fb][j] = prev;
+        LN_PIN;
+        LN_PROD(14);
+        double m = vmax_f64(prev, dpp_f64<0xB1>(prev));
+        m = vmax_f64(m, dpp_f64<0x4E>(m));
+        LN_PIN;
+        LN_PROD(15);
+        m = vmax_f64(m, dpp_f64<0x141>(m));
+        m = vmax_f64(m, dpp_f64<0x140>(m));
+        if (eval && c == 0 && primary) Ms[fb][2 * w + h] = m;
+        LN_PIN;
+        // row groups -> column halves: rows 0-1 half 0, rows 2-3 half 1, ((g0 + g2) + (g1 + g3))
+        double a0 = acc[0][0] + acc[0][1], a1 = acc[1][0] + acc[1][1];
+        swap32_f64(a0, a1);
+        double s02 = a0 + a1, s13 = s02;
+        swap16_f64(s02, s13);
+        const double sum = s02 + s13;
+        Es[nxt][j] = sum * G;                      // (the last turn writes a row nobody reads)
+        // once in a blue moon: a column whose sum left the safe range is redone from the log-domain row of the frame before
+        // (complete: a barrier ago), and what the straight line stored for it is overwritten before anybody reads it
+        if (__builtin_expect(eval && __any(!safe), 0)) {
+            if (!safe) {
+                val = exact_column_lse(&Cs[pb][0], Alog + jc, N);
+                prev = j < N ? val + b_prev : LN_NEG_INF;
+                if (opf) opf[oidx] = BACKWARD ? val : prev;
+                Cs[fb][j] = prev;
+            }
+            m = row_max_dpp(prev);
+            if (c == 0 && primary) Ms[fb][2 * w + h] = m;
+        }
+        saw_nan |= __ballot(eval && prev != prev);
+        sum_prev = sum;
+        b_prev = bcur;
+        sh_pp = sh_e;
+        sh_e = sh_new;
+        __syncthreads();
+    }
+#undef LN_PROD
+#undef LN_PIN
+    if (saw_nan != 0 && lane == 0) *nan_flag = nan_epoch;
+    // calc_prob: lse_j alpha[L-1, j]  (hmm.py:274)
+    if (!BACKWARD && loglik && w == 0) {
+        const int fin = (klen - 1) & 1;
+        const double mx = row_maxima(fin);
+        double sacc = 0.0;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const double pv = Cs[fin][lane + 64 * hh];
+            sacc += (mx == LN_NEG_INF || pv == LN_NEG_INF) ? 0.0 : exp(pv - mx);
+        }
+        sacc = wave_sum(sacc);
+        if (lane == 0) loglik[u] = (mx == LN_NEG_INF) ? mx : mx + log(sacc);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Tiny models (N <= 16; round 4): the toy HMMs of the reference's own test scripts (test/hmm-test.py n = 4,
 // test/gmmhmm-test.py n = 5) and segmentation-sized discrete HMMs (scripts/seg/seg.py, n = 4) through `train` /
@@ -914,7 +1168,11 @@ int forward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
             // per block), 1000 utterances 1.23 against 1.45 (fwdbwd_cols, four per block)
             if (!sw().no_colfwd && sw().fwd != 'c')
             {
-                if (dispatch::fwdbwd_one_per_block(U, ctx->prop.multiProcessorCount))
+                if (dispatch::fwdbwd_latency_tier(U, ctx->prop.multiProcessorCount) && !sw().no_latfwd)
+                    LN_LAUNCH(ctx, "forward_lat4_n128", (fwdbwd_lat4<false>), dim3(U), dim3(256), 0,
+                              (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
+                              (double*)alpha, loglik, U, T, N, ctx->nan_flag.as<unsigned>() + 2, ctx->nan_epoch);
+                else if (dispatch::fwdbwd_one_per_block(U, ctx->prop.multiProcessorCount))
                     LN_LAUNCH(ctx, "forward_cols1_n128", (fwdbwd_cols2<false, double, 1>), dim3(U), dim3(256), 0,
                               (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
                               (double*)alpha, loglik, U, T, N, ctx->nan_flag.as<unsigned>() + 2, ctx->nan_epoch);
@@ -991,7 +1249,11 @@ int backward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* 
         else
             if (!sw().no_colfwd && sw().fwd != 'c')
             {
-                if (dispatch::fwdbwd_one_per_block(U, ctx->prop.multiProcessorCount))
+                if (dispatch::fwdbwd_latency_tier(U, ctx->prop.multiProcessorCount) && !sw().no_latfwd)
+                    LN_LAUNCH(ctx, "backward_lat4_n128", (fwdbwd_lat4<true>), dim3(U), dim3(256), 0,
+                              (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
+                              (double*)nullptr, U, T, N, ctx->nan_flag.as<unsigned>() + 2, ctx->nan_epoch);
+                else if (dispatch::fwdbwd_one_per_block(U, ctx->prop.multiProcessorCount))
                     LN_LAUNCH(ctx, "backward_cols1_n128", (fwdbwd_cols2<true, double, 1>), dim3(U), dim3(256), 0,
                               (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
                               (double*)nullptr, U, T, N, ctx->nan_flag.as<unsigned>() + 2, ctx->nan_epoch);

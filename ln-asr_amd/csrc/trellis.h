@@ -48,6 +48,14 @@ inline bool fwdbwd_one_per_block(int U, int n_cu) {
     return U <= 2 * (n_cu > 0 ? n_cu : 256);
 }
 
+// ... and, fp64 storage, the kernel with the log / exp off the frame's chain (fwdbwd_lat4) while every block has a CU of its
+// own: only there does the LENGTH of the chain, rather than the instruction count, set the frame time.  forward, U = 1,
+// T = 1000: 0.757 ms (cols2<.., 1>) -> 0.621 ms.  LNASR_FWD_LAT_MAXU overrides; LNASR_NO_LATFWD disables.  Round 5.
+inline bool fwdbwd_latency_tier(int U, int n_cu) {
+    if (sw().fwd_lat_maxu >= 0) return U <= sw().fwd_lat_maxu;
+    return U <= (n_cu > 0 ? n_cu : 256);
+}
+
 // N > 256: frame-parallel kernels (ONE launch per frame over the whole batch) against per-utterance streaming
 // kernels.  tools/bign.py, T = 100, ms, frame-parallel / streaming, round 2:
 //   Viterbi  N=320: U=64 1.2/2.1  U=512 2.2/2.2  U=1024 3.0/2.4    N=512: 1.1/4.5  3.0/4.6  4.2/5.1

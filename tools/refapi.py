@@ -107,6 +107,35 @@ def measure(ctx, reps=20, obs=None, check_path=None):
         "wall_ms": wK, "best_ms": wK, "device_ms": dev, "host_ms": max(0.0, wK - dev), "first_iteration_ms": w1,
         "ms_per_further_iteration": (wK - w1) / (K - 1),
         "kernels": {k: round(v["ms_per_call"], 4) for k, v in list(kern.items())[:6]}}
+    # the front end through the reference's method names: MFCC.calc_mfcc on 10 s of audio (160,240 samples -> 1000 frames;
+    # the reference: 0.207 s) and the whole acoustic path PCM -> MFCC -> decode (Recognizer.recognize;
+    # upstream's is `pass`), model file loaded the reference's way
+    import tempfile
+    from lnasr.mfcc import MFCC
+    from lnasr.recognizer import Recognizer
+    sig = synth.synth_signal(160240, seed=7)
+    pcm = np.clip(sig, -32768, 32767).astype(np.int16)
+    mf = MFCC(ctx=ctx)
+    for name, fn in (("MFCC.calc_mfcc(10 s, float64)", lambda: mf.calc_mfcc(sig)),
+                     ("MFCC.calc_mfcc(10 s, int16)", lambda: mf.calc_mfcc(pcm))):
+        fn(), fn()
+        wall, best = _median_ms(fn, reps)
+        dev, kern = _device_ms(ctx, fn, max(3, reps // 4))
+        rows[name] = {"wall_ms": wall, "best_ms": best, "device_ms": dev, "host_ms": max(0.0, wall - dev),
+                      "reference_ms": 207.0, "kernels": {k: round(v["ms_per_call"], 4) for k, v in list(kern.items())[:5]}}
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "am.npz")
+        gh.save(path)
+        rec = Recognizer({"am": path, "lm": None})
+    rec.am.gmmhmm._ctx = ctx
+    rec.am.mfcc._ctx = ctx
+    fn = lambda: rec.recognize(pcm)
+    fn(), fn()
+    wall, best = _median_ms(fn, reps)
+    dev, kern = _device_ms(ctx, fn, max(3, reps // 4))
+    rows["Recognizer.recognize(10 s int16 PCM)"] = {
+        "wall_ms": wall, "best_ms": best, "device_ms": dev, "host_ms": max(0.0, wall - dev),
+        "kernels": {k: round(v["ms_per_call"], 4) for k, v in list(kern.items())[:6]}}
     toy = toy_scripts(ctx)
     return {"toy_scripts": toy,
             "what": "the reference's own method names on one utterance through the mirror classes (lnasr.gmmhmm.GMMHMM): "
@@ -162,9 +191,9 @@ def main():
     ctx = _ffi.default_ctx()
     r = measure(ctx)
     print(r["what"])
-    print("%-22s %9s %9s %9s %9s" % ("method", "wall ms", "best ms", "device ms", "host ms"))
+    print("%-38s %9s %9s %9s %9s" % ("method", "wall ms", "best ms", "device ms", "host ms"))
     for k, v in r["methods"].items():
-        print("%-22s %9.3f %9.3f %9.3f %9.3f   %s" % (k, v["wall_ms"], v["best_ms"], v["device_ms"], v["host_ms"], v["kernels"]))
+        print("%-38s %9.3f %9.3f %9.3f %9.3f   %s" % (k, v["wall_ms"], v["best_ms"], v["device_ms"], v["host_ms"], v["kernels"]))
     print("train(iters=1) kernels:", r["methods"]["train(iters=1)"]["all_kernels"])
     for k, v in r["methods"].items():
         if "ms_per_further_iteration" in v:
