@@ -156,7 +156,7 @@ __global__ __launch_bounds__(1024) void fwdbwd_stream(const double* __restrict__
                 for (int r = 1; r < RS; ++r) sum += Ps[(r * UB + k) * NP + j];
                 const double Sc = Ss[cur * UB + k];
                 double val;
-                if (sum >= kSafeSum && sum <= 1e290 && Sc != LN_NEG_INF) {
+                if (j >= N || (sum >= kSafeSum && sum <= 1e290 && Sc != LN_NEG_INF)) {   // (a padding column: nothing to redo)
                     val = Sc + log(sum);
                 } else {
                     const int jl = j < N ? j : N - 1;

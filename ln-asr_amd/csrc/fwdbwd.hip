@@ -267,7 +267,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
                     }
                     const double Sc = Ss[cur][k];
                     double val;
-                    if (sum >= kSafeSum && sum <= 1e290 && Sc != LN_NEG_INF) {
+                    if (j >= N || (sum >= kSafeSum && sum <= 1e290 && Sc != LN_NEG_INF)) {   // (a padding column: nothing to redo)
                         val = Sc + log_sum(sum, ltab);
                     } else {                       // exact log-domain column (rare)
                         val = exact_column_lse(&Cs[cur][k][0], Alog + (j < N ? j : N - 1), N);
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (step < klen) {
             const double Sc = Ss[cur][k];
             double val;
-            if (sum >= kSafeSum && sum <= 1e290 && Sc != LN_NEG_INF) {
+            if (j >= N || (sum >= kSafeSum && sum <= 1e290 && Sc != LN_NEG_INF)) {   // (a padding column: nothing to redo)
                 val = Sc + log_sum(sum, ltab);
             } else {                               // exact log-domain column (rare)
                 val = exact_column_lse(&Cs[cur][k][0], Alog + jc, N);
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (step < klen) {
             const double Sc = Ss[cur][k];
             double val;
-            if (sum >= kSafeSum && sum <= 1e290 && Sc != LN_NEG_INF) {
+            if (j >= N || (sum >= kSafeSum && sum <= 1e290 && Sc != LN_NEG_INF)) {   // (a padding column: nothing to redo)
                 val = Sc + log_sum(sum, ltab);
             } else {                               // exact log-domain column (rare)
                 val = exact_column_lse(&Cs[cur][k][0], Alog + jc, N);
@@ -825,7 +825,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int e = 0; e < NM; ++e) mrow[e] = Ms[eval ? nxt : 0][e];
         // ---- evaluation of frame f = step - 1, part 1 (registers only): range test, mantissa, table address
         const int fb = cur, pb = nxt;              // parity buffers of frame f and of frame f - 1
-        const bool safe = sum_prev >= kSafeSum && sum_prev <= 1e290 && sh_pp != LN_NEG_INF;
+        const bool safe = j >= N || (sum_prev >= kSafeSum && sum_prev <= 1e290 && sh_pp != LN_NEG_INF);   // (padding columns: nothing to redo)
         const double ls = safe ? sum_prev : 1.0;
         const int lhi = __double2hiint(ls);
         const int le = (lhi >> 20) - 1023;
@@ -1158,7 +1158,10 @@ int forward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
             return trellis256_device(ctx, 1, b, U, T, d_lens, LNASR_F32, alpha, loglik);
     }
     if (dtype == LNASR_F64 && N <= dispatch::kRegMaxN && !sw().no_regfwd) {
-        if (N <= dispatch::kReg64MaxN)
+        // (17 ... 64 states: the two-barrier blocks for batches; a few utterances take the column-owned latency kernels below,
+        // whose 128-column tiles run half empty but whose frame is 0.5 us against 2-4 -- round 5)
+        if (N <= dispatch::kReg64MaxN && !(dispatch::fwdbwd_latency_tier(U, ctx->prop.multiProcessorCount) && !sw().no_latfwd &&
+                                           !sw().no_colfwd && sw().fwd != 'c'))
             LN_LAUNCH(ctx, "forward_reg_n64", (fwdbwd_reg<false, 1, 2, 32, 2, 3>), dim3((U + 1) / 2), dim3(128), 0,
                       (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
                       (double*)alpha, loglik, U, T, N);
@@ -1242,7 +1245,8 @@ int backward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* 
             return trellis256_device(ctx, 2, b, U, T, d_lens, LNASR_F32, beta, nullptr);
     }
     if (dtype == LNASR_F64 && N <= dispatch::kRegMaxN && !sw().no_regfwd) {
-        if (N <= dispatch::kReg64MaxN)
+        if (N <= dispatch::kReg64MaxN && !(dispatch::fwdbwd_latency_tier(U, ctx->prop.multiProcessorCount) && !sw().no_latfwd &&
+                                           !sw().no_colfwd && sw().fwd != 'c'))
             LN_LAUNCH(ctx, "backward_reg_n64", (fwdbwd_reg<true, 1, 2, 32, 2, 3>), dim3((U + 1) / 2), dim3(128), 0,
                       (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
                       (double*)nullptr, U, T, N);

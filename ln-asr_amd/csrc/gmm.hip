@@ -41,8 +41,8 @@ __global__ void transpose_exp_kernel(const double* __restrict__ A, double* __res
     ET[(size_t)j * N + i] = e;
 }
 
-// flag[0] = 1 if any off-diagonal entry of any Sigma is not exactly zero.  A few hundred blocks walk the components and stop
-// at the first hit anybody has reported; a hit is reported with a plain (idempotent) store.  History: one atomicOr per non-zero
+// flag[0] = 1 if any off-diagonal entry of any Sigma is not exactly zero.  A block per component (up to 8192 blocks, which then
+// walk on) that stops at the first hit anybody has reported; a hit is reported with a plain (idempotent) store.  History: one atomicOr per non-zero
 // entry was three million atomics on one address (1.1 ms of every upload of a genuinely full model); one per wave still let
 // every RESIDENT wave of a one-thread-per-entry grid -- 8,000 of them, all started before the first report landed -- queue
 // its atomic at the same L2 line (0.12 ms per launch; round 5).  A diagonal model (the case that reads everything) streams
@@ -1039,7 +1039,7 @@ static int model_upload_impl(lnasr_ctx* ctx, int N, int M, int D, const double* 
         if (allow_diag_detect) {
             LN_TRY(md.flags.reserve(256));
             LN_HIP(hipMemsetAsync(md.flags.p, 0, 4, ctx->stream));
-            LN_LAUNCH(ctx, "detect_offdiag", detect_offdiag_kernel, dim3((unsigned)(NM < 512 ? NM : 512)), dim3(256), 0,
+            LN_LAUNCH(ctx, "detect_offdiag", detect_offdiag_kernel, dim3((unsigned)(NM < 8192 ? NM : 8192)), dim3(256), 0,
                       md.sigma_raw.as<double>(), (int)NM, D, md.flags.as<int>());
             int flag = 0;
             LN_HIP(hipMemcpyAsync(&flag, md.flags.p, 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -163,7 +163,7 @@ __device__ __forceinline__ void trellis256_role(double* sm, const TS* __restrict
                 const double sum = (part + Ps[jc]) + (Ps[NP + jc] + Ps[2 * NP + jc]);
                 const double Sc = Ss[cur];
                 double val;
-                if (sum >= kSafeSum && sum <= 1e290 && Sc != LN_NEG_INF) {
+                if (jc >= N || (sum >= kSafeSum && sum <= 1e290 && Sc != LN_NEG_INF)) {   // (a padding column: nothing to redo)
                     val = Sc + log_sum(sum, ltab);
                 } else {
                     val = exact_column_lse(Cs + cur * NP, Alog + jcl, N);

@@ -515,7 +515,10 @@ int viterbi_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
                   (const double*)b, A, pi, d_lens, (double*)v, U, T, N);                                     \
         return 0;                                                                                            \
     } while (0)
-        if (N <= dispatch::kReg64MaxN) LN_VIT("viterbi_reg_n64", 1, 2, 32, 2, 4);
+        // 17 ... 64 states: the two-wave blocks (two utterances each, many per CU) for batches; while every utterance can have a CU
+        // of its own the eight-wave single-barrier kernel below walks a frame in 0.51 us against 0.69 (its 128-column tiles half
+        // empty: the frame is latency, not work) -- tools/bench_rows.py midn, round 5
+        if (N <= dispatch::kReg64MaxN && !(U <= ctx->prop.multiProcessorCount && vsel != 'a')) LN_VIT("viterbi_reg_n64", 1, 2, 32, 2, 4);
         if (N <= dispatch::kRegMaxN) {
             // default: single-barrier kernel (LDS atomic max); LNASR_VIT=a selects the two-barrier one
             if (vsel == 'a' && U < dispatch::kViterbiPairFromU) LN_VIT("viterbi_reg_n128_u1", 2, 8, 16, 1, 4);

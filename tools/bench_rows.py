@@ -163,6 +163,29 @@ if what & {"fwd1"}:
     timed("forward U=1", lambda: _ffi.check(lib.lnasr_forward(ctx.handle, b.ptr, 1, T, None, 0, al.ptr, ll.ptr)), T, "frames", reps=10)
     timed("backward U=1", lambda: _ffi.check(lib.lnasr_backward(ctx.handle, b.ptr, 1, T, None, 0, al.ptr)), T, "frames", reps=10)
 
+if what & {"vit1"}:
+    # one utterance, N = 128: the latency tier of Viterbi + back-trace (for tools/pmc_rows.sh)
+    T, N, M, D = 1000, 128, 16, 39
+    mdl = synth.synth_model(N, M, D, seed=1)
+    ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
+    obs = ctx.to_device(synth.synth_obs(1, T, D, seed=1000))
+    timed("decode U=1", lambda: ctx.decode(obs), T, "frames", reps=10)
+
+if what & {"midn"}:
+    # 17 ... 64 states on ONE utterance (no BASELINE configuration; the reference's API takes any n)
+    from lnasr.hmm import HMM
+    for N in (24, 32, 64):
+        T = 4000
+        d = synth.synth_discrete(N, 4, T, seed=N)
+        ctx.upload_hmm(d["A"], d["pi"])
+        b = ctx.to_device(np.ascontiguousarray(-30.0 * np.random.default_rng(N).random((1, T, N))))
+        al = ctx.empty((1, T, N), np.float64)
+        ll = ctx.empty((1,), np.float64)
+        lib = _ffi.lib()
+        timed("forward U=1 N=%d T=%d" % (N, T), lambda: _ffi.check(lib.lnasr_forward(ctx.handle, b.ptr, 1, T, None, 0, al.ptr, ll.ptr)), T, "frames")
+        timed("backward U=1 N=%d" % N, lambda: _ffi.check(lib.lnasr_backward(ctx.handle, b.ptr, 1, T, None, 0, al.ptr)), T, "frames")
+        timed("viterbi U=1 N=%d" % N, lambda: ctx.viterbi(b, want_v=False, want_bt=False), T, "frames")
+
 if what & {"fwdsweep"}:
     # dispatch::fwdbwd_one_per_block (csrc/trellis.h): one utterance per four-wave block against two, N = 128, by batch size
     import contextlib
