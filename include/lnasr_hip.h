@@ -172,7 +172,11 @@ int lnasr_viterbi(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* le
 int lnasr_decode(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* lens,
                  uint32_t* path, double* best_score_or_null);
 /* HMM._forward (hmm.py:63-100) and calc_prob (hmm.py:268-274): alpha optional, loglik [U] optional.  A NaN emission
- * propagates as np.logaddexp propagates it: alpha NaN from that frame on (forward), beta NaN before it (backward). */
+ * propagates as np.logaddexp propagates it: alpha NaN from that frame on (forward), beta NaN before it (backward).
+ * Kernels are chosen by model AND batch size (csrc/trellis.h): Viterbi v / bt / path are the same bits whatever the batch
+ * size; fp64 alpha / beta agree between batch sizes to ~1e-13 relative (a handful of utterances take kernels that form the
+ * next frame's linear-domain row by one multiplication instead of a log / exp round trip), and to the reference's within
+ * 1e-11 either way. */
 int lnasr_forward(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* lens, int dtype,
                   void* alpha_or_null, double* loglik_or_null);
 /* HMM._backward (hmm.py:102-131) */
