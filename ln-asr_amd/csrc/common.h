@@ -117,7 +117,6 @@ struct Switches {
          no_fft512 = false, no_pipeline = false, f32_generic = false, no_f32_stats = false, no_pinned_ring = false,
          no_tinyfwd = false, no_reglu = false, no_tilepack = false, no_latfwd = false;
     char vit = 0;                 // LNASR_VIT: first character, 0 = unset
-    char fwd = 0;                 // LNASR_FWD: 'c' = the four-utterance column-owned forward / backward kernel (fwdbwd_cols)
     int framepar_maxu = -1;       // LNASR_FRAMEPAR_MAXU, -1 = unset (measured rule)
     int chase_maxu = -1;          // LNASR_CHASE_MAXU: back-pointer chase instead of the arg-max back-trace up to this batch size
     int fwd_lat_maxu = -1;        // LNASR_FWD_LAT_MAXU: the chain-shortened one-utterance forward / backward (fwdbwd_lat4) up to this batch size

@@ -86,7 +86,6 @@ static void load_switches(Switches& s) {
 #endif
     if (const char* e = getenv("LNASR_CHECK_PTRS")) s.check_ptrs = e[0] != '0';
     if (const char* e = getenv("LNASR_VIT")) s.vit = e[0];
-    if (const char* e = getenv("LNASR_FWD")) s.fwd = e[0];
     if (const char* e = getenv("LNASR_EMIT")) s.emit = e[0];
     if (const char* e = getenv("LNASR_FRAMEPAR_MAXU")) s.framepar_maxu = atoi(e);
     if (const char* e = getenv("LNASR_FWD_ONE_MAXU")) s.fwd_one_maxu = atoi(e);

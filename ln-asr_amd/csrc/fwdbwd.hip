@@ -323,14 +323,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
 }
 
 // ------------------------------------------------------------------------------------------
-// forward / backward, 64 < N <= 128, four utterances per block: COLUMN-owned blocking.
-// Wave w owns the 16 columns j = 16 w + (lane & 15); the four 16-lane DPP rows of the wave split the
-// 128 source states into groups of 32, so lane (g, c) keeps expA[32 g + r][16 w + c], r < 32, in
-// registers.  A transition is still one v_fmac_f64_dpp (the e value comes from lane n of the row), but
-// the row-group partial sums of a column now sit in the SAME wave: two v_permlane32_swap and one
-// v_permlane16_swap (gfx950) turn the four utterances' partials into "row k holds utterance k's sum",
-// so the whole finalisation (log, emission, store, exp) of 4 utterances x 16 columns runs on all 64
-// lanes of the wave that produced the sums -- no partial sums through the LDS, ONE barrier per frame
+// forward / backward, 64 < N <= 128: COLUMN-owned blocking (fwdbwd_cols2 below; round 1 introduced it with four utterances per
+// eight-wave block -- wave w owning 16 columns -- which round 3's two-utterance four-wave blocks beat at every batch size and
+// round 5 removed).  A wave owns its columns; the 16-lane DPP rows of the wave split the 128 source states into groups of 32, so a
+// transition is one v_fmac_f64_dpp (the e value comes from lane n of the row) and the row-group partial sums of a column sit in
+// the SAME wave: v_permlane32_swap / v_permlane16_swap (gfx950) turn them into totals, and the whole finalisation (log,
+// emission, store, exp) runs on the wave that produced the sums -- no partial sums through the LDS, ONE barrier per frame
 // (fwdbwd_reg: partials through the LDS, two barriers).  Same shift rule, same exact fallback.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void swap32_f64(double& a, double& b) {     // a[63:32] <-> b[31:0]
@@ -350,159 +348,6 @@ __device__ __forceinline__ double row_max_dpp(double x) {             // max ove
     x = vmax_f64(x, dpp_f64<0x4E>(x));
     x = vmax_f64(x, dpp_f64<0x141>(x));
     return vmax_f64(x, dpp_f64<0x140>(x));
-}
-
-template <bool BACKWARD>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void fwdbwd_cols(
-    const double* __restrict__ b, const double* __restrict__ Aexp, const double* __restrict__ Alog,
-    const double* __restrict__ pi, const int32_t* __restrict__ lens, double* __restrict__ out,
-    double* __restrict__ loglik, int U, int T, int N) {
-    constexpr int NP = 128, UB = 4, NW = 8;
-    __shared__ double Es[2][UB][NP];      // exp(prev - shift) of the frame being consumed
-    __shared__ double Cs[2][UB][NP];      // prev itself (log domain) for the exact fallback
-    __shared__ double Ms[2][UB][NW];      // per wave (16 columns) max of prev
-    __shared__ double Ss[2][UB];          // shift the e values of this buffer were computed with
-    __shared__ double etab[kExpTab];
-    __shared__ double ltab[2 * kLogTab];
-    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    exp_table_init(etab, threadIdx.x, 64 * NW);
-    log_table_init(ltab, threadIdx.x, 64 * NW);   // visible after the first __syncthreads below
-    const int u0 = blockIdx.x * UB;
-    const int g = lane >> 4, c = lane & 15;
-    const int j = 16 * w + c;                      // the lane's column, products and finalisation alike
-    const int jc = j < N ? j : N - 1;
-
-    double areg[32];
-#pragma unroll
-    for (int r = 0; r < 32; ++r) {
-        const int i = 32 * g + r;
-        areg[r] = (i < N && j < N) ? Aexp[(size_t)i * N + j] : 0.0;
-    }
-    int maxlen = 0;
-#pragma unroll
-    for (int k = 0; k < UB; ++k) {
-        const int l = (u0 + k < U) ? lens[u0 + k] : 0;
-        maxlen = l > maxlen ? l : maxlen;
-    }
-    // finalisation role: row g of the wave is utterance k = g
-    const int k = g;
-    const int uu = (u0 + k < U) ? u0 + k : U - 1;
-    const int klen = (u0 + k < U) ? lens[u0 + k] : 0;
-    const double* bp = b + (size_t)uu * T * N + jc;
-    double* op = out ? out + (size_t)uu * T * N + jc : nullptr;
-    auto frame_of = [&](int step) { return BACKWARD ? klen - 1 - step : step; };
-    auto clampt = [&](int t) { return t < 0 ? 0 : (t > T - 1 ? T - 1 : t); };
-
-    // step 0
-    {
-        double prev = LN_NEG_INF;
-        if (j < N && klen > 0) {
-            const int t0 = frame_of(0);
-            const double bv = bp[(size_t)t0 * N];
-            if (BACKWARD) {
-                if (op) op[(size_t)t0 * N] = 0.0;
-                prev = 0.0 + bv;
-            } else {
-                prev = pi[j] + bv;
-                if (op) op[0] = prev;
-            }
-        }
-        Cs[0][k][j] = prev;
-        const double m = row_max_dpp(prev);
-        if (c == 0) Ms[0][k][w] = m;
-    }
-    __syncthreads();
-    {
-        double S = Ms[0][k][0];
-#pragma unroll
-        for (int ww = 1; ww < NW; ++ww) S = fmax(S, Ms[0][k][ww]);
-        const double prev = Cs[0][k][j];
-        Es[0][k][j] = (S == LN_NEG_INF || prev == LN_NEG_INF) ? 0.0 : exp_clamped(prev - S, etab);
-        if (w == 0 && c == 0) Ss[0][k] = S;
-    }
-    double bnext = bp[(size_t)clampt(frame_of(1)) * N];
-    drain_vmem();                                  // areg resident: no vmcnt guards in the loop
-    __syncthreads();
-
-    for (int step = 1; step < maxlen; ++step) {
-        const int cur = (step - 1) & 1, nxt = step & 1;
-        const double bcur = bnext;
-        bnext = bp[(size_t)clampt(frame_of(step + 1)) * N];
-        // e values of the four utterances for this lane's row group: lane (g, c) holds e[32 g + 16 q + c]
-        double ek[UB][2];
-#pragma unroll
-        for (int kk = 0; kk < UB; ++kk)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) ek[kk][q] = Es[cur][kk][32 * g + 16 * q + c];
-        double acc[UB];
-#pragma unroll
-        for (int kk = 0; kk < UB; ++kk) acc[kk] = 0.0;
-        static_for<0, 32>([&](auto r) {
-#pragma unroll
-            for (int kk = 0; kk < UB; ++kk) fmac_bcast<(r.value & 15)>(acc[kk], ek[kk][r.value >> 4], areg[r.value]);
-        });
-        // row groups -> utterances: after the swaps row k of `sum` holds utterance k's total,
-        // ((g0 + g2) + (g1 + g3)) in every lane
-        swap32_f64(acc[0], acc[2]);
-        swap32_f64(acc[1], acc[3]);
-        double s02 = acc[0] + acc[2], s13 = acc[1] + acc[3];
-        swap16_f64(s02, s13);
-        const double sum = s02 + s13;
-
-        if (step < klen) {
-            const double Sc = Ss[cur][k];
-            double val;
-            if (j >= N || (sum >= kSafeSum && sum <= 1e290 && Sc != LN_NEG_INF)) {   // (a padding column: nothing to redo)
-                val = Sc + log_sum(sum, ltab);
-            } else {                               // exact log-domain column (rare)
-                val = exact_column_lse(&Cs[cur][k][0], Alog + jc, N);
-            }
-            const int t = frame_of(step);
-            double prev;
-            if (BACKWARD) {
-                if (j < N && op) op[(size_t)t * N] = val;
-                prev = val + bcur;
-            } else {
-                prev = val + bcur;
-                if (j < N && op) op[(size_t)t * N] = prev;
-            }
-            if (j >= N) prev = LN_NEG_INF;
-            double S = Ms[cur][k][0];
-#pragma unroll
-            for (int ww = 1; ww < NW; ++ww) S = fmax(S, Ms[cur][k][ww]);
-            Cs[nxt][k][j] = prev;
-            Es[nxt][k][j] = (S == LN_NEG_INF || prev == LN_NEG_INF) ? 0.0 : exp_clamped(prev - S, etab);
-            const double m = row_max_dpp(prev);
-            if (c == 0) Ms[nxt][k][w] = m;
-            if (w == 0 && c == 0) Ss[nxt][k] = S;
-        } else {                                   // this utterance has ended: carry its state
-            Cs[nxt][k][j] = Cs[cur][k][j];
-            Es[nxt][k][j] = Es[cur][k][j];
-            if (c == 0) Ms[nxt][k][w] = Ms[cur][k][w];
-            if (w == 0 && c == 0) Ss[nxt][k] = Ss[cur][k];
-        }
-        __syncthreads();
-    }
-    // calc_prob: lse_j alpha[L-1, j]  (hmm.py:274)
-    if (!BACKWARD && loglik && w == 0) {
-        const int fin = (maxlen > 0 ? maxlen - 1 : 0) & 1;
-#pragma unroll
-        for (int kk = 0; kk < UB; ++kk) {
-            if (u0 + kk < U && lens[u0 + kk] > 0) {
-                double mx = Ms[fin][kk][0];
-#pragma unroll
-                for (int ww = 1; ww < NW; ++ww) mx = fmax(mx, Ms[fin][kk][ww]);
-                double sacc = 0.0;
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const double pv = Cs[fin][kk][lane + 64 * h];
-                    sacc += (mx == LN_NEG_INF || pv == LN_NEG_INF) ? 0.0 : exp(pv - mx);
-                }
-                sacc = wave_sum(sacc);
-                if (lane == 0) loglik[u0 + kk] = (mx == LN_NEG_INF) ? mx : mx + log(sacc);
-            }
-        }
-    }
 }
 
 // The same column-owned scheme with TWO utterances per block of FOUR waves (round 3).  A wave owns 32 columns (two per
@@ -1161,15 +1006,15 @@ int forward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
         // (17 ... 64 states: the two-barrier blocks for batches; a few utterances take the column-owned latency kernels below,
         // whose 128-column tiles run half empty but whose frame is 0.5 us against 2-4 -- round 5)
         if (N <= dispatch::kReg64MaxN && !(dispatch::fwdbwd_latency_tier(U, ctx->prop.multiProcessorCount) && !sw().no_latfwd &&
-                                           !sw().no_colfwd && sw().fwd != 'c'))
+                                           !sw().no_colfwd))
             LN_LAUNCH(ctx, "forward_reg_n64", (fwdbwd_reg<false, 1, 2, 32, 2, 3>), dim3((U + 1) / 2), dim3(128), 0,
                       (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
                       (double*)alpha, loglik, U, T, N);
         else
             // column-owned waves, two utterances per four-wave block, two blocks per CU (fwdbwd_cols2): measured against the
             // eight-wave kernels at every batch size -- 16 ... 512 utterances 0.83-0.87 ms against 0.96-1.02 (fwdbwd_reg, two
-            // per block), 1000 utterances 1.23 against 1.45 (fwdbwd_cols, four per block)
-            if (!sw().no_colfwd && sw().fwd != 'c')
+            // per block), 1000 utterances 1.23 against 1.45 (four per eight-wave block: removed in round 5)
+            if (!sw().no_colfwd)
             {
                 if (dispatch::fwdbwd_latency_tier(U, ctx->prop.multiProcessorCount) && !sw().no_latfwd)
                     LN_LAUNCH(ctx, "forward_lat4_n128", (fwdbwd_lat4<false>), dim3(U), dim3(256), 0,
@@ -1185,10 +1030,6 @@ int forward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
                               (double*)alpha, loglik, U, T, N, ctx->nan_flag.as<unsigned>() + 2, ctx->nan_epoch);
                 ctx->fwd_nan_tested = true;
             }
-            else if (!sw().no_colfwd)            // LNASR_FWD=c: four per eight-wave block
-                LN_LAUNCH(ctx, "forward_cols_n128", (fwdbwd_cols<false>), dim3((U + 3) / 4), dim3(512), 0,
-                          (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
-                          (double*)alpha, loglik, U, T, N);
             else if (!dispatch::fwdbwd_reg_four_per_block(U, ctx->prop.multiProcessorCount))      // row-owned waves, partial sums through the LDS
                 LN_LAUNCH(ctx, "forward_reg_n128", (fwdbwd_reg<false, 2, 8, 16, 2, 4>), dim3((U + 1) / 2), dim3(512), 0,
                           (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
@@ -1246,12 +1087,12 @@ int backward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* 
     }
     if (dtype == LNASR_F64 && N <= dispatch::kRegMaxN && !sw().no_regfwd) {
         if (N <= dispatch::kReg64MaxN && !(dispatch::fwdbwd_latency_tier(U, ctx->prop.multiProcessorCount) && !sw().no_latfwd &&
-                                           !sw().no_colfwd && sw().fwd != 'c'))
+                                           !sw().no_colfwd))
             LN_LAUNCH(ctx, "backward_reg_n64", (fwdbwd_reg<true, 1, 2, 32, 2, 3>), dim3((U + 1) / 2), dim3(128), 0,
                       (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
                       (double*)nullptr, U, T, N);
         else
-            if (!sw().no_colfwd && sw().fwd != 'c')
+            if (!sw().no_colfwd)
             {
                 if (dispatch::fwdbwd_latency_tier(U, ctx->prop.multiProcessorCount) && !sw().no_latfwd)
                     LN_LAUNCH(ctx, "backward_lat4_n128", (fwdbwd_lat4<true>), dim3(U), dim3(256), 0,
@@ -1267,10 +1108,6 @@ int backward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* 
                               (double*)nullptr, U, T, N, ctx->nan_flag.as<unsigned>() + 2, ctx->nan_epoch);
                 ctx->fwd_nan_tested = true;
             }
-            else if (!sw().no_colfwd)
-                LN_LAUNCH(ctx, "backward_cols_n128", (fwdbwd_cols<true>), dim3((U + 3) / 4), dim3(512), 0,
-                          (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
-                          (double*)nullptr, U, T, N);
             else if (!dispatch::fwdbwd_reg_four_per_block(U, ctx->prop.multiProcessorCount))
                 LN_LAUNCH(ctx, "backward_reg_n128", (fwdbwd_reg<true, 2, 8, 16, 2, 4>), dim3((U + 1) / 2), dim3(512), 0,
                           (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,

@@ -380,7 +380,7 @@ def test_trellises_beyond_256_states_large_batch(N, synth, oracle, ctx):
 @pytest.mark.parametrize("N", [65, 100, 128])
 def test_forward_backward_column_owned_kernel(N, synth, oracle, ctx):
     """64 < N <= 128: the column-owned forward / backward kernels (row-group sums exchanged with permlane swaps) --
-    two utterances per four-wave block (the default) and four per eight-wave block (LNASR_FWD=c) -- against the oracle on
+    two utterances per four-wave block (batches), one per block and the chain-shortened kernel (small batches) -- against the oracle on
     a sample of utterances and against the row-sliced kernel (LNASR_NO_COLFWD) on all of them; an odd number of
     utterances (a half-empty last block), ragged lengths, a forbidden transition, an unreachable state, an utterance
     whose likelihood underflows the linear domain (exact fallback)."""
@@ -403,9 +403,6 @@ def test_forward_backward_column_owned_kernel(N, synth, oracle, ctx):
     with env_switch(LNASR_NO_COLFWD=1):
         alpha2, ll2 = ctx.forward(b, lens=lens)
         beta2 = ctx.backward(b, lens=lens)
-    with env_switch(LNASR_FWD="c"):
-        alpha3, ll3 = ctx.forward(b, lens=lens)
-        beta3 = ctx.backward(b, lens=lens)
     with env_switch(LNASR_FWD_ONE_MAXU=1 << 20, LNASR_FWD_LAT_MAXU=0):   # ONE utterance per four-wave block: batches up to 2 x CUs (round 5)
         alpha4, ll4 = ctx.forward(b, lens=lens)
         beta4 = ctx.backward(b, lens=lens)
@@ -424,12 +421,11 @@ def test_forward_backward_column_owned_kernel(N, synth, oracle, ctx):
     # same products, same swap network, same order of additions: the column-owned kernels agree to the bit
     for u in range(U):
         L = lens[u]
-        assert np.array_equal(alpha[u, :L], alpha3[u, :L]) and np.array_equal(beta[u, :L], beta3[u, :L]), u
         assert np.array_equal(alpha[u, :L], alpha4[u, :L]) and np.array_equal(beta[u, :L], beta4[u, :L]), u
     for u in range(9):
         L = lens[u]
         assert np.array_equal(alpha[u, :L], alpha5[u, :L]) and np.array_equal(beta[u, :L], beta5[u, :L]), u
-    assert np.array_equal(ll, ll3) and np.array_equal(ll, ll4) and np.array_equal(ll[:9], ll5)
+    assert np.array_equal(ll, ll4) and np.array_equal(ll[:9], ll5)
     for u in range(U):
         L = lens[u]
         assert_close(alpha[u, :L], alpha2[u, :L], 1e-12, msg="alpha vs row-sliced kernel u=%d" % u)
