@@ -259,22 +259,33 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
             Vs[2][k][j] = LN_NEG_INF;
         }
     }
-    // emission streams of this wave's columns (every wave needs b for all UB*CPT column blocks):
-    // one per-lane pointer per column block, utterance/frame offsets stay scalar
-    const TS* pl[CPT];
-    size_t uoff[UB];
+    // emission streams of this wave's columns (every wave needs b for all UB*CPT column blocks): a SCALAR row base per
+    // utterance (utterance and frame are wave-uniform: the 64-bit row offset is formed on the scalar unit) plus a per-lane 32-bit
+    // column offset -- the load takes both.  (Until round 5 the row offset was added to per-lane 64-bit pointers: eight vector
+    // instructions per frame and column block in a kernel whose bound is vector issue.)
+    int jcol[CPT];
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
         const int j = lane + 64 * c;
-        pl[c] = b + (j < N ? j : N - 1);
+        jcol[c] = j < N ? j : N - 1;
     }
+    const TS* ub[UB];                              // b + u * T * N, wave-uniform
 #pragma unroll
-    for (int k = 0; k < UB; ++k) uoff[k] = (size_t)((u0 + k < U) ? u0 + k : U - 1) * T;
+    for (int k = 0; k < UB; ++k) {
+        const int uk = __builtin_amdgcn_readfirstlane((u0 + k < U) ? u0 + k : U - 1);
+        ub[k] = b + (size_t)uk * T * N;
+    }
     double bnext[UB][CPT];
 #pragma unroll
     for (int k = 0; k < UB; ++k)
 #pragma unroll
-        for (int c = 0; c < CPT; ++c) bnext[k][c] = ld(pl[c], (uoff[k] + (T > 1 ? 1 : 0)) * N);
+        for (int c = 0; c < CPT; ++c) bnext[k][c] = ld(ub[k] + (size_t)(T > 1 ? 1 : 0) * N, jcol[c]);
+    constexpr bool LAT = UB == 1;                  // one utterance per block: the latency instantiation (see below)
+    // (LAT: per-lane pointers to the row after next, advanced by one row per turn -- one vector instruction per load and nothing
+    // in front of it: 0.433 against 0.448 ms per 1000 frames; the two-utterance blocks have no registers for them)
+    const TS* pb[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) pb[c] = ub[0] + (size_t)(T > 2 ? 2 : (T > 1 ? 1 : 0)) * N + jcol[c];
     // store duty: (utterance, column block) q = w + jj*NW written to global one frame late
     constexpr int NJOB = CPT * UB;
     __syncthreads();
@@ -286,14 +297,26 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
         if (ALT && (t & 7) == 0) alternate_priority(cls);     // devmath.h
         const int nxt = cur == 2 ? 0 : cur + 1, rst = nxt == 2 ? 0 : nxt + 1;
         double bcur[UB][CPT];
-        const int tn = t + 1 < T ? t + 1 : T - 1;
-#pragma unroll
-        for (int k = 0; k < UB; ++k)
+        if constexpr (LAT) {
+            const long adv = t + 2 < T ? N : 0;      // stays on the last row once it is reached (that value is never used)
 #pragma unroll
             for (int c = 0; c < CPT; ++c) {
-                bcur[k][c] = bnext[k][c];
-                bnext[k][c] = ld(pl[c], (uoff[k] + tn) * N);
+                bcur[0][c] = bnext[0][c];
+                bnext[0][c] = (double)*pb[c];
+                pb[c] += adv;
             }
+        } else {
+            const int tn = __builtin_amdgcn_readfirstlane(t + 1 < T ? t + 1 : T - 1);
+#pragma unroll
+            for (int k = 0; k < UB; ++k) {
+                const TS* row = ub[k] + (size_t)tn * N;          // scalar
+#pragma unroll
+                for (int c = 0; c < CPT; ++c) {
+                    bcur[k][c] = bnext[k][c];
+                    bnext[k][c] = ld(row, jcol[c]);
+                }
+            }
+        }
         if (CHKB && w == 0) {                      // wave-uniform: one wave looks at the frame's emissions for the block
 #pragma unroll
             for (int k = 0; k < UB; ++k)
@@ -301,10 +324,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
                 for (int c = 0; c < CPT; ++c)
                     saw_nan |= __ballot(bcur[k][c] != bcur[k][c] && t < len[k] && lane + 64 * c < N);
         }
-        // v[t-1] of the columns this wave stores to global (complete since the last barrier)
-        if (t > 1 && w < NJOB) {
-            const int k = w / CPT, c = w % CPT, j = lane + 64 * c;
-            if (j < N && t - 1 < len[k]) st(v, ((size_t)(u0 + k) * T + (t - 1)) * N + j, Vs[cur][k][j]);
+        // v[t-1] of the columns this wave stores to global (complete since the last barrier): read now, with the other LDS
+        // reads of the turn, stored AFTER the arithmetic -- the store's wait for its LDS read sat at the top of the frame of the
+        // waves that have the duty, and the barrier waits for the slowest wave (round 5)
+        double vst = 0.0;
+        const bool duty = t > 1 && w < NJOB && lane + 64 * (w % CPT) < N && t - 1 < len[w / CPT < UB ? w / CPT : 0];
+        if constexpr (LAT) {
+            if (t > 1 && w < NJOB) vst = Vs[cur][w / CPT][lane + 64 * (w % CPT)];
+        } else {
+            if (duty) st(v, ((size_t)(u0 + w / CPT) * T + (t - 1)) * N + lane + 64 * (w % CPT), Vs[cur][w / CPT][lane + 64 * (w % CPT)]);
         }
         // reset the buffer that frame t+1 will accumulate into
         if (w == NW - 1) {
@@ -314,9 +342,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
                 for (int c = 0; c < CPT; ++c) Vs[rst][k][lane + 64 * c] = LN_NEG_INF;
         }
         double acc[UB][CPT];
-        constexpr int HR = RPT / 2;                // two half slices keep the live v values to UB*HR doubles
+        // two half slices keep the live v values to UB*HR doubles; ONE utterance per block has the registers for the whole
+        // slice, and its second batch of LDS reads no longer waits in the middle of the frame (round 5)
+        constexpr int NH = UB == 1 ? 1 : 2, HR = RPT / NH;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NH; ++h) {
             double vr[UB][HR];
 #pragma unroll
             for (int k = 0; k < UB; ++k)
@@ -329,7 +359,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
 #pragma unroll
                     for (int c = 0; c < CPT; ++c) {
                         const double cand = vr[k][r] + areg[c][h * HR + r];
-                        acc[k][c] = (h == 0 && r == 0) ? cand : vmax_f64(acc[k][c], cand);
+                        acc[k][c] = (h == 0 && r == 0) ? cand : vmax_f64(acc[k][c], cand);     // (partial maxima per column -- four chains instead of two -- measured for one utterance: no gain)
                     }
         }
 #pragma unroll
@@ -338,6 +368,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
             for (int c = 0; c < CPT; ++c)
                 __hip_atomic_fetch_max(&Vs[nxt][k][lane + 64 * c], rnd<TS>(acc[k][c] + bcur[k][c]), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
+        if constexpr (LAT) {
+            if (duty) st(v, ((size_t)(u0 + w / CPT) * T + (t - 1)) * N + lane + 64 * (w % CPT), vst);
+        }
         __syncthreads();
         cur = nxt;
     }
