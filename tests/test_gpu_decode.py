@@ -416,3 +416,37 @@ def test_full_covariance_direct_form_on_the_matrix_cores(golden, synth, oracle, 
                 assert_close(bm[u].transpose(1, 2, 0), obm, 1e-11, 1e-10, msg="bm " + tag)
                 assert_close(b2[u].T, ob, 1e-11, 1e-10, msg="b (no bm) " + tag)
     ctx._model_fp = None
+
+
+@pytest.mark.parametrize("N,M", [(128, 16), (126, 12), (64, 32)])
+def test_emission_with_the_shift_known_in_advance(N, M, synth, oracle, ctx):
+    """The b-only matrix-core emission kernel (round 5) no longer finds the maximum of a state's weighted component densities
+    per frame: the state's largest possible value, max_m(log w + gconst), rides in the coefficient matrix's constant row and the
+    log-sum-exp is shift + log sum exp(acc).  Frames near the components, frames 6 / 40 / 1000 units away from every component
+    (where the sum would leave the double range and the exact-maximum form takes over), a state whose weights are all but one
+    -inf, and a model with padding (N = 126, M = 12): b equals the oracle's and equals the b of the per-mixture variant (which
+    still takes the maximum per frame); decode paths are the oracle's."""
+    D, U, T = 39, 2, 48
+    mdl = synth.synth_model(N, M, D, seed=N + M)
+    w = mdl["w"].copy()
+    w[3, 1:] = -np.inf
+    w[3, 0] = 0.0
+    obs = synth.synth_obs(U, T, D, seed=77)
+    obs[0, 5] = 6.0
+    obs[0, 9] = -40.0
+    obs[1, 11] = 1000.0
+    obs[1, 12, ::2] = -250.0
+    ctx.upload_gmmhmm(mdl["A"], mdl["pi"], w, mdl["mu"], mdl["var"], diag=True)
+    b_only = ctx.gmm_logprob(obs)
+    b_with, bm = ctx.gmm_logprob(obs, want_bm=True)
+    paths = ctx.decode(obs)
+    for u in range(U):
+        with np.errstate(divide="ignore"):
+            want, want_bm = oracle.gmm_map_b_diag(obs[u], w, mdl["mu"], mdl["var"])
+        assert_close(b_only[u], want.T, 1e-12, msg="b (shift in the constant row) u=%d" % u)
+        assert_close(b_with[u], want.T, 1e-12, msg="b (per-frame maximum) u=%d" % u)
+        assert_close(b_only[u], b_with[u], 1e-13)
+        assert np.isfinite(b_only[u]).all()
+        with np.errstate(divide="ignore"):
+            _, _, ref = oracle.viterbi(mdl["A"], mdl["pi"], want)
+        assert np.array_equal(paths[u], ref)
