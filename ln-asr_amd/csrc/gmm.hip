@@ -41,24 +41,25 @@ __global__ void transpose_exp_kernel(const double* __restrict__ A, double* __res
     ET[(size_t)j * N + i] = e;
 }
 
-// flag[0] = 1 if any off-diagonal entry of any Sigma is not exactly zero.  A block per component (up to 8192 blocks, which then
-// walk on) that stops at the first hit anybody has reported; a hit is reported with a plain (idempotent) store.  History: one atomicOr per non-zero
-// entry was three million atomics on one address (1.1 ms of every upload of a genuinely full model); one per wave still let
-// every RESIDENT wave of a one-thread-per-entry grid -- 8,000 of them, all started before the first report landed -- queue
-// its atomic at the same L2 line (0.12 ms per launch; round 5).  A diagonal model (the case that reads everything) streams
-// its 25 MB once.
+// flag[0] = 1 if any off-diagonal entry of any Sigma is not exactly zero.  256 blocks walk the components; a block that finds one
+// reports it with ONE store (thread 0, after a block-wide OR, and only if nobody has reported yet) and every block stops at the
+// first report.  What this kernel costs is the traffic on the flag's ONE L2 line, not the 25 MB it may read: an atomicOr per
+// non-zero entry was three million atomics (1.1 ms of every upload of a genuinely full model); one per wave still let every
+// resident wave of a one-thread-per-entry grid queue its atomic (0.12 ms); a store per wave from 2048 blocks, 0.30 ms (round 5,
+// measured on the way here).  A diagonal model -- the case that reads everything -- streams its matrices once.
 __global__ void detect_offdiag_kernel(const double* __restrict__ S, int NM, int D, int* flag) {
     const int DD = D * D;
     for (int c = blockIdx.x; c < NM; c += gridDim.x) {
-        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;     // (block-uniform: one word)
         const double* Sc = S + (size_t)c * DD;
         bool hit = false;
         for (int e = threadIdx.x; e < DD; e += blockDim.x) {
             const int r = e / D, col = e - r * D;
             hit |= r != col && !(Sc[e] == 0.0);
         }
-        if (__any(hit)) {
-            if ((threadIdx.x & 63) == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__syncthreads_or(hit)) {
+            if (threadIdx.x == 0 && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+                __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }
     }
@@ -1106,7 +1107,7 @@ static int model_upload_impl(lnasr_ctx* ctx, int N, int M, int D, const double* 
         if (allow_diag_detect) {
             LN_TRY(md.flags.reserve(256));
             LN_HIP(hipMemsetAsync(md.flags.p, 0, 4, ctx->stream));
-            LN_LAUNCH(ctx, "detect_offdiag", detect_offdiag_kernel, dim3((unsigned)(NM < 8192 ? NM : 8192)), dim3(256), 0,
+            LN_LAUNCH(ctx, "detect_offdiag", detect_offdiag_kernel, dim3((unsigned)(NM < 256 ? NM : 256)), dim3(256), 0,
                       md.sigma_raw.as<double>(), (int)NM, D, md.flags.as<int>());
             int flag = 0;
             LN_HIP(hipMemcpyAsync(&flag, md.flags.p, 4, hipMemcpyDeviceToHost, ctx->stream));
