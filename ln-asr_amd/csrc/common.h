@@ -76,7 +76,6 @@ struct Model {
     DevBuf sigma_raw;            // full upload staging [N,M,D,D]
     DevBuf lu_bad;               // [N,M] int: components the register LU declined (redone by the LDS kernel)
     DevBuf wpack, wpack_nw;      // MFMA-packed coefficient fragments (diag): with / without log w folded in
-    DevBuf wshift;               // [virtual states] max_m (log w + gconst): the log-sum-exp shift folded into wpack's constant row
     int wpack_Q = 0, wpack_KS = 0, wpack_NG = 0;
     DevBuf wdirect;              // N = 1: coefficient fragments of the single mixture (gmm.hip: emit_single_direct)
     int wdirect_KS = 0;

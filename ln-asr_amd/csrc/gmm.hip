@@ -335,8 +335,7 @@ __global__ __launch_bounds__(64) void lu_invert_reg_kernel(const double* __restr
 //   k >  2D     : 0 (padding)
 __global__ void pack_wfrag_kernel(const double* __restrict__ mu, const double* __restrict__ ivar,
                                   const double* __restrict__ gconst, const double* __restrict__ logw,
-                                  double* __restrict__ wpack, int N, int M, int D, int Q, int KS, int fold_w,
-                                  const double* __restrict__ shift) {
+                                  double* __restrict__ wpack, int N, int M, int D, int Q, int KS, int fold_w) {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t total = (size_t)(N / 4) * Q * KS * 64;
     if (idx >= total) return;
@@ -362,21 +361,8 @@ __global__ void pack_wfrag_kernel(const double* __restrict__ mu, const double* _
             s += m * m * ivar[c * D + d];
         }
         val = (fold_w ? logw[c] : 0.0) + gconst[c] - 0.5 * s;
-        // the state's shift (state_shift_kernel) rides in the constant: the GEMM then delivers w + log N - shift <= 0 directly
-        if (shift && shift[state] != LN_NEG_INF) val -= shift[state];
     }
     wpack[idx] = val;
-}
-
-// shift[n] = max_m (log w[n,m] + gconst[n,m]): the largest value any weighted component density of state n can take (at x =
-// mu, where the quadratic term vanishes).  -inf for a state without a live component (padding).  One thread per state.
-__global__ void state_shift_kernel(const double* __restrict__ logw, const double* __restrict__ gconst, int N, int M,
-                                   double* __restrict__ shift) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    double mx = LN_NEG_INF;
-    for (int m = 0; m < M; ++m) mx = fmax(mx, logw[(size_t)n * M + m] + gconst[(size_t)n * M + m]);
-    shift[n] = (mx - mx == 0.0) ? mx : LN_NEG_INF;
 }
 
 // Measured on MI355X (tools/ubench): v_mfma_f64_16x16x4 issues every 64.5 cycles per SIMD
@@ -397,28 +383,6 @@ __global__ void state_shift_kernel(const double* __restrict__ logw, const double
 // and read as the MFMA B operand by all waves.  blockIdx is decoded XCD-aware: the GY blocks
 // that share a frame chunk sit on one XCD (b and b+8 share an XCD), so the obs tile is fetched
 // from HBM once and served to the other slabs from that XCD's L2.
-// the exact-maximum form of the in-lane log-sum-exp, for the frames the shift known in advance cannot serve (below)
-template <int Q>
-struct Acc16 {
-    double4_t v[Q];
-};
-template <int Q>
-static __device__ __noinline__ double lse_exact_max(Acc16<Q> a, double csh, const double* etab, const double* ltab) {
-    double mx = a.v[0][0];
-#pragma unroll
-    for (int q = 0; q < Q; ++q)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (q + r > 0) mx = vmax_f64(mx, a.v[q][r]);
-    double s2 = 0.0;
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) s2 += exp_nonpos_big2(a.v[q][r] - mx, etab);
-    }
-    return (mx == LN_NEG_INF) ? mx : csh + (mx + log_sum(s2, ltab));
-}
-
 template <int Q, int KS, int NWV, int TPS, bool WRITE_BM, int ABL = 0>
 __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 2))) void emit_diag_mfma(
     const double* __restrict__ obs, const double* __restrict__ wpack, const double* __restrict__ logw,
@@ -468,9 +432,6 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int my_state = 4 * sgc + g;
     const double* lw = lws + (WRITE_BM ? (4 * w + g) * 4 * Q : 0);
     if (WRITE_BM && fr < 4 * Q) lws[(4 * w + g) * 4 * Q + fr] = logw[(size_t)my_state * M + fr];
-    // b-only launches: `logw` is the per-state shift array (state_shift_kernel); the lane's value is read through a pointer so
-    // that it costs an address, not two registers, across the MFMA chain (the kernel sits at 245 of 256)
-    if (!WRITE_BM) lw = logw + my_state;
 
     // constant rows of F (k >= 2D): 1 for k == 2D, 0 above
     {
@@ -591,34 +552,6 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 2))
                 for (int q = 0; q < Q; ++q)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[q][r] += lw[q * 4 + r];
-            }
-            if constexpr (!WRITE_BM) {
-                // in-lane M-way log-sum-exp with the shift KNOWN IN ADVANCE (round 5).  A weighted component density never
-                // exceeds log w + gconst (its value at x = mu), so the state's largest such value is a shift under which every
-                // term is <= 0 whatever the frame -- and being a constant per state it rides in the coefficient matrix's constant
-                // row (pack_wfrag_kernel): the MFMA delivers acc = w + log N - shift directly, and the 16 maxima and 16
-                // subtractions per (frame, state) that found and applied the exact maximum are gone (32 of ~290 vector
-                // instructions per wave-tile in a kernel that is MFMA time + vector time).  The result is shift + log sum exp(acc)
-                // as before; a frame so far from every component of a state that the sum would leave the double range
-                // (all acc < -640) takes the exact-maximum form below -- on the synthetic and the reference's data: never.
-                const double csh = lw[0];                             // (this lane's state: see `lw` above; held in a register instead: same time)
-                double s = 0.0;
-#pragma unroll
-                for (int q = 0; q < Q; ++q) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) s += exp_nonpos_big2(acc[q][r], etab);
-                }
-                double res = csh + log_sum(s, ltab);
-                if (__builtin_expect(__any(s < 1e-270 && csh != LN_NEG_INF), 0)) {
-                    // out of line: its registers (and the saves around the call) are the rare branch's business, not the loop's
-                    Acc16<Q> a;
-#pragma unroll
-                    for (int q = 0; q < Q; ++q) a.v[q] = acc[q];
-                    const double ex = lse_exact_max<Q>(a, csh, etab, ltab);
-                    if (s < 1e-270) res = ex;
-                }
-                ob[cur][tt][fr * OS + 4 * w + g] = res;
-                continue;
             }
             // in-lane M-way log-sum-exp: this lane holds c[q][r] = mixture 4q+r of state my_state
             double mx = acc[0][0];
@@ -1187,13 +1120,10 @@ static int model_upload_impl(lnasr_ctx* ctx, int N, int M, int D, const double* 
             size_t total = (size_t)(Nv / 4) * Q * KS * 64;
             LN_TRY(md.wpack.reserve(total * 8));
             LN_TRY(md.wpack_nw.reserve(total * 8));
-            LN_TRY(md.wshift.reserve((size_t)Nv * 8));
-            LN_LAUNCH(ctx, "state_shift", state_shift_kernel, dim3((unsigned)((Nv + 127) / 128)), dim3(128), 0, lw_s, gc_s, Nv, Mv,
-                      md.wshift.as<double>());
             LN_LAUNCH(ctx, "pack_wfrag", pack_wfrag_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, mu_s, iv_s,
-                      gc_s, lw_s, md.wpack.as<double>(), Nv, Mv, D, Q, KS, 1, (const double*)md.wshift.as<double>());
+                      gc_s, lw_s, md.wpack.as<double>(), Nv, Mv, D, Q, KS, 1);
             LN_LAUNCH(ctx, "pack_wfrag", pack_wfrag_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, mu_s, iv_s,
-                      gc_s, lw_s, md.wpack_nw.as<double>(), Nv, Mv, D, Q, KS, 0, (const double*)nullptr);
+                      gc_s, lw_s, md.wpack_nw.as<double>(), Nv, Mv, D, Q, KS, 0);
             md.wpack_Q = Q;
             md.wpack_KS = KS;
             md.wpack_NG = Nv / 4;
@@ -1255,8 +1185,7 @@ static int launch_mfma_cfg(lnasr_ctx* ctx, const double* obs, long F, double* b,
                   md.wpack_NG, GY, ntiles, (int)tpb, nchunks, ctx->nan_flag.as<unsigned>(), ctx->nan_epoch);
     } else {
         LN_LAUNCH(ctx, "emit_diag_mfma", (emit_diag_mfma<Q, KS, NWV, TPS, false>), dim3((unsigned)grid),
-                  dim3(64 * NWV), 0, obs, md.wpack.as<double>(), (const double*)md.wshift.as<double>(),
-                  (const double*)md.centre.as<double>(), b, bm, F, N, D,
+                  dim3(64 * NWV), 0, obs, md.wpack.as<double>(), lw, (const double*)md.centre.as<double>(), b, bm, F, N, D,
                   md.wpack_NG, GY, ntiles, (int)tpb, nchunks, ctx->nan_flag.as<unsigned>(), ctx->nan_epoch);
     }
     return 0;

@@ -419,13 +419,11 @@ def test_full_covariance_direct_form_on_the_matrix_cores(golden, synth, oracle, 
 
 
 @pytest.mark.parametrize("N,M", [(128, 16), (126, 12), (64, 32)])
-def test_emission_with_the_shift_known_in_advance(N, M, synth, oracle, ctx):
-    """The b-only matrix-core emission kernel (round 5) no longer finds the maximum of a state's weighted component densities
-    per frame: the state's largest possible value, max_m(log w + gconst), rides in the coefficient matrix's constant row and the
-    log-sum-exp is shift + log sum exp(acc).  Frames near the components, frames 6 / 40 / 1000 units away from every component
-    (where the sum would leave the double range and the exact-maximum form takes over), a state whose weights are all but one
-    -inf, and a model with padding (N = 126, M = 12): b equals the oracle's and equals the b of the per-mixture variant (which
-    still takes the maximum per frame); decode paths are the oracle's."""
+def test_emission_outlier_frames(N, M, synth, oracle, ctx):
+    """Outlier frames through the matrix-core emission kernels (written for round 5's experiment with a log-sum-exp shift known in
+    advance -- removed, DESIGN 4.1 -- and kept): frames near the components, frames 6 / 40 / 250 / 1000 units away from every
+    component, a state whose weights are all but one -inf, and a model with padding (N = 126, M = 12): b of the b-only kernel
+    equals the oracle's and the b of the per-mixture variant; decode paths are the oracle's."""
     D, U, T = 39, 2, 48
     mdl = synth.synth_model(N, M, D, seed=N + M)
     w = mdl["w"].copy()
@@ -443,8 +441,8 @@ def test_emission_with_the_shift_known_in_advance(N, M, synth, oracle, ctx):
     for u in range(U):
         with np.errstate(divide="ignore"):
             want, want_bm = oracle.gmm_map_b_diag(obs[u], w, mdl["mu"], mdl["var"])
-        assert_close(b_only[u], want.T, 1e-12, msg="b (shift in the constant row) u=%d" % u)
-        assert_close(b_with[u], want.T, 1e-12, msg="b (per-frame maximum) u=%d" % u)
+        assert_close(b_only[u], want.T, 1e-12, msg="b (b-only kernel) u=%d" % u)
+        assert_close(b_with[u], want.T, 1e-12, msg="b (per-mixture kernel) u=%d" % u)
         assert_close(b_only[u], b_with[u], 1e-13)
         assert np.isfinite(b_only[u]).all()
         with np.errstate(divide="ignore"):
