@@ -75,12 +75,26 @@ __global__ __launch_bounds__(1024) void viterbi_stream(const double* __restrict_
     }
 }
 
+// lvl[row] = max_j b[row, j]: the LEVEL of every emission row, which the scaled linear-domain recursions below add to their
+// lagged shift (fwdbwd.hip, fwdbwd_cols2, has the story: the lagged maximum alone assumes emissions of a steady size, and on
+// data a model does not fit every column took the exact fallback -- 98 ms for one 1000-frame utterance at N = 300).  One wave
+// per row; for these sizes one more pass over b is noise.
+__global__ void row_level_kernel(const double* __restrict__ b, long rows, int N, double* __restrict__ lvl) {
+    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    double m = LN_NEG_INF;
+    for (int j = lane; j < N; j += 64) m = vmax_f64(m, b[(size_t)row * N + j]);
+    m = wave_max_dpp(m);
+    if (lane == 0) lvl[row] = m;
+}
+
 template <bool BACKWARD, int UB>
 __global__ __launch_bounds__(1024) void fwdbwd_stream(const double* __restrict__ b, const double* __restrict__ Aexp,
                                                       const double* __restrict__ Alog, const double* __restrict__ pi,
                                                       const int32_t* __restrict__ lens, double* __restrict__ out,
                                                       double* __restrict__ loglik, int U, int T, int N, int NP, int RS,
-                                                      int RPS) {
+                                                      int RPS, const double* __restrict__ lvl) {
     extern __shared__ double sm[];
     const int NB = NP / 64;                    // 64-column blocks
     double* Es = sm;                           // [2][UB][NP]
@@ -185,6 +199,7 @@ __global__ __launch_bounds__(1024) void fwdbwd_stream(const double* __restrict__
                 }
                 double S = Ms[(cur * UB + k) * NB];
                 for (int c = 1; c < NB; ++c) S = fmax(S, Ms[(cur * UB + k) * NB + c]);
+                S += lvl[(size_t)(u0 + k) * T + t];    // the lagged maximum, carried to this frame's emission level
                 Cn[k * NP + j] = prev;
                 En[k * NP + j] = (S == LN_NEG_INF || prev == LN_NEG_INF) ? 0.0 : exp(prev - S);
                 const double m = wave_max_dpp(prev);
@@ -344,7 +359,8 @@ __global__ __launch_bounds__(256) void fwdbwd_frame_kernel(const double* __restr
                                                            const double* __restrict__ Alog,
                                                            const int32_t* __restrict__ lens, double* __restrict__ out,
                                                            double* __restrict__ E, double* __restrict__ P,
-                                                           double* __restrict__ Mring, int U, int T, int N, int s) {
+                                                           double* __restrict__ Mring, int U, int T, int N, int s,
+                                                          const double* __restrict__ lvl) {
     extern __shared__ double fsm[];
     double* Ep = fsm;                                   // [UT][NP]  e values of the previous step
     const int NP = (N + 7) / 8 * 8;
@@ -420,8 +436,11 @@ __global__ __launch_bounds__(256) void fwdbwd_frame_kernel(const double* __restr
         if (j < N && s < L) {
         const double sum = (part[(0 * UT + k) * 128 + c] + part[(1 * UT + k) * 128 + c]) +
                            (part[(2 * UT + k) * 128 + c] + part[(3 * UT + k) * 128 + c]);
-        const double hprev = Mring[(size_t)((s >= 2 ? s - 2 : 0) & 3) * U + u];       // shift of E_{s-1}
-        const double hcur = Mring[(size_t)((s - 1) & 3) * U + u];                     // shift for E_s
+        // shift of a row = the maximum of the log-domain row before it + the level of its own emission row (row 0: its own maximum)
+        const int tcur = BACKWARD ? L - 1 - s : s, tprv = BACKWARD ? L - s : s - 1;
+        const double hprev = s >= 2 ? Mring[(size_t)((s - 2) & 3) * U + u] + lvl[(size_t)u * T + tprv]
+                                    : Mring[(size_t)0 * U + u];                       // shift of E_{s-1}
+        const double hcur = Mring[(size_t)((s - 1) & 3) * U + u] + lvl[(size_t)u * T + tcur];   // shift for E_s
         double val;
         if (sum >= kSafeSum && sum <= 1e290 && hprev != LN_NEG_INF) {
             val = hprev + log_sum(sum, ltab);
@@ -495,6 +514,18 @@ __global__ void final_loglik_kernel(const double* __restrict__ alpha, const int3
     if (lane == 0) loglik[u] = (mx == LN_NEG_INF) ? mx : mx + log(sacc);
 }
 
+// levels of every emission row of the batch (row_level_kernel); the two directions of a statistics pass run on two streams and
+// each fills its own buffer
+static int emission_levels(lnasr_ctx* ctx, const double* b, int U, int T, bool backward, const double** out) {
+    DevBuf& ws = backward ? ctx->ws_lvl2 : ctx->ws_lvl;
+    const long rows = (long)U * T;
+    LN_TRY(ws.reserve((size_t)rows * 8));
+    LN_LAUNCH(ctx, "emission_levels", row_level_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, b, rows, ctx->model.N,
+              ws.as<double>());
+    *out = ws.as<double>();
+    return 0;
+}
+
 template <bool BACKWARD>
 static int fwdbwd_frames(lnasr_ctx* ctx, const double* b, const double* Aexp, const double* Alog, int U, int T,
                          const int32_t* d_lens, double* out, double* loglik) {
@@ -512,6 +543,8 @@ static int fwdbwd_frames(lnasr_ctx* ctx, const double* b, const double* Aexp, co
     double* E = ws.as<double>();
     double* P = E + 2 * un;
     double* Mring = P + 2 * un;
+    const double* lvl;
+    LN_TRY(emission_levels(ctx, b, U, T, BACKWARD, &lvl));
     LN_LAUNCH(ctx, "fwdbwd_fill", fill_value_kernel, dim3((unsigned)((4 * (size_t)U + 255) / 256)), dim3(256), 0, Mring,
               (size_t)4 * U, LN_NEG_INF);
     LN_LAUNCH(ctx, BACKWARD ? "backward_frame0" : "forward_frame0", fwdbwd_frame0a_kernel<BACKWARD>,
@@ -520,7 +553,7 @@ static int fwdbwd_frames(lnasr_ctx* ctx, const double* b, const double* Aexp, co
               dim3(256), 0, (const double*)P, (const double*)Mring, E, U, N);
     for (int s = 1; s < T; ++s)
         LN_LAUNCH(ctx, BACKWARD ? "backward_frame" : "forward_frame", (fwdbwd_frame_kernel<UT, BACKWARD>),
-                  dim3(ctiles, utiles), dim3(256), shm, b, Aexp, Alog, d_lens, out, E, P, Mring, U, T, N, s);
+                  dim3(ctiles, utiles), dim3(256), shm, b, Aexp, Alog, d_lens, out, E, P, Mring, U, T, N, s, lvl);
     if (!BACKWARD && loglik)
         LN_LAUNCH(ctx, "forward_loglik", final_loglik_kernel, dim3((U + 3) / 4), dim3(256), 0, (const double*)out, d_lens,
                   loglik, U, T, N);
@@ -598,15 +631,17 @@ static int fwdbwd_stream_launch(lnasr_ctx* ctx, const double* b, int U, int T, c
     const int ub = dispatch::fwdbwd_stream_ub(N, U, ctx->prop.multiProcessorCount);
     const size_t shm = ((size_t)(4 + RS) * ub * NP + 2 * ub * NB + 2 * ub) * 8;
     double* ll = BACKWARD ? nullptr : loglik;
+    const double* lvl;
+    LN_TRY(emission_levels(ctx, b, U, T, BACKWARD, &lvl));
     if (ub == 1)
         LN_LAUNCH(ctx, BACKWARD ? "backward_stream_u1" : "forward_stream_u1", (fwdbwd_stream<BACKWARD, 1>), dim3(U),
-                  dim3(NP * RS), shm, b, Alin, Alog, pi, d_lens, out, ll, U, T, N, NP, RS, RPS);
+                  dim3(NP * RS), shm, b, Alin, Alog, pi, d_lens, out, ll, U, T, N, NP, RS, RPS, lvl);
     else if (ub == 2)
         LN_LAUNCH(ctx, BACKWARD ? "backward_stream_u2" : "forward_stream_u2", (fwdbwd_stream<BACKWARD, 2>), dim3((U + 1) / 2),
-                  dim3(NP * RS), shm, b, Alin, Alog, pi, d_lens, out, ll, U, T, N, NP, RS, RPS);
+                  dim3(NP * RS), shm, b, Alin, Alog, pi, d_lens, out, ll, U, T, N, NP, RS, RPS, lvl);
     else
         LN_LAUNCH(ctx, BACKWARD ? "backward_stream" : "forward_stream", (fwdbwd_stream<BACKWARD, 4>), dim3((U + 3) / 4),
-                  dim3(NP * RS), shm, b, Alin, Alog, pi, d_lens, out, ll, U, T, N, NP, RS, RPS);
+                  dim3(NP * RS), shm, b, Alin, Alog, pi, d_lens, out, ll, U, T, N, NP, RS, RPS, lvl);
     return 0;
 }
 

@@ -158,6 +158,7 @@ struct lnasr_ctx {
     lnasr::DevBuf ws_w1, ws_w2, ws_w3;                     // float32 storage: widened inputs / outputs of the f64 kernels
     lnasr::DevBuf ws_pad;                                  // bm of a padded model before compaction
     lnasr::DevBuf ws_bp;                                   // byte back-pointers of the tiny-model Viterbi (N <= 16)
+    lnasr::DevBuf ws_lvl, ws_lvl2;                         // emission-row levels of the N > 256 forward / backward kernels (bign.hip)
     lnasr::DevBuf ws_btb;                                  // byte back-pointer rows of the small-batch back-trace (backtrace.hip)
     // non-finite data (nanfix.hip): a device word the hot kernels set to the running call's epoch when they meet a NaN or
     // an infinity, and the per-utterance slots of the scan that follows

@@ -297,7 +297,7 @@ void lnasr_ctx_destroy(lnasr_ctx* ctx) {
     ctx->model.release();
     DevBuf* all[] = {&ctx->ws_in, &ctx->ws_in2, &ctx->ws_in3, &ctx->ws_in4, &ctx->ws_in5, &ctx->ws_out, &ctx->ws_out2,
                      &ctx->ws_out3, &ctx->ws_b, &ctx->ws_bm, &ctx->ws_v, &ctx->ws_alpha, &ctx->ws_beta,
-                     &ctx->ws_misc, &ctx->ws_misc2, &ctx->ws_lens, &ctx->ws_stats, &ctx->ws_p, &ctx->ws_q, &ctx->ws_raw, &ctx->ws_w1, &ctx->ws_w2, &ctx->ws_w3, &ctx->ws_pad, &ctx->ws_bp, &ctx->ws_btb, &ctx->mfcc_const, &ctx->nan_flag, &ctx->nan_slots};
+                     &ctx->ws_misc, &ctx->ws_misc2, &ctx->ws_lens, &ctx->ws_stats, &ctx->ws_p, &ctx->ws_q, &ctx->ws_raw, &ctx->ws_w1, &ctx->ws_w2, &ctx->ws_w3, &ctx->ws_pad, &ctx->ws_bp, &ctx->ws_btb, &ctx->ws_lvl, &ctx->ws_lvl2, &ctx->mfcc_const, &ctx->nan_flag, &ctx->nan_slots};
     for (DevBuf* b : all) b->release();
     for (auto& r : ctx->prof_recs) {
         (void)hipEventDestroy(r.e0);

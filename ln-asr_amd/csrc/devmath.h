@@ -143,6 +143,17 @@ __device__ __forceinline__ double wave_sum_dpp(double x) {
     return (r0 + r1) + (r2 + r3);
 }
 
+// max over the 16 lanes of a DPP row of a FLOAT, left in every lane of the row (the compiler folds each move into a
+// v_max_f32_dpp).  Used for the LEVEL of an emission row -- max_j b[t, j] to float accuracy -- which the scaled linear-domain
+// recursions add to their lagged shift (fwdbwd.hip): a level is good to a few nats, it does not need fp64.
+__device__ __forceinline__ float row_max_f32(float x) {
+    x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, true)));
+    x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, true)));
+    x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x141, 0xf, 0xf, true)));
+    x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x140, 0xf, 0xf, true)));
+    return x;
+}
+
 // fp64 DPP exists on gfx950 for v_fmac_f64 / v_mov_b64 with row_newbcast only: lane NB of every
 // 16-lane row is broadcast to the whole row
 template <int NB>

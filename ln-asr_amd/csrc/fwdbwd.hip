@@ -124,6 +124,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
     __shared__ double Cs[2][UB][NP];      // prev itself (log domain) for the exact fallback
     __shared__ double Ps[NW > 1 ? NW : 1][UB][NP];
     __shared__ double Ms[2][UB][CPT];     // per column-block max of prev
+    __shared__ float Lb[UB][CPT * 4];     // per DPP row max of the emissions of the frame being finalised (see fwdbwd_cols2)
     __shared__ double Ss[2][UB];          // shift the e values of this buffer were computed with
     __shared__ double etab[kExpTab];      // table-driven exp / log (devmath.h)
     __shared__ double ltab[2 * kLogTab];
@@ -245,6 +246,16 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
 #pragma unroll
                 for (int c = 0; c < CPT; ++c) fmac_bcast<(r.value & 15)>(acc[k][c], ek[k][r.value >> 4], areg[c][r.value]);
         });
+        static_assert(NW > 1, "the level partials below travel with the first barrier");
+        // level of this frame's emission row, for the shift (fwdbwd_cols2 has the story): the lagged maximum alone assumes
+        // emissions of a steady size
+#pragma unroll
+        for (int jj = 0; jj < JPW; ++jj) {
+            if (jvalid[jj]) {
+                const float lv = row_max_f32(lane + 64 * jc[jj] < N ? (float)bcur[jj] : -__builtin_huge_valf());
+                if ((lane & 15) == 0) Lb[jk[jj]][jc[jj] * 4 + (lane >> 4)] = lv;
+            }
+        }
         if (NW > 1) {
 #pragma unroll
             for (int k = 0; k < UB; ++k)
@@ -285,6 +296,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
                     double S = Ms[cur][k][0];
 #pragma unroll
                     for (int cc = 1; cc < CPT; ++cc) S = fmax(S, Ms[cur][k][cc]);
+                    {
+                        float lvl = Lb[k][0];
+#pragma unroll
+                        for (int e = 1; e < CPT * 4; ++e) lvl = fmaxf(lvl, Lb[k][e]);
+                        S += (double)lvl;          // the lagged maximum, carried to this frame's emission level
+                    }
                     Cs[nxt][k][j] = prev;
                     Es[nxt][k][j] = (S == LN_NEG_INF || prev == LN_NEG_INF) ? 0.0 : exp_clamped(prev - S, etab);
                     const double m = wave_max_dpp(prev);
@@ -380,6 +397,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __shared__ double Es[2][UB][NP];      // exp(prev - shift) of the frame being consumed
     __shared__ double Cs[2][UB][NP];      // prev itself (log domain) for the exact fallback
     __shared__ double Ms[2][UB][NM];      // per DPP row (16 columns) max of prev
+    __shared__ float Lb[2][UB][NM];       // per DPP row max of the EMISSIONS of the frame whose e row goes into this buffer
     __shared__ double Ss[2][UB];          // shift the e values of this buffer were computed with
     __shared__ double etab[kExpTab];
     __shared__ double ltab[2 * kLogTab];
@@ -445,6 +463,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (w == 0 && h == 0 && c == 0) Ss[0][k] = S;
     }
     double bnext = (double)bp[(size_t)clampt(frame_of(1)) * N];
+    double bnext2 = (double)bp[(size_t)clampt(frame_of(2)) * N];       // emissions are prefetched TWO frames ahead (see below)
+    // The shift of a row lags one frame (the maximum of the row just consumed: no reduction on the frame's path) -- which
+    // assumed that consecutive frames' emissions have about the same SIZE.  On data a model does not fit they do not (MFCCs of
+    // a test signal against a random model: row maxima around -2000 with a frame-to-frame spread of 800 nats), every e row
+    // then underflowed or overflowed and every column took the exact fallback: 35 us a frame instead of 0.5 (round 5,
+    // tools/mismatch.py).  The level of the emission row of the frame being produced -- max_j b[t, j], to float accuracy,
+    // formed one frame ahead from the prefetched row and combined through the LDS like the row maxima -- is therefore added
+    // to the lagged shift: what is left to the exponent range is the spread WITHIN a row.
+    {
+        const float lv = row_max_f32(j < N ? (float)bnext : -__builtin_huge_valf());
+        if (c == 0) Lb[0][k][2 * w + h] = lv;
+    }
     drain_vmem();                                  // areg resident: no vmcnt guards in the loop
     __syncthreads();
 
@@ -454,7 +484,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if ((step & 7) == 0) alternate_priority(cls);
         const int cur = (step - 1) & 1, nxt = step & 1;
         const double bcur = bnext;
-        bnext = (double)bp[(size_t)clampt(frame_of(step + 1)) * N];
+        bnext = bnext2;
+        bnext2 = (double)bp[(size_t)clampt(frame_of(step + 2)) * N];
+        {
+            // level of the row after this one, for the next turn's shift: from a value that was requested a whole frame ago
+            // (taken from the row requested in this turn, the wait for it sat in every frame: forward 1.31 -> 1.68 ms)
+            const float lv = row_max_f32(j < N ? (float)bnext : -__builtin_huge_valf());
+            if (c == 0) Lb[nxt][k][2 * w + h] = lv;
+        }
         // e values of both utterances for this lane's row group: lane (g, c) holds e[32 g + 16 q + c]
         double ek[UB][2];
 #pragma unroll
@@ -510,8 +547,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (j >= N) prev = LN_NEG_INF;
             prev_nan = prev != prev;
             double S = Ms[cur][k][0];
+            float lvl = Lb[cur][k][0];
 #pragma unroll
-            for (int e = 1; e < NM; ++e) S = fmax(S, Ms[cur][k][e]);
+            for (int e = 1; e < NM; ++e) {
+                S = fmax(S, Ms[cur][k][e]);
+                lvl = fmaxf(lvl, Lb[cur][k][e]);
+            }
+            S += (double)lvl;                      // the lagged maximum, carried to this frame's emission level
             Cs[nxt][k][j] = prev;
             Es[nxt][k][j] = (S == LN_NEG_INF || prev == LN_NEG_INF) ? 0.0 : exp_clamped(prev - S, etab);
             const double m = row_max_dpp(prev);
@@ -557,8 +599,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // issues 37 % of the time.  (Eight waves of 16 columns -- built, measured, removed -- shorten each wave's chain but finalise every column
 // four times over: 1,050 instructions per CU, 0.72 ms against 0.75.)  Here the chain loses its log / exp half:
 //     e[t, j] = sum[t, j] * G[t, j],   G[t, j] = exp((Sh[t-1] - Sh[t]) + b[t, j]),
-// where Sh[t] -- the shift the row e[t, :] is expressed in -- is extrapolated from the maxima of the log-domain rows of frames
-// t - 2 and t - 3: known when the frame starts, so G is formed beside the products and the chain is  LDS -> products -> swaps -> one multiply -> LDS ->
+// where Sh[t] -- the shift the row e[t, :] is expressed in -- is the maximum of the log-domain row of frame t - 2 plus the levels
+// of the emission rows t - 1 and t: known when the frame starts, so G is formed beside the products and the chain is  LDS -> products -> swaps -> one multiply -> LDS ->
 // barrier.  The log-domain value  Sh[t-1] + log(sum[t, j]) + b[t, j]  (the result, the input of the exact fallback and of the
 // shift two frames on) is evaluated one iteration LATER, in the same straight-line block as the next frame's products, where
 // it fills the issue slots their dependences leave.  A sum outside [1e-290, 1e290] (or a non-finite one) is redone from the
@@ -576,6 +618,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     __shared__ double Es[2][NP];          // e row (linear domain) of the frame being consumed / produced
     __shared__ double Cs[2][NP];          // log-domain row by frame parity (exact fallback, likelihood)
     __shared__ double Ms[2][NM];          // per DPP row (16 columns) maximum of the log-domain row, by frame parity
+    __shared__ float Lb[2][NM];           // per DPP row maximum of the EMISSIONS of the frame whose e row goes into this buffer
     __shared__ double etab[kExpTab];
     __shared__ double ltab[2 * kLogTab];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -636,6 +679,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         Es[0][j] = (sh_e == LN_NEG_INF || prev == LN_NEG_INF) ? 0.0 : exp_clamped(prev - sh_e, etab);
     }
     double bnext = bp[(size_t)clampt(frame_of(1)) * N];
+    double bnext2 = bp[(size_t)clampt(frame_of(2)) * N];              // emissions are prefetched two frames ahead: the level of a
+    {                                                                  // row is formed from a value requested a whole frame ago
+        const float lv = row_max_f32(j < N ? (float)bnext : -__builtin_huge_valf());     // level of the next emission row
+        if (c == 0 && primary) Lb[0][2 * w + h] = lv;
+    }
     drain_vmem();                                  // areg resident: no vmcnt guards in the loop
     __syncthreads();
 
@@ -655,19 +703,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define LN_PIN __builtin_amdgcn_sched_barrier(0)
     constexpr double kInvStep = 369.32993046757463, kStepHi = 2.7076061740622863e-03, kStepLo = 9.058776616587108e-20;
     constexpr double kMagic = 6755399441055744.0, kLn2 = 0.69314718055994530942;
-    double sum_prev = 1.0, b_prev = 0.0, sh_pp = 0.0, m3 = LN_NEG_INF;
+    double sum_prev = 1.0, b_prev = 0.0, sh_pp = 0.0;
+    float lvl_prev = 0.0f;
     for (int step = 1; step <= klen; ++step) {
         const int cur = (step - 1) & 1, nxt = step & 1;
         const bool eval = step >= 2;
         const double bcur = bnext;
-        bnext = bp[(size_t)clampt(frame_of(step + 1)) * N];
+        bnext = bnext2;
+        bnext2 = bp[(size_t)clampt(frame_of(step + 2)) * N];
         double ek[2];
         ek[0] = Es[cur][32 * g + c];
         ek[1] = Es[cur][32 * g + 16 + c];
         // the shift of the row this iteration produces: the maximum of the log-domain row two frames back (frame 0 for step 1)
         double mrow[NM];
+        float lrow[NM];
 #pragma unroll
-        for (int e = 0; e < NM; ++e) mrow[e] = Ms[eval ? nxt : 0][e];
+        for (int e = 0; e < NM; ++e) {
+            mrow[e] = Ms[eval ? nxt : 0][e];
+            lrow[e] = Lb[cur][e];
+        }
+
         // ---- evaluation of frame f = step - 1, part 1 (registers only): range test, mantissa, table address
         const int fb = cur, pb = nxt;              // parity buffers of frame f and of frame f - 1
         const bool safe = j >= N || (sum_prev >= kSafeSum && sum_prev <= 1e290 && sh_pp != LN_NEG_INF);   // (padding columns: nothing to redo)
@@ -684,23 +739,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         LN_PIN;
         LN_PROD(1);
         double m45 = vmax_f64(mrow[4], mrow[5]), m67 = vmax_f64(mrow[6], mrow[7]);
+        {
+            const float lv = row_max_f32(j < N ? (float)bnext : -__builtin_huge_valf());     // level of the row after this one
+            if (c == 0 && primary) Lb[nxt][2 * w + h] = lv;
+        }
         LN_PIN;
         LN_PROD(2);
         m01 = vmax_f64(m01, m23);
         m45 = vmax_f64(m45, m67);
         LN_PIN;
         LN_PROD(3);
-        // ... carried forward by the last step the maxima took, twice (the row produced now is two frames further on): whatever
-        // the per-frame size of the emissions (-60 or -600), e stays near 1 and the whole exponent range is left for the spread
-        // WITHIN a row.  Any value works as a shift as long as every lane computes the same one -- these all read the same words.
+        // ... carried forward by the LEVELS of the emission rows in between (max_j b[t, j] to float accuracy: formed a frame
+        // ahead from the prefetched row, combined through the LDS like the maxima): whatever the size of the emissions and however
+        // it jumps from frame to frame (MFCCs of a test signal against a random model: -2000 +- 800 nats), e stays near 1 and
+        // the whole exponent range is left for the spread WITHIN a row.  Any value works as a shift as long as every lane computes
+        // the same one -- these all read the same words.
         const double m2 = vmax_f64(m01, m45);
-        const double trend = (m2 != LN_NEG_INF && m3 != LN_NEG_INF && eval) ? m2 - m3 : 0.0;
-        const double sh_new = fma(2.0, trend, m2);
-        m3 = m2;
-        // ---- G = exp((Sh[t-1] - Sh[t]) + b[t, j]) (0 where a shift is -inf: the exact fallback takes over), part 1
-        const bool sh_ok = sh_new != LN_NEG_INF && sh_e != LN_NEG_INF && j < N;
+        const float l01 = fmaxf(fmaxf(lrow[0], lrow[1]), fmaxf(lrow[2], lrow[3]));
+        const float l45 = fmaxf(fmaxf(lrow[4], lrow[5]), fmaxf(lrow[6], lrow[7]));
+        const float lvl = fmaxf(l01, l45);
+        const double sh_new = m2 + ((double)lvl + (eval ? (double)lvl_prev : 0.0));
+        lvl_prev = lvl;
+        const bool sh_ok = sh_new != LN_NEG_INF && sh_e != LN_NEG_INF && j < N && sh_new == sh_new;
         const double gx0 = sh_ok ? (sh_e - sh_new) + bcur : 0.0;
         LN_PIN;
+        // ---- G = exp((Sh[t-1] - Sh[t]) + b[t, j]) (0 where a shift is -inf: the exact fallback takes over), part 1
         LN_PROD(4);
         double gx = gx0;
         asm("v_min_f64 %0, %1, %2" : "=v"(gx) : "v"(gx0), "v"(690.0));

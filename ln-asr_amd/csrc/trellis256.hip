@@ -25,7 +25,8 @@ constexpr int kT256Cs = kT256Vs + 2 * 256;                               // [2][
 constexpr int kT256Ps = kT256Cs + 2 * 256;                               // [3][256] partials of slices 1..3
 constexpr int kT256Ms = kT256Ps + 3 * 256;                               // [3][4]   per 64-column block max (ring of three frames)
 constexpr int kT256Ss = kT256Ms + 12;                                    // [2]      shift of each e buffer
-constexpr int kT256Et = kT256Ss + 2;                                     // [kExpTab]
+constexpr int kT256Lb = kT256Ss + 2;                                     // [16] floats (8 doubles): emission-row level partials
+constexpr int kT256Et = kT256Lb + 8;                                     // [kExpTab]
 constexpr int kT256Lt = kT256Et + kExpTab;                               // [2 * kLogTab]
 constexpr int kT256End = kT256Lt + 2 * kLogTab;
 
@@ -59,6 +60,7 @@ __device__ __forceinline__ void trellis256_role(double* sm, const TS* __restrict
     double* Ps = sm + kT256Ps;
     double* Ms = sm + kT256Ms;
     double* Ss = sm + kT256Ss;
+    float* Lb = reinterpret_cast<float*>(sm + kT256Lb);
     const double* etab = sm + kT256Et;
     const double* ltab = sm + kT256Lt;
     const double pad = VIT ? LN_NEG_INF : 0.0;
@@ -148,6 +150,14 @@ __device__ __forceinline__ void trellis256_role(double* sm, const TS* __restrict
             part = (acc[0] + acc[1]) + (acc[2] + acc[3]);
         }
         if (!FIN) Ps[(rs - 1) * NP + jc] = part;
+        if (FIN && !VIT) {
+            // level of this frame's emission row (max_j b[t, j], float accuracy) for the shift below: the lagged maximum
+            // alone assumes that consecutive frames' emissions have about the same size, and on data a model does not fit --
+            // row maxima jumping by hundreds of nats -- every e row under- or overflowed and every column took the exact
+            // fallback (fwdbwd.hip, round 5).  Partials of the sixteen DPP rows go through the LDS with the first barrier.
+            const float lv = row_max_f32(jc < N ? (float)bcur : -__builtin_huge_valf());
+            if ((lane & 15) == 0) Lb[tid >> 4] = lv;
+        }
         __syncthreads();
         if (FIN) {
             const int t = frame_of(step);
@@ -179,7 +189,13 @@ __device__ __forceinline__ void trellis256_role(double* sm, const TS* __restrict
                         if (ou) ou[(size_t)t * N + jc] = (TS)prev;
                     }
                 }
-                const double S = fmax(fmax(Ms[cur * 4], Ms[cur * 4 + 1]), fmax(Ms[cur * 4 + 2], Ms[cur * 4 + 3]));
+                double S = fmax(fmax(Ms[cur * 4], Ms[cur * 4 + 1]), fmax(Ms[cur * 4 + 2], Ms[cur * 4 + 3]));
+                {
+                    float lvl = Lb[0];
+#pragma unroll
+                    for (int e = 1; e < 16; ++e) lvl = fmaxf(lvl, Lb[e]);
+                    S += (double)lvl;              // the lagged maximum, carried to this frame's emission level
+                }
                 Cs[nxt * NP + jc] = prev;
                 Vs[nxt * NP + jc] = (S == LN_NEG_INF || prev == LN_NEG_INF) ? 0.0 : exp_clamped(prev - S, etab);
                 const double m = wave_max_dpp(prev);
