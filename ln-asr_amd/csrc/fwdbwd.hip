@@ -533,6 +533,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 val = Sc + log_sum(sum, ltab);
             } else {                               // exact log-domain column (rare)
                 val = exact_column_lse(&Cs[cur][k][0], Alog + jc, N);
+                atomicAdd(nan_flag + 1, 1u);       // diagnostic count of such columns (lnasr_debug_fallback_columns)
             }
             const int t = frame_of(step);
             double prev;
@@ -835,6 +836,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (__builtin_expect(eval && __any(!safe), 0)) {
             if (!safe) {
                 val = exact_column_lse(&Cs[pb][0], Alog + jc, N);
+                atomicAdd(nan_flag + 1, 1u);       // diagnostic count of such columns (lnasr_debug_fallback_columns)
                 prev = j < N ? val + b_prev : LN_NEG_INF;
                 if (opf) opf[oidx] = BACKWARD ? val : prev;
                 Cs[fb][j] = prev;

@@ -45,6 +45,7 @@ SIGNATURES = {
     "lnasr_hash128_begin": [_P(_vp), _P(_sz), _i, C.c_uint64, _P(_vp)],
     "lnasr_hash128_end": [_vp, _P(C.c_uint64)],
     "lnasr_debug_require_device_ptr": [_vp],
+    "lnasr_debug_fallback_columns": [_vp, _P(C.c_uint)],
     "lnasr_dev_alloc": [_vp, _sz, _P(_vp)],
     "lnasr_dev_free": [_vp, _vp],
     "lnasr_memcpy_h2d": [_vp, _vp, _vp, _sz],
@@ -340,6 +341,13 @@ class Context:
 
     def to_device(self, arr, dtype=None):
         return DeviceArray.from_host(self, arr, dtype)
+
+    def fallback_columns(self):
+        """Diagnostic (lnasr_debug_fallback_columns): columns the column-owned forward / backward kernels redid in the exact
+        log-domain form since the last call; reading clears the counter."""
+        n = C.c_uint(0)
+        check(lib().lnasr_debug_fallback_columns(self.handle, C.byref(n)))
+        return n.value
 
     def prof_enable(self, on=True):
         check(lib().lnasr_prof_enable(self.handle, 1 if on else 0))

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import assert_close, env_switch
+from conftest import assert_close, env_switch, tuned
 
 pytestmark = pytest.mark.gpu
 
@@ -707,3 +707,35 @@ def test_chain_shortened_forward_backward_at_any_emission_size(scale, synth, ora
         assert_close(alpha[u], ra, 1e-12, msg="alpha scale=%g u=%d" % (scale, u))
         assert_close(beta[u], rb, 1e-12, msg="beta scale=%g u=%d" % (scale, u))
         assert_close(ll[u], oracle.loglik(ra), 1e-12)
+
+
+@pytest.mark.parametrize("U", [3, 600])
+def test_emission_levels_that_jump_stay_in_the_linear_domain(U, synth, oracle, ctx):
+    """Data a model does not fit (round 5, tools/mismatch.py): the row maximum of b around -2200 nats, jumping by +-800 from
+    frame to frame.  The shift of a linear-domain row used to be the lagged log-domain maximum alone, every column of every
+    frame then left the exponent range and was redone in the exact form -- right, and 65 times slower.  With the level of the
+    emission row in the shift NO column does (lnasr_debug_fallback_columns counts them; both batch tiers); a model with an
+    unreachable state still takes the exact form for that state's column, which shows that the counter counts."""
+    N, T = 128, 50
+    rng = np.random.default_rng(U)
+    d = synth.synth_discrete(N, 4, 8, seed=9)
+    ctx.upload_hmm(d["A"], d["pi"])
+    level = -2200.0 + 800.0 * rng.standard_normal((U, T, 1))
+    b = np.ascontiguousarray(level - 40.0 * rng.random((U, T, N)))
+    ctx.fallback_columns()
+    alpha, ll = ctx.forward(b)
+    beta = ctx.backward(b)
+    if tuned():
+        assert ctx.fallback_columns() == 0
+    for u in (0, U // 2, U - 1):
+        ob = np.ascontiguousarray(b[u].T)
+        ra, rb = oracle.forward(d["A"], d["pi"], ob), oracle.backward(d["A"], ob)
+        assert_close(alpha[u], ra, 1e-12, msg="alpha u=%d" % u)
+        assert_close(beta[u], rb, 1e-12, msg="beta u=%d" % u)
+        assert_close(ll[u], oracle.loglik(ra), 1e-12)
+    A = d["A"].copy()
+    A[:, 7] = -np.inf                                    # state 7 cannot be entered: its column sum is 0 in every frame
+    ctx.upload_hmm(A, d["pi"])
+    ctx.forward(b[:1])
+    if tuned():
+        assert ctx.fallback_columns() >= T - 1
