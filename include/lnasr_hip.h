@@ -99,11 +99,11 @@ int lnasr_host_free(lnasr_ctx* ctx, void* p);
  * host-sanitizer build): LNASR_E_INVALID unless p is null or device memory.  Exposed so that the CPU suite can prove
  * the guard fires on a heap pointer (tests/test_host_asan.py). */
 int lnasr_debug_require_device_ptr(const void* p);
-/* Diagnostic: the number of columns (state x frame) of the column-owned forward / backward kernels (64 < N <= 128, and up
- * to 128 states on a handful of utterances) that left the scaled linear domain and were redone in the exact log-domain form
- * (hmm.py:97-99's logaddexp fold, a state at a time) since the counter was last read; reading clears it.  The results do not
- * depend on it, the time does: the parity suite uses it to pin that emissions whose size jumps from frame to frame -- data a
- * model does not fit -- stay on the fast path (tests/test_gpu_trellis.py). */
+/* Diagnostic: the number of columns (state x frame) the scaled linear-domain forward / backward kernels (every family
+ * above 16 states) found outside the exponent range and redid in the exact log-domain form (hmm.py:97-99's logaddexp fold,
+ * a state at a time) since the counter was last read; reading clears it.  The results do not depend on it, the time does:
+ * the parity suite uses it to pin that emissions whose size jumps from frame to frame -- data a model does not fit -- stay
+ * on the fast path (tests/test_gpu_trellis.py). */
 int lnasr_debug_fallback_columns(lnasr_ctx* ctx, unsigned* count);
 
 /* 128-bit fingerprint of a HOST buffer (no context, no device).  The reference's methods re-read self.A / self.mu /

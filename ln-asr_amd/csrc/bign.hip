@@ -94,7 +94,7 @@ __global__ __launch_bounds__(1024) void fwdbwd_stream(const double* __restrict__
                                                       const double* __restrict__ Alog, const double* __restrict__ pi,
                                                       const int32_t* __restrict__ lens, double* __restrict__ out,
                                                       double* __restrict__ loglik, int U, int T, int N, int NP, int RS,
-                                                      int RPS, const double* __restrict__ lvl) {
+                                                      int RPS, const double* __restrict__ lvl, unsigned* __restrict__ fb_count) {
     extern __shared__ double sm[];
     const int NB = NP / 64;                    // 64-column blocks
     double* Es = sm;                           // [2][UB][NP]
@@ -174,6 +174,7 @@ __global__ __launch_bounds__(1024) void fwdbwd_stream(const double* __restrict__
                     val = Sc + log(sum);
                 } else {
                     const int jl = j < N ? j : N - 1;
+                    atomicAdd(fb_count, 1u);       // diagnostic (lnasr_debug_fallback_columns)
                     double mx = LN_NEG_INF;
                     for (int i = 0; i < N; ++i) mx = fmax(mx, Cc[k * NP + i] + Alog[(size_t)i * N + jl]);
                     if (mx == LN_NEG_INF || mx != mx) {
@@ -360,7 +361,8 @@ __global__ __launch_bounds__(256) void fwdbwd_frame_kernel(const double* __restr
                                                            const int32_t* __restrict__ lens, double* __restrict__ out,
                                                            double* __restrict__ E, double* __restrict__ P,
                                                            double* __restrict__ Mring, int U, int T, int N, int s,
-                                                          const double* __restrict__ lvl) {
+                                                           const double* __restrict__ lvl,
+                                                           unsigned* __restrict__ fb_count) {
     extern __shared__ double fsm[];
     double* Ep = fsm;                                   // [UT][NP]  e values of the previous step
     const int NP = (N + 7) / 8 * 8;
@@ -446,6 +448,7 @@ __global__ __launch_bounds__(256) void fwdbwd_frame_kernel(const double* __restr
             val = hprev + log_sum(sum, ltab);
         } else {
             val = exact_column_lse(P + ((size_t)cur * U + u) * N, Alog + j, N);
+            atomicAdd(fb_count, 1u);               // diagnostic (lnasr_debug_fallback_columns)
         }
         const int t = BACKWARD ? L - 1 - s : s;
         const size_t o = ((size_t)u * T + t) * N + j;
@@ -553,7 +556,7 @@ static int fwdbwd_frames(lnasr_ctx* ctx, const double* b, const double* Aexp, co
               dim3(256), 0, (const double*)P, (const double*)Mring, E, U, N);
     for (int s = 1; s < T; ++s)
         LN_LAUNCH(ctx, BACKWARD ? "backward_frame" : "forward_frame", (fwdbwd_frame_kernel<UT, BACKWARD>),
-                  dim3(ctiles, utiles), dim3(256), shm, b, Aexp, Alog, d_lens, out, E, P, Mring, U, T, N, s, lvl);
+                  dim3(ctiles, utiles), dim3(256), shm, b, Aexp, Alog, d_lens, out, E, P, Mring, U, T, N, s, lvl, ctx->nan_flag.as<unsigned>() + 3);
     if (!BACKWARD && loglik)
         LN_LAUNCH(ctx, "forward_loglik", final_loglik_kernel, dim3((U + 3) / 4), dim3(256), 0, (const double*)out, d_lens,
                   loglik, U, T, N);
@@ -635,13 +638,13 @@ static int fwdbwd_stream_launch(lnasr_ctx* ctx, const double* b, int U, int T, c
     LN_TRY(emission_levels(ctx, b, U, T, BACKWARD, &lvl));
     if (ub == 1)
         LN_LAUNCH(ctx, BACKWARD ? "backward_stream_u1" : "forward_stream_u1", (fwdbwd_stream<BACKWARD, 1>), dim3(U),
-                  dim3(NP * RS), shm, b, Alin, Alog, pi, d_lens, out, ll, U, T, N, NP, RS, RPS, lvl);
+                  dim3(NP * RS), shm, b, Alin, Alog, pi, d_lens, out, ll, U, T, N, NP, RS, RPS, lvl, ctx->nan_flag.as<unsigned>() + 3);
     else if (ub == 2)
         LN_LAUNCH(ctx, BACKWARD ? "backward_stream_u2" : "forward_stream_u2", (fwdbwd_stream<BACKWARD, 2>), dim3((U + 1) / 2),
-                  dim3(NP * RS), shm, b, Alin, Alog, pi, d_lens, out, ll, U, T, N, NP, RS, RPS, lvl);
+                  dim3(NP * RS), shm, b, Alin, Alog, pi, d_lens, out, ll, U, T, N, NP, RS, RPS, lvl, ctx->nan_flag.as<unsigned>() + 3);
     else
         LN_LAUNCH(ctx, BACKWARD ? "backward_stream" : "forward_stream", (fwdbwd_stream<BACKWARD, 4>), dim3((U + 3) / 4),
-                  dim3(NP * RS), shm, b, Alin, Alog, pi, d_lens, out, ll, U, T, N, NP, RS, RPS, lvl);
+                  dim3(NP * RS), shm, b, Alin, Alog, pi, d_lens, out, ll, U, T, N, NP, RS, RPS, lvl, ctx->nan_flag.as<unsigned>() + 3);
     return 0;
 }
 

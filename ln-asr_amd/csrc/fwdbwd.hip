@@ -116,7 +116,7 @@ template <bool BACKWARD, int CPT, int NW, int RPT, int UB, int WPE>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void fwdbwd_reg(
     const double* __restrict__ b, const double* __restrict__ Aexp, const double* __restrict__ Alog,
     const double* __restrict__ pi, const int32_t* __restrict__ lens, double* __restrict__ out,
-    double* __restrict__ loglik, int U, int T, int N) {
+    double* __restrict__ loglik, int U, int T, int N, unsigned* __restrict__ fb_count) {
     constexpr int NP = 64 * CPT;
     constexpr int NJOB = CPT * UB;
     constexpr int JPW = (NJOB + NW - 1) / NW;
@@ -282,6 +282,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
                         val = Sc + log_sum(sum, ltab);
                     } else {                       // exact log-domain column (rare)
                         val = exact_column_lse(&Cs[cur][k][0], Alog + (j < N ? j : N - 1), N);
+                        atomicAdd(fb_count, 1u);   // diagnostic (lnasr_debug_fallback_columns)
                     }
                     const int t = frame_of(jj, step);
                     double prev;
@@ -1074,7 +1075,7 @@ int forward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
                                            !sw().no_colfwd))
             LN_LAUNCH(ctx, "forward_reg_n64", (fwdbwd_reg<false, 1, 2, 32, 2, 3>), dim3((U + 1) / 2), dim3(128), 0,
                       (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
-                      (double*)alpha, loglik, U, T, N);
+                      (double*)alpha, loglik, U, T, N, ctx->nan_flag.as<unsigned>() + 3);
         else
             // column-owned waves, two utterances per four-wave block, two blocks per CU (fwdbwd_cols2): measured against the
             // eight-wave kernels at every batch size -- 16 ... 512 utterances 0.83-0.87 ms against 0.96-1.02 (fwdbwd_reg, two
@@ -1098,11 +1099,11 @@ int forward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* d
             else if (!dispatch::fwdbwd_reg_four_per_block(U, ctx->prop.multiProcessorCount))      // row-owned waves, partial sums through the LDS
                 LN_LAUNCH(ctx, "forward_reg_n128", (fwdbwd_reg<false, 2, 8, 16, 2, 4>), dim3((U + 1) / 2), dim3(512), 0,
                           (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
-                          (double*)alpha, loglik, U, T, N);
+                          (double*)alpha, loglik, U, T, N, ctx->nan_flag.as<unsigned>() + 3);
             else
                 LN_LAUNCH(ctx, "forward_reg_n128", (fwdbwd_reg<false, 2, 8, 16, 4, 2>), dim3((U + 3) / 4), dim3(512), 0,
                           (const double*)b, md.expA.as<double>(), md.logA.as<double>(), md.logpi.as<double>(), d_lens,
-                          (double*)alpha, loglik, U, T, N);
+                          (double*)alpha, loglik, U, T, N, ctx->nan_flag.as<unsigned>() + 3);
         return 0;
     }
     if (dtype == LNASR_F64 && N > dispatch::kRegMaxN && N <= dispatch::kOnChipMaxN && !sw().no_t256)
@@ -1155,7 +1156,7 @@ int backward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* 
                                            !sw().no_colfwd))
             LN_LAUNCH(ctx, "backward_reg_n64", (fwdbwd_reg<true, 1, 2, 32, 2, 3>), dim3((U + 1) / 2), dim3(128), 0,
                       (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
-                      (double*)nullptr, U, T, N);
+                      (double*)nullptr, U, T, N, ctx->nan_flag.as<unsigned>() + 3);
         else
             if (!sw().no_colfwd)
             {
@@ -1176,11 +1177,11 @@ int backward_device(lnasr_ctx* ctx, const void* b, int U, int T, const int32_t* 
             else if (!dispatch::fwdbwd_reg_four_per_block(U, ctx->prop.multiProcessorCount))
                 LN_LAUNCH(ctx, "backward_reg_n128", (fwdbwd_reg<true, 2, 8, 16, 2, 4>), dim3((U + 1) / 2), dim3(512), 0,
                           (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
-                          (double*)nullptr, U, T, N);
+                          (double*)nullptr, U, T, N, ctx->nan_flag.as<unsigned>() + 3);
             else
                 LN_LAUNCH(ctx, "backward_reg_n128", (fwdbwd_reg<true, 2, 8, 16, 4, 2>), dim3((U + 3) / 4), dim3(512), 0,
                           (const double*)b, expAT, md.logAT.as<double>(), md.logpi.as<double>(), d_lens, (double*)beta,
-                          (double*)nullptr, U, T, N);
+                          (double*)nullptr, U, T, N, ctx->nan_flag.as<unsigned>() + 3);
         return 0;
     }
     if (dtype == LNASR_F64 && N > dispatch::kRegMaxN && N <= dispatch::kOnChipMaxN && !sw().no_t256)

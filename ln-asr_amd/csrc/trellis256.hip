@@ -43,7 +43,8 @@ constexpr int kT256End = kT256Lt + 2 * kLogTab;
 template <int MODE, bool FIN, typename TS = double>
 __device__ __forceinline__ void trellis256_role(double* sm, const TS* __restrict__ bu, const double* __restrict__ Amat,
                                                 const double* __restrict__ Alog, const double* __restrict__ pi,
-                                                TS* __restrict__ ou, double* __restrict__ loglik_u, int L, int T, int N) {
+                                                TS* __restrict__ ou, double* __restrict__ loglik_u, int L, int T, int N,
+                                                unsigned* __restrict__ fb_count) {
     constexpr bool VIT = MODE == 0, BACKWARD = MODE == 2;
     constexpr int NP = 256, RPS = 64;
     constexpr int NREG = FIN ? kT256FinReg : kT256CmpReg, NLDS = 64 - NREG;
@@ -177,6 +178,7 @@ __device__ __forceinline__ void trellis256_role(double* sm, const TS* __restrict
                     val = Sc + log_sum(sum, ltab);
                 } else {
                     val = exact_column_lse(Cs + cur * NP, Alog + jcl, N);
+                    atomicAdd(fb_count, 1u);       // diagnostic (lnasr_debug_fallback_columns)
                 }
                 double prev = LN_NEG_INF;
                 if (jc < N) {
@@ -225,7 +227,8 @@ __global__ __launch_bounds__(1024) void trellis256_kernel(const TS* __restrict__
                                                           const double* __restrict__ Alog,   // logA or logA^T (fallback)
                                                           const double* __restrict__ pi,
                                                           const int32_t* __restrict__ lens, TS* __restrict__ out,
-                                                          double* __restrict__ loglik, int U, int T, int N) {
+                                                          double* __restrict__ loglik, int U, int T, int N,
+                                                          unsigned* __restrict__ fb_count) {
     extern __shared__ double sm[];
     const int u = blockIdx.x;
     const int L = lens[u];
@@ -238,9 +241,9 @@ __global__ __launch_bounds__(1024) void trellis256_kernel(const TS* __restrict__
     TS* ou = out ? out + (size_t)u * T * N : nullptr;
     // wave-uniform role split (threadIdx.x >> 8 is constant within a wave); the barriers of the two roles pair up
     if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 8) == 0)
-        trellis256_role<MODE, true, TS>(sm, bu, Amat, Alog, pi, ou, loglik ? loglik + u : nullptr, L, T, N);
+        trellis256_role<MODE, true, TS>(sm, bu, Amat, Alog, pi, ou, loglik ? loglik + u : nullptr, L, T, N, fb_count);
     else
-        trellis256_role<MODE, false, TS>(sm, bu, Amat, Alog, pi, ou, nullptr, L, T, N);
+        trellis256_role<MODE, false, TS>(sm, bu, Amat, Alog, pi, ou, nullptr, L, T, N, fb_count);
 }
 
 static inline size_t trellis256_lds() { return (size_t)kT256End * 8; }
@@ -257,24 +260,24 @@ int trellis256_device(lnasr_ctx* ctx, int mode, const void* b, int U, int T, con
         const double* A = md.logA.as<double>();
         if (dtype == LNASR_F32)      // precision=np.float32: float storage, v rounded where the reference's array rounds it
             LN_LAUNCH(ctx, "viterbi_onchip256_f32", (trellis256_kernel<0, float>), grid, block, lds, (const float*)b, A, A, pi,
-                      d_lens, (float*)out, (double*)nullptr, U, T, N);
+                      d_lens, (float*)out, (double*)nullptr, U, T, N, ctx->nan_flag.as<unsigned>() + 3);
         else
             LN_LAUNCH(ctx, "viterbi_onchip256", trellis256_kernel<0>, grid, block, lds, (const double*)b, A, A, pi, d_lens,
-                      (double*)out, (double*)nullptr, U, T, N);
+                      (double*)out, (double*)nullptr, U, T, N, ctx->nan_flag.as<unsigned>() + 3);
         return 0;
     }
     if (mode == 1 && dtype == LNASR_F32)
         LN_LAUNCH(ctx, "forward_onchip256_f32", (trellis256_kernel<1, float>), grid, block, lds, (const float*)b,
-                  md.expA.as<double>(), md.logA.as<double>(), pi, d_lens, (float*)out, loglik, U, T, N);
+                  md.expA.as<double>(), md.logA.as<double>(), pi, d_lens, (float*)out, loglik, U, T, N, ctx->nan_flag.as<unsigned>() + 3);
     else if (mode == 1)
         LN_LAUNCH(ctx, "forward_onchip256", (trellis256_kernel<1, double>), grid, block, lds, (const double*)b,
-                  md.expA.as<double>(), md.logA.as<double>(), pi, d_lens, (double*)out, loglik, U, T, N);
+                  md.expA.as<double>(), md.logA.as<double>(), pi, d_lens, (double*)out, loglik, U, T, N, ctx->nan_flag.as<unsigned>() + 3);
     else if (dtype == LNASR_F32)
         LN_LAUNCH(ctx, "backward_onchip256_f32", (trellis256_kernel<2, float>), grid, block, lds, (const float*)b,
-                  md.expAT.as<double>(), md.logAT.as<double>(), pi, d_lens, (float*)out, (double*)nullptr, U, T, N);
+                  md.expAT.as<double>(), md.logAT.as<double>(), pi, d_lens, (float*)out, (double*)nullptr, U, T, N, ctx->nan_flag.as<unsigned>() + 3);
     else
         LN_LAUNCH(ctx, "backward_onchip256", (trellis256_kernel<2, double>), grid, block, lds, (const double*)b,
-                  md.expAT.as<double>(), md.logAT.as<double>(), pi, d_lens, (double*)out, (double*)nullptr, U, T, N);
+                  md.expAT.as<double>(), md.logAT.as<double>(), pi, d_lens, (double*)out, (double*)nullptr, U, T, N, ctx->nan_flag.as<unsigned>() + 3);
     return 0;
 }
 

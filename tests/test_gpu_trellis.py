@@ -709,15 +709,16 @@ def test_chain_shortened_forward_backward_at_any_emission_size(scale, synth, ora
         assert_close(ll[u], oracle.loglik(ra), 1e-12)
 
 
-@pytest.mark.parametrize("U", [3, 600])
-def test_emission_levels_that_jump_stay_in_the_linear_domain(U, synth, oracle, ctx):
+@pytest.mark.parametrize("N,U", [(128, 3), (128, 600), (32, 5), (32, 600), (96, 300), (200, 4), (300, 3), (300, 40), (1100, 2)])
+def test_emission_levels_that_jump_stay_in_the_linear_domain(N, U, synth, oracle, ctx):
     """Data a model does not fit (round 5, tools/mismatch.py): the row maximum of b around -2200 nats, jumping by +-800 from
     frame to frame.  The shift of a linear-domain row used to be the lagged log-domain maximum alone, every column of every
     frame then left the exponent range and was redone in the exact form -- right, and 65 times slower.  With the level of the
-    emission row in the shift NO column does (lnasr_debug_fallback_columns counts them; both batch tiers); a model with an
-    unreachable state still takes the exact form for that state's column, which shows that the counter counts."""
-    N, T = 128, 50
-    rng = np.random.default_rng(U)
+    emission row in the shift NO column does (lnasr_debug_fallback_columns counts them; every kernel family of the scaled
+    recursion and both batch tiers); a model with an unreachable state still takes the exact form for that state's column,
+    which shows that the counter counts."""
+    T = 50
+    rng = np.random.default_rng(U + N)
     d = synth.synth_discrete(N, 4, 8, seed=9)
     ctx.upload_hmm(d["A"], d["pi"])
     level = -2200.0 + 800.0 * rng.standard_normal((U, T, 1))
