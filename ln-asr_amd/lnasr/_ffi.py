@@ -414,6 +414,21 @@ class Context:
         self.model_shape = (N,)
         self._model_fp = fp
 
+    def upload_hmm_device(self, A, pi, token=None):
+        """The same upload from DeviceArrays (the A and pi an on-device M-step left in HBM: lnasr.hmm.HMM.train): device to
+        device, no fingerprint -- nobody outside can have edited these arrays; `token` is recorded as what the context holds."""
+        for x in (A, pi):
+            if not isinstance(x, DeviceArray) or x.ctx is not self or not x.ptr or x.dtype != np.float64:
+                raise LnasrError("upload_hmm_device takes float64 DeviceArrays of this context")
+        N = A.shape[0]
+        if A.shape != (N, N) or pi.shape != (N,):
+            raise ValueError("A must be [N,N] and pi [N]; got %s, %s" % (A.shape, pi.shape))
+        self.model_owner = None
+        self._model_fp = None
+        check(lib().lnasr_hmm_upload(self.handle, N, A.ptr, pi.ptr))
+        self.model_shape = (N,)
+        self._model_fp = token
+
     def upload_gmmhmm(self, A, pi, w, mu, sigma, diag=False, force_full=False, owner=None):
         """sigma: [N,M,D,D] (diag=False) or [N,M,D] (diag=True).  owner: id of the model object these parameters
         belong to (recorded as self.model_owner: the mirror classes speculate only on a model they uploaded themselves)."""
@@ -501,8 +516,8 @@ class Context:
         when its shape and dtype fit (saves an allocation per call)."""
         logB = _in(logB, np.float64)
         obs = _in(obs, np.int32)
-        if obs.ndim == 1:
-            obs = obs.reshape(1, -1)
+        if len(obs.shape) == 1:
+            obs = obs.view((1, obs.shape[0])) if isinstance(obs, DeviceArray) else obs.reshape(1, -1)
         U, T = obs.shape
         N, K = logB.shape
         code = dtype_code(precision)
@@ -587,21 +602,29 @@ class Context:
         check(lib().lnasr_decode(self.handle, _ptr(obs), U, T, _ptr(self._lens(lens, U)), _ptr(path), _ptr(score)))
         return (path, score) if (want_score or score_out is not None) else path
 
-    def forward(self, b, want_alpha=True, want_loglik=True, lens=None, host_out=False):
+    def forward(self, b, want_alpha=True, want_loglik=True, lens=None, host_out=False, alpha_out=None):
+        """alpha_out (and beta_out / xi_out / gamma_out below): a DeviceArray to write into when shape and dtype fit."""
         code = dtype_code(b.dtype)
         b = _in(b, np_dtype(code))
         U, T, N = b.shape
         dev = isinstance(b, DeviceArray) and not host_out
-        alpha = self._out(dev, (U, T, N), np_dtype(code)) if want_alpha else None
+        alpha = None
+        if want_alpha:
+            alpha = self._reuse(alpha_out, (U, T, N), np_dtype(code)) if dev else None
+            if alpha is None:
+                alpha = self._out(dev, (U, T, N), np_dtype(code))
         ll = self._out(dev, (U,), np.float64) if want_loglik else None
         check(lib().lnasr_forward(self.handle, _ptr(b), U, T, _ptr(self._lens(lens, U)), code, _ptr(alpha), _ptr(ll)))
         return alpha, ll
 
-    def backward(self, b, lens=None, host_out=False):
+    def backward(self, b, lens=None, host_out=False, beta_out=None):
         code = dtype_code(b.dtype)
         b = _in(b, np_dtype(code))
         U, T, N = b.shape
-        beta = self._out(isinstance(b, DeviceArray) and not host_out, (U, T, N), np_dtype(code))
+        dev = isinstance(b, DeviceArray) and not host_out
+        beta = self._reuse(beta_out, (U, T, N), np_dtype(code)) if dev else None
+        if beta is None:
+            beta = self._out(dev, (U, T, N), np_dtype(code))
         check(lib().lnasr_backward(self.handle, _ptr(b), U, T, _ptr(self._lens(lens, U)), code, _ptr(beta)))
         return beta
 
@@ -615,27 +638,37 @@ class Context:
                                       _ptr(ll)))
         return ll
 
-    def baumwelch(self, b, alpha, beta, want_xi=True, lens=None, host_out=False):
+    def baumwelch(self, b, alpha, beta, want_xi=True, lens=None, host_out=False, xi_out=None, gamma_out=None):
         code = dtype_code(b.dtype)
         dt = np_dtype(code)
         b, alpha, beta = _in(b, dt), _in(alpha, dt), _in(beta, dt)
         U, T, N = b.shape
         dev = isinstance(b, DeviceArray) and not host_out
-        xi = self._out(dev, (U, T, N, N), dt) if want_xi else None
-        gamma = self._out(dev, (U, T, N), dt)
+        xi = None
+        if want_xi:
+            xi = self._reuse(xi_out, (U, T, N, N), dt) if dev else None
+            if xi is None:
+                xi = self._out(dev, (U, T, N, N), dt)
+        gamma = self._reuse(gamma_out, (U, T, N), dt) if dev else None
+        if gamma is None:
+            gamma = self._out(dev, (U, T, N), dt)
         check(lib().lnasr_baumwelch(self.handle, _ptr(b), _ptr(alpha), _ptr(beta), U, T, _ptr(self._lens(lens, U)),
                                     code, _ptr(xi), _ptr(gamma)))
         return xi, gamma
 
-    def estimate_discrete(self, obs, K, xi, gamma):
+    def estimate_discrete(self, obs, K, xi, gamma, device_out=False, out=None):
+        """device_out: the new A, B, pi stay in HBM as DeviceArrays (`out`: a dict of DeviceArrays to write into where shape
+        and dtype fit)."""
         code = dtype_code(gamma.dtype)
         dt = np_dtype(code)
-        obs = np.ascontiguousarray(obs, dtype=np.int32)
+        obs = _in(obs, np.int32)
         xi, gamma = _in(xi, dt), _in(gamma, dt)
         T, N = gamma.shape
-        A = np.empty((N, N), dt)
-        B = np.empty((N, K), dt)
-        pi = np.empty(N, dt)
+        res = {}
+        for k, shp in (("A", (N, N)), ("B", (N, K)), ("pi", (N,))):
+            buf = self._reuse((out or {}).get(k), shp, dt) if device_out else None
+            res[k] = buf if buf is not None else self._out(device_out, shp, dt)
+        A, B, pi = res["A"], res["B"], res["pi"]
         check(lib().lnasr_estimate_discrete(self.handle, _ptr(obs), T, N, K, code, _ptr(xi), _ptr(gamma), _ptr(A),
                                             _ptr(B), _ptr(pi)))
         return {"A": A, "B": B, "pi": pi}

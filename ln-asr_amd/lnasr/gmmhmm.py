@@ -13,19 +13,11 @@ diagonal `[N,M,D]` (extension).
 Batch extras (not in the reference): `upload()`, `decode_batch`, `calc_prob_batch`,
 `accumulate` / `apply_stats` (multi-utterance Baum-Welch, statistics all-reducible over RCCL).
 """
-import itertools
 
 import numpy as np
 
 from . import _ffi
-from .hmm import HMM, _save, _load, _log_normalised, _log_uniform, _report_iteration
-
-
-def _same(x):
-    return x
-
-
-_SERIAL = itertools.count(1)          # one number per device-resident parameter set, process-wide (never reused)
+from .hmm import HMM, _SERIAL, _save, _load, _log_normalised, _log_uniform, _report_iteration
 
 
 class GMMHMM(HMM):
@@ -51,19 +43,6 @@ class GMMHMM(HMM):
     w = property(lambda self: self._host_get("w"), lambda self, value: self._host_set("w", value))
     mu = property(lambda self: self._host_get("mu"), lambda self, value: self._host_set("mu", value))
     si = property(lambda self: self._host_get("si"), lambda self, value: self._host_set("si", value))
-
-    def _keep_param(self, name, dev):
-        """A parameter the device produced: resident until somebody reads the attribute; the array it replaces is kept as
-        the output buffer of the next M-step (two buffers per parameter, no allocation per iteration)."""
-        res = self.__dict__.setdefault("_resident", {})
-        spare = self.__dict__.setdefault("_spare", {})
-        old = res.pop(name, None)
-        if old is not None and old[0] is not dev:
-            spare[name] = old[0]
-        elif spare.get(name) is dev:
-            spare.pop(name)
-        res[name] = (dev, _same)
-        self.__dict__.setdefault("_host", {}).pop(name, None)
 
     def _upload_gmm(self, force_full=False):
         """All parameters -> device (per call on the reference API; unchanged parameters are recognised by their
@@ -201,13 +180,6 @@ class GMMHMM(HMM):
         if stats is not None:                          # stopped on eps right after an E-step: the state calc_prob leaves
             self._map_b(d_obs.view(obs.shape))
         d_obs.free()
-
-    def _reuse_buffer(self, name, shape, dtype=np.float64):
-        buf = self.__dict__.get(name)
-        if buf is None or buf.ctx is not self.ctx or not buf.ptr or buf.shape != tuple(shape) or buf.dtype != np.dtype(dtype):
-            buf = self.ctx.empty(shape, dtype)
-            self.__dict__[name] = buf
-        return buf
 
     def _updatemodel(self, model):
         self._replaced = True

@@ -16,12 +16,20 @@ Extras (keyword-only / new methods, not in the reference): `ctx=` selects the GP
 `decode_batch` / `calc_prob_batch` take `[U, T]` symbol batches.
 """
 import contextlib
+import itertools
 from typing import Tuple
 
 import numpy as np
 
 from . import _ffi
 from .utils import lse
+
+
+def _same(x):
+    return x
+
+
+_SERIAL = itertools.count(1)          # one number per device-resident parameter set, process-wide (never reused)
 
 
 class HMM:
@@ -45,9 +53,19 @@ class HMM:
 
     def _upload(self):
         """Transition model -> device.  Checked per call (the reference lets callers mutate A / pi in place between
-        calls); the device keeps what it has when the fingerprint is unchanged."""
-        if not self._params_current():
-            self.ctx.upload_hmm(self.A, self.pi)
+        calls); the device keeps what it has when the fingerprint is unchanged.  A and pi an on-device M-step left in HBM
+        (`train`) are installed device to device, unchecked: nobody outside this object has seen them."""
+        if self._params_current():
+            return
+        ctx = self.ctx
+        res = self.__dict__.get("_resident", {})
+        if "A" in res or "pi" in res:
+            if all(k in res and res[k][0].ctx is ctx and res[k][0].ptr for k in ("A", "pi")):
+                token = ("dev-hmm", self._dev_serial)
+                if ctx._model_fp != token:
+                    ctx.upload_hmm_device(res["A"][0], res["pi"][0], token=token)
+                return
+        ctx.upload_hmm(self.A, self.pi)                    # (reading a resident one makes it a host array)
 
     @contextlib.contextmanager
     def _one_check(self, enabled):
@@ -109,6 +127,35 @@ class HMM:
     b = property(lambda self: self._host_get("b"), lambda self, value: self._host_set("b", value),
                  doc="emission log-probabilities [N,T] of the last _map_b (hmm.py:58-61)")
 
+    # A, B, pi are numpy arrays as in the reference -- except right after the on-device M-step of `train`, which leaves the
+    # NEW parameters in HBM for the next iteration.  Same mechanism as `b`: reading one copies it to a numpy array, and from
+    # then on -- or when the caller assigns an array -- the host array is the parameter (it may be edited in place) and goes
+    # through the fingerprinted upload again.
+    _PARAMS = ("A", "B", "pi")
+    A = property(lambda self: self._host_get("A"), lambda self, value: self._host_set("A", value))
+    B = property(lambda self: self._host_get("B"), lambda self, value: self._host_set("B", value))
+    pi = property(lambda self: self._host_get("pi"), lambda self, value: self._host_set("pi", value))
+
+    def _keep_param(self, name, dev):
+        """A parameter the device produced: resident until somebody reads the attribute; the array it replaces is kept as
+        the output buffer of the next M-step (two buffers per parameter, no allocation per iteration)."""
+        res = self.__dict__.setdefault("_resident", {})
+        spare = self.__dict__.setdefault("_spare", {})
+        old = res.pop(name, None)
+        if old is not None and old[0] is not dev:
+            spare[name] = old[0]
+        elif spare.get(name) is dev:
+            spare.pop(name)
+        res[name] = (dev, _same)
+        self.__dict__.setdefault("_host", {}).pop(name, None)
+
+    def _reuse_buffer(self, name, shape, dtype=np.float64):
+        buf = self.__dict__.get(name)
+        if buf is None or buf.ctx is not self.ctx or not buf.ptr or buf.shape != tuple(shape) or buf.dtype != np.dtype(dtype):
+            buf = self.ctx.empty(shape, dtype)
+            self.__dict__[name] = buf
+        return buf
+
     def _b_dev(self):
         """The emissions as the kernels take them, frame-major [1,T,N]: the array _map_b left in HBM, or the host
         array (the caller's, or one already read through `self.b`) in the storage dtype."""
@@ -139,6 +186,9 @@ class HMM:
     def _B_resident(self):
         """The emission table in HBM, sent again only when its bytes changed (scripts/seg/seg.py's B is [4, 65536]: 2 MB per
         `decode` otherwise; the check is the same fingerprint the transition model gets)."""
+        res = self.__dict__.get("_resident", {})
+        if "B" in res and res["B"][0].ctx is self.ctx and res["B"][0].ptr:
+            return res["B"][0]                              # the table the M-step of `train` left there
         B = np.asarray(self.B)
         fp = self.ctx._fingerprint("B", (B,))
         held = self.__dict__.get("_B_dev")
@@ -185,9 +235,12 @@ class HMM:
         return self.ctx.estimate_discrete(np.asarray(obs), self.m, np.asarray(xi, dtype=dt), np.asarray(gamma, dtype=dt))
 
     def _updatemodel(self, model: dict):
-        self.A = model["A"]
-        self.B = model["B"]
-        self.pi = model["pi"]
+        for k in ("A", "B", "pi"):
+            if isinstance(model[k], _ffi.DeviceArray):
+                self._keep_param(k, model[k])
+            else:
+                setattr(self, k, model[k])
+        self._dev_serial = next(_SERIAL)
 
     def reset(self, init_type):
         """'uniform' or 'random' initial parameters; anything else is a silent no-op (hmm.py:233-250).
@@ -267,6 +320,8 @@ class HMM:
         through the overridable methods in the reference's order, so subclasses that replace one of them keep working."""
         ours = self._ours(*self._REF_STEPS)
         if ours and type(self)._estimate is HMM._estimate:
+            if self.precision in (np.double, np.float64):
+                return self._train_fused(obs, iters, eps, verbose)
             return self._train_resident(obs, iters, eps, verbose)
         for k in range(iters):
             with self._one_check(ours):
@@ -279,6 +334,42 @@ class HMM:
             after = self.calc_prob(obs)
             if _report_iteration(k, before, after, verbose) < eps:
                 break
+
+    def _train_fused(self, obs, iters, eps, verbose):
+        """float64, no step overridden: the whole loop in HBM.  The observations go up once; alpha, beta, xi [T,N,N], gamma and
+        the M-step's new A, B, pi stay there (the parameters are installed as the next model device to device and become numpy
+        arrays when somebody reads the attributes); the buffers are allocated once.  Per iteration ONE row crosses PCIe:
+        alpha[T-1], for the reference's `lse(alpha[-1])`.  And L(lambda_new | O) of iteration k is L(lambda | O) of
+        iteration k + 1 -- the reference runs that forward pass twice over the same model (`calc_prob` at hmm.py:304, then
+        `_forward` at :295), here it runs once.  `self.b` ends as the reference's closing `calc_prob` leaves it: the final
+        model's emissions.  test/hmm-test.py's 48 iterations: 0.65 -> 0.3 ms each."""
+        ctx = self.ctx
+        obs_i = np.ascontiguousarray(obs, dtype=np.int32)
+        T, N = obs_i.shape[0], self.n
+        d_obs = ctx.to_device(obs_i[None])
+        buf = {k: self._reuse_buffer("_train_" + k, shp)
+               for k, shp in (("alpha", (1, T, N)), ("beta", (1, T, N)), ("xi", (1, T, N, N)), ("gamma", (1, T, N)))}
+
+        def forward_pass():                                  # `_map_b` + `_forward` of the current model -> lse(alpha[-1])
+            self._upload()
+            b = ctx.discrete_map_b(self._B_resident(), d_obs, self.precision, device_out=True, b_out=self._device_buffer("b"))
+            self._keep("b", b, lambda h: h[0].T)
+            ctx.forward(b, want_alpha=True, want_loglik=False, alpha_out=buf["alpha"])
+            return b, lse(buf["alpha"].rows_to_host(T - 1, 1, N)[0])
+
+        b, before = forward_pass()
+        for k in range(iters):
+            ctx.backward(b, beta_out=buf["beta"])
+            ctx.baumwelch(b, buf["alpha"], buf["beta"], xi_out=buf["xi"], gamma_out=buf["gamma"])
+            spare = self.__dict__.get("_spare", {})
+            self._updatemodel(ctx.estimate_discrete(d_obs.view((T,)), self.m, buf["xi"].view((T, N, N)),
+                                                    buf["gamma"].view((T, N)), device_out=True,
+                                                    out={p: spare.get(p) for p in self._PARAMS}))
+            b, after = forward_pass()
+            if _report_iteration(k, before, after, verbose) < eps:
+                break
+            before = after
+        d_obs.free()
 
     def _train_resident(self, obs, iters, eps, verbose):
         """The same iteration with every intermediate left in HBM (taken when no step is overridden): `_map_b`, forward, backward,

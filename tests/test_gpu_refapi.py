@@ -35,7 +35,7 @@ def test_b_and_bm_read_as_golden_after_decode(golden):
         gh = GMMHMM(N, M, D, g["A"], g["pi"], g["w"], g["mu"], si)
         assert np.array_equal(gh.decode(g["obs"]), g["path"]), name
         # nothing came back but the path (the parameters the caller handed over are host arrays, as given)
-        assert set(gh._resident) == {"b", "bm"} and set(gh._host) == set(GMMHMM._PARAMS)
+        assert set(gh._resident) == {"b", "bm"} and set(gh._host) == set(GMMHMM._PARAMS) | {"B"}
         assert_close(gh.b, g["b"], 1e-12, 1e-12, msg=name + " b")
         assert_close(gh.bm, g["bm"], 1e-12, 1e-12, msg=name + " bm")
         assert gh.b.shape == g["b"].shape and gh.bm.shape == g["bm"].shape
@@ -57,7 +57,7 @@ def test_remap_false_reads_the_resident_b(golden):
     v, bt, path = gh._viterbi(g["obs"])
     xi, gamma = gh._baumwelch(g["obs"], alpha, beta)
     est = gh._estimate(g["obs"], alpha, beta, xi, gamma)
-    assert set(gh._resident) == {"b", "bm"} and set(gh._host) == set(GMMHMM._PARAMS)    # (the parameters: host arrays as given)
+    assert set(gh._resident) == {"b", "bm"} and set(gh._host) == set(GMMHMM._PARAMS) | {"B"}    # (the parameters: host arrays as given)
     assert_close(alpha, g["alpha"], 1e-12), assert_close(beta, g["beta"], 1e-12)
     assert np.array_equal(path, g["path"]) and np.array_equal(bt, g["bt"])
     assert_close(v, g["v"], 1e-12), assert_close(xi, g["xi"], 1e-11, 1e-11), assert_close(gamma, g["gamma"], 1e-11, 1e-11)
@@ -267,3 +267,51 @@ def test_train_stops_on_eps_with_the_state_calc_prob_leaves(synth):
     b_state, bm_state = a.b.copy(), a.bm.copy()
     a._map_b(obs)
     assert np.array_equal(a.b, b_state) and np.array_equal(a.bm, bm_state)
+
+
+def test_discrete_train_keeps_the_loop_in_hbm(golden, synth):
+    """HMM.train on the fused route (round 5): observations up once, alpha / beta / xi / gamma and the M-step's A, B, pi stay in
+    HBM, L(lambda_new | O) comes from the forward pass the next iteration needs anyway.  Pinned: the printed lines and the
+    parameters are the imported reference's (hmm_train_4x5), a subclass that overrides a step walks the reference's call
+    sequence to the same lines and the same state, and the resident parameters behave as arrays the moment they are read."""
+    import contextlib
+    import io
+    from lnasr.hmm import HMM
+    from lnasr import _ffi
+    g = golden("hmm_train_4x5")
+    h = HMM(4, 5, g["A0"].copy(), g["B0"].copy(), g["pi0"].copy())
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        h.train(g["obs"], 3, 1e-4, True)
+    assert buf.getvalue() == str(g["train3_log"])
+    assert set(HMM._PARAMS) <= set(h._resident) and all(isinstance(h._resident[k][0], _ffi.DeviceArray) for k in HMM._PARAMS)
+    p_res = h.calc_prob(g["obs"])                       # scoring and decoding go on from the resident model
+    path_res = h.decode(g["obs"])
+    assert set(HMM._PARAMS) <= set(h._resident)
+    assert_close(h.A, g["train3_A"], 1e-10)             # reading makes them numpy arrays: the reference's values
+    for k in HMM._PARAMS:
+        assert isinstance(getattr(h, k), np.ndarray) and k not in h._resident
+    assert h.calc_prob(g["obs"]) == p_res and np.array_equal(h.decode(g["obs"]), path_res)   # the checked (host) road
+    h.B[:, 0] -= 0.3                                    # an in-place edit of a parameter that was read reaches the device
+    assert h.calc_prob(g["obs"]) != p_res
+    with contextlib.redirect_stdout(io.StringIO()):
+        h.train(g["obs"], 2, 0.0, True)                 # starts from the edited host arrays, ends resident again
+    assert set(HMM._PARAMS) <= set(h._resident)
+
+    class Stepwise(HMM):                                # an overridden step: the reference's call sequence
+        def _baumwelch(self, *a, **k):
+            return super()._baumwelch(*a, **k)
+    d = synth.synth_discrete(6, 9, 300, seed=31)
+    runs = []
+    for cls in (HMM, Stepwise):
+        m = cls(6, 9, d["A"].copy(), d["B"].copy(), d["pi"].copy())
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            m.train(d["obs"], 300, 1e-2, True)
+        runs.append((buf.getvalue(), m))
+    (log_a, a), (log_b, b) = runs
+    assert "A" in a._resident and "A" not in b.__dict__.get("_resident", {})
+    assert log_a == log_b and 1 < log_a.count("Iter:") < 300                 # stopped on eps, same iteration, same lines
+    assert_close(a.b, b.b, 1e-9, 1e-9)                                        # the final model's emissions, as calc_prob leaves them
+    for k in HMM._PARAMS:
+        assert_close(getattr(a, k), getattr(b, k), 1e-8, 1e-10, msg=k)
