@@ -100,6 +100,9 @@ struct Model {
     // fp32 matrix-core pass (f32stats.hip): float coefficient fragments, packed on first use after an upload
     DevBuf wpack32;
     unsigned long upload_serial = 0, wpack32_for = ~0ul;
+    // integer matrix-core bank (gmm_i8.hip): digit planes of the coefficients, row scales, component constants
+    DevBuf i8_g, i8_pow2g, i8_wq, i8_const;
+    int i8_NG = 0;               // state groups packed (0: none)
     void release();
 };
 
@@ -115,11 +118,12 @@ struct Switches {
     bool no_mfma = false, no_pad = false, no_tinyvit = false, no_regvit = false, no_regfwd = false, no_colfwd = false,
          no_t256 = false, no_framepar = false, no_stream = false, no_ldsbt = false, no_mfma_stats = false,
          no_fft512 = false, no_pipeline = false, f32_generic = false, no_f32_stats = false, no_pinned_ring = false,
-         no_tinyfwd = false, no_reglu = false, no_tilepack = false, no_latfwd = false;
+         no_tinyfwd = false, no_reglu = false, no_tilepack = false, no_latfwd = false, no_i8emit = false;
     char vit = 0;                 // LNASR_VIT: first character, 0 = unset
     int framepar_maxu = -1;       // LNASR_FRAMEPAR_MAXU, -1 = unset (measured rule)
     int chase_maxu = -1;          // LNASR_CHASE_MAXU: back-pointer chase instead of the arg-max back-trace up to this batch size
     int fwd_lat_maxu = -1;        // LNASR_FWD_LAT_MAXU: the chain-shortened one-utterance forward / backward (fwdbwd_lat4) up to this batch size
+    long i8_min_frames = -1;      // LNASR_I8_MIN_FRAMES: the integer matrix-core bank from this many frames per launch (-1: measured rule)
     int fwd_one_maxu = -1;        // LNASR_FWD_ONE_MAXU: one utterance per block in the column-owned forward / backward up to this batch size
     double kappa_max = kKappaMax; // LNASR_KAPPA_MAX
     int h2d_threads = 4;          // LNASR_H2D_THREADS: host threads filling the pinned staging ring
@@ -159,6 +163,7 @@ struct lnasr_ctx {
     lnasr::DevBuf ws_pad;                                  // bm of a padded model before compaction
     lnasr::DevBuf ws_bp;                                   // byte back-pointers of the tiny-model Viterbi (N <= 16)
     lnasr::DevBuf ws_lvl, ws_lvl2;                         // emission-row levels of the N > 256 forward / backward kernels (bign.hip)
+    lnasr::DevBuf ws_fs;                                   // digit planes of the features (gmm_i8.hip)
     lnasr::DevBuf ws_btb;                                  // byte back-pointer rows of the small-batch back-trace (backtrace.hip)
     // non-finite data (nanfix.hip): a device word the hot kernels set to the running call's epoch when they meet a NaN or
     // an infinity, and the per-utterance slots of the scan that follows
@@ -257,6 +262,10 @@ int mix_stats_device_f32(lnasr_ctx* ctx, const double* obs, const double* alpha,
                          const float* q32, const double* c1, const int32_t* d_lens, int U, int T, double* mix,
                          double* mix_x, double* mix_xx, int phase = kMixAll);
 int emit_device(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, void* bm);
+// gmm_i8.hip: the diagonal bank on the integer matrix cores (exact sliced arithmetic)
+bool i8_emit_shape_ok(int Nv, int Mv, int D);
+int pack_i8_model(lnasr_ctx* ctx, const double* mu_s, const double* iv_s, const double* gc_s, const double* lw_s, int Nv);
+int emit_diag_i8_device(lnasr_ctx* ctx, const double* obs, long F, double* b);
 // emit_device without the pass over non-finite frames; *scanned: the kernel tested the features it staged and raised
 // ctx->nan_flag itself (emit_batch runs the kernels chunk by chunk and the pass once)
 int emit_device_raw(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, void* bm, bool* scanned,

@@ -49,7 +49,7 @@ void DevBuf::release() {
 }
 
 void Model::release() {
-    DevBuf* all[] = {&logA, &logAT, &logpi, &expA, &expAT, &logw, &mu, &ivar, &var, &prec, &gconst, &sigma_raw, &wpack, &wpack_nw, &wdirect, &pad_mu, &pad_ivar, &pad_gconst, &pad_logw, &pad_prec, &wfull, &wfull_nw, &pairtab, &flags, &centre, &mu_c, &wpack32, &lu_bad};
+    DevBuf* all[] = {&logA, &logAT, &logpi, &expA, &expAT, &logw, &mu, &ivar, &var, &prec, &gconst, &sigma_raw, &wpack, &wpack_nw, &wdirect, &pad_mu, &pad_ivar, &pad_gconst, &pad_logw, &pad_prec, &wfull, &wfull_nw, &pairtab, &flags, &centre, &mu_c, &wpack32, &lu_bad, &i8_g, &i8_pow2g, &i8_wq, &i8_const};
     for (DevBuf* b : all) b->release();
     has_hmm = has_gmm = false;
 }
@@ -68,6 +68,8 @@ static void load_switches(Switches& s) {
     s.no_reglu = on("LNASR_NO_REGLU");
     s.no_tilepack = on("LNASR_NO_TILEPACK");
     s.no_latfwd = on("LNASR_NO_LATFWD");
+    s.no_i8emit = on("LNASR_NO_I8EMIT");
+    if (const char* v = getenv("LNASR_I8_MIN_FRAMES")) s.i8_min_frames = atol(v);
     s.no_regvit = on("LNASR_NO_REGVIT");
     s.no_regfwd = on("LNASR_NO_REGFWD");
     s.no_colfwd = on("LNASR_NO_COLFWD");
@@ -297,7 +299,7 @@ void lnasr_ctx_destroy(lnasr_ctx* ctx) {
     ctx->model.release();
     DevBuf* all[] = {&ctx->ws_in, &ctx->ws_in2, &ctx->ws_in3, &ctx->ws_in4, &ctx->ws_in5, &ctx->ws_out, &ctx->ws_out2,
                      &ctx->ws_out3, &ctx->ws_b, &ctx->ws_bm, &ctx->ws_v, &ctx->ws_alpha, &ctx->ws_beta,
-                     &ctx->ws_misc, &ctx->ws_misc2, &ctx->ws_lens, &ctx->ws_stats, &ctx->ws_p, &ctx->ws_q, &ctx->ws_raw, &ctx->ws_w1, &ctx->ws_w2, &ctx->ws_w3, &ctx->ws_pad, &ctx->ws_bp, &ctx->ws_btb, &ctx->ws_lvl, &ctx->ws_lvl2, &ctx->mfcc_const, &ctx->nan_flag, &ctx->nan_slots};
+                     &ctx->ws_misc, &ctx->ws_misc2, &ctx->ws_lens, &ctx->ws_stats, &ctx->ws_p, &ctx->ws_q, &ctx->ws_raw, &ctx->ws_w1, &ctx->ws_w2, &ctx->ws_w3, &ctx->ws_pad, &ctx->ws_bp, &ctx->ws_btb, &ctx->ws_fs, &ctx->ws_lvl, &ctx->ws_lvl2, &ctx->mfcc_const, &ctx->nan_flag, &ctx->nan_slots};
     for (DevBuf* b : all) b->release();
     for (auto& r : ctx->prof_recs) {
         (void)hipEventDestroy(r.e0);

@@ -1,0 +1,512 @@
+// The diagonal GMM bank with its GEMM on the INTEGER matrix cores (gmm.py:46-67 / gmmhmm.py:46-67 over a batch).
+//
+// MI355X halves the fp64 matrix rate of its predecessor (78.6 TFLOP/s = the fp64 vector rate, and an fp64 MFMA blocks every
+// vector instruction of its SIMD, gmm.hip) and doubles the int8 rate (v_mfma_i32_16x16x64_i8: 2048 int-ops per cycle and
+// SIMD, 64 x the fp64 rate).  The quadratic part of the component log-density,
+//   Q[c, f] = sum_k W[k, c] phi_k(x_f),   phi = (x_d^2 | x_d),  W = (-1/2 / var | mu / var),   K = 2 D <= 80,
+// is therefore evaluated EXACTLY in integers (an Ozaki-type splitting of both operands):
+//   * both operands are brought to a common binary scale per GEMM row / column -- W[k, :] by 2^-g_k (g_k from the largest
+//     coefficient of row k, folded into phi_k as 2^g_k), the features of frame f by 2^-e_f (e_f from its largest scaled
+//     feature) -- so that every entry is a fixed-point number |v| <= 0.498, and written in SEVEN balanced base-256 digits
+//     v = sum_i s_i 256^-(i+1), s_i in [-128, 127] (56 bits below the row's / column's largest entry; what is dropped is
+//     <= 2^-57);
+//   * the digit planes are int8 matrices; the products of planes i and j with i + j = d all carry the weight 256^-(d+2) and
+//     are summed by the matrix core in ONE int32 accumulator per d (|acc_d| <= 7 * 80 * 128^2 < 2^24: exact); planes with
+//     i + j > 6 (weight <= 256^-9 = 2^-72 against a sum of size 1) are not formed: 28 plane products, K = 80 each;
+//   * Q = 2^e_f sum_d acc_d 256^-(d+2): the diagonals are joined pairwise in int32 (acc_2n * 256 + acc_2n+1 < 2^31 for
+//     2n <= 4), converted and summed in fp64, three fused multiply-adds.  One short rounding sequence at the END of an exact
+//     sum, where the fp64 GEMM of gmm.hip rounds after each of its 80 terms -- against a long-double evaluation the sliced
+//     result is the more accurate of the two (tests/test_gpu_i8.py).
+// The constant of the component (log w + gconst - 1/2 sum mu^2 / var) is added in fp64, then the M-way log-sum-exp of gmm.hip.
+//
+// Work per 16-component x 16-frame tile: 38 integer MFMAs (28 plane pairs x K = 64, plus the K = 64..79 remainders of up to
+// four pairs of one diagonal packed into one instruction: 10) at 16.7 cycles against 20 fp64 MFMAs at 64.  The integer
+// instruction does not hide vector work either (measured, tools/ubench/i8coexec, i8rate: beside a saturated integer matrix
+// pipe an fp64 vector instruction costs 2.9 of its 4 cycles), so the kernel is bound by ISSUE: 76 matrix + ~235 vector
+// instructions per wave and tile; what the design wins is the matrix share, 1270 cycles per wave-tile instead of 2560.
+//
+// Kernels: i8_row_scale_kernel / pack_wslice_kernel (once per model), slice_features_kernel (once per batch: digit planes of
+// the features, [tile][plane][k-chunk][frame][16 B], 568 B per frame), emit_diag_i8 (the bank).
+#include <cstdio>
+#include <vector>
+
+#include "common.h"
+#include "devmath.h"
+
+namespace lnasr {
+namespace {
+
+typedef int int4_t __attribute__((ext_vector_type(4)));
+
+constexpr int kS = 7;                                 // digit planes per operand (balanced base-256 digits)
+constexpr int kChunks = 5;                            // K = 80 in chunks of 16
+constexpr int kPlaneI4 = kChunks * 16;                // int4 (16-byte) units per plane of a 16-frame tile: [chunk][frame]
+constexpr int kTileI4 = kS * kPlaneI4 + 8;            // + 16 frame scales (doubles) = 568 int4 = 9,088 B
+constexpr int kSlots = kS + 2;                        // stationary A quads per tile: the planes' K = 0..63, two packed remainders
+constexpr int kZeroI4 = kTileI4;                      // a chunk of zeros behind the tile in the LDS image
+constexpr int kLdsI4 = kTileI4 + 16;
+
+// |v| <= 0.498 -> s[0..6], v = sum s_i 256^-(i+1) + r, |r| <= 2^-57; s_0 in [-127, 127], the others in [-128, 127]
+__device__ __forceinline__ void split_digits(double v, int s[kS]) {
+    const double a = v * 4294967296.0;                // 2^32
+    const double hd = __builtin_rint(a);
+    const double ld = __builtin_rint((a - hd) * 16777216.0);   // 2^24; a - hd is exact
+    int hi = (int)hd, lo = (int)ld;
+#pragma unroll
+    for (int i = kS - 1; i >= 4; --i) {
+        const int d = ((lo + 128) & 255) - 128;
+        s[i] = d;
+        lo = (lo - d) >> 8;
+    }
+    hi += lo;
+#pragma unroll
+    for (int i = 3; i >= 1; --i) {
+        const int d = ((hi + 128) & 255) - 128;
+        s[i] = d;
+        hi = (hi - d) >> 8;
+    }
+    s[0] = hi;
+}
+
+// exponent e with m 2^-e <= 0.498 (the top digit stays within an int8), m > 0 finite
+__device__ __forceinline__ int scale_exponent(double m) {
+    int e = ilogb(m) + 2;
+    if (ldexp(m, -e) > 0.498) ++e;
+    return e;
+}
+
+__device__ __forceinline__ double coef_of(const double* __restrict__ mu, const double* __restrict__ ivar, size_t c, int k, int D) {
+    if (k < D) return -0.5 * ivar[c * D + k];
+    if (k < 2 * D) return mu[c * D + (k - D)] * ivar[c * D + (k - D)];
+    return 0.0;
+}
+
+// g[k] = exponent with |W[k, c]| 2^-g[k] <= 0.498 for every component (0 for an all-zero row); pow2g[k] = 2^g[k]
+__global__ void i8_row_scale_kernel(const double* __restrict__ mu, const double* __restrict__ ivar, int NM, int D,
+                                    int* __restrict__ g, double* __restrict__ pow2g) {
+    const int k = blockIdx.x;
+    __shared__ double red[256];
+    double mx = 0.0;
+    for (int c = threadIdx.x; c < NM; c += 256) mx = fmax(mx, fabs(coef_of(mu, ivar, (size_t)c, k, D)));
+    red[threadIdx.x] = mx;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int e = red[0] > 0.0 ? scale_exponent(red[0]) : 0;
+        g[k] = e;
+        pow2g[k] = ldexp(1.0, e);
+    }
+}
+
+// Digit planes of the coefficients as stationary MFMA A operands, per state pair sp, tile q (0, 1):
+//   wq[(((sp*2 + q)*9 + slot)*64 + lane)]  (16 bytes)   row r = lane & 15 <-> state 2 sp + ((r >> 2) & 1), mixture 8 (r >> 3) + 4 q + (r & 3)
+//   slot j < 7 : plane j, k = 16 (lane >> 4) + byte                   (the K = 0..63 step of a plane pair)
+//   slot 7 + p : plane (lane >> 4) + 4 p, k = 64 + byte               (the packed remainder steps; plane 7 does not exist: zeros)
+// constc[state*16 + m] = log w + gconst - 1/2 sum mu^2 / var
+__global__ void pack_wslice_kernel(const double* __restrict__ mu, const double* __restrict__ ivar,
+                                   const double* __restrict__ gconst, const double* __restrict__ logw,
+                                   const int* __restrict__ g, int4_t* __restrict__ wq, double* __restrict__ constc, int N,
+                                   int D) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)(N / 2) * 2 * kSlots * 64;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    size_t r1 = idx >> 6;
+    const int slot = (int)(r1 % kSlots);
+    r1 /= kSlots;
+    const int q = (int)(r1 & 1);
+    const int sp = (int)(r1 >> 1);
+    const int r = lane & 15, h = lane >> 4;
+    const int state = 2 * sp + ((r >> 2) & 1), mix = 8 * (r >> 3) + 4 * q + (r & 3);
+    const size_t c = (size_t)state * 16 + mix;
+    const int plane = slot < kS ? slot : h + 4 * (slot - kS);
+    const int k0 = slot < kS ? 16 * h : 64;
+    unsigned w[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int by = 0; by < 16; ++by) {
+        const int k = k0 + by;
+        int s[kS];
+        split_digits(ldexp(coef_of(mu, ivar, c, k, D), -g[k]), s);
+        int dg = 0;
+#pragma unroll
+        for (int i = 0; i < kS; ++i) dg = plane == i ? s[i] : dg;      // (plane 7 of the last remainder slot: zero)
+        w[by >> 2] |= ((unsigned)dg & 255u) << (8 * (by & 3));
+    }
+    wq[idx] = int4_t{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
+    if (slot == 0 && h == 0) {
+        double sq = 0.0;
+        for (int d = 0; d < D; ++d) {
+            const double m = mu[c * D + d];
+            sq += m * m * ivar[c * D + d];
+        }
+        constc[c] = logw[c] + gconst[c] - 0.5 * sq;
+    }
+}
+
+// Digit planes of the features.  Eight lanes per frame (five of them own a 16-wide k-chunk), 32 frames per block.
+//   Fs[tile*kTileI4 + (plane*5 + chunk)*16 + frame]  (16 bytes: k = 16 chunk + byte),   then 16 doubles: 2^(e_f - 24)
+// (NaN for a frame with a NaN / infinite feature: every density of that frame comes out NaN, as the reference's does).
+__global__ __launch_bounds__(256) void slice_features_kernel(const double* __restrict__ obs, const double* __restrict__ centre,
+                                                             const double* __restrict__ pow2g, int4_t* __restrict__ Fs,
+                                                             long F, int D, unsigned* __restrict__ nan_flag,
+                                                             unsigned nan_epoch) {
+    const int tid = threadIdx.x;
+    const long frame0 = (long)blockIdx.x * 32;
+    const long frame = frame0 + (tid >> 3);
+    const int ch = tid & 7;
+    const bool live = ch < kChunks && frame < F;
+    // the block's 32 frames are one contiguous run of obs: coalesced into the LDS, centred on the way
+    __shared__ double xs[32 * 40];
+    {
+        const long base = frame0 * D, lim = F * (long)D;
+        for (int e = tid; e < 32 * D; e += 256) {
+            const long ge = base + e;
+            xs[e] = ge < lim ? obs[ge] - centre[e % D] : 0.0;
+        }
+    }
+    __syncthreads();
+    const double* xf = xs + (tid >> 3) * D;
+    double val[16];
+    double mx = 0.0;
+    bool bad = false;
+#pragma unroll
+    for (int by = 0; by < 16; ++by) {
+        const int k = 16 * ch + by;
+        const int d = k < D ? k : k - D;
+        const double x = xf[d < D ? d : D - 1];           // (rows past 2 D and the idle lanes: any valid address, scaled by 0)
+        const double sc = (live && k < 2 * D) ? pow2g[k < 80 ? k : 79] : 0.0;
+        bad |= sc != 0.0 && !__builtin_isfinite(x);
+        const double v = (k < D ? x * x : x) * sc;
+        val[by] = sc != 0.0 ? v : 0.0;
+        mx = fmax(mx, fabs(val[by]));
+    }
+    int badi = bad ? 1 : 0;
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        mx = fmax(mx, __shfl_xor(mx, o));
+        badi |= __shfl_xor(badi, o);
+    }
+    if (!__builtin_isfinite(mx)) badi = 1;            // x^2 overflowed
+    const int ef = (mx > 0.0 && !badi) ? scale_exponent(mx) : 0;
+    const long tile = frame >> 4;
+    const int f16 = (int)(frame & 15);
+    int4_t* dst = Fs + tile * kTileI4;
+    if (ch < kChunks && (frame >> 4) <= ((F - 1) >> 4)) {         // frames past F inside the last tile: zero planes
+        // all seven digits of a value at once: t = v 2^56 as an integer; adding 0x80 at every byte position carries exactly
+        // as the digit-by-digit extraction does, and (byte ^ 0x80) is the balanced digit.  Byte 6 = plane 0 ... byte 0 = plane 6.
+        unsigned lo32[16], hi32[16];
+        const double down = badi ? 0.0 : ldexp(1.0, 32 - ef);
+#pragma unroll
+        for (int by = 0; by < 16; ++by) {
+            const double a = val[by] * down;              // v 2^32, |v| <= 0.498
+            const double hd = __builtin_rint(a);
+            const double ld = __builtin_rint((a - hd) * 16777216.0);
+            const long long t = ((long long)(int)hd << 24) + (long long)(int)ld;
+            const unsigned long long u = (unsigned long long)(t + 0x0080808080808080LL) ^ 0x0080808080808080ULL;
+            lo32[by] = (unsigned)u;
+            hi32[by] = (unsigned)(u >> 32);
+        }
+#pragma unroll
+        for (int i = 0; i < kS; ++i) {
+            const int bi = 6 - i;                         // byte of u that holds plane i
+            const unsigned sel = bi < 4 ? (unsigned)(bi | ((4 + bi) << 8) | 0x0c0c0000u)
+                                        : (unsigned)((bi - 4) | ((bi) << 8) | 0x0c0c0000u);
+            unsigned w[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const unsigned* src = bi < 4 ? lo32 : hi32;
+                const unsigned t01 = __builtin_amdgcn_perm(src[4 * m + 1], src[4 * m], sel);
+                const unsigned t23 = __builtin_amdgcn_perm(src[4 * m + 3], src[4 * m + 2], sel);
+                w[m] = __builtin_amdgcn_perm(t23, t01, 0x05040100u);
+            }
+            dst[(i * kChunks + ch) * 16 + f16] = int4_t{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
+        }
+        if (ch == 0) {
+            double* sc = reinterpret_cast<double*>(dst + kS * kPlaneI4);
+            sc[f16] = badi ? __builtin_nan("") : ldexp(1.0, ef - 24);
+        }
+    }
+    if (badi && frame < F && ch == 0) *nan_flag = nan_epoch;
+}
+
+// The bank.  Block = 8 waves, two per SIMD; wave w owns the state pair sp = 8 y + w of slab y (16 states per block): two
+// 16-component tiles, W planes in 72 registers.  Row r of tile q <-> state 2 sp + ((r >> 2) & 1), mixture 8 (r >> 3) + 4 q + (r & 3):
+// lane group g = lane >> 4 then holds, for frame lane & 15, the mixtures 8 (g >> 1) + {0..7} of state 2 sp + (g & 1) -- the M-way
+// log-sum-exp is eight values in the lane and one exchange with lane ^ 32 (v_permlane32_swap).  The block walks a range of
+// 16-frame tiles whose digit planes it copies into the LDS (double buffered); a wave reads the seven K = 0..63 fragments of a
+// tile ONCE and keeps them for all 28 plane pairs.  Diagonals go from the least significant to the most significant one
+// (d = 6, then the pairs (5, 4), (3, 2), (1, 0), each pair joined in an int32: |acc_d| 256 + |acc_d+1| < 2^31 for d <= 4),
+// each group folded into the running fp64 value while the next one is in the matrix core.  Per iteration: the planes of tile t
+// go from the LDS to registers, and BEHIND those reads the log-sum-exp of tile t - 1 runs (its values were carried over).
+template <int ABL>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void emit_diag_i8(
+    const int4_t* __restrict__ Fs, const int4_t* __restrict__ wq, const double* __restrict__ constc, double* __restrict__ b,
+    long F, int N, int GY, long ntiles, int tiles_per_block, long nchunks, unsigned long long* __restrict__ dbg) {
+    __shared__ int4_t Fl[2][kLdsI4];
+    __shared__ double ob[2][16 * 17];
+    unsigned long long ph[5] = {0, 0, 0, 0, 0}, ts = 0;
+    const unsigned long long k0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#define LN_STAMP(i)                                                \
+    if (ABL == 6) {                                                \
+        const unsigned long long now = __builtin_amdgcn_s_memtime(); \
+        ph[i] += now - ts;                                         \
+        ts = now;                                                  \
+    }
+    __shared__ double etab[kExpTabBig];
+    __shared__ double ltab[2 * kLogTab];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    exp_table_big_init(etab, tid, 512);
+    log_table_init(ltab, tid, 512);
+    if (tid < 32) Fl[tid >> 4][kZeroI4 + (tid & 15)] = int4_t{0, 0, 0, 0};
+    const long bid = blockIdx.x;
+    const int xcd = (int)(bid & 7);
+    const long bi = bid >> 3;
+    const int y = (int)(bi % GY);
+    const long chunk = (bi / GY) * 8 + xcd;
+    if (chunk >= nchunks) return;
+    const long tile0 = chunk * tiles_per_block;
+    long tile1 = tile0 + tiles_per_block;
+    if (tile1 > ntiles) tile1 = ntiles;
+    const int sp = 8 * y + w;
+    const int g = lane >> 4, col = lane & 15;
+
+    int4_t Wm[2][kS], Wl[2][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+        for (int j = 0; j < kS; ++j) Wm[q][j] = wq[(((size_t)sp * 2 + q) * kSlots + j) * 64 + lane];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) Wl[q][p] = wq[(((size_t)sp * 2 + q) * kSlots + kS + p) * 64 + lane];
+    }
+    double cst[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) cst[m] = constc[(size_t)(2 * sp + (g & 1)) * 16 + 8 * (g >> 1) + m];
+
+    int4_t pre[2];
+    auto load_tile = [&](long tile) {
+        const int4_t* src = Fs + tile * kTileI4;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int e = tid + 512 * r;
+            pre[r] = src[e < kTileI4 ? e : kTileI4 - 1];
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int e = tid + 512 * r;
+            if (e < kTileI4) Fl[buf][e] = pre[r];
+        }
+    };
+    auto flush = [&](int buf, long tile) {               // 16 frames x 16 states: 128-byte rows (waves 0-3)
+        if (tid < 256) {
+            const int f = tid >> 4, st = tid & 15;
+            const long frame = tile * 16 + f;
+            if (frame < F) b[frame * N + 16 * y + st] = ob[buf][f * 17 + st];
+        }
+    };
+
+    load_tile(tile0);
+    store_tile(0);
+    drain_vmem();
+    __syncthreads();
+
+    const int hb = g * 16 + col;
+    // max / sum of the two halves of a state's mixtures (lanes l and l ^ 32), left in both lanes
+    auto pair_max = [](double x) {
+        auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(x), false, false);
+        auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(x), false, false);
+        return vmax_f64(__hiloint2double((int)hi[0], (int)lo[0]), __hiloint2double((int)hi[1], (int)lo[1]));
+    };
+    auto pair_sum = [](double x) {
+        auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(x), false, false);
+        auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(x), false, false);
+        return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+    };
+    // log-sum-exp of the tile whose values `v` carries (this lane: frame `col`, state 2 sp + (g & 1), mixtures
+    // 8 (g >> 1) + 4 q + e; the other eight are in lane ^ 32) -> the staging row of that tile
+    double v[2][4];
+    auto lse_to = [&](double* obuf) {
+        double mx = v[0][0];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (q + e > 0) mx = vmax_f64(mx, v[q][e]);
+        mx = pair_max(mx);
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s += exp_nonpos_big2(v[q][e] - mx, etab);
+        s = pair_sum(s);
+        if (g < 2) obuf[col * 17 + 2 * w + g] = (mx == LN_NEG_INF) ? mx : mx + log_sum(s, ltab);
+    };
+
+    // the matrix phase of one tile: planes from the LDS to registers, 76 matrix instructions with the folds between them -> v
+    auto matrix_phase = [&](int buf) {
+        const int4_t* Fc = &Fl[buf][0];
+        const double scale = reinterpret_cast<const double*>(Fc + kS * kPlaneI4)[col];
+        // (reads in the order of use: diagonal d needs planes 0..d, so the matrix instructions start behind the first read)
+        int4_t fm[kS], fl[kS][2];
+#pragma unroll
+        for (int d = 0; d < kS; ++d) {
+            fm[d] = Fc[d * kPlaneI4 + hb];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {                 // K = 64..79: lane group g carries planes (d - g - 4p, g + 4p)
+                if (4 * p > d) continue;
+                const int i = d - g - 4 * p;
+                fl[d][p] = Fc[i >= 0 ? i * kPlaneI4 + 64 + col : kZeroI4 + col];
+            }
+        }
+        double r[2][4];                                   // running fp64 value of the diagonals folded so far
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            int4_t acc[2][2];
+#pragma unroll
+            for (int dd = 0; dd < 2; ++dd) {
+                const int d = 2 * n + dd;
+                if (d >= kS) continue;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) acc[dd][q] = int4_t{0, 0, 0, 0};
+#pragma unroll
+                for (int i = 0; i <= d; ++i)              // K = 0..63 of planes (i, d - i)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        acc[dd][q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Wm[q][d - i], fm[i], acc[dd][q], 0, 0, 0);
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    if (4 * p > d) continue;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        acc[dd][q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Wl[q][p], fl[d][p], acc[dd][q], 0, 0, 0);
+                }
+            }
+            // unit: the weight of diagonal 1; the pair (2n, 2n+1) sits 2^-16n below it, diagonal 6 2^-40
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const double pn = n == 3 ? (double)acc[0][q][e] : (double)(acc[0][q][e] * 256 + acc[1][q][e]);
+                    r[q][e] = n == 0 ? pn : fma(pn, n == 1 ? 0x1p-16 : (n == 2 ? 0x1p-32 : 0x1p-40), r[q][e]);
+                }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[q][e] = fma(r[q][e], scale, cst[4 * q + e]);
+    };
+
+    // Two phases per tile, the two waves of a SIMD in OPPOSITE ones: waves 0-3 run the matrix phase of tile t while waves 4-7
+    // run the log-sum-exp of tile t - 1, then the roles swap -- the vector work of one wave issues beside the matrix
+    // instructions of the other instead of both waves wanting the same unit at the same time.
+    const int half = w >> 2;
+    for (long tile = tile0; tile < tile1; ++tile) {
+        const int cur = (int)((tile - tile0) & 1);
+        const bool has_next = tile + 1 < tile1;
+        if (ABL == 6) ts = __builtin_amdgcn_s_memtime();
+        if (has_next) load_tile(tile + 1);
+        if (half == 0) matrix_phase(cur);
+        else if (tile > tile0) lse_to(&ob[cur ^ 1][0]);
+        LN_STAMP(0);
+        __syncthreads();
+        LN_STAMP(1);
+        if (half == 0) {
+            lse_to(&ob[cur][0]);
+            if (tile > tile0) flush(cur ^ 1, tile - 1);   // both halves have staged tile t - 1 by now
+        } else {
+            matrix_phase(cur);
+        }
+        if (has_next) store_tile(cur ^ 1);
+        LN_STAMP(3);
+        __syncthreads();
+        LN_STAMP(4);
+    }
+    if (tile1 > tile0) {
+        const int last = (int)((tile1 - 1 - tile0) & 1);
+        if (half == 1) lse_to(&ob[last][0]);
+        __syncthreads();
+        flush(last, tile1 - 1);
+    }
+    if (ABL == 6 && lane == 0) {
+        for (int i = 0; i < 5; ++i) dbg[((size_t)blockIdx.x * 8 + w) * 7 + i] = ph[i];
+        dbg[((size_t)blockIdx.x * 8 + w) * 7 + 5] = __builtin_amdgcn_s_memtime() - k0;
+        dbg[((size_t)blockIdx.x * 8 + w) * 7 + 6] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
+#undef LN_STAMP
+}
+
+}  // namespace
+
+bool i8_emit_shape_ok(int Nv, int Mv, int D) { return Mv == 16 && Nv % 16 == 0 && D >= 1 && 2 * D <= 80; }
+
+// once per model (after prep_diag / centre_and_kappa): digit planes of the coefficients
+int pack_i8_model(lnasr_ctx* ctx, const double* mu_s, const double* iv_s, const double* gc_s, const double* lw_s, int Nv) {
+    Model& md = ctx->model;
+    const int D = md.D;
+    const size_t NMv = (size_t)Nv * 16;
+    LN_TRY(md.i8_g.reserve(80 * 4));
+    LN_TRY(md.i8_pow2g.reserve(80 * 8));
+    LN_TRY(md.i8_wq.reserve((size_t)(Nv / 2) * 2 * kSlots * 64 * 16));
+    LN_TRY(md.i8_const.reserve(NMv * 8));
+    LN_LAUNCH(ctx, "i8_row_scale", i8_row_scale_kernel, dim3(80), dim3(256), 0, mu_s, iv_s, (int)NMv, D, md.i8_g.as<int>(),
+              md.i8_pow2g.as<double>());
+    const size_t total = (size_t)(Nv / 2) * 2 * kSlots * 64;
+    LN_LAUNCH(ctx, "pack_wslice", pack_wslice_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, mu_s, iv_s, gc_s,
+              lw_s, (const int*)md.i8_g.as<int>(), md.i8_wq.as<int4_t>(), md.i8_const.as<double>(), Nv, D);
+    md.i8_NG = Nv / 4;
+    return 0;
+}
+
+// b [F, Nv] for the (virtual, padded) states of the packed model
+int emit_diag_i8_device(lnasr_ctx* ctx, const double* obs, long F, double* b) {
+    Model& md = ctx->model;
+    const int Nv = md.i8_NG * 4, D = md.D;
+    const long ntiles = (F + 15) / 16;
+    LN_TRY(ctx->ws_fs.reserve((size_t)ntiles * kTileI4 * 16));
+    int4_t* Fs = ctx->ws_fs.as<int4_t>();
+    LN_LAUNCH(ctx, "slice_features", slice_features_kernel, dim3((unsigned)((ntiles * 16 + 31) / 32)), dim3(256), 0, obs,
+              (const double*)md.centre.as<double>(), (const double*)md.i8_pow2g.as<double>(), Fs, F, D,
+              ctx->nan_flag.as<unsigned>(), ctx->nan_epoch);
+    const int GY = Nv / 16;
+    const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+    long want_chunks = (long)cus / GY;                   // one 8-wave block per CU: two waves per SIMD
+    if (want_chunks < 8) want_chunks = 8;
+    want_chunks = (want_chunks / 8) * 8;
+    long tpb = (ntiles + want_chunks - 1) / want_chunks;
+    if (tpb < 1) tpb = 1;
+    const long nchunks = (ntiles + tpb - 1) / tpb;
+    const long grid = ((nchunks + 7) / 8) * 8 * GY;
+#define LN_I8(abl, name)                                                                                          \
+    LN_LAUNCH(ctx, name, emit_diag_i8<abl>, dim3((unsigned)grid), dim3(512), 0, (const int4_t*)Fs,                  \
+              (const int4_t*)md.i8_wq.as<int4_t>(), (const double*)md.i8_const.as<double>(), b, F, Nv, GY, ntiles,   \
+              (int)tpb, nchunks, dbg)
+    unsigned long long* dbg = nullptr;
+#ifdef LNASR_I8_STAMPS                                    // diagnostic build: in-kernel phase stamps (s_memtime), printed per launch
+    if (getenv("LNASR_I8_STAMPS")) {
+        const size_t n = (size_t)grid * 8 * 7;
+        LN_HIP(hipMalloc((void**)&dbg, n * 8));           // (diagnostic build: not a workspace of the context, freed below)
+        LN_HIP(hipMemsetAsync(dbg, 0, n * 8, ctx->stream));
+        LN_I8(6, "emit_i8_stamps");
+        std::vector<unsigned long long> h(n);
+        LN_HIP(hipMemcpyAsync(h.data(), dbg, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        LN_HIP(hipStreamSynchronize(ctx->stream));
+        LN_HIP(hipFree(dbg));
+        double sum[7] = {0, 0, 0, 0, 0, 0, 0};
+        for (size_t i = 0; i < n; ++i) sum[i % 7] += (double)h[i];
+        const double per = 1.0 / ((double)grid * 8 * (double)tpb);
+        fprintf(stderr, "i8 stamps, cycles per wave-tile: phase one %.0f  barrier %.0f  (%.0f)  phase two %.0f  barrier %.0f\n",
+                sum[0] * per, sum[1] * per, sum[2] * per, sum[3] * per, sum[4] * per);
+        fprintf(stderr, "   wave lifetime %.0f cycles = %.3f ms: clock %.2f GHz\n", sum[5] / ((double)grid * 8),
+                sum[6] / ((double)grid * 8) * 1e-5, sum[5] / sum[6] * 0.1);
+    } else
+#endif
+        LN_I8(0, "emit_diag_i8");
+#undef LN_I8
+    return 0;
+}
+
+}  // namespace lnasr

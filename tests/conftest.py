@@ -61,7 +61,7 @@ import contextlib
 def tuned():
     """False when the process runs under fallback switches (tools/fallback_suite.sh): tests then check results only,
     not WHICH kernel produced them."""
-    return not any(k.startswith("LNASR_NO_") or k in ("LNASR_F32_GENERIC", "LNASR_VIT", "LNASR_FWD_ONE_MAXU", "LNASR_FWD_LAT_MAXU", "LNASR_CHASE_MAXU") for k in os.environ)
+    return not any(k.startswith("LNASR_NO_") or k in ("LNASR_F32_GENERIC", "LNASR_VIT", "LNASR_FWD_ONE_MAXU", "LNASR_FWD_LAT_MAXU", "LNASR_CHASE_MAXU", "LNASR_I8_MIN_FRAMES") for k in os.environ)
 
 
 @contextlib.contextmanager

@@ -1,0 +1,148 @@
+"""The diagonal GMM bank on the INTEGER matrix cores (csrc/gmm_i8.hip, round 5): exact sliced arithmetic for the quadratic
+form, the reference's values (gmmhmm.py:46-67) to the same 1e-12 as the fp64 matrix-core kernel -- and closer to a
+long-double evaluation than that kernel is."""
+import numpy as np
+import pytest
+
+from conftest import assert_close, env_switch, tuned
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from lnasr import _ffi
+    return _ffi.default_ctx()
+
+
+def _kernels_of(ctx, fn):
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    out = fn()
+    names = set(ctx.prof_report())
+    ctx.prof_enable(False)
+    return out, names
+
+
+def _upload(ctx, mdl):
+    ctx._model_fp = None
+    ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
+
+
+@pytest.mark.parametrize("N,M,D,U,T", [(16, 16, 39, 3, 77), (32, 16, 39, 2, 16), (16, 16, 28, 1, 1), (16, 32, 39, 2, 45),
+                                       (48, 16, 33, 1, 130), (128, 16, 39, 5, 1000)])
+def test_integer_bank_equals_the_reference(N, M, D, U, T, synth, oracle, ctx):
+    """b from the sliced integer GEMM against the oracle's numpy emission, against the fp64 matrix-core kernel (LNASR_NO_I8EMIT)
+    and through every layout case: frames not a multiple of 16, one frame, M = 32 as two virtual 16-mixture states,
+    D below 39 (zero planes above 2 D), a zero-weight mixture."""
+    mdl = synth.synth_model(N, M, D, seed=N + M + D)
+    mdl["w"][1, 3] = -np.inf
+    obs = synth.synth_obs(U, T, D, seed=T)
+    with env_switch(LNASR_I8_MIN_FRAMES=0):
+        _upload(ctx, mdl)
+        b, names = _kernels_of(ctx, lambda: ctx.gmm_logprob(obs))
+    assert "emit_diag_i8" in names or not tuned()
+    with env_switch(LNASR_NO_I8EMIT=1):
+        _upload(ctx, mdl)
+        b64, names64 = _kernels_of(ctx, lambda: ctx.gmm_logprob(obs))
+    assert "emit_diag_i8" not in names64
+    assert_close(b, b64, 1e-13)
+    for u in (0, U - 1):
+        with np.errstate(divide="ignore"):
+            ob, _ = oracle.gmm_map_b_diag(obs[u], mdl["w"], mdl["mu"], mdl["var"])
+        assert_close(b[u].T, ob, 1e-12)
+
+
+def test_integer_bank_is_at_least_as_accurate_as_the_fp64_kernel(synth, ctx):
+    """Both kernels evaluate the expanded quadratic; the integer one sums its 2 D products exactly and rounds a few times at
+    the end, the fp64 matrix instruction rounds after every product.  Against the direct form in long double (80-bit here),
+    on centred unit-scale data and on data a few standard deviations out: the integer bank's worst error is not above the
+    fp64 kernel's (and both are far inside 1e-12)."""
+    N, M, D, T = 16, 16, 39, 300
+    rng = np.random.default_rng(3)
+    mdl = synth.synth_model(N, M, D, seed=4)
+    mdl["w"][...] = np.log(1.0 / M)                     # equal weights: b is the log-sum-exp of the quadratics plus a constant
+    for spread in (1.0, 4.0):
+        obs = (spread * rng.standard_normal((1, T, D)))
+        x = obs[0].astype(np.longdouble)
+        mu, var = mdl["mu"].astype(np.longdouble), mdl["var"].astype(np.longdouble)
+        q = -0.5 * (((x[:, None, None, :] - mu[None]) ** 2) / var[None]).sum(-1)          # [T, N, M]
+        q = q - 0.5 * (D * np.log(2 * np.longdouble(np.pi)) + np.log(var).sum(-1))[None] + np.longdouble(np.log(1.0 / M))
+        mx = q.max(-1, keepdims=True)
+        ref = (mx[..., 0] + np.log(np.exp(q - mx).sum(-1)))
+        errs = {}
+        for name, env in (("i8", dict(LNASR_I8_MIN_FRAMES=0)), ("f64", dict(LNASR_NO_I8EMIT=1))):
+            with env_switch(**env):
+                _upload(ctx, mdl)
+                b = ctx.gmm_logprob(obs)[0]
+            errs[name] = float(np.abs(b.astype(np.longdouble) - ref).max())
+        assert errs["i8"] < 2e-12 * spread ** 2 and errs["f64"] < 2e-12 * spread ** 2, errs
+        assert errs["i8"] <= 1.25 * errs["f64"] + 1e-14, errs
+
+
+def test_integer_bank_outliers_and_bad_frames(synth, oracle, ctx):
+    """Frames far from every component (the per-frame scale follows them), an all-zero frame (scale 2^0, every digit zero),
+    and frames with a NaN / an infinite feature: NaN rows, as the reference's arithmetic gives and as the fp64 kernel plus
+    its repair pass give."""
+    N, M, D, T = 32, 16, 39, 96
+    mdl = synth.synth_model(N, M, D, seed=8)
+    obs = synth.synth_obs(1, T, D, seed=9)
+    obs[0, 5] = 0.0
+    obs[0, 6] *= 40.0
+    obs[0, 7] += 1000.0
+    obs[0, 8, 3] = 1e150                                # x^2 overflows: non-finite as far as the densities go
+    obs[0, 20, 0] = np.nan
+    obs[0, 21, 38] = np.inf
+    obs[0, 95, 1] = -np.inf
+    with env_switch(LNASR_I8_MIN_FRAMES=0):
+        _upload(ctx, mdl)
+        b = ctx.gmm_logprob(obs)[0]
+    with env_switch(LNASR_NO_I8EMIT=1):
+        _upload(ctx, mdl)
+        b64 = ctx.gmm_logprob(obs)[0]
+    bad = [20, 21, 95]
+    assert np.isnan(b[bad]).all() and np.isnan(b64[bad]).all()
+    good = [t for t in range(T) if t not in bad and t != 8]
+    assert np.isfinite(b[good]).all()
+    assert_close(b[good], b64[good], 1e-12)
+    with np.errstate(all="ignore"):
+        ob, _ = oracle.gmm_map_b_diag(obs[0], mdl["w"], mdl["mu"], mdl["var"])
+    assert_close(b[good], ob.T[good], 1e-12)
+    assert np.array_equal(np.isnan(b[8]), np.isnan(b64[8])) or np.isneginf(b64[8]).all()
+
+
+def test_decode_over_the_integer_bank_gives_the_same_paths(synth, oracle, ctx):
+    """Emission -> Viterbi -> back-trace with the integer bank under it (the metric's route at batch sizes from four
+    utterances up): the paths of the fp64 route, the oracle's on the utterances checked."""
+    N, M, D, U, T = 128, 16, 39, 8, 250
+    mdl = synth.synth_model(N, M, D, seed=21)
+    obs = synth.synth_obs(U, T, D, seed=22)
+    with env_switch(LNASR_I8_MIN_FRAMES=0):
+        _upload(ctx, mdl)
+        (paths, names) = _kernels_of(ctx, lambda: ctx.decode(obs))
+    assert "emit_diag_i8" in names or not tuned()
+    with env_switch(LNASR_NO_I8EMIT=1):
+        _upload(ctx, mdl)
+        paths64 = ctx.decode(obs)
+    assert np.array_equal(paths, paths64)
+    for u in (0, U - 1):
+        ob, _ = oracle.gmm_map_b_diag(obs[u], mdl["w"], mdl["mu"], mdl["var"])
+        _, _, ref = oracle.viterbi(mdl["A"], mdl["pi"], ob)
+        assert np.array_equal(paths[u], ref)
+
+
+def test_integer_bank_dispatch_rule(synth, ctx):
+    """Default rule: b alone, 4096 frames or more, 64 (virtual) states or more, M = 16 k, 28 <= D <= 39; b + bm, small batches
+    and small banks stay on the fp64 kernel."""
+    if not tuned():
+        pytest.skip("kernel selection is what is under test")
+    mdl = synth.synth_model(64, 16, 39, seed=2)
+    _upload(ctx, mdl)
+    big, small = synth.synth_obs(5, 1000, 39, seed=3), synth.synth_obs(1, 1000, 39, seed=3)
+    assert "emit_diag_i8" in _kernels_of(ctx, lambda: ctx.gmm_logprob(big))[1]
+    assert "emit_diag_i8" not in _kernels_of(ctx, lambda: ctx.gmm_logprob(small))[1]
+    assert "emit_diag_i8" not in _kernels_of(ctx, lambda: ctx.gmm_logprob(big, want_bm=True))[1]
+    _upload(ctx, synth.synth_model(32, 16, 39, seed=2))
+    assert "emit_diag_i8" not in _kernels_of(ctx, lambda: ctx.gmm_logprob(big))[1]
+    _upload(ctx, synth.synth_model(64, 16, 20, seed=2))
+    assert "emit_diag_i8" not in _kernels_of(ctx, lambda: ctx.gmm_logprob(synth.synth_obs(5, 1000, 20, seed=3)))[1]
