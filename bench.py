@@ -75,6 +75,7 @@ FLOP_DECODE = FLOP_EMIT + FLOP_TRELLIS              # 272,384 per frame
 BYTES_DECODE = 8 * N_DIM + 4                        # 316 B per frame (obs in, path out)
 PEAK_FP64_TFLOPS = 78.6                             # MI355X fp64 matrix = vector peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
+PEAK_I8_TOPS = 5000.0                               # dense int8 matrix peak: 2 x the bf16 rate per clock (same guide)
 METRIC = "frames/sec Viterbi decode, 128-state 16-mix GMM-HMM, D=39 MFCC"
 N_CHECK = 4                                         # utterances per rank compared with the oracle before timing
 BW_SHAPE = dict(N=256, M=32, D=39, T=2000, U=64)    # BASELINE configs[4], per GPU
@@ -661,6 +662,20 @@ def main():
         else:
             flop = FLOP_DECODE
         achieved = flop * frames_launch / avg_s / 1e12
+        extra = {}
+        if name == "emit_diag_i8":
+            # the bank evaluates the fp64 quadratic form EXACTLY on the int8 matrix cores (csrc/gmm_i8.hip): 28 digit-plane
+            # products, 38 v_mfma_i32_16x16x64_i8 per 16 x 16 tile.  `achieved` / `frac` stay the ALGORITHMIC fp64 figure
+            # against the fp64 matrix peak (the yardstick of every earlier round); the integer unit's own utilisation and
+            # the digit-plane pass that precedes the bank (slice_features) are reported beside it.
+            i8_ops = 38 * 64 * 2 * N_STATES * N_MIX                       # integer multiply-adds x 2 per frame
+            sl = prof.get("slice_features")
+            both = avg_s + (sl[1] / sl[0] * 1e-3 if sl else 0.0)
+            extra = {"matrix_unit": "int8 (v_mfma_i32_16x16x64_i8), exact: results are fp64 values",
+                     "int8_ops_per_frame": i8_ops, "int8_achieved_tops": i8_ops * frames_launch / avg_s / 1e12,
+                     "int8_peak_tops": PEAK_I8_TOPS, "int8_frac": i8_ops * frames_launch / avg_s / 1e12 / PEAK_I8_TOPS,
+                     "with_slice_features": {"ms": both * 1e3, "achieved": flop * frames_launch / both / 1e12,
+                                             "frac": flop * frames_launch / both / 1e12 / PEAK_FP64_TFLOPS}}
         kernels = {k: {"launches": n, "avg_ms": m / n} for k, (n, m) in sorted(prof.items(), key=lambda kv: -kv[1][1])}
         out = {
             "metric": METRIC,
@@ -677,7 +692,7 @@ def main():
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_TFLOPS,
                          "traffic": _pmc_traffic(name),
                          "algorithmic_flop_per_frame": flop, "frames_per_launch": frames_launch,
-                         "avg_launch_ms": avg_s * 1e3,
+                         "avg_launch_ms": avg_s * 1e3, **extra,
                          "whole_step": {"flop_per_frame": FLOP_DECODE,
                                         "achieved_tflops": FLOP_DECODE * n_ranks_rccl * U * T / step_s / 1e12,
                                         "frac_of_fp64_peak": FLOP_DECODE * U * T / step_s / 1e12 / PEAK_FP64_TFLOPS,

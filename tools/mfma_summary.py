@@ -17,7 +17,7 @@ for d in sys.argv[2:]:
     f = max(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)   # gpurun merges runs: the newest
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
-        m = re.search(r"lnasr::([a-z_0-9]+)", r["Kernel_Name"])
+        m = re.search(r"lnasr::(?:\(anonymous namespace\)::)?([a-z_0-9]+)", r["Kernel_Name"])
         agg[m.group(1) if m else r["Kernel_Name"][:30]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, c in agg.items():
         for n, v in c.items():

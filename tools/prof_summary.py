@@ -25,7 +25,7 @@ print(open(ks).read()[:1500])
 
 
 def short(name):
-    m = re.search(r"lnasr::([a-z_0-9]+)", name)
+    m = re.search(r"lnasr::(?:\(anonymous namespace\)::)?([a-z_0-9]+)", name)
     return m.group(1) if m else name[:40]
 
 
