@@ -23,7 +23,7 @@ for d in sys.argv[2:]:
         for n, v in c.items():
             rows[k][n] = sum(v) / len(v)
 cols = ["MfmaUtil", "VALUBusy", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_VALU_MFMA_COEXEC_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F64",
-        "SQ_BUSY_CU_CYCLES", "GRBM_GUI_ACTIVE"]
+        "SQ_INSTS_VALU_MFMA_MOPS_I8", "SQ_BUSY_CU_CYCLES", "GRBM_GUI_ACTIVE"]
 out = os.path.join(REPO, "profiles", tag + "_mfma_util.csv")
 with open(out, "w") as fp:
     fp.write("# rocprofv3 --pmc passes of `bench.py --steps 3 --warmup 1` (per-launch averages): MfmaUtil / VALUBusy in percent,\n"

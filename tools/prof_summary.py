@@ -44,7 +44,8 @@ if len(sys.argv) >= 5:
             hbm = (2 * fe + wr) * 1024
             fp.write("%s,%d,%.1f,%.1f,%.0f\n" % (k, len(c.get("FETCH_SIZE", [])), fe, wr, hbm))
             out[k] = {"fetch_kib": fe, "write_kib": wr, "hbm_bytes_per_launch": hbm}
-    key_map = {"emit_diag_mfma": "emit_diag_mfma", "viterbi_reg": "viterbi_reg_n128", "viterbi_reg1b": "viterbi_reg1b_n128",
+    key_map = {"emit_diag_mfma": "emit_diag_mfma", "emit_diag_i8": "emit_diag_i8", "slice_features_kernel": "slice_features",
+               "viterbi_reg": "viterbi_reg_n128", "viterbi_reg1b": "viterbi_reg1b_n128",
                "backtrace_lds_kernel": "backtrace_lds"}
     traffic = {v: out[k] for k, v in key_map.items() if k in out}
     traffic["_source"] = "%s: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of bench.py (U=1024, T=1000)" % tag

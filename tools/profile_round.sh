@@ -22,7 +22,7 @@ rocprofv3 --pmc WRITE_SIZE -f csv -d $O/prof_${tag}_write -- python3 $R/bench.py
 
 # matrix-core utilisation and MFMA / VALU co-execution (tools/mfma_summary.py)
 rm -rf $O/prof_${tag}_mfma1 $O/prof_${tag}_mfma2
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F64 -f csv -d $O/prof_${tag}_mfma1 -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $O/prof_${tag}_mfma1.err
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_MFMA_MOPS_I8 -f csv -d $O/prof_${tag}_mfma1 -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $O/prof_${tag}_mfma1.err
 rocprofv3 --pmc MfmaUtil VALUBusy -f csv -d $O/prof_${tag}_mfma2 -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $O/prof_${tag}_mfma2.err
 
 # the other rows of SURVEY 8d (MFCC, single GMM, bank, forward / backward, Baum-Welch statistics, full covariance)

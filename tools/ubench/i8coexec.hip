@@ -4,7 +4,7 @@
 #include <cstdio>
 typedef int int4_t __attribute__((ext_vector_type(4)));
 
-template <int NV, int WAVES, bool LDSREAD, bool MF = true>
+template <int NV, int WAVES, bool LDSREAD, bool MF = true, int KIND = 0>
 __global__ __launch_bounds__(64 * WAVES) void k(double* out, unsigned long long* cyc, int iters, double a, double b) {
     __shared__ int4_t F[2048];
     for (int i = threadIdx.x; i < 2048; i += 64 * WAVES) F[i] = int4_t{i * 3 + 1, i * 5 + 2, i * 7 + 3, i * 11 + 4};
@@ -14,7 +14,9 @@ __global__ __launch_bounds__(64 * WAVES) void k(double* out, unsigned long long*
     int4_t acc[4];
     for (int i = 0; i < 4; ++i) acc[i] = int4_t{0, 0, 0, 0};
     double v[8];
-    for (int i = 0; i < 8; ++i) v[i] = a + i + threadIdx.x;
+    float vf[8];
+    unsigned vi[8];
+    for (int i = 0; i < 8; ++i) { v[i] = a + i + threadIdx.x; vf[i] = (float)v[i]; vi[i] = threadIdx.x * 3 + i; }
     const int lane = threadIdx.x & 63;
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
@@ -28,7 +30,12 @@ __global__ __launch_bounds__(64 * WAVES) void k(double* out, unsigned long long*
         for (int t = 0; t < 4; ++t) {
             if (MF) acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(f, W[t + 4 * U], acc[t], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < NV; ++j) v[(t * NV + j) % 8] = fma(v[(t * NV + j) % 8], b, a);
+            for (int j = 0; j < NV; ++j) {
+                const int c = (t * NV + j) % 8;
+                if (KIND == 0) v[c] = fma(v[c], b, a);
+                if (KIND == 1) vf[c] = fmaf(vf[c], (float)b, (float)a);
+                if (KIND == 2) vi[c] = (vi[c] << 7) + (unsigned)iters;
+            }
         }
         f = fn;
       }
@@ -37,7 +44,7 @@ __global__ __launch_bounds__(64 * WAVES) void k(double* out, unsigned long long*
     const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
     double s = 0;
     for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
-    for (int i = 0; i < 8; ++i) s += v[i];
+    for (int i = 0; i < 8; ++i) s += v[i] + vf[i] + vi[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
     if (threadIdx.x == 0) { cyc[2 * blockIdx.x] = t1 - t0; cyc[2 * blockIdx.x + 1] = r1 - r0; }
 }
@@ -81,5 +88,9 @@ int main() {
     RUN("2 waves/SIMD + LDS + 2 f64 fma per MFMA", (k<2, 8, true>), 512);
     RUN("2 waves/SIMD + LDS + 3 f64 fma per MFMA", (k<3, 8, true>), 512);
     RUN("2 waves/SIMD + LDS + 4 f64 fma per MFMA", (k<4, 8, true>), 512);
+    RUN("2 waves/SIMD + LDS + 2 f32 fma per MFMA", (k<2, 8, true, true, 1>), 512);
+    RUN("2 waves/SIMD + LDS + 4 f32 fma per MFMA", (k<4, 8, true, true, 1>), 512);
+    RUN("2 waves/SIMD + LDS + 2 int shift-add per MFMA", (k<2, 8, true, true, 2>), 512);
+    RUN("2 waves/SIMD + LDS + 4 int shift-add per MFMA", (k<4, 8, true, true, 2>), 512);
     return 0;
 }
