@@ -146,55 +146,62 @@ __global__ void pack_wslice_kernel(const double* __restrict__ mu, const double* 
     }
 }
 
-// Digit planes of the features.  Eight lanes per frame (five of them own a 16-wide k-chunk), 32 frames per block.
+// Digit planes of the features.  Block = 5 waves x 64 frames: wave `ch` owns the k-chunk 16 ch .. 16 ch + 15 of the block's 64
+// frames (every lane works; a plane row of a wave is 4 tiles x 256 contiguous bytes).
 //   Fs[tile*kTileI4 + (plane*5 + chunk)*16 + frame]  (16 bytes: k = 16 chunk + byte),   then 16 doubles: 2^(e_f - 24)
 // (NaN for a frame with a NaN / infinite feature: every density of that frame comes out NaN, as the reference's does).
-__global__ __launch_bounds__(256) void slice_features_kernel(const double* __restrict__ obs, const double* __restrict__ centre,
+__global__ __launch_bounds__(320) void slice_features_kernel(const double* __restrict__ obs, const double* __restrict__ centre,
                                                              const double* __restrict__ pow2g, int4_t* __restrict__ Fs,
                                                              long F, int D, unsigned* __restrict__ nan_flag,
                                                              unsigned nan_epoch) {
     const int tid = threadIdx.x;
-    const long frame0 = (long)blockIdx.x * 32;
-    const long frame = frame0 + (tid >> 3);
-    const int ch = tid & 7;
-    const bool live = ch < kChunks && frame < F;
-    // the block's 32 frames are one contiguous run of obs: coalesced into the LDS, centred on the way
-    __shared__ double xs[32 * 40];
+    const int ch = tid >> 6, fl = tid & 63;
+    const long frame0 = (long)blockIdx.x * 64;
+    const long frame = frame0 + fl;
+    const bool live = frame < F;
+    // the block's 64 frames are one contiguous run of obs: coalesced into the LDS, centred on the way
+    __shared__ double xs[64 * 40];
+    __shared__ double smax[kChunks][64];
+    __shared__ int sbad[kChunks][64];
     {
         const long base = frame0 * D, lim = F * (long)D;
-        for (int e = tid; e < 32 * D; e += 256) {
+        for (int e = tid; e < 64 * D; e += 320) {
             const long ge = base + e;
             xs[e] = ge < lim ? obs[ge] - centre[e % D] : 0.0;
         }
     }
     __syncthreads();
-    const double* xf = xs + (tid >> 3) * D;
+    const double* xf = xs + fl * D;
     double val[16];
     double mx = 0.0;
     bool bad = false;
 #pragma unroll
     for (int by = 0; by < 16; ++by) {
-        const int k = 16 * ch + by;
-        const int d = k < D ? k : k - D;
-        const double x = xf[d < D ? d : D - 1];           // (rows past 2 D and the idle lanes: any valid address, scaled by 0)
-        const double sc = (live && k < 2 * D) ? pow2g[k < 80 ? k : 79] : 0.0;
-        bad |= sc != 0.0 && !__builtin_isfinite(x);
-        const double v = (k < D ? x * x : x) * sc;
-        val[by] = sc != 0.0 ? v : 0.0;
+        const int k = 16 * ch + by;                       // wave-uniform
+        double v = 0.0;
+        if (k < 2 * D) {
+            const double x = xf[k < D ? k : k - D];
+            bad |= !__builtin_isfinite(x);
+            v = (k < D ? x * x : x) * pow2g[k];
+        }
+        val[by] = live ? v : 0.0;
         mx = fmax(mx, fabs(val[by]));
     }
-    int badi = bad ? 1 : 0;
+    smax[ch][fl] = mx;
+    sbad[ch][fl] = (bad && live) ? 1 : 0;
+    __syncthreads();
+    int badi = 0;
 #pragma unroll
-    for (int o = 1; o < 8; o <<= 1) {
-        mx = fmax(mx, __shfl_xor(mx, o));
-        badi |= __shfl_xor(badi, o);
+    for (int c = 0; c < kChunks; ++c) {
+        mx = fmax(mx, smax[c][fl]);
+        badi |= sbad[c][fl];
     }
     if (!__builtin_isfinite(mx)) badi = 1;            // x^2 overflowed
     const int ef = (mx > 0.0 && !badi) ? scale_exponent(mx) : 0;
     const long tile = frame >> 4;
     const int f16 = (int)(frame & 15);
     int4_t* dst = Fs + tile * kTileI4;
-    if (ch < kChunks && (frame >> 4) <= ((F - 1) >> 4)) {         // frames past F inside the last tile: zero planes
+    if (tile <= ((F - 1) >> 4)) {                         // frames past F inside the last tile: zero planes
         // all seven digits of a value at once: t = v 2^56 as an integer; adding 0x80 at every byte position carries exactly
         // as the digit-by-digit extraction does, and (byte ^ 0x80) is the balanced digit.  Byte 6 = plane 0 ... byte 0 = plane 6.
         unsigned lo32[16], hi32[16];
@@ -229,7 +236,7 @@ __global__ __launch_bounds__(256) void slice_features_kernel(const double* __res
             sc[f16] = badi ? __builtin_nan("") : ldexp(1.0, ef - 24);
         }
     }
-    if (badi && frame < F && ch == 0) *nan_flag = nan_epoch;
+    if (badi && live && ch == 0) *nan_flag = nan_epoch;
 }
 
 // The bank.  Block = 8 waves, two per SIMD; wave w owns the state pair sp = 8 y + w of slab y (16 states per block): two
@@ -362,6 +369,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 fl[d][p] = Fc[i >= 0 ? i * kPlaneI4 + 64 + col : kZeroI4 + col];
             }
         }
+        // (The fold in 64-bit INTEGER arithmetic -- T = p0 2^32 + p1 2^16 + p2 + round(acc_6 / 256), two conversions and one
+        // fused multiply-add: 4 fp64 + 11 integer instructions per value instead of 8 + 3 -- was built on the strength of
+        // tools/ubench/i8coexec showing shift-adds free beside the integer matrix pipe: 4.94 ms against 4.73 on one box, three
+        // alternations.  In this instruction mix they are not free.)
         double r[2][4];                                   // running fp64 value of the diagonals folded so far
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
@@ -468,7 +479,7 @@ int emit_diag_i8_device(lnasr_ctx* ctx, const double* obs, long F, double* b) {
     const long ntiles = (F + 15) / 16;
     LN_TRY(ctx->ws_fs.reserve((size_t)ntiles * kTileI4 * 16));
     int4_t* Fs = ctx->ws_fs.as<int4_t>();
-    LN_LAUNCH(ctx, "slice_features", slice_features_kernel, dim3((unsigned)((ntiles * 16 + 31) / 32)), dim3(256), 0, obs,
+    LN_LAUNCH(ctx, "slice_features", slice_features_kernel, dim3((unsigned)((ntiles * 16 + 63) / 64)), dim3(320), 0, obs,
               (const double*)md.centre.as<double>(), (const double*)md.i8_pow2g.as<double>(), Fs, F, D,
               ctx->nan_flag.as<unsigned>(), ctx->nan_epoch);
     const int GY = Nv / 16;
