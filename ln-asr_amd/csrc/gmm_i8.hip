@@ -244,10 +244,13 @@ __global__ __launch_bounds__(320) void slice_features_kernel(const double* __res
 // lane group g = lane >> 4 then holds, for frame lane & 15, the mixtures 8 (g >> 1) + {0..7} of state 2 sp + (g & 1) -- the M-way
 // log-sum-exp is eight values in the lane and one exchange with lane ^ 32 (v_permlane32_swap).  The block walks a range of
 // 16-frame tiles whose digit planes it copies into the LDS (double buffered); a wave reads the seven K = 0..63 fragments of a
-// tile ONCE and keeps them for all 28 plane pairs.  Diagonals go from the least significant to the most significant one
-// (d = 6, then the pairs (5, 4), (3, 2), (1, 0), each pair joined in an int32: |acc_d| 256 + |acc_d+1| < 2^31 for d <= 4),
-// each group folded into the running fp64 value while the next one is in the matrix core.  Per iteration: the planes of tile t
-// go from the LDS to registers, and BEHIND those reads the log-sum-exp of tile t - 1 runs (its values were carried over).
+// tile ONCE (with the ten remainder fragments: 17 x 16 bytes per lane) and keeps them for all 28 plane pairs.  Diagonals go in
+// ascending order (d = 0 needs plane 0 only: its matrix instructions start behind the first LDS read), in the groups (0, 1),
+// (2, 3), (4, 5), 6; a group's two accumulators are joined in an int32 (|acc_d| 256 + |acc_d+1| < 2^31 for d <= 4) and folded
+// into the running fp64 value while the next group is in the matrix core.
+// Two phases per tile, the two waves of a SIMD in OPPOSITE ones (waves 0-3: matrix phase of tile t, then its log-sum-exp;
+// waves 4-7: log-sum-exp of tile t - 1, then the matrix phase of tile t): the vector work of one wave issues beside the matrix
+// instructions of the other.  ABL = 6 is the diagnostic build's instantiation with s_memtime stamps around the phases.
 template <int ABL>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void emit_diag_i8(
     const int4_t* __restrict__ Fs, const int4_t* __restrict__ wq, const double* __restrict__ constc, double* __restrict__ b,
