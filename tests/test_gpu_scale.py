@@ -26,7 +26,14 @@ def test_metric_config_full_size(synth, oracle):
     obs = synth.synth_obs(U, T, D, seed=1000)
     ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
     d_obs = ctx.to_device(obs)
+    ctx.prof_enable(True)
+    ctx.prof_reset()
     p1, s1 = ctx.decode(d_obs, want_score=True)
+    names = set(ctx.prof_report())
+    ctx.prof_enable(False)
+    # (round 5: at this size the emission is the integer matrix-core bank, csrc/gmm_i8.hip -- every check below, the exhaustive
+    # comparison with the oracle included, is a check of that kernel)
+    assert "emit_diag_i8" in names or not tuned(), names
     p2, s2 = ctx.decode(d_obs, want_score=True)
     path, score = p1.to_host(), s1.to_host()
     assert np.array_equal(path, p2.to_host()) and np.array_equal(score, s2.to_host())      # deterministic
