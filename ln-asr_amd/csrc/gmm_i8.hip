@@ -12,7 +12,9 @@
 //     <= 2^-57);
 //   * the digit planes are int8 matrices; the products of planes i and j with i + j = d all carry the weight 256^-(d+2) and
 //     are summed by the matrix core in ONE int32 accumulator per d (|acc_d| <= 7 * 80 * 128^2 < 2^24: exact); planes with
-//     i + j > 6 (weight <= 256^-9 = 2^-72 against a sum of size 1) are not formed: 28 plane products, K = 80 each;
+//     i + j > 6 are not formed: 28 plane products, K = 80 each.  What that drops: the six pairs of diagonal 7 weigh 2^-72,
+//     their digit products reach 2^14 and there are 80 of each -- at most 2^-49 of the scale 2^(g_k + e_f), 2^-55 for digits of
+//     random sign (the size of the double's own last bit at that scale); every later diagonal is 2^-8 of the one before;
 //   * Q = 2^e_f sum_d acc_d 256^-(d+2): the diagonals are joined pairwise in int32 (acc_2n * 256 + acc_2n+1 < 2^31 for
 //     2n <= 4), converted and summed in fp64, three fused multiply-adds.  One short rounding sequence at the END of an exact
 //     sum, where the fp64 GEMM of gmm.hip rounds after each of its 80 terms -- against a long-double evaluation the sliced
