@@ -250,10 +250,11 @@ __global__ __launch_bounds__(320) void slice_features_kernel(const double* __res
 // ascending order (d = 0 needs plane 0 only: its matrix instructions start behind the first LDS read), in the groups (0, 1),
 // (2, 3), (4, 5), 6; a group's two accumulators are joined in an int32 (|acc_d| 256 + |acc_d+1| < 2^31 for d <= 4) and folded
 // into the running fp64 value while the next group is in the matrix core.
+// REM = false (2 D <= 64): no remainder instructions, 28 per tile.
 // Two phases per tile, the two waves of a SIMD in OPPOSITE ones (waves 0-3: matrix phase of tile t, then its log-sum-exp;
 // waves 4-7: log-sum-exp of tile t - 1, then the matrix phase of tile t): the vector work of one wave issues beside the matrix
 // instructions of the other.  ABL = 6 is the diagnostic build's instantiation with s_memtime stamps around the phases.
-template <int ABL>
+template <int ABL, bool REM = true>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void emit_diag_i8(
     const int4_t* __restrict__ Fs, const int4_t* __restrict__ wq, const double* __restrict__ constc, double* __restrict__ b,
     long F, int N, int GY, long ntiles, int tiles_per_block, long nchunks, unsigned long long* __restrict__ dbg) {
@@ -291,7 +292,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int j = 0; j < kS; ++j) Wm[q][j] = wq[(((size_t)sp * 2 + q) * kSlots + j) * 64 + lane];
 #pragma unroll
-        for (int p = 0; p < 2; ++p) Wl[q][p] = wq[(((size_t)sp * 2 + q) * kSlots + kS + p) * 64 + lane];
+        for (int p = 0; p < 2; ++p)
+            if (REM) Wl[q][p] = wq[(((size_t)sp * 2 + q) * kSlots + kS + p) * 64 + lane];
     }
     double cst[8];
 #pragma unroll
@@ -369,7 +371,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             fm[d] = Fc[d * kPlaneI4 + hb];
 #pragma unroll
             for (int p = 0; p < 2; ++p) {                 // K = 64..79: lane group g carries planes (d - g - 4p, g + 4p)
-                if (4 * p > d) continue;
+                if (4 * p > d || !REM) continue;
                 const int i = d - g - 4 * p;
                 fl[d][p] = Fc[i >= 0 ? i * kPlaneI4 + 64 + col : kZeroI4 + col];
             }
@@ -395,7 +397,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         acc[dd][q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Wm[q][d - i], fm[i], acc[dd][q], 0, 0, 0);
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
-                    if (4 * p > d) continue;
+                    if (4 * p > d || !REM) continue;
 #pragma unroll
                     for (int q = 0; q < 2; ++q)
                         acc[dd][q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Wl[q][p], fl[d][p], acc[dd][q], 0, 0, 0);
@@ -497,7 +499,7 @@ int emit_diag_i8_device(lnasr_ctx* ctx, const double* obs, long F, double* b) {
     const long nchunks = (ntiles + tpb - 1) / tpb;
     const long grid = ((nchunks + 7) / 8) * 8 * GY;
 #define LN_I8(abl, name)                                                                                          \
-    LN_LAUNCH(ctx, name, emit_diag_i8<abl>, dim3((unsigned)grid), dim3(512), 0, (const int4_t*)Fs,                  \
+    LN_LAUNCH(ctx, name, (emit_diag_i8<abl, true>), dim3((unsigned)grid), dim3(512), 0, (const int4_t*)Fs,          \
               (const int4_t*)md.i8_wq.as<int4_t>(), (const double*)md.i8_const.as<double>(), b, F, Nv, GY, ntiles,   \
               (int)tpb, nchunks, dbg)
     unsigned long long* dbg = nullptr;
@@ -520,6 +522,11 @@ int emit_diag_i8_device(lnasr_ctx* ctx, const double* obs, long F, double* b) {
                 sum[6] / ((double)grid * 8) * 1e-5, sum[5] / sum[6] * 0.1);
     } else
 #endif
+    if (2 * D <= 64)                                      // K <= 64: the 28 plane pairs and nothing else
+        LN_LAUNCH(ctx, "emit_diag_i8_k64", (emit_diag_i8<0, false>), dim3((unsigned)grid), dim3(512), 0, (const int4_t*)Fs,
+                  (const int4_t*)md.i8_wq.as<int4_t>(), (const double*)md.i8_const.as<double>(), b, F, Nv, GY, ntiles,
+                  (int)tpb, nchunks, dbg);
+    else
         LN_I8(0, "emit_diag_i8");
 #undef LN_I8
     return 0;

@@ -30,22 +30,24 @@ def _upload(ctx, mdl):
 
 
 @pytest.mark.parametrize("N,M,D,U,T", [(16, 16, 39, 3, 77), (32, 16, 39, 2, 16), (16, 16, 28, 1, 1), (16, 32, 39, 2, 45),
-                                       (48, 16, 33, 1, 130), (128, 16, 39, 5, 1000)])
+                                       (48, 16, 33, 1, 130), (128, 16, 39, 5, 1000), (32, 16, 26, 2, 50), (16, 16, 14, 1, 33),
+                                       (64, 16, 32, 1, 40)])
 def test_integer_bank_equals_the_reference(N, M, D, U, T, synth, oracle, ctx):
     """b from the sliced integer GEMM against the oracle's numpy emission, against the fp64 matrix-core kernel (LNASR_NO_I8EMIT)
     and through every layout case: frames not a multiple of 16, one frame, M = 32 as two virtual 16-mixture states,
-    D below 39 (zero planes above 2 D), a zero-weight mixture."""
+    D below 39 (zero planes above 2 D), 2 D <= 64 (the instantiation without remainder instructions: D = 14 .. 32), a
+    zero-weight mixture."""
     mdl = synth.synth_model(N, M, D, seed=N + M + D)
     mdl["w"][1, 3] = -np.inf
     obs = synth.synth_obs(U, T, D, seed=T)
     with env_switch(LNASR_I8_MIN_FRAMES=0):
         _upload(ctx, mdl)
         b, names = _kernels_of(ctx, lambda: ctx.gmm_logprob(obs))
-    assert "emit_diag_i8" in names or not tuned()
+    assert ("emit_diag_i8" if 2 * D > 64 else "emit_diag_i8_k64") in names or not tuned()
     with env_switch(LNASR_NO_I8EMIT=1):
         _upload(ctx, mdl)
         b64, names64 = _kernels_of(ctx, lambda: ctx.gmm_logprob(obs))
-    assert "emit_diag_i8" not in names64
+    assert not {"emit_diag_i8", "emit_diag_i8_k64"} & names64
     assert_close(b, b64, 1e-13)
     for u in (0, U - 1):
         with np.errstate(divide="ignore"):
@@ -132,8 +134,9 @@ def test_decode_over_the_integer_bank_gives_the_same_paths(synth, oracle, ctx):
 
 
 def test_integer_bank_dispatch_rule(synth, ctx):
-    """Default rule: b alone, 4096 frames or more, 64 (virtual) states or more, M = 16 k, 28 <= D <= 39; b + bm, small batches
-    and small banks stay on the fp64 kernel."""
+    """Default rule: b alone, 4096 frames or more, 64 (virtual) states or more, M = 16 k, 14 <= D <= 39; b + bm, small batches,
+    small banks and D <= 13 (K = 28: seven fp64 matrix instructions per tile are no slower than 28 integer ones) stay on the
+    fp64 kernel."""
     if not tuned():
         pytest.skip("kernel selection is what is under test")
     mdl = synth.synth_model(64, 16, 39, seed=2)
@@ -145,4 +148,6 @@ def test_integer_bank_dispatch_rule(synth, ctx):
     _upload(ctx, synth.synth_model(32, 16, 39, seed=2))
     assert "emit_diag_i8" not in _kernels_of(ctx, lambda: ctx.gmm_logprob(big))[1]
     _upload(ctx, synth.synth_model(64, 16, 20, seed=2))
-    assert "emit_diag_i8" not in _kernels_of(ctx, lambda: ctx.gmm_logprob(synth.synth_obs(5, 1000, 20, seed=3)))[1]
+    assert "emit_diag_i8_k64" in _kernels_of(ctx, lambda: ctx.gmm_logprob(synth.synth_obs(5, 1000, 20, seed=3)))[1]
+    _upload(ctx, synth.synth_model(64, 16, 13, seed=2))
+    assert not {"emit_diag_i8", "emit_diag_i8_k64"} & _kernels_of(ctx, lambda: ctx.gmm_logprob(synth.synth_obs(5, 1000, 13, seed=3)))[1]

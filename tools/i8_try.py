@@ -42,6 +42,9 @@ if __name__ == "__main__":
             run(128, 16, 39, U, 1000, reps=20)
         run(256, 32, 39, 64, 2000)
         run(32, 16, 39, 512, 1000)
+        run(128, 16, 26, 1024, 1000)
+        run(128, 16, 32, 1024, 1000)
+        run(128, 16, 14, 1024, 1000)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "abl":
         for a in (sys.argv[2:] or ("0", "3", "4", "5")):
