@@ -151,3 +151,54 @@ def test_integer_bank_dispatch_rule(synth, ctx):
     assert "emit_diag_i8_k64" in _kernels_of(ctx, lambda: ctx.gmm_logprob(synth.synth_obs(5, 1000, 20, seed=3)))[1]
     _upload(ctx, synth.synth_model(64, 16, 13, seed=2))
     assert not {"emit_diag_i8", "emit_diag_i8_k64"} & _kernels_of(ctx, lambda: ctx.gmm_logprob(synth.synth_obs(5, 1000, 13, seed=3)))[1]
+
+
+# LNASR_TEST_SEEDS="a:b" widens the seed range for a soak run (as in test_gpu_random_shapes.py)
+import os
+_lo, _hi = (int(x) for x in os.environ.get("LNASR_TEST_SEEDS", "0:16").split(":"))
+
+
+@pytest.mark.parametrize("seed", range(_lo, _lo + max(1, (_hi - _lo) * 16 // 28)))
+def test_integer_bank_over_shapes_and_feature_scales(seed, oracle, ctx):
+    """Seeded shapes the bank takes (N in 16..128, M = 16 / 32, D in 14..39) at real-feature scales -- a common offset of 0 / 5 /
+    50 units, means spread by 0.3 .. 15, variances down to 0.02, observations drawn around the components plus outliers:
+    b within 1e-12 (of max(1, |b|)) of the fp64 matrix-core kernel and within 1e-11 of the oracle's DIRECT (x - mu)^2 / var
+    form, decode paths of the two routes identical.  Models past the conditioning gate take neither bank: both routes are
+    then the same direct-form kernel."""
+    rng = np.random.default_rng(90000 + seed)
+    N = int(rng.choice([16, 32, 48, 64, 128]))
+    M = int(rng.choice([16, 16, 32]))
+    D = int(rng.choice([14, 20, 26, 27, 28, 32, 33, 38, 39]))
+    U, T = int(rng.integers(1, 4)), int(rng.integers(1, 70))
+    offset = float(rng.choice([0.0, 0.0, 5.0, 50.0]))
+    spread = float(rng.choice([0.3, 1.0, 3.0, 15.0]))
+    vlo = float(rng.choice([0.5, 0.1, 0.02]))
+    mu = offset + spread * rng.standard_normal((N, M, D))
+    var = vlo + rng.random((N, M, D)) * float(rng.choice([1.0, 4.0]))
+    w = rng.random((N, M)) + 1e-3
+    w = np.log(w / w.sum(1, keepdims=True))
+    if seed % 5 == 0:
+        w[0, 1] = -np.inf
+    a = rng.random((N, N)) + 1e-3
+    A = np.log(a / a.sum(1, keepdims=True))
+    pi = np.log(np.full(N, 1.0 / N))
+    comp = rng.integers(0, N * M, (U, T))
+    obs = mu.reshape(-1, D)[comp] + np.sqrt(var.reshape(-1, D)[comp]) * rng.standard_normal((U, T, D))
+    if T > 3:
+        obs[0, 1] += 8.0 * spread
+        obs[0, 2] = offset
+    mdl = {"A": A, "pi": pi, "w": w, "mu": mu, "var": var}
+    out = {}
+    for name, env in (("i8", dict(LNASR_I8_MIN_FRAMES=0)), ("f64", dict(LNASR_NO_I8EMIT=1))):
+        with env_switch(**env):
+            _upload(ctx, mdl)
+            kappa, direct = ctx.model_conditioning()
+            out[name] = (ctx.gmm_logprob(obs), np.asarray(ctx.decode(obs)))
+    (bi, p8), (bf, pf) = out["i8"], out["f64"]
+    tag = "seed=%d N=%d M=%d D=%d U=%d T=%d offset=%g spread=%g vlo=%g kappa=%.3g direct=%d" % (
+        seed, N, M, D, U, T, offset, spread, vlo, kappa, direct)
+    assert float(np.max(np.abs(bi - bf) / np.maximum(1.0, np.abs(bf)))) <= 1e-12, tag
+    with np.errstate(divide="ignore"):
+        ob, _ = oracle.gmm_map_b_diag_direct(obs[0], w, mu, var)
+    assert float(np.max(np.abs(bi[0] - ob.T) / np.maximum(1.0, np.abs(ob.T)))) <= 1e-11, tag
+    assert np.array_equal(p8, pf), tag
