@@ -283,7 +283,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const long tile0 = chunk * tiles_per_block;
     long tile1 = tile0 + tiles_per_block;
     if (tile1 > ntiles) tile1 = ntiles;
-    const int sp = 8 * y + w;
+    // (N a multiple of 2, not of 16: the waves of the last slab that have no state pair score pair 0 again and stage values
+    // nobody flushes)
+    const int sp = 2 * (8 * y + w) < N ? 8 * y + w : 0;
     const int g = lane >> 4, col = lane & 15;
 
     int4_t Wm[2][kS], Wl[2][2];
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (tid < 256) {
             const int f = tid >> 4, st = tid & 15;
             const long frame = tile * 16 + f;
-            if (frame < F) b[frame * N + 16 * y + st] = ob[buf][f * 17 + st];
+            if (frame < F && 16 * y + st < N) b[frame * N + 16 * y + st] = ob[buf][f * 17 + st];
         }
     };
 
@@ -459,7 +461,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 }  // namespace
 
-bool i8_emit_shape_ok(int Nv, int Mv, int D) { return Mv == 16 && Nv % 16 == 0 && D >= 1 && 2 * D <= 80; }
+bool i8_emit_shape_ok(int Nv, int Mv, int D) { return Mv == 16 && Nv % 2 == 0 && D >= 1 && 2 * D <= 80; }
 
 // once per model (after prep_diag / centre_and_kappa): digit planes of the coefficients
 int pack_i8_model(lnasr_ctx* ctx, const double* mu_s, const double* iv_s, const double* gc_s, const double* lw_s, int Nv) {
@@ -489,7 +491,7 @@ int emit_diag_i8_device(lnasr_ctx* ctx, const double* obs, long F, double* b) {
     LN_LAUNCH(ctx, "slice_features", slice_features_kernel, dim3((unsigned)((ntiles * 16 + 63) / 64)), dim3(320), 0, obs,
               (const double*)md.centre.as<double>(), (const double*)md.i8_pow2g.as<double>(), Fs, F, D,
               ctx->nan_flag.as<unsigned>(), ctx->nan_epoch);
-    const int GY = Nv / 16;
+    const int GY = (Nv + 15) / 16;
     const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
     long want_chunks = (long)cus / GY;                   // one 8-wave block per CU: two waves per SIMD
     if (want_chunks < 8) want_chunks = 8;
