@@ -101,7 +101,8 @@ struct Model {
     DevBuf wpack32;
     unsigned long upload_serial = 0, wpack32_for = ~0ul;
     // integer matrix-core bank (gmm_i8.hip): digit planes of the coefficients, row scales, component constants
-    DevBuf i8_g, i8_pow2g, i8_wq, i8_const;
+    DevBuf i8_g, i8_pow2g, i8_wq, i8_const, i8_const_nw;
+    const double* i8_logw = nullptr;   // the (padded) log weights the planes were packed with: [Nv,16]
     int i8_NG = 0;               // state groups packed (0: none)
     void release();
 };
@@ -265,7 +266,7 @@ int emit_device(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, v
 // gmm_i8.hip: the diagonal bank on the integer matrix cores (exact sliced arithmetic)
 bool i8_emit_shape_ok(int Nv, int Mv, int D);
 int pack_i8_model(lnasr_ctx* ctx, const double* mu_s, const double* iv_s, const double* gc_s, const double* lw_s, int Nv);
-int emit_diag_i8_device(lnasr_ctx* ctx, const double* obs, long F, double* b);
+int emit_diag_i8_device(lnasr_ctx* ctx, const double* obs, long F, double* b, double* bm);
 // emit_device without the pass over non-finite frames; *scanned: the kernel tested the features it staged and raised
 // ctx->nan_flag itself (emit_batch runs the kernels chunk by chunk and the pass once)
 int emit_device_raw(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, void* bm, bool* scanned,

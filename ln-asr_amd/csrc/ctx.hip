@@ -49,7 +49,7 @@ void DevBuf::release() {
 }
 
 void Model::release() {
-    DevBuf* all[] = {&logA, &logAT, &logpi, &expA, &expAT, &logw, &mu, &ivar, &var, &prec, &gconst, &sigma_raw, &wpack, &wpack_nw, &wdirect, &pad_mu, &pad_ivar, &pad_gconst, &pad_logw, &pad_prec, &wfull, &wfull_nw, &pairtab, &flags, &centre, &mu_c, &wpack32, &lu_bad, &i8_g, &i8_pow2g, &i8_wq, &i8_const};
+    DevBuf* all[] = {&logA, &logAT, &logpi, &expA, &expAT, &logw, &mu, &ivar, &var, &prec, &gconst, &sigma_raw, &wpack, &wpack_nw, &wdirect, &pad_mu, &pad_ivar, &pad_gconst, &pad_logw, &pad_prec, &wfull, &wfull_nw, &pairtab, &flags, &centre, &mu_c, &wpack32, &lu_bad, &i8_g, &i8_pow2g, &i8_wq, &i8_const, &i8_const_nw};
     for (DevBuf* b : all) b->release();
     has_hmm = has_gmm = false;
 }

@@ -107,11 +107,11 @@ __global__ void i8_row_scale_kernel(const double* __restrict__ mu, const double*
 //   wq[(((sp*2 + q)*9 + slot)*64 + lane)]  (16 bytes)   row r = lane & 15 <-> state 2 sp + ((r >> 2) & 1), mixture 8 (r >> 3) + 4 q + (r & 3)
 //   slot j < 7 : plane j, k = 16 (lane >> 4) + byte                   (the K = 0..63 step of a plane pair)
 //   slot 7 + p : plane (lane >> 4) + 4 p, k = 64 + byte               (the packed remainder steps; plane 7 does not exist: zeros)
-// constc[state*16 + m] = log w + gconst - 1/2 sum mu^2 / var
+// constc[state*16 + m] = log w + gconst - 1/2 sum mu^2 / var;  constc_nw: the same without log w
 __global__ void pack_wslice_kernel(const double* __restrict__ mu, const double* __restrict__ ivar,
                                    const double* __restrict__ gconst, const double* __restrict__ logw,
-                                   const int* __restrict__ g, int4_t* __restrict__ wq, double* __restrict__ constc, int N,
-                                   int D) {
+                                   const int* __restrict__ g, int4_t* __restrict__ wq, double* __restrict__ constc,
+                                   double* __restrict__ constc_nw, int N, int D) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)(N / 2) * 2 * kSlots * 64;
     if (idx >= total) return;
@@ -145,6 +145,7 @@ __global__ void pack_wslice_kernel(const double* __restrict__ mu, const double* 
             sq += m * m * ivar[c * D + d];
         }
         constc[c] = logw[c] + gconst[c] - 0.5 * sq;
+        constc_nw[c] = gconst[c] - 0.5 * sq;             // without the weight: what bm holds (gmmhmm.py:57-60)
     }
 }
 
@@ -254,10 +255,17 @@ __global__ __launch_bounds__(320) void slice_features_kernel(const double* __res
 // Two phases per tile, the two waves of a SIMD in OPPOSITE ones (waves 0-3: matrix phase of tile t, then its log-sum-exp;
 // waves 4-7: log-sum-exp of tile t - 1, then the matrix phase of tile t): the vector work of one wave issues beside the matrix
 // instructions of the other.  ABL = 6 is the diagnostic build's instantiation with s_memtime stamps around the phases.
-template <int ABL, bool REM = true>
+// WRITE_BM: also bm [F, N, 16], the component log-densities WITHOUT the weights (constc is then the weightless constant; the
+// weights of the block's 16 states wait in the LDS and are added on the way into the log-sum-exp).  The block's share of a
+// frame's bm row is 2 KB contiguous (16 states x 16 mixtures): the waves park their values in an LDS image of the tile
+// ([frame][state][mixture], double buffered) and the log-sum-exp waves of the NEXT phase write it out as whole rows, 16
+// bytes per lane -- tools/ubench/wpattern: 6.1 TB/s, against 3.8 for the 32-byte pieces a lane could store directly.
+constexpr int kBmRow = 16 * 16 + 4;                   // doubles per frame of the image (padded: two-way bank conflicts at most)
+template <int ABL, bool REM = true, bool WRITE_BM = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void emit_diag_i8(
-    const int4_t* __restrict__ Fs, const int4_t* __restrict__ wq, const double* __restrict__ constc, double* __restrict__ b,
-    long F, int N, int GY, long ntiles, int tiles_per_block, long nchunks, unsigned long long* __restrict__ dbg) {
+    const int4_t* __restrict__ Fs, const int4_t* __restrict__ wq, const double* __restrict__ constc,
+    const double* __restrict__ logw, double* __restrict__ b, double* __restrict__ bm, long F, int N, int GY, long ntiles,
+    int tiles_per_block, long nchunks, unsigned long long* __restrict__ dbg) {
     __shared__ int4_t Fl[2][kLdsI4];
     __shared__ double ob[2][16 * 17];
     unsigned long long ph[5] = {0, 0, 0, 0, 0}, ts = 0;
@@ -274,6 +282,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     exp_table_big_init(etab, tid, 512);
     log_table_init(ltab, tid, 512);
     if (tid < 32) Fl[tid >> 4][kZeroI4 + (tid & 15)] = int4_t{0, 0, 0, 0};
+    __shared__ double lws[WRITE_BM ? 256 : 1];
+    __shared__ double csts[WRITE_BM ? 256 : 1];
+    __shared__ double bms[WRITE_BM ? 2 * 16 * kBmRow : 1];
     const long bid = blockIdx.x;
     const int xcd = (int)(bid & 7);
     const long bi = bid >> 3;
@@ -287,6 +298,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // nobody flushes)
     const int sp = 2 * (8 * y + w) < N ? 8 * y + w : 0;
     const int g = lane >> 4, col = lane & 15;
+    if (WRITE_BM && tid < 256) {                          // [state of the slab][mixture]; states past N: never used
+        const long st = 16L * y + (tid >> 4);
+        lws[tid] = logw[(st < N ? st : N - 1) * 16 + (tid & 15)];
+    }
 
     int4_t Wm[2][kS], Wl[2][2];
 #pragma unroll
@@ -297,9 +312,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int p = 0; p < 2; ++p)
             if (REM) Wl[q][p] = wq[(((size_t)sp * 2 + q) * kSlots + kS + p) * 64 + lane];
     }
-    double cst[8];
+    // (WRITE_BM: the constants wait in the LDS beside the weights -- 16 registers the instantiation does not have)
+    double cst[WRITE_BM ? 1 : 8];
+    const double* cstp = cst;
+    if (WRITE_BM) {
+        if (tid < 256) {
+            const long st = 16L * y + (tid >> 4);
+            csts[tid] = constc[(st < N ? st : N - 1) * 16 + (tid & 15)];
+        }
+        cstp = csts + (2 * w + (g & 1)) * 16 + 8 * (g >> 1);
+    } else {
 #pragma unroll
-    for (int m = 0; m < 8; ++m) cst[m] = constc[(size_t)(2 * sp + (g & 1)) * 16 + 8 * (g >> 1) + m];
+        for (int m = 0; m < 8; ++m) cst[m] = constc[(size_t)(2 * sp + (g & 1)) * 16 + 8 * (g >> 1) + m];
+    }
 
     int4_t pre[2];
     auto load_tile = [&](long tile) {
@@ -346,6 +371,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // 8 (g >> 1) + 4 q + e; the other eight are in lane ^ 32) -> the staging row of that tile
     double v[2][4];
     auto lse_to = [&](double* obuf) {
+        if (WRITE_BM) {
+            const double* lw = lws + (2 * w + (g & 1)) * 16 + 8 * (g >> 1);
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[q][e] += lw[4 * q + e];
+        }
         double mx = v[0][0];
 #pragma unroll
         for (int q = 0; q < 2; ++q)
@@ -373,8 +405,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             fm[d] = Fc[d * kPlaneI4 + hb];
 #pragma unroll
             for (int p = 0; p < 2; ++p) {                 // K = 64..79: lane group g carries planes (d - g - 4p, g + 4p)
-                if (4 * p > d || !REM) continue;
-                const int i = d - g - 4 * p;
+                if (4 * p > d || !REM || (WRITE_BM && d >= 4)) continue;   // (WRITE_BM: 24 registers short -- the last six
+                const int i = d - g - 4 * p;                               // remainder fragments are read next to their use)
                 fl[d][p] = Fc[i >= 0 ? i * kPlaneI4 + 64 + col : kZeroI4 + col];
             }
         }
@@ -400,6 +432,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
                     if (4 * p > d || !REM) continue;
+                    if (WRITE_BM && d >= 4) {
+                        const int i = d - g - 4 * p;
+                        fl[d][p] = Fc[i >= 0 ? i * kPlaneI4 + 64 + col : kZeroI4 + col];
+                    }
 #pragma unroll
                     for (int q = 0; q < 2; ++q)
                         acc[dd][q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Wl[q][p], fl[d][p], acc[dd][q], 0, 0, 0);
@@ -417,7 +453,28 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[q][e] = fma(r[q][e], scale, cst[4 * q + e]);
+            for (int e = 0; e < 4; ++e) v[q][e] = fma(r[q][e], scale, cstp[4 * q + e]);
+        if (WRITE_BM) {                                   // this lane: eight consecutive mixtures of (frame col, its state)
+            typedef double double4v __attribute__((ext_vector_type(4)));
+            double4v* dst = reinterpret_cast<double4v*>(bms + (size_t)buf * 16 * kBmRow + col * kBmRow + (2 * w + (g & 1)) * 16 +
+                                                        8 * (g >> 1));
+            dst[0] = double4v{v[0][0], v[0][1], v[0][2], v[0][3]};
+            dst[1] = double4v{v[1][0], v[1][1], v[1][2], v[1][3]};
+        }
+    };
+    // the parked tile -> bm: 256 threads, 16 bytes each, eight times: whole 2 KB rows
+    auto flush_bm = [&](int buf, long tile, int t256) {
+        typedef double double2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int idx = k * 256 + t256;
+            const int f = idx >> 7, off = idx & 127;      // frame of the tile, 16-byte piece of its 2 KB
+            const long frame = tile * 16 + f;
+            const int st = 16 * y + (off >> 3);
+            if (frame < F && st < N)
+                *reinterpret_cast<double2v*>(bm + ((size_t)frame * N + 16 * y) * 16 + off * 2) =
+                    *reinterpret_cast<const double2v*>(bms + (size_t)buf * 16 * kBmRow + f * kBmRow + off * 2);
+        }
     };
 
     // Two phases per tile, the two waves of a SIMD in OPPOSITE ones: waves 0-3 run the matrix phase of tile t while waves 4-7
@@ -430,7 +487,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (ABL == 6) ts = __builtin_amdgcn_s_memtime();
         if (has_next) load_tile(tile + 1);
         if (half == 0) matrix_phase(cur);
-        else if (tile > tile0) lse_to(&ob[cur ^ 1][0]);
+        else if (tile > tile0) {
+            lse_to(&ob[cur ^ 1][0]);
+            if (WRITE_BM) flush_bm(cur ^ 1, tile - 1, tid - 256);      // complete since the last barrier
+        }
         LN_STAMP(0);
         __syncthreads();
         LN_STAMP(1);
@@ -450,6 +510,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (half == 1) lse_to(&ob[last][0]);
         __syncthreads();
         flush(last, tile1 - 1);
+        if (WRITE_BM && half == 1) flush_bm(last, tile1 - 1, tid - 256);
     }
     if (ABL == 6 && lane == 0) {
         for (int i = 0; i < 5; ++i) dbg[((size_t)blockIdx.x * 8 + w) * 7 + i] = ph[i];
@@ -465,6 +526,7 @@ bool i8_emit_shape_ok(int Nv, int Mv, int D) { return Mv == 16 && Nv % 2 == 0 &&
 
 // once per model (after prep_diag / centre_and_kappa): digit planes of the coefficients
 int pack_i8_model(lnasr_ctx* ctx, const double* mu_s, const double* iv_s, const double* gc_s, const double* lw_s, int Nv) {
+    ctx->model.i8_logw = lw_s;
     Model& md = ctx->model;
     const int D = md.D;
     const size_t NMv = (size_t)Nv * 16;
@@ -472,17 +534,18 @@ int pack_i8_model(lnasr_ctx* ctx, const double* mu_s, const double* iv_s, const 
     LN_TRY(md.i8_pow2g.reserve(80 * 8));
     LN_TRY(md.i8_wq.reserve((size_t)(Nv / 2) * 2 * kSlots * 64 * 16));
     LN_TRY(md.i8_const.reserve(NMv * 8));
+    LN_TRY(md.i8_const_nw.reserve(NMv * 8));
     LN_LAUNCH(ctx, "i8_row_scale", i8_row_scale_kernel, dim3(80), dim3(256), 0, mu_s, iv_s, (int)NMv, D, md.i8_g.as<int>(),
               md.i8_pow2g.as<double>());
     const size_t total = (size_t)(Nv / 2) * 2 * kSlots * 64;
     LN_LAUNCH(ctx, "pack_wslice", pack_wslice_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, mu_s, iv_s, gc_s,
-              lw_s, (const int*)md.i8_g.as<int>(), md.i8_wq.as<int4_t>(), md.i8_const.as<double>(), Nv, D);
+              lw_s, (const int*)md.i8_g.as<int>(), md.i8_wq.as<int4_t>(), md.i8_const.as<double>(), md.i8_const_nw.as<double>(), Nv, D);
     md.i8_NG = Nv / 4;
     return 0;
 }
 
-// b [F, Nv] for the (virtual, padded) states of the packed model
-int emit_diag_i8_device(lnasr_ctx* ctx, const double* obs, long F, double* b) {
+// b [F, Nv] (and bm [F, Nv, 16] unless null) for the (virtual, padded) states of the packed model
+int emit_diag_i8_device(lnasr_ctx* ctx, const double* obs, long F, double* b, double* bm) {
     Model& md = ctx->model;
     const int Nv = md.i8_NG * 4, D = md.D;
     const long ntiles = (F + 15) / 16;
@@ -500,17 +563,18 @@ int emit_diag_i8_device(lnasr_ctx* ctx, const double* obs, long F, double* b) {
     if (tpb < 1) tpb = 1;
     const long nchunks = (ntiles + tpb - 1) / tpb;
     const long grid = ((nchunks + 7) / 8) * 8 * GY;
-#define LN_I8(abl, name)                                                                                          \
-    LN_LAUNCH(ctx, name, (emit_diag_i8<abl, true>), dim3((unsigned)grid), dim3(512), 0, (const int4_t*)Fs,          \
-              (const int4_t*)md.i8_wq.as<int4_t>(), (const double*)md.i8_const.as<double>(), b, F, Nv, GY, ntiles,   \
-              (int)tpb, nchunks, dbg)
+#define LN_I8K(abl, rem, wbm, name)                                                                               \
+    LN_LAUNCH(ctx, name, (emit_diag_i8<abl, rem, wbm>), dim3((unsigned)grid), dim3(512), 0, (const int4_t*)Fs,      \
+              (const int4_t*)md.i8_wq.as<int4_t>(),                                                                  \
+              (const double*)(wbm ? md.i8_const_nw.as<double>() : md.i8_const.as<double>()), md.i8_logw, b, bm, F,   \
+              Nv, GY, ntiles, (int)tpb, nchunks, dbg)
     unsigned long long* dbg = nullptr;
 #ifdef LNASR_I8_STAMPS                                    // diagnostic build: in-kernel phase stamps (s_memtime), printed per launch
-    if (getenv("LNASR_I8_STAMPS")) {
+    if (getenv("LNASR_I8_STAMPS") && !bm) {
         const size_t n = (size_t)grid * 8 * 7;
         LN_HIP(hipMalloc((void**)&dbg, n * 8));           // (diagnostic build: not a workspace of the context, freed below)
         LN_HIP(hipMemsetAsync(dbg, 0, n * 8, ctx->stream));
-        LN_I8(6, "emit_i8_stamps");
+        LN_I8K(6, true, false, "emit_i8_stamps");
         std::vector<unsigned long long> h(n);
         LN_HIP(hipMemcpyAsync(h.data(), dbg, n * 8, hipMemcpyDeviceToHost, ctx->stream));
         LN_HIP(hipStreamSynchronize(ctx->stream));
@@ -522,15 +586,15 @@ int emit_diag_i8_device(lnasr_ctx* ctx, const double* obs, long F, double* b) {
                 sum[0] * per, sum[1] * per, sum[2] * per, sum[3] * per, sum[4] * per);
         fprintf(stderr, "   wave lifetime %.0f cycles = %.3f ms: clock %.2f GHz\n", sum[5] / ((double)grid * 8),
                 sum[6] / ((double)grid * 8) * 1e-5, sum[5] / sum[6] * 0.1);
-    } else
+        return 0;
+    }
 #endif
-    if (2 * D <= 64)                                      // K <= 64: the 28 plane pairs and nothing else
-        LN_LAUNCH(ctx, "emit_diag_i8_k64", (emit_diag_i8<0, false>), dim3((unsigned)grid), dim3(512), 0, (const int4_t*)Fs,
-                  (const int4_t*)md.i8_wq.as<int4_t>(), (const double*)md.i8_const.as<double>(), b, F, Nv, GY, ntiles,
-                  (int)tpb, nchunks, dbg);
-    else
-        LN_I8(0, "emit_diag_i8");
-#undef LN_I8
+    const bool k64 = 2 * D <= 64;                         // K <= 64: the 28 plane pairs and nothing else
+    if (bm && k64) LN_I8K(0, false, true, "emit_diag_i8_k64_bm");
+    else if (bm) LN_I8K(0, true, true, "emit_diag_i8_bm");
+    else if (k64) LN_I8K(0, false, false, "emit_diag_i8_k64");
+    else LN_I8K(0, true, false, "emit_diag_i8");
+#undef LN_I8K
     return 0;
 }
 

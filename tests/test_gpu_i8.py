@@ -51,10 +51,18 @@ def test_integer_bank_equals_the_reference(N, M, D, U, T, synth, oracle, ctx):
         b64, names64 = _kernels_of(ctx, lambda: ctx.gmm_logprob(obs))
     assert not {"emit_diag_i8", "emit_diag_i8_k64"} & names64
     assert_close(b, b64, 1e-13)
+    # b + bm: the same planes, the weights added on the way into the log-sum-exp (bm carries none: gmmhmm.py:57-60), bm parked
+    # in the LDS and written as whole rows
+    with env_switch(LNASR_I8_MIN_FRAMES=0):
+        _upload(ctx, mdl)
+        (b2, bm2), names2 = _kernels_of(ctx, lambda: ctx.gmm_logprob(obs, want_bm=True))
+    assert ("emit_diag_i8_bm" if 2 * D > 64 else "emit_diag_i8_k64_bm") in names2 or not tuned()
+    assert_close(b2, b, 1e-13)
     for u in (0, U - 1):
         with np.errstate(divide="ignore"):
-            ob, _ = oracle.gmm_map_b_diag(obs[u], mdl["w"], mdl["mu"], mdl["var"])
+            ob, obm = oracle.gmm_map_b_diag(obs[u], mdl["w"], mdl["mu"], mdl["var"])
         assert_close(b[u].T, ob, 1e-12)
+        assert_close(bm2[u].transpose(1, 2, 0), obm, 1e-12)
 
 
 def test_integer_bank_is_at_least_as_accurate_as_the_fp64_kernel(synth, ctx):
@@ -136,7 +144,7 @@ def test_decode_over_the_integer_bank_gives_the_same_paths(synth, oracle, ctx):
 
 
 def test_integer_bank_dispatch_rule(synth, ctx):
-    """Default rule: b alone, 4096 frames or more, 64 (virtual) states or more, M = 16 k, 14 <= D <= 39; b + bm, small batches,
+    """Default rule: 4096 frames or more, 64 (virtual) states or more, 14 <= D <= 39, b alone or b + bm; small batches,
     small banks and D <= 13 (K = 28: seven fp64 matrix instructions per tile are no slower than 28 integer ones) stay on the
     fp64 kernel."""
     if not tuned():
@@ -146,9 +154,9 @@ def test_integer_bank_dispatch_rule(synth, ctx):
     big, small = synth.synth_obs(5, 1000, 39, seed=3), synth.synth_obs(1, 1000, 39, seed=3)
     assert "emit_diag_i8" in _kernels_of(ctx, lambda: ctx.gmm_logprob(big))[1]
     assert "emit_diag_i8" not in _kernels_of(ctx, lambda: ctx.gmm_logprob(small))[1]
-    assert "emit_diag_i8" not in _kernels_of(ctx, lambda: ctx.gmm_logprob(big, want_bm=True))[1]
+    assert "emit_diag_i8_bm" in _kernels_of(ctx, lambda: ctx.gmm_logprob(big, want_bm=True))[1]
     _upload(ctx, synth.synth_model(32, 16, 39, seed=2))
-    assert "emit_diag_i8" not in _kernels_of(ctx, lambda: ctx.gmm_logprob(big))[1]
+    assert not {"emit_diag_i8", "emit_diag_i8_bm"} & _kernels_of(ctx, lambda: ctx.gmm_logprob(big))[1]
     _upload(ctx, synth.synth_model(64, 16, 20, seed=2))
     assert "emit_diag_i8_k64" in _kernels_of(ctx, lambda: ctx.gmm_logprob(synth.synth_obs(5, 1000, 20, seed=3)))[1]
     _upload(ctx, synth.synth_model(64, 16, 13, seed=2))
