@@ -104,6 +104,7 @@ struct Model {
     DevBuf i8_g, i8_pow2g, i8_wq, i8_const, i8_const_nw;
     const double* i8_logw = nullptr;   // the (padded) log weights the planes were packed with: [Nv,16]
     int i8_NG = 0;               // state groups packed (0: none)
+    int i8_mix = 16;             // mixtures per (virtual) state of the packed planes: 16 or 8
     void release();
 };
 
@@ -265,7 +266,7 @@ int mix_stats_device_f32(lnasr_ctx* ctx, const double* obs, const double* alpha,
 int emit_device(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, void* bm);
 // gmm_i8.hip: the diagonal bank on the integer matrix cores (exact sliced arithmetic)
 bool i8_emit_shape_ok(int Nv, int Mv, int D);
-int pack_i8_model(lnasr_ctx* ctx, const double* mu_s, const double* iv_s, const double* gc_s, const double* lw_s, int Nv);
+int pack_i8_model(lnasr_ctx* ctx, const double* mu_s, const double* iv_s, const double* gc_s, const double* lw_s, int Nv, int Mv);
 int emit_diag_i8_device(lnasr_ctx* ctx, const double* obs, long F, double* b, double* bm);
 // emit_device without the pass over non-finite frames; *scanned: the kernel tested the features it staged and raised
 // ctx->nan_flag itself (emit_batch runs the kernels chunk by chunk and the pass once)

@@ -1130,8 +1130,8 @@ static int model_upload_impl(lnasr_ctx* ctx, int N, int M, int D, const double* 
             md.wpack_NG = Nv / 4;
             md.wpack_virt = virt;
             md.i8_NG = 0;
-            if (Q == 4 && (KS == 20 || KS == 14) && i8_emit_shape_ok(Nv, Mv, D) && !sw().no_i8emit)
-                LN_TRY(pack_i8_model(ctx, mu_s, iv_s, gc_s, lw_s, Nv));
+            if ((Q == 4 || Q == 2) && (KS == 20 || KS == 14) && i8_emit_shape_ok(Nv, Mv, D) && !sw().no_i8emit)
+                LN_TRY(pack_i8_model(ctx, mu_s, iv_s, gc_s, lw_s, Nv, Mv));
         }
     } else {
         LN_TRY(md.prec.reserve(NMD * D * 8));
@@ -1220,7 +1220,8 @@ static int launch_mfma(lnasr_ctx* ctx, const double* obs, long F, double* b, dou
     // b alone, a few thousand frames to amortise 36 KB of digit planes per wave, four slabs of 16 states or more: the integer
     // matrix cores (gmm_i8.hip; 128 states x 1000 frames: 0.018 against 0.016 ms for one utterance, 0.033 / 0.036 for four,
     // 0.36 / 0.41 for 64; 32 states x 512,000 frames: 0.87 / 0.83)
-    if (Q == 4 && (KS == 20 || KS == 14) && ctx->model.i8_NG == ctx->model.wpack_NG && ctx->model.i8_NG > 0 && !sw().no_i8emit &&
+    if (((Q == 4 && ctx->model.i8_mix == 16) || (Q == 2 && ctx->model.i8_mix == 8 && !bm)) && (KS == 20 || KS == 14) &&
+        ctx->model.i8_NG == ctx->model.wpack_NG && ctx->model.i8_NG > 0 && !sw().no_i8emit &&
         (sw().i8_min_frames >= 0 ? F >= sw().i8_min_frames : (F >= 4096 && ctx->model.i8_NG >= 16)))
         return emit_diag_i8_device(ctx, obs, F, b, bm);
     // 8 waves per block (32 states), one 16-frame tile per barrier interval: fastest of the tilings tried

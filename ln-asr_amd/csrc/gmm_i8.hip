@@ -111,9 +111,9 @@ __global__ void i8_row_scale_kernel(const double* __restrict__ mu, const double*
 __global__ void pack_wslice_kernel(const double* __restrict__ mu, const double* __restrict__ ivar,
                                    const double* __restrict__ gconst, const double* __restrict__ logw,
                                    const int* __restrict__ g, int4_t* __restrict__ wq, double* __restrict__ constc,
-                                   double* __restrict__ constc_nw, int N, int D) {
+                                   double* __restrict__ constc_nw, int N, int D, int MX) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t total = (size_t)(N / 2) * 2 * kSlots * 64;
+    const size_t total = (size_t)(MX == 16 ? N / 2 : N / 4) * 2 * kSlots * 64;
     if (idx >= total) return;
     const int lane = (int)(idx & 63);
     size_t r1 = idx >> 6;
@@ -122,8 +122,11 @@ __global__ void pack_wslice_kernel(const double* __restrict__ mu, const double* 
     const int q = (int)(r1 & 1);
     const int sp = (int)(r1 >> 1);
     const int r = lane & 15, h = lane >> 4;
-    const int state = 2 * sp + ((r >> 2) & 1), mix = 8 * (r >> 3) + 4 * q + (r & 3);
-    const size_t c = (size_t)state * 16 + mix;
+    // 8 mixtures per state (MX = 8): a wave's two tiles are 4 states x 8 mixtures, row r <-> state 4 sp + (r >> 2), mixture
+    // 4 q + (r & 3) -- a lane then holds all eight mixtures of its state
+    const int state = MX == 16 ? 2 * sp + ((r >> 2) & 1) : 4 * sp + (r >> 2);
+    const int mix = MX == 16 ? 8 * (r >> 3) + 4 * q + (r & 3) : 4 * q + (r & 3);
+    const size_t c = (size_t)state * MX + mix;
     const int plane = slot < kS ? slot : h + 4 * (slot - kS);
     const int k0 = slot < kS ? 16 * h : 64;
     unsigned w[4] = {0, 0, 0, 0};
@@ -261,13 +264,15 @@ __global__ __launch_bounds__(320) void slice_features_kernel(const double* __res
 // ([frame][state][mixture], double buffered) and the log-sum-exp waves of the NEXT phase write it out as whole rows, 16
 // bytes per lane -- tools/ubench/wpattern: 6.1 TB/s, against 3.8 for the 32-byte pieces a lane could store directly.
 constexpr int kBmRow = 16 * 16 + 4;                   // doubles per frame of the image (padded: two-way bank conflicts at most)
-template <int ABL, bool REM = true, bool WRITE_BM = false>
+template <int ABL, bool REM = true, bool WRITE_BM = false, bool M8 = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void emit_diag_i8(
     const int4_t* __restrict__ Fs, const int4_t* __restrict__ wq, const double* __restrict__ constc,
     const double* __restrict__ logw, double* __restrict__ b, double* __restrict__ bm, long F, int N, int GY, long ntiles,
     int tiles_per_block, long nchunks, unsigned long long* __restrict__ dbg) {
     __shared__ int4_t Fl[2][kLdsI4];
-    __shared__ double ob[2][16 * 17];
+    static_assert(!(M8 && WRITE_BM), "the 8-mixture instantiation writes b only");
+    constexpr int SPB = M8 ? 32 : 16, OST = SPB + 1;      // states per block, padded row of the staged outputs
+    __shared__ double ob[2][16 * 33];
     unsigned long long ph[5] = {0, 0, 0, 0, 0}, ts = 0;
     const unsigned long long k0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
 #define LN_STAMP(i)                                                \
@@ -296,7 +301,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (tile1 > ntiles) tile1 = ntiles;
     // (N a multiple of 2, not of 16: the waves of the last slab that have no state pair score pair 0 again and stage values
     // nobody flushes)
-    const int sp = 2 * (8 * y + w) < N ? 8 * y + w : 0;
+    const int sp = (M8 ? 4 : 2) * (8 * y + w) < N ? 8 * y + w : 0;     // (M8: the wave's four states, else its state pair)
     const int g = lane >> 4, col = lane & 15;
     if (WRITE_BM && tid < 256) {                          // [state of the slab][mixture]; states past N: never used
         const long st = 16L * y + (tid >> 4);
@@ -323,7 +328,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         cstp = csts + (2 * w + (g & 1)) * 16 + 8 * (g >> 1);
     } else {
 #pragma unroll
-        for (int m = 0; m < 8; ++m) cst[m] = constc[(size_t)(2 * sp + (g & 1)) * 16 + 8 * (g >> 1) + m];
+        for (int m = 0; m < 8; ++m)
+            cst[m] = M8 ? constc[(size_t)(4 * sp + g) * 8 + m] : constc[(size_t)(2 * sp + (g & 1)) * 16 + 8 * (g >> 1) + m];
     }
 
     int4_t pre[2];
@@ -342,11 +348,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (e < kTileI4) Fl[buf][e] = pre[r];
         }
     };
-    auto flush = [&](int buf, long tile) {               // 16 frames x 16 states: 128-byte rows (waves 0-3)
-        if (tid < 256) {
-            const int f = tid >> 4, st = tid & 15;
+    auto flush = [&](int buf, long tile) {               // 16 frames x 16 states: 128-byte rows (waves 0-3); M8: x 32
+        if (M8 || tid < 256) {
+            const int f = M8 ? tid >> 5 : tid >> 4, st = M8 ? tid & 31 : tid & 15;
             const long frame = tile * 16 + f;
-            if (frame < F && 16 * y + st < N) b[frame * N + 16 * y + st] = ob[buf][f * 17 + st];
+            if (frame < F && SPB * y + st < N) b[frame * N + SPB * y + st] = ob[buf][f * OST + st];
         }
     };
 
@@ -384,14 +390,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 if (q + e > 0) mx = vmax_f64(mx, v[q][e]);
-        mx = pair_max(mx);
+        if (!M8) mx = pair_max(mx);
         double s = 0.0;
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
             for (int e = 0; e < 4; ++e) s += exp_nonpos_big2(v[q][e] - mx, etab);
-        s = pair_sum(s);
-        if (g < 2) obuf[col * 17 + 2 * w + g] = (mx == LN_NEG_INF) ? mx : mx + log_sum(s, ltab);
+        if (!M8) s = pair_sum(s);
+        const double res = (mx == LN_NEG_INF) ? mx : mx + log_sum(s, ltab);
+        if (M8) obuf[col * OST + 4 * w + g] = res;
+        else if (g < 2) obuf[col * OST + 2 * w + g] = res;
     };
 
     // the matrix phase of one tile: planes from the LDS to registers, 76 matrix instructions with the folds between them -> v
@@ -496,10 +504,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         LN_STAMP(1);
         if (half == 0) {
             lse_to(&ob[cur][0]);
-            if (tile > tile0) flush(cur ^ 1, tile - 1);   // both halves have staged tile t - 1 by now
+            if (!M8 && tile > tile0) flush(cur ^ 1, tile - 1);   // both halves have staged tile t - 1 by now
         } else {
             matrix_phase(cur);
         }
+        if (M8 && tile > tile0) flush(cur ^ 1, tile - 1);  // (32 states: every thread has a value to write)
         if (has_next) store_tile(cur ^ 1);
         LN_STAMP(3);
         __syncthreads();
@@ -522,24 +531,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 }  // namespace
 
-bool i8_emit_shape_ok(int Nv, int Mv, int D) { return Mv == 16 && Nv % 2 == 0 && D >= 1 && 2 * D <= 80; }
+bool i8_emit_shape_ok(int Nv, int Mv, int D) { return (Mv == 16 || Mv == 8) && Nv % 4 == 0 && D >= 1 && 2 * D <= 80; }
 
 // once per model (after prep_diag / centre_and_kappa): digit planes of the coefficients
-int pack_i8_model(lnasr_ctx* ctx, const double* mu_s, const double* iv_s, const double* gc_s, const double* lw_s, int Nv) {
+int pack_i8_model(lnasr_ctx* ctx, const double* mu_s, const double* iv_s, const double* gc_s, const double* lw_s, int Nv,
+                  int Mv) {
     ctx->model.i8_logw = lw_s;
+    ctx->model.i8_mix = Mv;
     Model& md = ctx->model;
     const int D = md.D;
-    const size_t NMv = (size_t)Nv * 16;
+    const size_t NMv = (size_t)Nv * Mv;
     LN_TRY(md.i8_g.reserve(80 * 4));
     LN_TRY(md.i8_pow2g.reserve(80 * 8));
-    LN_TRY(md.i8_wq.reserve((size_t)(Nv / 2) * 2 * kSlots * 64 * 16));
+    const size_t units = Mv == 16 ? Nv / 2 : Nv / 4;       // waves' worth of components: 32 each
+    LN_TRY(md.i8_wq.reserve(units * 2 * kSlots * 64 * 16));
     LN_TRY(md.i8_const.reserve(NMv * 8));
     LN_TRY(md.i8_const_nw.reserve(NMv * 8));
     LN_LAUNCH(ctx, "i8_row_scale", i8_row_scale_kernel, dim3(80), dim3(256), 0, mu_s, iv_s, (int)NMv, D, md.i8_g.as<int>(),
               md.i8_pow2g.as<double>());
-    const size_t total = (size_t)(Nv / 2) * 2 * kSlots * 64;
+    const size_t total = units * 2 * kSlots * 64;
     LN_LAUNCH(ctx, "pack_wslice", pack_wslice_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, mu_s, iv_s, gc_s,
-              lw_s, (const int*)md.i8_g.as<int>(), md.i8_wq.as<int4_t>(), md.i8_const.as<double>(), md.i8_const_nw.as<double>(), Nv, D);
+              lw_s, (const int*)md.i8_g.as<int>(), md.i8_wq.as<int4_t>(), md.i8_const.as<double>(), md.i8_const_nw.as<double>(), Nv, D, Mv);
     md.i8_NG = Nv / 4;
     return 0;
 }
@@ -554,7 +566,8 @@ int emit_diag_i8_device(lnasr_ctx* ctx, const double* obs, long F, double* b, do
     LN_LAUNCH(ctx, "slice_features", slice_features_kernel, dim3((unsigned)((ntiles * 16 + 63) / 64)), dim3(320), 0, obs,
               (const double*)md.centre.as<double>(), (const double*)md.i8_pow2g.as<double>(), Fs, F, D,
               ctx->nan_flag.as<unsigned>(), ctx->nan_epoch);
-    const int GY = (Nv + 15) / 16;
+    const bool m8 = md.i8_mix == 8;
+    const int GY = m8 ? (Nv + 31) / 32 : (Nv + 15) / 16;
     const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
     long want_chunks = (long)cus / GY;                   // one 8-wave block per CU: two waves per SIMD
     if (want_chunks < 8) want_chunks = 8;
@@ -564,7 +577,7 @@ int emit_diag_i8_device(lnasr_ctx* ctx, const double* obs, long F, double* b, do
     const long nchunks = (ntiles + tpb - 1) / tpb;
     const long grid = ((nchunks + 7) / 8) * 8 * GY;
 #define LN_I8K(abl, rem, wbm, name)                                                                               \
-    LN_LAUNCH(ctx, name, (emit_diag_i8<abl, rem, wbm>), dim3((unsigned)grid), dim3(512), 0, (const int4_t*)Fs,      \
+    LN_LAUNCH(ctx, name, (emit_diag_i8<abl, rem, wbm, false>), dim3((unsigned)grid), dim3(512), 0, (const int4_t*)Fs, \
               (const int4_t*)md.i8_wq.as<int4_t>(),                                                                  \
               (const double*)(wbm ? md.i8_const_nw.as<double>() : md.i8_const.as<double>()), md.i8_logw, b, bm, F,   \
               Nv, GY, ntiles, (int)tpb, nchunks, dbg)
@@ -590,6 +603,17 @@ int emit_diag_i8_device(lnasr_ctx* ctx, const double* obs, long F, double* b, do
     }
 #endif
     const bool k64 = 2 * D <= 64;                         // K <= 64: the 28 plane pairs and nothing else
+#define LN_I8M8(rem, name)                                                                                        \
+    LN_LAUNCH(ctx, name, (emit_diag_i8<0, rem, false, true>), dim3((unsigned)grid), dim3(512), 0, (const int4_t*)Fs, \
+              (const int4_t*)md.i8_wq.as<int4_t>(), (const double*)md.i8_const.as<double>(), md.i8_logw, b,         \
+              (double*)nullptr, F, Nv, GY, ntiles, (int)tpb, nchunks, dbg)
+    if (m8) {
+        LN_REQUIRE(!bm, "the 8-mixture integer bank writes b only");
+        if (k64) LN_I8M8(false, "emit_diag_i8_m8_k64");
+        else LN_I8M8(true, "emit_diag_i8_m8");
+        return 0;
+    }
+#undef LN_I8M8
     if (bm && k64) LN_I8K(0, false, true, "emit_diag_i8_k64_bm");
     else if (bm) LN_I8K(0, true, true, "emit_diag_i8_bm");
     else if (k64) LN_I8K(0, false, false, "emit_diag_i8_k64");

@@ -45,6 +45,8 @@ if __name__ == "__main__":
         run(128, 16, 26, 1024, 1000)
         run(128, 16, 32, 1024, 1000)
         run(128, 16, 14, 1024, 1000)
+        run(128, 8, 39, 1024, 1000)
+        run(256, 8, 26, 512, 1000)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "abl":
         for a in (sys.argv[2:] or ("0", "3", "4", "5")):
