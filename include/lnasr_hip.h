@@ -153,7 +153,7 @@ int lnasr_discrete_map_b(lnasr_ctx* ctx, const double* logB, int N, int K,
 /* GMMHMM._map_b (gmmhmm.py:46-67): b and (optionally) the per-mixture bm.  A frame with a NaN or an infinite feature
  * gets what the reference's product with the full inverse matrix gives (gmm.py:63-68): NaN rows (inf * 0 for a diagonal
  * Sigma), or -inf / NaN component by component where an infinity meets no zero (a genuinely full Sigma, D = 1).
- * Which kernel scores a call depends on the shape (4096 frames or more of a diagonal bank of 64 states or more with
+ * Which kernel scores a call depends on the shape (4096 frames or more of a diagonal bank of 48 states or more with
  * 14 <= D <= 39 and at least 5 mixtures take the integer matrix cores: the same fp64 values from an exact integer sum, csrc/gmm_i8.hip); every
  * route returns the reference's b to 1e-12, and two routes agree to ~1e-13 -- the b of a small batch and of a large one that
  * contains it are therefore not guaranteed to be the same bits. */

@@ -1219,10 +1219,10 @@ static int launch_mfma(lnasr_ctx* ctx, const double* obs, long F, double* b, dou
 #endif
     // b alone, a few thousand frames to amortise 36 KB of digit planes per wave, four slabs of 16 states or more: the integer
     // matrix cores (gmm_i8.hip; 128 states x 1000 frames: 0.018 against 0.016 ms for one utterance, 0.033 / 0.036 for four,
-    // 0.36 / 0.41 for 64; 32 states x 512,000 frames: 0.87 / 0.83)
+    // 0.36 / 0.41 for 64; 512,000 frames of 32 states: 0.87 / 0.83, of 48: 1.17 / 1.57, of 64: 1.46 / 1.59)
     if (((Q == 4 && ctx->model.i8_mix == 16) || (Q == 2 && ctx->model.i8_mix == 8 && !bm)) && (KS == 20 || KS == 14) &&
         ctx->model.i8_NG == ctx->model.wpack_NG && ctx->model.i8_NG > 0 && !sw().no_i8emit &&
-        (sw().i8_min_frames >= 0 ? F >= sw().i8_min_frames : (F >= 4096 && ctx->model.i8_NG >= 16)))
+        (sw().i8_min_frames >= 0 ? F >= sw().i8_min_frames : (F >= 4096 && ctx->model.i8_NG >= 12)))
         return emit_diag_i8_device(ctx, obs, F, b, bm);
     // 8 waves per block (32 states), one 16-frame tile per barrier interval: fastest of the tilings tried
     // (4 or 8 waves x 1, 2, 4 tiles per interval) on MI355X

@@ -148,7 +148,7 @@ def test_decode_over_the_integer_bank_gives_the_same_paths(synth, oracle, ctx):
 
 
 def test_integer_bank_dispatch_rule(synth, ctx):
-    """Default rule: 4096 frames or more, 64 (virtual) states or more, 14 <= D <= 39, b alone or b + bm; small batches,
+    """Default rule: 4096 frames or more, 48 (virtual) states or more, 14 <= D <= 39, b alone or b + bm; small batches,
     small banks and D <= 13 (K = 28: seven fp64 matrix instructions per tile are no slower than 28 integer ones) stay on the
     fp64 kernel."""
     if not tuned():

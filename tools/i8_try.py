@@ -48,6 +48,10 @@ if __name__ == "__main__":
         run(128, 8, 39, 1024, 1000)
         run(256, 8, 26, 512, 1000)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "small":
+        for N, M in ((64, 16), (64, 8), (96, 16), (32, 32), (48, 16), (64, 32)):
+            run(N, M, 39, 512, 1000, reps=10)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "abl":
         for a in (sys.argv[2:] or ("0", "3", "4", "5")):
             os.environ["LNASR_I8_ABL"] = a
