@@ -1130,8 +1130,12 @@ static int model_upload_impl(lnasr_ctx* ctx, int N, int M, int D, const double* 
             md.wpack_NG = Nv / 4;
             md.wpack_virt = virt;
             md.i8_NG = 0;
-            if ((Q == 4 || Q == 2) && (KS == 20 || KS == 14) && i8_emit_shape_ok(Nv, Mv, D) && !sw().no_i8emit)
-                LN_TRY(pack_i8_model(ctx, mu_s, iv_s, gc_s, lw_s, Nv, Mv));
+            if ((Q == 4 || Q == 2) && (KS == 20 || KS == 14) && i8_emit_shape_ok(Nv, Mv, D) && !sw().no_i8emit) {
+                // M = 32 on the model as it is: a wave scores one state's 32 mixtures and joins them itself -- no virtual
+                // states, no merge pass (the arrays are the same memory either way: [N, 32, D] = [2 N, 16, D])
+                if (virt == 2 && Mv == 16 && Np == N && Mp == M) LN_TRY(pack_i8_model(ctx, mu_s, iv_s, gc_s, lw_s, N, 32));
+                else LN_TRY(pack_i8_model(ctx, mu_s, iv_s, gc_s, lw_s, Nv, Mv));
+            }
         }
     } else {
         LN_TRY(md.prec.reserve(NMD * D * 8));
@@ -1291,6 +1295,13 @@ int emit_device_raw(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* 
         const int Q = md.wpack_Q, KS = md.wpack_KS;
         const int Np = md.pad_N ? md.pad_N : N, Mp = md.pad_M ? md.pad_M : M, virt = md.wpack_virt;
         const bool padded = md.pad_N != 0;
+        // M = 32 on the integer matrix cores: b [F, N] and bm [F, N, 32] directly (gmm_i8.hip; same rule as in launch_mfma)
+        if (md.i8_mix == 32 && md.i8_NG == md.wpack_NG && md.i8_NG > 0 && !sw().no_i8emit && !padded &&
+            (sw().i8_min_frames >= 0 ? F >= sw().i8_min_frames : (F >= 4096 && md.i8_NG >= 12))) {
+            LN_TRY(emit_diag_i8_device(ctx, obs, F, (double*)b, (double*)bm));
+            *scanned = true;
+            return 0;
+        }
         double* bdst = (double*)b;
         double* bmdst = (double*)bm;
         if (virt > 1 || padded) {

@@ -113,7 +113,7 @@ __global__ void pack_wslice_kernel(const double* __restrict__ mu, const double* 
                                    const int* __restrict__ g, int4_t* __restrict__ wq, double* __restrict__ constc,
                                    double* __restrict__ constc_nw, int N, int D, int MX) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t total = (size_t)(MX == 16 ? N / 2 : N / 4) * 2 * kSlots * 64;
+    const size_t total = (size_t)(MX == 16 ? N / 2 : (MX == 8 ? N / 4 : N)) * 2 * kSlots * 64;
     if (idx >= total) return;
     const int lane = (int)(idx & 63);
     size_t r1 = idx >> 6;
@@ -124,8 +124,9 @@ __global__ void pack_wslice_kernel(const double* __restrict__ mu, const double* 
     const int r = lane & 15, h = lane >> 4;
     // 8 mixtures per state (MX = 8): a wave's two tiles are 4 states x 8 mixtures, row r <-> state 4 sp + (r >> 2), mixture
     // 4 q + (r & 3) -- a lane then holds all eight mixtures of its state
-    const int state = MX == 16 ? 2 * sp + ((r >> 2) & 1) : 4 * sp + (r >> 2);
-    const int mix = MX == 16 ? 8 * (r >> 3) + 4 * q + (r & 3) : 4 * q + (r & 3);
+    // 32 mixtures per state (MX = 32): the two tiles are ONE state, row r <-> mixture 8 (r >> 2) + 4 q + (r & 3)
+    const int state = MX == 16 ? 2 * sp + ((r >> 2) & 1) : (MX == 8 ? 4 * sp + (r >> 2) : sp);
+    const int mix = MX == 16 ? 8 * (r >> 3) + 4 * q + (r & 3) : (MX == 8 ? 4 * q + (r & 3) : 8 * (r >> 2) + 4 * q + (r & 3));
     const size_t c = (size_t)state * MX + mix;
     const int plane = slot < kS ? slot : h + 4 * (slot - kS);
     const int k0 = slot < kS ? 16 * h : 64;
@@ -264,14 +265,19 @@ __global__ __launch_bounds__(320) void slice_features_kernel(const double* __res
 // ([frame][state][mixture], double buffered) and the log-sum-exp waves of the NEXT phase write it out as whole rows, 16
 // bytes per lane -- tools/ubench/wpattern: 6.1 TB/s, against 3.8 for the 32-byte pieces a lane could store directly.
 constexpr int kBmRow = 16 * 16 + 4;                   // doubles per frame of the image (padded: two-way bank conflicts at most)
-template <int ABL, bool REM = true, bool WRITE_BM = false, bool M8 = false>
+template <int ABL, bool REM = true, bool WRITE_BM = false, int MIX = 16>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void emit_diag_i8(
     const int4_t* __restrict__ Fs, const int4_t* __restrict__ wq, const double* __restrict__ constc,
     const double* __restrict__ logw, double* __restrict__ b, double* __restrict__ bm, long F, int N, int GY, long ntiles,
     int tiles_per_block, long nchunks, unsigned long long* __restrict__ dbg) {
     __shared__ int4_t Fl[2][kLdsI4];
+    // MIX mixtures per state: 16 (a wave = 2 states, a state's mixtures in lanes l and l ^ 32), 8 (4 states, all eight in the
+    // lane), 32 (1 state, its mixtures in the four lanes l, l ^ 16, l ^ 32, l ^ 48: M = 32 without a merge pass)
+    constexpr bool M8 = MIX == 8;
+    static_assert(MIX == 16 || MIX == 8 || MIX == 32, "mixtures per state");
     static_assert(!(M8 && WRITE_BM), "the 8-mixture instantiation writes b only");
-    constexpr int SPB = M8 ? 32 : 16, OST = SPB + 1;      // states per block, padded row of the staged outputs
+    constexpr int SW = MIX == 16 ? 2 : (MIX == 8 ? 4 : 1);  // states per wave
+    constexpr int SPB = 8 * SW, OST = SPB + 1;            // states per block, padded row of the staged outputs
     __shared__ double ob[2][16 * 33];
     unsigned long long ph[5] = {0, 0, 0, 0, 0}, ts = 0;
     const unsigned long long k0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
@@ -301,11 +307,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (tile1 > ntiles) tile1 = ntiles;
     // (N a multiple of 2, not of 16: the waves of the last slab that have no state pair score pair 0 again and stage values
     // nobody flushes)
-    const int sp = (M8 ? 4 : 2) * (8 * y + w) < N ? 8 * y + w : 0;     // (M8: the wave's four states, else its state pair)
+    const int sp = SW * (8 * y + w) < N ? 8 * y + w : 0;               // the wave's unit: state pair / four states / state
     const int g = lane >> 4, col = lane & 15;
+    const int lst = MIX == 16 ? (g & 1) : (MIX == 8 ? g : 0);          // the lane's state within the wave's unit
+    const int mb = MIX == 16 ? 8 * (g >> 1) : (MIX == 8 ? 0 : 8 * g);  // its first mixture (eight consecutive ones)
+    const int sl = SW * w + lst;                                       // its state within the block's slab
     if (WRITE_BM && tid < 256) {                          // [state of the slab][mixture]; states past N: never used
-        const long st = 16L * y + (tid >> 4);
-        lws[tid] = logw[(st < N ? st : N - 1) * 16 + (tid & 15)];
+        const long st = (long)SPB * y + tid / MIX;
+        lws[tid] = logw[(st < N ? st : N - 1) * MIX + tid % MIX];
     }
 
     int4_t Wm[2][kS], Wl[2][2];
@@ -322,14 +331,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const double* cstp = cst;
     if (WRITE_BM) {
         if (tid < 256) {
-            const long st = 16L * y + (tid >> 4);
-            csts[tid] = constc[(st < N ? st : N - 1) * 16 + (tid & 15)];
+            const long st = (long)SPB * y + tid / MIX;
+            csts[tid] = constc[(st < N ? st : N - 1) * MIX + tid % MIX];
         }
-        cstp = csts + (2 * w + (g & 1)) * 16 + 8 * (g >> 1);
+        cstp = csts + sl * MIX + mb;
     } else {
 #pragma unroll
-        for (int m = 0; m < 8; ++m)
-            cst[m] = M8 ? constc[(size_t)(4 * sp + g) * 8 + m] : constc[(size_t)(2 * sp + (g & 1)) * 16 + 8 * (g >> 1) + m];
+        for (int m = 0; m < 8; ++m) cst[m] = constc[(size_t)(SW * sp + lst) * MIX + mb + m];
     }
 
     int4_t pre[2];
@@ -348,9 +356,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (e < kTileI4) Fl[buf][e] = pre[r];
         }
     };
-    auto flush = [&](int buf, long tile) {               // 16 frames x 16 states: 128-byte rows (waves 0-3); M8: x 32
-        if (M8 || tid < 256) {
-            const int f = M8 ? tid >> 5 : tid >> 4, st = M8 ? tid & 31 : tid & 15;
+    auto flush = [&](int buf, long tile) {               // 16 frames x SPB states (16: waves 0-3; 8 mixtures: every thread)
+        if (tid < 16 * SPB) {
+            const int f = tid / SPB, st = tid % SPB;
             const long frame = tile * 16 + f;
             if (frame < F && SPB * y + st < N) b[frame * N + SPB * y + st] = ob[buf][f * OST + st];
         }
@@ -373,12 +381,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(x), false, false);
         return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
     };
+    // (32 mixtures: the halves of lanes l and l ^ 16 as well)
+    auto quad_max = [](double x) {
+        auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(x), false, false);
+        auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(x), false, false);
+        return vmax_f64(__hiloint2double((int)hi[0], (int)lo[0]), __hiloint2double((int)hi[1], (int)lo[1]));
+    };
+    auto quad_sum = [](double x) {
+        auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(x), false, false);
+        auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(x), false, false);
+        return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+    };
     // log-sum-exp of the tile whose values `v` carries (this lane: frame `col`, state 2 sp + (g & 1), mixtures
     // 8 (g >> 1) + 4 q + e; the other eight are in lane ^ 32) -> the staging row of that tile
     double v[2][4];
     auto lse_to = [&](double* obuf) {
         if (WRITE_BM) {
-            const double* lw = lws + (2 * w + (g & 1)) * 16 + 8 * (g >> 1);
+            const double* lw = lws + sl * MIX + mb;
 #pragma unroll
             for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -391,15 +410,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int e = 0; e < 4; ++e)
                 if (q + e > 0) mx = vmax_f64(mx, v[q][e]);
         if (!M8) mx = pair_max(mx);
+        if (MIX == 32) mx = quad_max(mx);
         double s = 0.0;
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
             for (int e = 0; e < 4; ++e) s += exp_nonpos_big2(v[q][e] - mx, etab);
         if (!M8) s = pair_sum(s);
+        if (MIX == 32) s = quad_sum(s);
         const double res = (mx == LN_NEG_INF) ? mx : mx + log_sum(s, ltab);
-        if (M8) obuf[col * OST + 4 * w + g] = res;
-        else if (g < 2) obuf[col * OST + 2 * w + g] = res;
+        if (M8 || (MIX == 16 && g < 2) || (MIX == 32 && g == 0)) obuf[col * OST + sl] = res;
     };
 
     // the matrix phase of one tile: planes from the LDS to registers, 76 matrix instructions with the folds between them -> v
@@ -464,8 +484,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int e = 0; e < 4; ++e) v[q][e] = fma(r[q][e], scale, cstp[4 * q + e]);
         if (WRITE_BM) {                                   // this lane: eight consecutive mixtures of (frame col, its state)
             typedef double double4v __attribute__((ext_vector_type(4)));
-            double4v* dst = reinterpret_cast<double4v*>(bms + (size_t)buf * 16 * kBmRow + col * kBmRow + (2 * w + (g & 1)) * 16 +
-                                                        8 * (g >> 1));
+            double4v* dst = reinterpret_cast<double4v*>(bms + (size_t)buf * 16 * kBmRow + col * kBmRow + sl * MIX + mb);
             dst[0] = double4v{v[0][0], v[0][1], v[0][2], v[0][3]};
             dst[1] = double4v{v[1][0], v[1][1], v[1][2], v[1][3]};
         }
@@ -478,9 +497,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int idx = k * 256 + t256;
             const int f = idx >> 7, off = idx & 127;      // frame of the tile, 16-byte piece of its 2 KB
             const long frame = tile * 16 + f;
-            const int st = 16 * y + (off >> 3);
+            const int st = SPB * y + off * 2 / MIX;
             if (frame < F && st < N)
-                *reinterpret_cast<double2v*>(bm + ((size_t)frame * N + 16 * y) * 16 + off * 2) =
+                *reinterpret_cast<double2v*>(bm + ((size_t)frame * N + SPB * y) * MIX + off * 2) =
                     *reinterpret_cast<const double2v*>(bms + (size_t)buf * 16 * kBmRow + f * kBmRow + off * 2);
         }
     };
@@ -531,7 +550,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 }  // namespace
 
-bool i8_emit_shape_ok(int Nv, int Mv, int D) { return (Mv == 16 || Mv == 8) && Nv % 4 == 0 && D >= 1 && 2 * D <= 80; }
+bool i8_emit_shape_ok(int Nv, int Mv, int D) {
+    // a wave scores 32 components: two 16-mixture states, four 8-mixture states or one 32-mixture state
+    const bool units = (Mv == 16 && Nv % 2 == 0) || (Mv == 8 && Nv % 4 == 0) || Mv == 32;
+    return units && D >= 1 && 2 * D <= 80;
+}
 
 // once per model (after prep_diag / centre_and_kappa): digit planes of the coefficients
 int pack_i8_model(lnasr_ctx* ctx, const double* mu_s, const double* iv_s, const double* gc_s, const double* lw_s, int Nv,
@@ -543,7 +566,7 @@ int pack_i8_model(lnasr_ctx* ctx, const double* mu_s, const double* iv_s, const 
     const size_t NMv = (size_t)Nv * Mv;
     LN_TRY(md.i8_g.reserve(80 * 4));
     LN_TRY(md.i8_pow2g.reserve(80 * 8));
-    const size_t units = Mv == 16 ? Nv / 2 : Nv / 4;       // waves' worth of components: 32 each
+    const size_t units = Mv == 16 ? Nv / 2 : (Mv == 8 ? Nv / 4 : Nv);   // waves' worth of components: 32 each
     LN_TRY(md.i8_wq.reserve(units * 2 * kSlots * 64 * 16));
     LN_TRY(md.i8_const.reserve(NMv * 8));
     LN_TRY(md.i8_const_nw.reserve(NMv * 8));
@@ -552,22 +575,24 @@ int pack_i8_model(lnasr_ctx* ctx, const double* mu_s, const double* iv_s, const 
     const size_t total = units * 2 * kSlots * 64;
     LN_LAUNCH(ctx, "pack_wslice", pack_wslice_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, mu_s, iv_s, gc_s,
               lw_s, (const int*)md.i8_g.as<int>(), md.i8_wq.as<int4_t>(), md.i8_const.as<double>(), md.i8_const_nw.as<double>(), Nv, D, Mv);
-    md.i8_NG = Nv / 4;
+    md.i8_NG = (Mv == 32 ? 2 * Nv : Nv) / 4;             // in units of four 16-mixture (virtual) states, like wpack_NG
     return 0;
 }
 
-// b [F, Nv] (and bm [F, Nv, 16] unless null) for the (virtual, padded) states of the packed model
+// b [F, Nk] (and bm [F, Nk, mix] unless null); Nk = the (virtual, padded) states the planes were packed for -- with 32
+// mixtures per state (i8_mix = 32) the model's real states: b and bm then need no merge / no virtual layout
 int emit_diag_i8_device(lnasr_ctx* ctx, const double* obs, long F, double* b, double* bm) {
     Model& md = ctx->model;
-    const int Nv = md.i8_NG * 4, D = md.D;
+    const int mix = md.i8_mix, D = md.D;
+    const int Nk = mix == 32 ? md.i8_NG * 2 : md.i8_NG * 4;
     const long ntiles = (F + 15) / 16;
     LN_TRY(ctx->ws_fs.reserve((size_t)ntiles * kTileI4 * 16));
     int4_t* Fs = ctx->ws_fs.as<int4_t>();
     LN_LAUNCH(ctx, "slice_features", slice_features_kernel, dim3((unsigned)((ntiles * 16 + 63) / 64)), dim3(320), 0, obs,
               (const double*)md.centre.as<double>(), (const double*)md.i8_pow2g.as<double>(), Fs, F, D,
               ctx->nan_flag.as<unsigned>(), ctx->nan_epoch);
-    const bool m8 = md.i8_mix == 8;
-    const int GY = m8 ? (Nv + 31) / 32 : (Nv + 15) / 16;
+    const int spb = mix == 16 ? 16 : (mix == 8 ? 32 : 8);            // states per block
+    const int GY = (Nk + spb - 1) / spb;
     const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
     long want_chunks = (long)cus / GY;                   // one 8-wave block per CU: two waves per SIMD
     if (want_chunks < 8) want_chunks = 8;
@@ -576,18 +601,18 @@ int emit_diag_i8_device(lnasr_ctx* ctx, const double* obs, long F, double* b, do
     if (tpb < 1) tpb = 1;
     const long nchunks = (ntiles + tpb - 1) / tpb;
     const long grid = ((nchunks + 7) / 8) * 8 * GY;
-#define LN_I8K(abl, rem, wbm, name)                                                                               \
-    LN_LAUNCH(ctx, name, (emit_diag_i8<abl, rem, wbm, false>), dim3((unsigned)grid), dim3(512), 0, (const int4_t*)Fs, \
+#define LN_I8K(abl, rem, wbm, mixv, name)                                                                         \
+    LN_LAUNCH(ctx, name, (emit_diag_i8<abl, rem, wbm, mixv>), dim3((unsigned)grid), dim3(512), 0, (const int4_t*)Fs, \
               (const int4_t*)md.i8_wq.as<int4_t>(),                                                                  \
               (const double*)(wbm ? md.i8_const_nw.as<double>() : md.i8_const.as<double>()), md.i8_logw, b, bm, F,   \
-              Nv, GY, ntiles, (int)tpb, nchunks, dbg)
+              Nk, GY, ntiles, (int)tpb, nchunks, dbg)
     unsigned long long* dbg = nullptr;
 #ifdef LNASR_I8_STAMPS                                    // diagnostic build: in-kernel phase stamps (s_memtime), printed per launch
-    if (getenv("LNASR_I8_STAMPS") && !bm) {
+    if (getenv("LNASR_I8_STAMPS") && !bm && mix == 16) {
         const size_t n = (size_t)grid * 8 * 7;
         LN_HIP(hipMalloc((void**)&dbg, n * 8));           // (diagnostic build: not a workspace of the context, freed below)
         LN_HIP(hipMemsetAsync(dbg, 0, n * 8, ctx->stream));
-        LN_I8K(6, true, false, "emit_i8_stamps");
+        LN_I8K(6, true, false, 16, "emit_i8_stamps");
         std::vector<unsigned long long> h(n);
         LN_HIP(hipMemcpyAsync(h.data(), dbg, n * 8, hipMemcpyDeviceToHost, ctx->stream));
         LN_HIP(hipStreamSynchronize(ctx->stream));
@@ -603,21 +628,21 @@ int emit_diag_i8_device(lnasr_ctx* ctx, const double* obs, long F, double* b, do
     }
 #endif
     const bool k64 = 2 * D <= 64;                         // K <= 64: the 28 plane pairs and nothing else
-#define LN_I8M8(rem, name)                                                                                        \
-    LN_LAUNCH(ctx, name, (emit_diag_i8<0, rem, false, true>), dim3((unsigned)grid), dim3(512), 0, (const int4_t*)Fs, \
-              (const int4_t*)md.i8_wq.as<int4_t>(), (const double*)md.i8_const.as<double>(), md.i8_logw, b,         \
-              (double*)nullptr, F, Nv, GY, ntiles, (int)tpb, nchunks, dbg)
-    if (m8) {
+    if (mix == 8) {
         LN_REQUIRE(!bm, "the 8-mixture integer bank writes b only");
-        if (k64) LN_I8M8(false, "emit_diag_i8_m8_k64");
-        else LN_I8M8(true, "emit_diag_i8_m8");
-        return 0;
+        if (k64) LN_I8K(0, false, false, 8, "emit_diag_i8_m8_k64");
+        else LN_I8K(0, true, false, 8, "emit_diag_i8_m8");
+    } else if (mix == 32) {
+        if (bm && k64) LN_I8K(0, false, true, 32, "emit_diag_i8_m32_k64_bm");
+        else if (bm) LN_I8K(0, true, true, 32, "emit_diag_i8_m32_bm");
+        else if (k64) LN_I8K(0, false, false, 32, "emit_diag_i8_m32_k64");
+        else LN_I8K(0, true, false, 32, "emit_diag_i8_m32");
+    } else {
+        if (bm && k64) LN_I8K(0, false, true, 16, "emit_diag_i8_k64_bm");
+        else if (bm) LN_I8K(0, true, true, 16, "emit_diag_i8_bm");
+        else if (k64) LN_I8K(0, false, false, 16, "emit_diag_i8_k64");
+        else LN_I8K(0, true, false, 16, "emit_diag_i8");
     }
-#undef LN_I8M8
-    if (bm && k64) LN_I8K(0, false, true, "emit_diag_i8_k64_bm");
-    else if (bm) LN_I8K(0, true, true, "emit_diag_i8_bm");
-    else if (k64) LN_I8K(0, false, false, "emit_diag_i8_k64");
-    else LN_I8K(0, true, false, "emit_diag_i8");
 #undef LN_I8K
     return 0;
 }

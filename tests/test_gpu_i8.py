@@ -33,14 +33,15 @@ def _upload(ctx, mdl):
                                        (48, 16, 33, 1, 130), (128, 16, 39, 5, 1000), (32, 16, 26, 2, 50), (16, 16, 14, 1, 33),
                                        (64, 16, 32, 1, 40), (120, 12, 39, 2, 37), (20, 16, 39, 1, 50), (6, 16, 30, 3, 20),
                                        (5, 10, 39, 2, 18), (64, 8, 39, 2, 33), (32, 8, 26, 1, 70), (20, 7, 39, 2, 21),
-                                       (128, 5, 30, 1, 16)])
+                                       (128, 5, 30, 1, 16), (64, 32, 39, 2, 40), (12, 32, 26, 1, 50), (256, 32, 39, 1, 20)])
 def test_integer_bank_equals_the_reference(N, M, D, U, T, synth, oracle, ctx):
     """b from the sliced integer GEMM against the oracle's numpy emission, against the fp64 matrix-core kernel (LNASR_NO_I8EMIT)
     and through every layout case: frames not a multiple of 16, one frame, M = 32 as two virtual 16-mixture states,
     D below 39 (zero planes above 2 D), 2 D <= 64 (the instantiation without remainder instructions: D = 14 .. 32), state
     counts that are not a multiple of 16 (a last slab with idle waves) or of 4 and M = 12 / 10 (scored on the padded copy
     of the parameters: the shapes the reference's own M-step leaves), 5 .. 8 mixtures (the instantiation whose lanes hold a
-    state's eight mixtures: no exchange), a zero-weight mixture."""
+    state's eight mixtures: no exchange), M = 32 on the model as it is (a wave = one state, its mixtures in four lanes:
+    no virtual states, no merge pass), a zero-weight mixture."""
     mdl = synth.synth_model(N, M, D, seed=N + M + D)
     mdl["w"][1, 3] = -np.inf
     obs = synth.synth_obs(U, T, D, seed=T)
@@ -48,7 +49,8 @@ def test_integer_bank_equals_the_reference(N, M, D, U, T, synth, oracle, ctx):
         _upload(ctx, mdl)
         b, names = _kernels_of(ctx, lambda: ctx.gmm_logprob(obs))
     m8 = M <= 8                                         # 5 .. 8 mixtures: the 8-mixture instantiation (b only)
-    kname = "emit_diag_i8" + ("_m8" if m8 else "") + ("" if 2 * D > 64 else "_k64")
+    m32 = M == 32 and N % 4 == 0                        # 32 mixtures on the model as it is: one state per wave, no merge pass
+    kname = "emit_diag_i8" + ("_m8" if m8 else ("_m32" if m32 else "")) + ("" if 2 * D > 64 else "_k64")
     assert kname in names or not tuned()
     with env_switch(LNASR_NO_I8EMIT=1):
         _upload(ctx, mdl)
@@ -60,7 +62,7 @@ def test_integer_bank_equals_the_reference(N, M, D, U, T, synth, oracle, ctx):
     with env_switch(LNASR_I8_MIN_FRAMES=0):
         _upload(ctx, mdl)
         (b2, bm2), names2 = _kernels_of(ctx, lambda: ctx.gmm_logprob(obs, want_bm=True))
-    assert m8 or ("emit_diag_i8_bm" if 2 * D > 64 else "emit_diag_i8_k64_bm") in names2 or not tuned()
+    assert m8 or (kname + "_bm") in names2 or not tuned()
     assert_close(b2, b, 1e-13)
     for u in (0, U - 1):
         with np.errstate(divide="ignore"):
