@@ -56,7 +56,10 @@ __global__ void pack_wfrag32_kernel(const double* __restrict__ mu_c, const doubl
 // resident in registers; the block walks 16-frame tiles whose feature matrix [x'^2 | x' | 1] (x' = x - centre, formed
 // in fp64, stored as float) is built once in LDS and read as the B operand by all waves.  XCD-aware block decode as
 // in emit_diag_mfma.
-template <int Q, int KS>
+// PAIR (M = 32 scored as two virtual 16-mixture states per state): the halves of a state are the virtual states 2 j and 2 j + 1,
+// i.e. adjacent lane groups of one wave -- they share their maximum and add their sums through lane ^ 16, and b [F, N / 2] holds
+// the real states' values: no merge pass over b afterwards (q32 keeps its layout, which is the same memory either way).
+template <int Q, int KS, bool PAIR = false>
 __global__ __launch_bounds__(512) void emit_diag_mfma_f32(const double* __restrict__ obs, const float* __restrict__ wpack,
                                                           const double* __restrict__ centre, double* __restrict__ b,
                                                           float* __restrict__ q32, long F, int N, int D, int NG, int GY,
@@ -135,7 +138,11 @@ __global__ __launch_bounds__(512) void emit_diag_mfma_f32(const double* __restri
         const int f = tid / SPB, st = tid % SPB;
         const long frame = tile * 16 + f;
         const int state = SPB * y + st;
-        if (tile < tile1 && frame < F && state < N) b[frame * N + state] = ob[buf][f * OS + st];
+        if (PAIR) {                                          // the even virtual state's slot holds the real state's value
+            if (tile < tile1 && frame < F && state < N && !(st & 1)) b[frame * (N / 2) + state / 2] = ob[buf][f * OS + st];
+        } else if (tile < tile1 && frame < F && state < N) {
+            b[frame * N + state] = ob[buf][f * OS + st];
+        }
     };
 
     load_stage(tile0);
@@ -170,11 +177,13 @@ __global__ __launch_bounds__(512) void emit_diag_mfma_f32(const double* __restri
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (q + r > 0) mx = fmaxf(mx, acc[q][r]);
+        if (PAIR) mx = fmaxf(mx, __shfl_xor(mx, 16));
         float s = 0.f;
 #pragma unroll
         for (int q = 0; q < Q; ++q)
 #pragma unroll
             for (int r = 0; r < 4; ++r) s += __expf(acc[q][r] - mx);
+        if (PAIR) s += __shfl_xor(s, 16);
         // mx = -inf: the differences are NaN, s is NaN; the state's value is -inf
         ob[cur][fr * OS + 4 * w + g] = (mx == -__builtin_huge_valf()) ? (double)mx : (double)mx + (double)__logf(s);
         if (has_next) store_stage(cur ^ 1);
@@ -403,9 +412,14 @@ static int launch_emit32(lnasr_ctx* ctx, const double* obs, long F, double* bv, 
     if (tpb < 1) tpb = 1;
     const long nchunks = (ntiles + tpb - 1) / tpb;
     const long grid = ((nchunks + 7) / 8) * 8 * GY;
-    LN_LAUNCH(ctx, "emit_diag_mfma_f32", (emit_diag_mfma_f32<Q, KS>), dim3((unsigned)grid), dim3(512), 0, obs,
-              (const float*)md.wpack32.as<float>(), (const double*)md.centre.as<double>(), bv, q32, F, Nv, D, md.wpack_NG,
-              GY, ntiles, (int)tpb, nchunks);
+    if (Q == 4 && md.wpack_virt == 2)      // bv is b itself here (emit_device_f32): the kernel joins the halves
+        LN_LAUNCH(ctx, "emit_diag_mfma_f32", (emit_diag_mfma_f32<Q, KS, true>), dim3((unsigned)grid), dim3(512), 0, obs,
+                  (const float*)md.wpack32.as<float>(), (const double*)md.centre.as<double>(), bv, q32, F, Nv, D, md.wpack_NG,
+                  GY, ntiles, (int)tpb, nchunks);
+    else
+        LN_LAUNCH(ctx, "emit_diag_mfma_f32", (emit_diag_mfma_f32<Q, KS>), dim3((unsigned)grid), dim3(512), 0, obs,
+                  (const float*)md.wpack32.as<float>(), (const double*)md.centre.as<double>(), bv, q32, F, Nv, D, md.wpack_NG,
+                  GY, ntiles, (int)tpb, nchunks);
     return 0;
 }
 
@@ -416,7 +430,8 @@ int emit_device_f32(lnasr_ctx* ctx, const double* obs, long F, double* b, float*
     LN_TRY(pack32(ctx));
     const int Q = md.wpack_Q, KS = md.wpack_KS, virt = md.wpack_virt;
     double* bv = b;
-    if (virt > 1) {
+    const bool joined = virt == 2 && Q == 4;              // the kernel joins the two halves of a state itself (PAIR)
+    if (virt > 1 && !joined) {
         LN_TRY(ctx->ws_misc2.reserve((size_t)F * md.N * virt * 8));
         bv = ctx->ws_misc2.as<double>();
     }
@@ -427,7 +442,7 @@ int emit_device_f32(lnasr_ctx* ctx, const double* obs, long F, double* b, float*
     LN_CASE(1, 7)
 #undef LN_CASE
     LN_TRY(rc);
-    if (virt > 1) {
+    if (virt > 1 && !joined) {
         const size_t cells = (size_t)F * md.N;
         LN_LAUNCH(ctx, "merge_virtual_states", merge_virtual32_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0,
                   (const double*)bv, cells, virt, b);
