@@ -1,5 +1,11 @@
 #!/usr/bin/env python3
-"""Development aid: the integer matrix-core bank (gmm_i8.hip) against the fp64 one -- values and time."""
+"""Development aid: the integer matrix-core bank (gmm_i8.hip) against the fp64 one -- values and time.
+
+    python tools/i8_try.py            a few shapes
+    python tools/i8_try.py big        the metric shard (1024 x 1000 frames, N=128, M=16, D=39)
+    python tools/i8_try.py sweep      batch sizes 1 .. 256 utterances and other shapes (D = 14 .. 39, M = 8 / 16 / 32)
+    python tools/i8_try.py small      banks of 32 .. 96 states (the dispatch threshold)
+"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ln-asr_amd"))
 import numpy as np
@@ -51,12 +57,6 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "small":
         for N, M in ((64, 16), (64, 8), (96, 16), (32, 32), (48, 16), (64, 32)):
             run(N, M, 39, 512, 1000, reps=10)
-        sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == "abl":
-        for a in (sys.argv[2:] or ("0", "3", "4", "5")):
-            os.environ["LNASR_I8_ABL"] = a
-            print("ablation", a, end=": ")
-            run(128, 16, 39, 1024, 1000)
         sys.exit(0)
     run(16, 16, 39, 4, 100)
     run(16, 16, 39, 3, 77)
