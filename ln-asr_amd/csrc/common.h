@@ -267,7 +267,7 @@ int emit_device(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, v
 // gmm_i8.hip: the diagonal bank on the integer matrix cores (exact sliced arithmetic)
 bool i8_emit_shape_ok(int Nv, int Mv, int D);
 int pack_i8_model(lnasr_ctx* ctx, const double* mu_s, const double* iv_s, const double* gc_s, const double* lw_s, int Nv, int Mv);
-int emit_diag_i8_device(lnasr_ctx* ctx, const double* obs, long F, double* b, double* bm);
+int emit_diag_i8_device(lnasr_ctx* ctx, const double* obs, long F, double* b, double* bm, float* q32 = nullptr);
 // emit_device without the pass over non-finite frames; *scanned: the kernel tested the features it staged and raised
 // ctx->nan_flag itself (emit_batch runs the kernels chunk by chunk and the pass once)
 int emit_device_raw(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, void* bm, bool* scanned,

@@ -427,8 +427,12 @@ static int launch_emit32(lnasr_ctx* ctx, const double* obs, long F, double* bv, 
 int emit_device_f32(lnasr_ctx* ctx, const double* obs, long F, double* b, float* q32) {
     LN_DEVPTR(obs); LN_DEVPTR(b); LN_DEVPTR(q32);
     Model& md = ctx->model;
-    LN_TRY(pack32(ctx));
     const int Q = md.wpack_Q, KS = md.wpack_KS, virt = md.wpack_virt;
+    // batches the integer matrix-core bank takes (gmm_i8.hip): its four-plane instantiation hands over the same b + q32
+    if (md.i8_NG > 0 && md.i8_NG == md.wpack_NG && !sw().no_i8emit && ((md.i8_mix == 16 && virt == 1) || md.i8_mix == 32) &&
+        (sw().i8_min_frames >= 0 ? F >= sw().i8_min_frames : (F >= 4096 && md.i8_NG >= 12)))
+        return emit_diag_i8_device(ctx, obs, F, b, nullptr, q32);
+    LN_TRY(pack32(ctx));
     double* bv = b;
     const bool joined = virt == 2 && Q == 4;              // the kernel joins the two halves of a state itself (PAIR)
     if (virt > 1 && !joined) {

@@ -265,11 +265,17 @@ __global__ __launch_bounds__(320) void slice_features_kernel(const double* __res
 // ([frame][state][mixture], double buffered) and the log-sum-exp waves of the NEXT phase write it out as whole rows, 16
 // bytes per lane -- tools/ubench/wpattern: 6.1 TB/s, against 3.8 for the 32-byte pieces a lane could store directly.
 constexpr int kBmRow = 16 * 16 + 4;                   // doubles per frame of the image (padded: two-way bank conflicts at most)
-template <int ABL, bool REM = true, bool WRITE_BM = false, int MIX = 16>
+template <int ABL, bool REM = true, bool WRITE_BM = false, int MIX = 16, int NPL = kS, bool Q32 = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void emit_diag_i8(
     const int4_t* __restrict__ Fs, const int4_t* __restrict__ wq, const double* __restrict__ constc,
     const double* __restrict__ logw, double* __restrict__ b, double* __restrict__ bm, long F, int N, int GY, long ntiles,
-    int tiles_per_block, long nchunks, unsigned long long* __restrict__ dbg) {
+    int tiles_per_block, long nchunks, unsigned long long* __restrict__ dbg, float* __restrict__ q32 = nullptr) {
+    // Q32 (the float32 statistics pass, f32stats.hip): only the first NPL = 4 digit planes of either operand are multiplied (ten
+    // plane pairs: 32 bits below the row's / column's scale, ~1e-6 absolute on a log-density where that pass promises 8e-6), the
+    // weighted component log-densities go out as float q32 [F, N, MIX] and b is the float log-sum-exp of those rounded values,
+    // exactly the arithmetic emit_diag_mfma_f32 has after ITS matrix product.
+    static_assert(!Q32 || (!WRITE_BM && MIX != 8 && NPL == 4), "float32 hand-off: b + q32, 16 / 32 mixtures, four planes");
+    static_assert(Q32 || NPL == kS, "the fp64 results need every plane");
     __shared__ int4_t Fl[2][kLdsI4];
     // MIX mixtures per state: 16 (a wave = 2 states, a state's mixtures in lanes l and l ^ 32), 8 (4 states, all eight in the
     // lane), 32 (1 state, its mixtures in the four lanes l, l ^ 16, l ^ 32, l ^ 48: M = 32 without a merge pass)
@@ -296,6 +302,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __shared__ double lws[WRITE_BM ? 256 : 1];
     __shared__ double csts[WRITE_BM ? 256 : 1];
     __shared__ double bms[WRITE_BM ? 2 * 16 * kBmRow : 1];
+    constexpr int kQRow = 16 * 16 + 8;                    // floats per frame of the q32 image (the block's 1 KB of a frame + pad)
+    __shared__ float qms[Q32 ? 2 * 16 * kQRow : 1];
     const long bid = blockIdx.x;
     const int xcd = (int)(bid & 7);
     const long bi = bid >> 3;
@@ -395,7 +403,45 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // log-sum-exp of the tile whose values `v` carries (this lane: frame `col`, state 2 sp + (g & 1), mixtures
     // 8 (g >> 1) + 4 q + e; the other eight are in lane ^ 32) -> the staging row of that tile
     double v[2][4];
+    float vf[2][4];                                       // Q32: the rounded values, carried instead of v
     auto lse_to = [&](double* obuf) {
+        if (Q32) {
+            auto swap32 = [](float x) {
+                auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+                return fmaxf(__uint_as_float(t[0]), __uint_as_float(t[1]));
+            };
+            auto add32 = [](float x) {
+                auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+                return __uint_as_float(t[0]) + __uint_as_float(t[1]);
+            };
+            auto swap16 = [](float x) {
+                auto t = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+                return fmaxf(__uint_as_float(t[0]), __uint_as_float(t[1]));
+            };
+            auto add16 = [](float x) {
+                auto t = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+                return __uint_as_float(t[0]) + __uint_as_float(t[1]);
+            };
+            float mxf = vf[0][0];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (q + e > 0) mxf = fmaxf(mxf, vf[q][e]);
+            mxf = swap32(mxf);
+            if (MIX == 32) mxf = swap16(mxf);
+            float sf = 0.f;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sf += __expf(vf[q][e] - mxf);
+            sf = add32(sf);
+            if (MIX == 32) sf = add16(sf);
+            // mx = -inf: the differences are NaN, s is NaN; the state's value is -inf (as in emit_diag_mfma_f32)
+            const double resf = (mxf == -__builtin_huge_valf()) ? (double)mxf : (double)mxf + (double)__logf(sf);
+            if ((MIX == 16 && g < 2) || (MIX == 32 && g == 0)) obuf[col * OST + sl] = resf;
+            return;
+        }
         if (WRITE_BM) {
             const double* lw = lws + sl * MIX + mb;
 #pragma unroll
@@ -423,13 +469,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
 
     // the matrix phase of one tile: planes from the LDS to registers, 76 matrix instructions with the folds between them -> v
-    auto matrix_phase = [&](int buf) {
+    auto matrix_phase = [&](int buf, long tile) {
         const int4_t* Fc = &Fl[buf][0];
         const double scale = reinterpret_cast<const double*>(Fc + kS * kPlaneI4)[col];
         // (reads in the order of use: diagonal d needs planes 0..d, so the matrix instructions start behind the first read)
-        int4_t fm[kS], fl[kS][2];
+        int4_t fm[NPL], fl[NPL][2];
 #pragma unroll
-        for (int d = 0; d < kS; ++d) {
+        for (int d = 0; d < NPL; ++d) {
             fm[d] = Fc[d * kPlaneI4 + hb];
 #pragma unroll
             for (int p = 0; p < 2; ++p) {                 // K = 64..79: lane group g carries planes (d - g - 4p, g + 4p)
@@ -444,12 +490,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // alternations.  In this instruction mix they are not free.)
         double r[2][4];                                   // running fp64 value of the diagonals folded so far
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
+        for (int n = 0; n < (NPL + 1) / 2; ++n) {
             int4_t acc[2][2];
 #pragma unroll
             for (int dd = 0; dd < 2; ++dd) {
                 const int d = 2 * n + dd;
-                if (d >= kS) continue;
+                if (d >= NPL) continue;
 #pragma unroll
                 for (int q = 0; q < 2; ++q) acc[dd][q] = int4_t{0, 0, 0, 0};
 #pragma unroll
@@ -474,7 +520,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int q = 0; q < 2; ++q)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const double pn = n == 3 ? (double)acc[0][q][e] : (double)(acc[0][q][e] * 256 + acc[1][q][e]);
+                    const double pn = 2 * n + 1 >= NPL ? (double)acc[0][q][e] : (double)(acc[0][q][e] * 256 + acc[1][q][e]);
                     r[q][e] = n == 0 ? pn : fma(pn, n == 1 ? 0x1p-16 : (n == 2 ? 0x1p-32 : 0x1p-40), r[q][e]);
                 }
         }
@@ -482,6 +528,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int q = 0; q < 2; ++q)
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[q][e] = fma(r[q][e], scale, cstp[4 * q + e]);
+        if (Q32) {                                        // eight consecutive mixtures of (frame col, the lane's state): 32 bytes
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vf[q][e] = (float)v[q][e];
+            typedef float float4v __attribute__((ext_vector_type(4)));   // parked like bm: whole rows go out in the next phase
+            float4v* dst = reinterpret_cast<float4v*>(qms + (size_t)buf * 16 * kQRow + col * kQRow + sl * MIX + mb);
+            dst[0] = float4v{vf[0][0], vf[0][1], vf[0][2], vf[0][3]};
+            dst[1] = float4v{vf[1][0], vf[1][1], vf[1][2], vf[1][3]};
+        }
         if (WRITE_BM) {                                   // this lane: eight consecutive mixtures of (frame col, its state)
             typedef double double4v __attribute__((ext_vector_type(4)));
             double4v* dst = reinterpret_cast<double4v*>(bms + (size_t)buf * 16 * kBmRow + col * kBmRow + sl * MIX + mb);
@@ -504,6 +560,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     };
 
+    // the parked q32 tile -> global: 256 threads, 16 bytes each, four times: whole 1 KB rows
+    auto flush_q = [&](int buf, long tile, int t256) {
+        typedef float float4v __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = k * 256 + t256;
+            const int f = idx >> 6, off = idx & 63;       // frame of the tile, 16-byte piece of its 1 KB
+            const long frame = tile * 16 + f;
+            const int st = SPB * y + off * 4 / MIX;
+            if (frame < F && st < N)
+                *reinterpret_cast<float4v*>(q32 + ((size_t)frame * N + SPB * y) * MIX + off * 4) =
+                    *reinterpret_cast<const float4v*>(qms + (size_t)buf * 16 * kQRow + f * kQRow + off * 4);
+        }
+    };
+
     // Two phases per tile, the two waves of a SIMD in OPPOSITE ones: waves 0-3 run the matrix phase of tile t while waves 4-7
     // run the log-sum-exp of tile t - 1, then the roles swap -- the vector work of one wave issues beside the matrix
     // instructions of the other instead of both waves wanting the same unit at the same time.
@@ -513,10 +584,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const bool has_next = tile + 1 < tile1;
         if (ABL == 6) ts = __builtin_amdgcn_s_memtime();
         if (has_next) load_tile(tile + 1);
-        if (half == 0) matrix_phase(cur);
+        if (half == 0) matrix_phase(cur, tile);
         else if (tile > tile0) {
             lse_to(&ob[cur ^ 1][0]);
             if (WRITE_BM) flush_bm(cur ^ 1, tile - 1, tid - 256);      // complete since the last barrier
+            if (Q32) flush_q(cur ^ 1, tile - 1, tid - 256);
         }
         LN_STAMP(0);
         __syncthreads();
@@ -525,7 +597,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             lse_to(&ob[cur][0]);
             if (!M8 && tile > tile0) flush(cur ^ 1, tile - 1);   // both halves have staged tile t - 1 by now
         } else {
-            matrix_phase(cur);
+            matrix_phase(cur, tile);
         }
         if (M8 && tile > tile0) flush(cur ^ 1, tile - 1);  // (32 states: every thread has a value to write)
         if (has_next) store_tile(cur ^ 1);
@@ -539,6 +611,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __syncthreads();
         flush(last, tile1 - 1);
         if (WRITE_BM && half == 1) flush_bm(last, tile1 - 1, tid - 256);
+        if (Q32 && half == 1) flush_q(last, tile1 - 1, tid - 256);
     }
     if (ABL == 6 && lane == 0) {
         for (int i = 0; i < 5; ++i) dbg[((size_t)blockIdx.x * 8 + w) * 7 + i] = ph[i];
@@ -581,7 +654,7 @@ int pack_i8_model(lnasr_ctx* ctx, const double* mu_s, const double* iv_s, const 
 
 // b [F, Nk] (and bm [F, Nk, mix] unless null); Nk = the (virtual, padded) states the planes were packed for -- with 32
 // mixtures per state (i8_mix = 32) the model's real states: b and bm then need no merge / no virtual layout
-int emit_diag_i8_device(lnasr_ctx* ctx, const double* obs, long F, double* b, double* bm) {
+int emit_diag_i8_device(lnasr_ctx* ctx, const double* obs, long F, double* b, double* bm, float* q32) {
     Model& md = ctx->model;
     const int mix = md.i8_mix, D = md.D;
     const int Nk = mix == 32 ? md.i8_NG * 2 : md.i8_NG * 4;
@@ -602,10 +675,14 @@ int emit_diag_i8_device(lnasr_ctx* ctx, const double* obs, long F, double* b, do
     const long nchunks = (ntiles + tpb - 1) / tpb;
     const long grid = ((nchunks + 7) / 8) * 8 * GY;
 #define LN_I8K(abl, rem, wbm, mixv, name)                                                                         \
-    LN_LAUNCH(ctx, name, (emit_diag_i8<abl, rem, wbm, mixv>), dim3((unsigned)grid), dim3(512), 0, (const int4_t*)Fs, \
-              (const int4_t*)md.i8_wq.as<int4_t>(),                                                                  \
+    LN_LAUNCH(ctx, name, (emit_diag_i8<abl, rem, wbm, mixv, kS, false>), dim3((unsigned)grid), dim3(512), 0,         \
+              (const int4_t*)Fs, (const int4_t*)md.i8_wq.as<int4_t>(),                                               \
               (const double*)(wbm ? md.i8_const_nw.as<double>() : md.i8_const.as<double>()), md.i8_logw, b, bm, F,   \
-              Nk, GY, ntiles, (int)tpb, nchunks, dbg)
+              Nk, GY, ntiles, (int)tpb, nchunks, dbg, (float*)nullptr)
+#define LN_I8Q(rem, mixv, name)                                                                                   \
+    LN_LAUNCH(ctx, name, (emit_diag_i8<0, rem, false, mixv, 4, true>), dim3((unsigned)grid), dim3(512), 0,           \
+              (const int4_t*)Fs, (const int4_t*)md.i8_wq.as<int4_t>(), (const double*)md.i8_const.as<double>(),      \
+              md.i8_logw, b, (double*)nullptr, F, Nk, GY, ntiles, (int)tpb, nchunks, dbg, q32)
     unsigned long long* dbg = nullptr;
 #ifdef LNASR_I8_STAMPS                                    // diagnostic build: in-kernel phase stamps (s_memtime), printed per launch
     if (getenv("LNASR_I8_STAMPS") && !bm && mix == 16) {
@@ -628,6 +705,14 @@ int emit_diag_i8_device(lnasr_ctx* ctx, const double* obs, long F, double* b, do
     }
 #endif
     const bool k64 = 2 * D <= 64;                         // K <= 64: the 28 plane pairs and nothing else
+    if (q32) {                                            // the float32 statistics pass's hand-off: b + q32, four planes
+        LN_REQUIRE(!bm && mix != 8, "the float32 hand-off takes 16 or 32 mixtures per state and no bm");
+        if (mix == 32 && k64) LN_I8Q(false, 32, "emit_diag_i8_q32_m32_k64");
+        else if (mix == 32) LN_I8Q(true, 32, "emit_diag_i8_q32_m32");
+        else if (k64) LN_I8Q(false, 16, "emit_diag_i8_q32_k64");
+        else LN_I8Q(true, 16, "emit_diag_i8_q32");
+        return 0;
+    }
     if (mix == 8) {
         LN_REQUIRE(!bm, "the 8-mixture integer bank writes b only");
         if (k64) LN_I8K(0, false, false, 8, "emit_diag_i8_m8_k64");
@@ -644,6 +729,7 @@ int emit_diag_i8_device(lnasr_ctx* ctx, const double* obs, long F, double* b, do
         else LN_I8K(0, true, false, 16, "emit_diag_i8");
     }
 #undef LN_I8K
+#undef LN_I8Q
     return 0;
 }
 

@@ -252,7 +252,8 @@ def test_float32_pass_full_size_and_mirror(synth, ctx):
     d_obs = ctx.to_device(obs)
     gh32.upload()
     st32, names = _kernels_of(ctx, lambda: gh32.accumulate(d_obs))
-    assert ("emit_diag_mfma_f32" in names and "mix_mfma_f32" in names) or not tuned()
+    # (at this size the emission is the integer bank's four-plane float hand-off, csrc/gmm_i8.hip: same b + q32)
+    assert ("emit_diag_i8_q32_m32" in names and "mix_mfma_f32" in names) or not tuned()
     st64 = ctx.bw_accumulate(d_obs)
     a, b = _split(st32), _split(st64)
     for key in ("xi_sum", "gamma_sum", "gamma0", "mix", "mix_x", "mix_xx"):
