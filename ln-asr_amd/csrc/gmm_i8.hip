@@ -28,7 +28,10 @@
 // instructions per wave and tile; what the design wins is the matrix share, 1270 cycles per wave-tile instead of 2560.
 //
 // Kernels: i8_row_scale_kernel / pack_wslice_kernel (once per model), slice_features_kernel (once per batch: digit planes of
-// the features, [tile][plane][k-chunk][frame][16 B], 568 B per frame), emit_diag_i8 (the bank).
+// the features, [tile][plane][k-chunk][frame][16 B], 568 B per frame), emit_diag_i8 (the bank).  Instantiations of the bank:
+// 16 mixtures per (virtual) state, 8 (M = 5 .. 8) or 32 (M = 32 as it is: no virtual states, no merge pass); with or without the
+// K = 64 .. 79 remainder instructions (2 D <= 64 has none); b alone, b + bm (whole rows through an LDS image), or b + float q32
+// from the first four planes only (the float32 statistics pass's hand-off).
 #include <cstdio>
 #include <vector>
 
