@@ -352,19 +352,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 
     int4_t pre[2];
+    // (NPL < kS: only the first NPL planes and the scales behind plane kS - 1 are copied; they keep their places in the image)
+    constexpr int kUsedI4 = NPL * kPlaneI4 + 8;
+    auto tile_index = [](int e) { return e < NPL * kPlaneI4 ? e : e + (kS - NPL) * kPlaneI4; };
     auto load_tile = [&](long tile) {
         const int4_t* src = Fs + tile * kTileI4;
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < (kUsedI4 + 511) / 512; ++r) {
             const int e = tid + 512 * r;
-            pre[r] = src[e < kTileI4 ? e : kTileI4 - 1];
+            pre[r] = src[tile_index(e < kUsedI4 ? e : kUsedI4 - 1)];
         }
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < (kUsedI4 + 511) / 512; ++r) {
             const int e = tid + 512 * r;
-            if (e < kTileI4) Fl[buf][e] = pre[r];
+            if (e < kUsedI4) Fl[buf][tile_index(e)] = pre[r];
         }
     };
     auto flush = [&](int buf, long tile) {               // 16 frames x SPB states (16: waves 0-3; 8 mixtures: every thread)
