@@ -218,3 +218,33 @@ def test_integer_bank_over_shapes_and_feature_scales(seed, oracle, ctx):
         ob, _ = oracle.gmm_map_b_diag_direct(obs[0], w, mu, var)
     assert float(np.max(np.abs(bi[0] - ob.T) / np.maximum(1.0, np.abs(ob.T)))) <= 1e-11, tag
     assert np.array_equal(p8, pf), tag
+
+
+@pytest.mark.parametrize("N,M,D", [(64, 16, 39), (64, 32, 39), (32, 16, 26), (48, 32, 30)])
+def test_float32_statistics_over_the_four_plane_hand_off(N, M, D, synth, oracle, ctx):
+    """precision=float32 statistics with the emission on the integer bank's four-plane float hand-off (b + q32 from the ten
+    plane pairs with i + j <= 3): the packed statistics against the fp64 oracle to float32 accuracy, and against the pass with
+    the fp32 matrix-core emission kernel (LNASR_NO_I8EMIT) to the same -- 16 and 32 mixtures, with and without remainder
+    instructions, ragged utterances."""
+    mdl = synth.synth_model(N, M, D, seed=N + M)
+    U, T = 3, 40
+    lens = np.array([40, 23, 7], dtype=np.int32)
+    obs = synth.synth_obs(U, T, D, seed=77)
+    out = {}
+    for name, env in (("i8", dict(LNASR_I8_MIN_FRAMES=0)), ("f32", dict(LNASR_NO_I8EMIT=1))):
+        with env_switch(**env):
+            _upload(ctx, mdl)
+            out[name] = _kernels_of(ctx, lambda: np.asarray(ctx.bw_accumulate(obs, lens=lens, precision=np.float32)))
+    (st8, names8), (st32, names32) = out["i8"], out["f32"]
+    assert any(n.startswith("emit_diag_i8_q32") for n in names8) or not tuned(), names8
+    assert not any(n.startswith("emit_diag_i8") for n in names32)
+    with np.errstate(divide="ignore", invalid="ignore", under="ignore"):
+        ref = oracle.bw_stats_diag([obs[u, :lens[u]] for u in range(U)], mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"])
+    o = 0
+    for key, n in (("xi_sum", N * N), ("gamma_sum", N), ("gamma0", N), ("mix", N * M), ("mix_x", N * M * D), ("mix_xx", N * M * D)):
+        a, b32, r = st8[o:o + n], st32[o:o + n], np.asarray(ref[key]).ravel()
+        o += n
+        scale = max(1e-30, float(np.abs(r).max()))
+        assert float(np.abs(a - r).max()) / scale < 2e-4, key
+        assert float(np.abs(a - b32).max()) / scale < 2e-4, key
+    assert abs(st8[o] - st32[o]) < 1e-5 * abs(st32[o])          # summed log-likelihood
