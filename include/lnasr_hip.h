@@ -145,6 +145,15 @@ int lnasr_model_is_diag(lnasr_ctx* ctx, int* out);
  * log-density ~ 3e-16 * kappa; the reference's direct (x - mu) form, gmm.py:59-68, has ~1e-14).  direct_form = 1:
  * kappa exceeds 4096 (or is not finite) and the model is scored by the direct-form kernels instead. */
 int lnasr_model_conditioning(lnasr_ctx* ctx, double* kappa, int* direct_form);
+/* Range of the uploaded diagonal model as the integer matrix-core bank's fixed point sees it (csrc/gmm_i8.hip): that bank
+ * keeps 56 bits below each component's largest scaled coefficient and below each frame's largest scaled feature, so its
+ * absolute error on a component's log-density is ~3 * 2^-53 * A_c * X_f.  rho = max over components of A_c * X_c, X_c taken
+ * at frames within four standard deviations of the component's own mean: a component whose own variances (relative to the
+ * model's scale in each dimension) span decades has a large rho, one sharp component among broad ones does not.
+ * integer_bank = 1: the model's shape takes that bank and rho <= 2048 (error <= 1e-12); 0: large batches are scored by the
+ * fp64 matrix-core bank as small ones are (shape not taken: rho = 0).  Replaces nothing in the reference, whose direct form
+ * (gmm.py:59-68) has no such limit -- this is how the limit of the fast path is made visible. */
+int lnasr_model_range(lnasr_ctx* ctx, double* rho, int* integer_bank);
 
 /* ---- emission --------------------------------------------------------------- */
 /* HMM._map_b (hmm.py:47-61): b[u,t,:] = B[:, obs[u,t]];  B is [N,K] */
@@ -153,10 +162,13 @@ int lnasr_discrete_map_b(lnasr_ctx* ctx, const double* logB, int N, int K,
 /* GMMHMM._map_b (gmmhmm.py:46-67): b and (optionally) the per-mixture bm.  A frame with a NaN or an infinite feature
  * gets what the reference's product with the full inverse matrix gives (gmm.py:63-68): NaN rows (inf * 0 for a diagonal
  * Sigma), or -inf / NaN component by component where an infinity meets no zero (a genuinely full Sigma, D = 1).
- * Which kernel scores a call depends on the shape (4096 frames or more of a diagonal bank of 48 states or more with
- * 14 <= D <= 39 and at least 5 mixtures take the integer matrix cores: the same fp64 values from an exact integer sum, csrc/gmm_i8.hip); every
- * route returns the reference's b to 1e-12, and two routes agree to ~1e-13 -- the b of a small batch and of a large one that
- * contains it are therefore not guaranteed to be the same bits. */
+ * Which kernel scores a call depends on the shape and on the model: 4096 frames or more of a diagonal bank of 48 states or
+ * more with 14 <= D <= 39 and at least 5 mixtures take the integer matrix cores (a 56-bit fixed-point product, csrc/gmm_i8.hip)
+ * when the model's range allows it (lnasr_model_range: rho <= 2048), the fp64 matrix cores otherwise; models whose means lie
+ * many standard deviations apart (lnasr_model_conditioning) take the direct form.  The gates are set so that every route
+ * returns the reference's b to 1e-12 * max(1, |b|) at the frames the model describes (measured: tests/test_gpu_i8.py; frames
+ * far outside the model lose accuracy in proportion to their distance on every expanded-form route), and two routes agree
+ * to ~1e-13 -- the b of a small batch and of a large one that contains it are therefore not guaranteed to be the same bits. */
 int lnasr_gmm_logprob(lnasr_ctx* ctx, const double* obs, int U, int T, const int32_t* lens,
                       int dtype, void* b, void* bm_or_null);
 /* free functions of gmm.py (one Gaussian / one mixture, no HMM):

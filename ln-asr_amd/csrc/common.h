@@ -86,7 +86,7 @@ struct Model {
     // scored on a padded copy of the parameters (padding components have weight -inf) and compacted afterwards
     DevBuf pad_mu, pad_ivar, pad_gconst, pad_logw, pad_prec;
     int pad_N = 0, pad_M = 0;    // padded sizes, 0 = the model is used as it is
-    DevBuf flags;                // small scratch: [0] int flag (diag detection / degenerate variance), [8] kappa bits
+    DevBuf flags;                // small scratch: [0] int flag (diag detection / degenerate variance), [8] kappa bits, [16] rho bits
     // The matrix-core emission kernels evaluate the EXPANDED quadratic  x'^T S x' + L.x' + K  on centred observations
     // x' = x - centre (centre[d] = mean of the component means): the expansion cancels terms of size kappa =
     // max_c (mu_c - centre)^T Sigma_c^-1 (mu_c - centre), so its absolute error is ~ 3e-16 * kappa where the direct
@@ -101,7 +101,8 @@ struct Model {
     DevBuf wpack32;
     unsigned long upload_serial = 0, wpack32_for = ~0ul;
     // integer matrix-core bank (gmm_i8.hip): digit planes of the coefficients, row scales, component constants
-    DevBuf i8_g, i8_pow2g, i8_wq, i8_const, i8_const_nw;
+    DevBuf i8_g, i8_pow2g, i8_h, i8_wq, i8_const, i8_const_nw;   // i8_h [Nv, mix] int: the components' exponents
+    double i8_rho = 0.0;         // the model's range as the fixed point sees it (gmm_i8.hip); beyond kI8RhoMax: the fp64 bank
     const double* i8_logw = nullptr;   // the (padded) log weights the planes were packed with: [Nv,16]
     int i8_NG = 0;               // state groups packed (0: none)
     int i8_mix = 16;             // mixtures per (virtual) state of the packed planes: 16 or 8
@@ -109,6 +110,13 @@ struct Model {
 };
 
 constexpr double kKappaMax = 4096.0;
+// The integer matrix-core bank is a fixed-point product: its absolute error on a component's log-density is ~3 * 2^-53 * rho at
+// the frames that component describes (gmm_i8.hip header; rho = 26 for the metric's model).  2048 -> <= 1e-12; beyond it the
+// fp64 matrix-core bank scores the model.
+constexpr double kI8RhoMax = 2048.0;
+// its four-plane instantiation (the float32 statistics pass's hand-off) keeps 32 bits: ~3 * 2^-30 * rho, 512 -> <= 1.5e-6 of
+// the 8e-6 that pass promises
+constexpr double kI8RhoMaxF32 = 512.0;
 // The fp32 matrix-core statistics pass (f32stats.hip) evaluates the same expanded quadratic in FLOAT: its
 // cancellation error is ~6e-8 * kappa in every component log-density, so it gets a tighter gate than the fp64
 // kernels (128 -> <= 8e-6 absolute, the float32 accuracy include/lnasr_hip.h promises); above it the fp64 pass runs.
@@ -128,6 +136,7 @@ struct Switches {
     long i8_min_frames = -1;      // LNASR_I8_MIN_FRAMES: the integer matrix-core bank from this many frames per launch (-1: measured rule)
     int fwd_one_maxu = -1;        // LNASR_FWD_ONE_MAXU: one utterance per block in the column-owned forward / backward up to this batch size
     double kappa_max = kKappaMax; // LNASR_KAPPA_MAX
+    double i8_rho_max = kI8RhoMax; // LNASR_I8_RHO_MAX
     int h2d_threads = 4;          // LNASR_H2D_THREADS: host threads filling the pinned staging ring
     bool check_ptrs = false;      // LNASR_CHECK_PTRS: LN_DEVPTR verifies every pointer a launch helper is handed
     char emit = 0;                // LNASR_EMIT (ablation builds only)
@@ -264,8 +273,10 @@ int mix_stats_device_f32(lnasr_ctx* ctx, const double* obs, const double* alpha,
                          const float* q32, const double* c1, const int32_t* d_lens, int U, int T, double* mix,
                          double* mix_x, double* mix_xx, int phase = kMixAll);
 int emit_device(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, void* bm);
-// gmm_i8.hip: the diagonal bank on the integer matrix cores (exact sliced arithmetic)
+// gmm_i8.hip: the diagonal bank on the integer matrix cores (fixed-point digit planes)
 bool i8_emit_shape_ok(int Nv, int Mv, int D);
+bool i8_model_ok(const Model& md);          // planes packed, range within the gate, not switched off
+bool i8_route(const Model& md, long F);     // ... and a batch of F frames is large enough to take it
 int pack_i8_model(lnasr_ctx* ctx, const double* mu_s, const double* iv_s, const double* gc_s, const double* lw_s, int Nv, int Mv);
 int emit_diag_i8_device(lnasr_ctx* ctx, const double* obs, long F, double* b, double* bm, float* q32 = nullptr);
 // emit_device without the pass over non-finite frames; *scanned: the kernel tested the features it staged and raised

@@ -429,8 +429,9 @@ int emit_device_f32(lnasr_ctx* ctx, const double* obs, long F, double* b, float*
     Model& md = ctx->model;
     const int Q = md.wpack_Q, KS = md.wpack_KS, virt = md.wpack_virt;
     // batches the integer matrix-core bank takes (gmm_i8.hip): its four-plane instantiation hands over the same b + q32
-    if (md.i8_NG > 0 && md.i8_NG == md.wpack_NG && !sw().no_i8emit && ((md.i8_mix == 16 && virt == 1) || md.i8_mix == 32) &&
-        (sw().i8_min_frames >= 0 ? F >= sw().i8_min_frames : (F >= 4096 && md.i8_NG >= 12)))
+    // (four planes keep 32 bits below the scales: ~3 * 2^-30 * rho on a component's log-density -- its own, tighter range gate)
+    if (((md.i8_mix == 16 && virt == 1) || md.i8_mix == 32) && i8_route(md, F) &&
+        md.i8_rho <= (sw().i8_rho_max < kI8RhoMaxF32 ? sw().i8_rho_max : kI8RhoMaxF32))
         return emit_diag_i8_device(ctx, obs, F, b, nullptr, q32);
     LN_TRY(pack32(ctx));
     double* bv = b;

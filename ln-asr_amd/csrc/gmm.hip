@@ -1059,6 +1059,7 @@ static int model_upload_impl(lnasr_ctx* ctx, int N, int M, int D, const double* 
     md.diag = diag;
     md.wpack_Q = md.wpack_KS = 0;
     md.i8_NG = 0;
+    md.i8_rho = 0.0;
     md.pad_N = md.pad_M = 0;
     md.wfull_Q = 0;
     if (diag) {
@@ -1221,12 +1222,9 @@ static int launch_mfma(lnasr_ctx* ctx, const double* obs, long F, double* b, dou
         }
     }
 #endif
-    // b alone, a few thousand frames to amortise 36 KB of digit planes per wave, four slabs of 16 states or more: the integer
-    // matrix cores (gmm_i8.hip; 128 states x 1000 frames: 0.018 against 0.016 ms for one utterance, 0.033 / 0.036 for four,
-    // 0.36 / 0.41 for 64; 512,000 frames of 32 states: 0.87 / 0.83, of 48: 1.17 / 1.57, of 64: 1.46 / 1.59)
+    // the integer matrix cores (gmm_i8.hip: i8_route has the rule)
     if (((Q == 4 && ctx->model.i8_mix == 16) || (Q == 2 && ctx->model.i8_mix == 8 && !bm)) && (KS == 20 || KS == 14) &&
-        ctx->model.i8_NG == ctx->model.wpack_NG && ctx->model.i8_NG > 0 && !sw().no_i8emit &&
-        (sw().i8_min_frames >= 0 ? F >= sw().i8_min_frames : (F >= 4096 && ctx->model.i8_NG >= 12)))
+        i8_route(ctx->model, F))
         return emit_diag_i8_device(ctx, obs, F, b, bm);
     // 8 waves per block (32 states), one 16-frame tile per barrier interval: fastest of the tilings tried
     // (4 or 8 waves x 1, 2, 4 tiles per interval) on MI355X
@@ -1296,8 +1294,7 @@ int emit_device_raw(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* 
         const int Np = md.pad_N ? md.pad_N : N, Mp = md.pad_M ? md.pad_M : M, virt = md.wpack_virt;
         const bool padded = md.pad_N != 0;
         // M = 32 on the integer matrix cores: b [F, N] and bm [F, N, 32] directly (gmm_i8.hip; same rule as in launch_mfma)
-        if (md.i8_mix == 32 && md.i8_NG == md.wpack_NG && md.i8_NG > 0 && !sw().no_i8emit && !padded &&
-            (sw().i8_min_frames >= 0 ? F >= sw().i8_min_frames : (F >= 4096 && md.i8_NG >= 12))) {
+        if (md.i8_mix == 32 && !padded && i8_route(md, F)) {
             LN_TRY(emit_diag_i8_device(ctx, obs, F, (double*)b, (double*)bm));
             *scanned = true;
             return 0;
@@ -1612,6 +1609,15 @@ int lnasr_model_conditioning(lnasr_ctx* ctx, double* kappa, int* direct_form) {
     if (!ctx->model.has_gmm) return fail(LNASR_E_NOMODEL, "no GMM-HMM model uploaded");
     if (kappa) *kappa = ctx->model.kappa;
     if (direct_form) *direct_form = ctx->model.direct_form ? 1 : 0;
+    return 0;
+}
+
+int lnasr_model_range(lnasr_ctx* ctx, double* rho, int* integer_bank) {
+    LN_ENTER(ctx);
+    LN_REQUIRE(ctx, "null ctx");
+    if (!ctx->model.has_gmm) return fail(LNASR_E_NOMODEL, "no GMM-HMM model uploaded");
+    if (rho) *rho = ctx->model.i8_rho;
+    if (integer_bank) *integer_bank = i8_model_ok(ctx->model) ? 1 : 0;
     return 0;
 }
 

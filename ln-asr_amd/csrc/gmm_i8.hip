@@ -4,34 +4,49 @@
 // vector instruction of its SIMD, gmm.hip) and doubles the int8 rate (v_mfma_i32_16x16x64_i8: 2048 int-ops per cycle and
 // SIMD, 64 x the fp64 rate).  The quadratic part of the component log-density,
 //   Q[c, f] = sum_k W[k, c] phi_k(x_f),   phi = (x_d^2 | x_d),  W = (-1/2 / var | mu / var),   K = 2 D <= 80,
-// is therefore evaluated EXACTLY in integers (an Ozaki-type splitting of both operands):
-//   * both operands are brought to a common binary scale per GEMM row / column -- W[k, :] by 2^-g_k (g_k from the largest
-//     coefficient of row k, folded into phi_k as 2^g_k), the features of frame f by 2^-e_f (e_f from its largest scaled
-//     feature) -- so that every entry is a fixed-point number |v| <= 0.498, and written in SEVEN balanced base-256 digits
-//     v = sum_i s_i 256^-(i+1), s_i in [-128, 127] (56 bits below the row's / column's largest entry; what is dropped is
-//     <= 2^-57);
+// is therefore evaluated in FIXED POINT on the integer matrix cores (an Ozaki-type splitting of both operands).  It is a
+// fixed-point product with stated scales, not an exact one; what it keeps and what it drops:
+//   * three families of binary scales bring the operands to |v| <= 0.498:
+//       g_k  per GEMM row, from the model's own data scale in that dimension, s_d^2 = geometric mean over the components of
+//            var + (mu - centre)^2: the quadratic row of dimension d is scaled by 2^-g ~ s_d^2, the linear one by ~ s_d, the
+//            features by the inverse (x / s_d is O(1) for the frames the model describes, whatever the units of the data);
+//       h_c  per COMPONENT, from its largest scaled coefficient (W[k, c] 2^-g_k 2^-h_c <= 0.498);
+//       e_f  per FRAME, from its largest scaled feature (phi_k 2^g_k 2^-e_f <= 0.498);
+//   * both operands are written in SEVEN balanced base-256 digits v = sum_i s_i 256^-(i+1), s_i in [-128, 127]: 56 bits
+//     below the component's / the frame's own largest entry, what is dropped is <= 2^-57 of that;
 //   * the digit planes are int8 matrices; the products of planes i and j with i + j = d all carry the weight 256^-(d+2) and
-//     are summed by the matrix core in ONE int32 accumulator per d (|acc_d| <= 7 * 80 * 128^2 < 2^24: exact); planes with
-//     i + j > 6 are not formed: 28 plane products, K = 80 each.  What that drops: the six pairs of diagonal 7 weigh 2^-72,
-//     their digit products reach 2^14 and there are 80 of each -- at most 2^-49 of the scale 2^(g_k + e_f), 2^-55 for digits of
-//     random sign (the size of the double's own last bit at that scale); every later diagonal is 2^-8 of the one before;
-//   * Q = 2^e_f sum_d acc_d 256^-(d+2): the diagonals are joined pairwise in int32 (acc_2n * 256 + acc_2n+1 < 2^31 for
-//     2n <= 4), converted and summed in fp64, three fused multiply-adds.  One short rounding sequence at the END of an exact
-//     sum, where the fp64 GEMM of gmm.hip rounds after each of its 80 terms -- against a long-double evaluation the sliced
-//     result is the more accurate of the two (tests/test_gpu_i8.py).
+//     are summed by the matrix core in ONE int32 accumulator per d (|acc_d| <= 7 * 80 * 128^2 < 2^24: no overflow, no
+//     rounding); planes with i + j > 6 are not formed: 28 plane products, K = 80 each.  What that drops: the six pairs of
+//     diagonal 7 weigh 2^-72, their digit products reach 2^14 and there are 80 of each -- at most 2^-49 of the scale
+//     2^(h_c + e_f), 2^-55 for digits of random sign; every later diagonal is 2^-8 of the one before;
+//   * Q = 2^(h_c + e_f) sum_d acc_d 256^-(d+2): the diagonals are joined pairwise in int32 (acc_2n * 256 + acc_2n+1 < 2^31 for
+//     2n <= 4), converted and summed in fp64, three fused multiply-adds.
+// ERROR.  |dQ[c, f]| ~ 3 * 2^-53 * A_c X_f (measured, tools/i8_emulate.py and tests/test_gpu_i8.py; worst case ~ 2^-49 A_c X_f),
+// A_c = the component's largest scaled coefficient, X_f = the frame's largest scaled feature: the error of a component is
+// relative to ITS OWN largest possible term at that frame, as a floating-point GEMM's is -- a sharp component (small var)
+// costs the broad ones nothing.  (Round 5 scaled row k by the largest |W[k, c]| over ALL components: one component with
+// var / 10^3 then cost every other component ten bits, 1e-11 instead of 1e-14 on b.)  What the fixed point cannot give is
+// range WITHIN a component: a component that is sharp in one dimension and broad in another keeps 56 bits below its
+// sharpest coefficient only.  pack_i8_model therefore measures rho = max_c A_c X_c, X_c = the largest scaled feature of a
+// frame within four standard deviations of the component's own mean (i8_comp_scale_kernel): 2^-53 rho is the size of the
+// absolute error on a component's log-density at the frames that component describes.  Models with rho > kI8RhoMax
+// (2048: <= 1e-12) are scored by the fp64 matrix-core bank (emit_diag_mfma, gmm.hip) instead -- like kappa > 4096 sends a
+// model to the direct form.  lnasr_model_range reports rho and the decision.  On the metric's model (var in [0.5, 1.5],
+// rho = 26) the integer bank is the more accurate of the two matrix-core routes against a long-double evaluation (9e-15
+// against 4e-14 for the fp64 GEMM, which rounds after each of its 80 terms).
 // The constant of the component (log w + gconst - 1/2 sum mu^2 / var) is added in fp64, then the M-way log-sum-exp of gmm.hip.
 //
 // Work per 16-component x 16-frame tile: 38 integer MFMAs (28 plane pairs x K = 64, plus the K = 64..79 remainders of up to
 // four pairs of one diagonal packed into one instruction: 10) at 16.7 cycles against 20 fp64 MFMAs at 64.  The integer
 // instruction does not hide vector work either (measured, tools/ubench/i8coexec, i8rate: beside a saturated integer matrix
-// pipe an fp64 vector instruction costs 2.9 of its 4 cycles), so the kernel is bound by ISSUE: 76 matrix + ~235 vector
+// pipe an fp64 vector instruction costs 2.9 of its 4 cycles), so the kernel is bound by ISSUE: 76 matrix + ~245 vector
 // instructions per wave and tile; what the design wins is the matrix share, 1270 cycles per wave-tile instead of 2560.
 //
-// Kernels: i8_row_scale_kernel / pack_wslice_kernel (once per model), slice_features_kernel (once per batch: digit planes of
-// the features, [tile][plane][k-chunk][frame][16 B], 568 B per frame), emit_diag_i8 (the bank).  Instantiations of the bank:
-// 16 mixtures per (virtual) state, 8 (M = 5 .. 8) or 32 (M = 32 as it is: no virtual states, no merge pass); with or without the
-// K = 64 .. 79 remainder instructions (2 D <= 64 has none); b alone, b + bm (whole rows through an LDS image), or b + float q32
-// from the first four planes only (the float32 statistics pass's hand-off).
+// Kernels: i8_row_scale_kernel / i8_comp_scale_kernel / pack_wslice_kernel (once per model), slice_features_kernel (once per
+// batch: digit planes of the features, [tile][plane][k-chunk][frame][16 B], 568 B per frame), emit_diag_i8 (the bank).
+// Instantiations of the bank: 16 mixtures per (virtual) state, 8 (M = 5 .. 8) or 32 (M = 32 as it is: no virtual states, no
+// merge pass); with or without the K = 64 .. 79 remainder instructions (2 D <= 64 has none); b alone, b + bm (whole rows
+// through an LDS image), or b + float q32 from the first four planes only (the float32 statistics pass's hand-off).
 #include <cstdio>
 #include <vector>
 
@@ -86,23 +101,81 @@ __device__ __forceinline__ double coef_of(const double* __restrict__ mu, const d
     return 0.0;
 }
 
-// g[k] = exponent with |W[k, c]| 2^-g[k] <= 0.498 for every component (0 for an all-zero row); pow2g[k] = 2^g[k]
+// Row scales from the model's own data scale.  Block d: l = mean over the real components (ivar > 0: padding components
+// have none) of log2(var + mu_c^2) in dimension d; the quadratic row of d gets g = -round(l), the linear row -round(l / 2);
+// pow2g[k] = 2^g[k].  Rows past 2 D (zero coefficients): g = 0.
 __global__ void i8_row_scale_kernel(const double* __restrict__ mu, const double* __restrict__ ivar, int NM, int D,
                                     int* __restrict__ g, double* __restrict__ pow2g) {
-    const int k = blockIdx.x;
+    const int d = blockIdx.x;
     __shared__ double red[256];
-    double mx = 0.0;
-    for (int c = threadIdx.x; c < NM; c += 256) mx = fmax(mx, fabs(coef_of(mu, ivar, (size_t)c, k, D)));
-    red[threadIdx.x] = mx;
+    __shared__ int cnt[256];
+    double sum = 0.0;
+    int n = 0;
+    for (int c = threadIdx.x; c < NM; c += 256) {
+        const double iv = ivar[(size_t)c * D + d], m = mu[(size_t)c * D + d];
+        if (iv > 0.0) {
+            sum += log2(1.0 / iv + m * m);
+            ++n;
+        }
+    }
+    red[threadIdx.x] = sum;
+    cnt[threadIdx.x] = n;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s]);
+        if ((int)threadIdx.x < s) {
+            red[threadIdx.x] += red[threadIdx.x + s];
+            cnt[threadIdx.x] += cnt[threadIdx.x + s];
+        }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        const int e = red[0] > 0.0 ? scale_exponent(red[0]) : 0;
-        g[k] = e;
-        pow2g[k] = ldexp(1.0, e);
+        double l = cnt[0] > 0 ? red[0] / cnt[0] : 0.0;
+        if (!(l > -900.0)) l = -900.0;                    // (also a NaN: the packers' results are then refused by rho)
+        if (l > 900.0) l = 900.0;
+        const int gq = -(int)__builtin_rint(l), gl = -(int)__builtin_rint(0.5 * l);
+        g[d] = gq;
+        pow2g[d] = ldexp(1.0, gq);
+        g[D + d] = gl;
+        pow2g[D + d] = ldexp(1.0, gl);
+    }
+    if (d == 0)
+        for (int k = 2 * D + threadIdx.x; k < 80; k += 256) {
+            g[k] = 0;
+            pow2g[k] = 1.0;
+        }
+}
+
+// Component scales and the model's range.  One wave per component c:
+//   h[c] = exponent with |W[k, c]| 2^-g[k] 2^-h[c] <= 0.498 for every row k (0 for a padding component);
+//   rho  = max_c A_c X_c (atomic max of the bit pattern; the values are >= 0), A_c = max_k |W[k, c]| 2^-g[k] and X_c = the
+//          largest scaled feature of a frame within kI8Reach standard deviations of the component's mean:
+//          max_d max((|mu_c| + 4 sd)^2 2^g[d], (|mu_c| + 4 sd) 2^g[D + d]).  A non-finite value counts as +infinity.
+constexpr double kI8Reach = 4.0;
+__global__ __launch_bounds__(256) void i8_comp_scale_kernel(const double* __restrict__ mu, const double* __restrict__ ivar,
+                                                            const int* __restrict__ g, int NM, int D, int* __restrict__ h,
+                                                            unsigned long long* __restrict__ rho_bits) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= NM) return;
+    double A = 0.0, X = 0.0;
+    bool real = false;
+    for (int d = lane; d < D; d += 64) {
+        const double iv = ivar[(size_t)c * D + d], m = mu[(size_t)c * D + d];
+        if (!(iv > 0.0)) continue;
+        real = true;
+        A = fmax(A, fmax(ldexp(0.5 * iv, -g[d]), ldexp(fabs(m) * iv, -g[D + d])));
+        const double reach = fabs(m) + kI8Reach / sqrt(iv);
+        X = fmax(X, fmax(ldexp(reach * reach, g[d]), ldexp(reach, g[D + d])));
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        A = fmax(A, __shfl_xor(A, o));
+        X = fmax(X, __shfl_xor(X, o));
+        real |= __shfl_xor((int)real, o) != 0;
+    }
+    if (lane == 0) {
+        h[c] = (real && A > 0.0 && __builtin_isfinite(A)) ? scale_exponent(A) : 0;
+        double r = real ? A * X : 0.0;
+        if (!__builtin_isfinite(r)) r = __builtin_huge_val();
+        atomicMax(rho_bits, (unsigned long long)__double_as_longlong(r));
     }
 }
 
@@ -113,8 +186,8 @@ __global__ void i8_row_scale_kernel(const double* __restrict__ mu, const double*
 // constc[state*16 + m] = log w + gconst - 1/2 sum mu^2 / var;  constc_nw: the same without log w
 __global__ void pack_wslice_kernel(const double* __restrict__ mu, const double* __restrict__ ivar,
                                    const double* __restrict__ gconst, const double* __restrict__ logw,
-                                   const int* __restrict__ g, int4_t* __restrict__ wq, double* __restrict__ constc,
-                                   double* __restrict__ constc_nw, int N, int D, int MX) {
+                                   const int* __restrict__ g, const int* __restrict__ hexp, int4_t* __restrict__ wq,
+                                   double* __restrict__ constc, double* __restrict__ constc_nw, int N, int D, int MX) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)(MX == 16 ? N / 2 : (MX == 8 ? N / 4 : N)) * 2 * kSlots * 64;
     if (idx >= total) return;
@@ -138,7 +211,7 @@ __global__ void pack_wslice_kernel(const double* __restrict__ mu, const double* 
     for (int by = 0; by < 16; ++by) {
         const int k = k0 + by;
         int s[kS];
-        split_digits(ldexp(coef_of(mu, ivar, c, k, D), -g[k]), s);
+        split_digits(ldexp(coef_of(mu, ivar, c, k, D), -g[k] - hexp[c]), s);
         int dg = 0;
 #pragma unroll
         for (int i = 0; i < kS; ++i) dg = plane == i ? s[i] : dg;      // (plane 7 of the last remainder slot: zero)
@@ -271,7 +344,8 @@ constexpr int kBmRow = 16 * 16 + 4;                   // doubles per frame of th
 template <int ABL, bool REM = true, bool WRITE_BM = false, int MIX = 16, int NPL = kS, bool Q32 = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void emit_diag_i8(
     const int4_t* __restrict__ Fs, const int4_t* __restrict__ wq, const double* __restrict__ constc,
-    const double* __restrict__ logw, double* __restrict__ b, double* __restrict__ bm, long F, int N, int GY, long ntiles,
+    const int* __restrict__ hexp, const double* __restrict__ logw, double* __restrict__ b, double* __restrict__ bm, long F,
+    int N, int GY, long ntiles,
     int tiles_per_block, long nchunks, unsigned long long* __restrict__ dbg, float* __restrict__ q32 = nullptr) {
     // Q32 (the float32 statistics pass, f32stats.hip): only the first NPL = 4 digit planes of either operand are multiplied (ten
     // plane pairs: 32 bits below the row's / column's scale, ~1e-6 absolute on a log-density where that pass promises 8e-6), the
@@ -304,6 +378,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (tid < 32) Fl[tid >> 4][kZeroI4 + (tid & 15)] = int4_t{0, 0, 0, 0};
     __shared__ double lws[WRITE_BM ? 256 : 1];
     __shared__ double csts[WRITE_BM ? 256 : 1];
+    __shared__ int hs[WRITE_BM ? 256 : 1];
     __shared__ double bms[WRITE_BM ? 2 * 16 * kBmRow : 1];
     constexpr int kQRow = 16 * 16 + 8;                    // floats per frame of the q32 image (the block's 1 KB of a frame + pad)
     __shared__ float qms[Q32 ? 2 * 16 * kQRow : 1];
@@ -337,25 +412,51 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int p = 0; p < 2; ++p)
             if (REM) Wl[q][p] = wq[(((size_t)sp * 2 + q) * kSlots + kS + p) * 64 + lane];
     }
-    // (WRITE_BM: the constants wait in the LDS beside the weights -- 16 registers the instantiation does not have)
+    // the components' constants and their exponents h_c (the planes hold W 2^-g 2^-h: the product is put back by 2^(e_f + h_c))
+    // (WRITE_BM: both wait in the LDS beside the weights -- 24 registers the instantiation does not have)
     double cst[WRITE_BM ? 1 : 8];
+    int hx[WRITE_BM ? 1 : 8];
     const double* cstp = cst;
+    const int* hxp = hx;
     if (WRITE_BM) {
         if (tid < 256) {
             const long st = (long)SPB * y + tid / MIX;
             csts[tid] = constc[(st < N ? st : N - 1) * MIX + tid % MIX];
+            hs[tid] = hexp[(st < N ? st : N - 1) * MIX + tid % MIX];
         }
         cstp = csts + sl * MIX + mb;
+        hxp = hs + sl * MIX + mb;
     } else {
 #pragma unroll
-        for (int m = 0; m < 8; ++m) cst[m] = constc[(size_t)(SW * sp + lst) * MIX + mb + m];
+        for (int m = 0; m < 8; ++m) {
+            cst[m] = constc[(size_t)(SW * sp + lst) * MIX + mb + m];
+            hx[m] = hexp[(size_t)(SW * sp + lst) * MIX + mb + m];
+        }
     }
 
-    int4_t pre[2];
     // (NPL < kS: only the first NPL planes and the scales behind plane kS - 1 are copied; they keep their places in the image)
     constexpr int kUsedI4 = NPL * kPlaneI4 + 8;
     auto tile_index = [](int e) { return e < NPL * kPlaneI4 ? e : e + (kS - NPL) * kPlaneI4; };
-    auto load_tile = [&](long tile) {
+#ifndef LNASR_I8_NO_GLDS
+    // The next tile's planes go from global memory straight into the LDS image (global_load_lds_dwordx4: 1 KB per wave and
+    // instruction, LDS address = a wave-uniform base + 16 lane -- the image is lane-linear, NPL * kPlaneI4 is a multiple of
+    // 64), no staging registers and no ds_write pass.  Issued at the top of a tile into the buffer the barrier that ended the
+    // previous tile has freed; the barrier in the middle of the tile waits for it (a pending LDS-DMA is a pending LDS write
+    // on the VM counter: __syncthreads drains it), a phase of ~1500 cycles later.
+    auto load_tile = [&](long tile, int buf) {
+        const int4_t* src = Fs + tile * kTileI4;
+#pragma unroll
+        for (int r = 0; r < (kUsedI4 + 511) / 512; ++r) {
+            const int e0 = 64 * w + 512 * r, e = e0 + lane;        // e0: wave-uniform
+            if (e < kUsedI4)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + tile_index(e)),
+                                                 (__attribute__((address_space(3))) void*)(&Fl[buf][tile_index(e0)]), 16, 0, 0);
+        }
+    };
+    auto store_tile = [](int) {};
+#else
+    int4_t pre[2];
+    auto load_tile = [&](long tile, int) {
         const int4_t* src = Fs + tile * kTileI4;
 #pragma unroll
         for (int r = 0; r < (kUsedI4 + 511) / 512; ++r) {
@@ -370,6 +471,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (e < kUsedI4) Fl[buf][tile_index(e)] = pre[r];
         }
     };
+#endif
     auto flush = [&](int buf, long tile) {               // 16 frames x SPB states (16: waves 0-3; 8 mixtures: every thread)
         if (tid < 16 * SPB) {
             const int f = tid / SPB, st = tid % SPB;
@@ -378,7 +480,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     };
 
-    load_tile(tile0);
+    load_tile(tile0, 0);
     store_tile(0);
     drain_vmem();
     __syncthreads();
@@ -533,7 +635,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[q][e] = fma(r[q][e], scale, cstp[4 * q + e]);
+            for (int e = 0; e < 4; ++e) v[q][e] = fma(r[q][e], ldexp(scale, hxp[4 * q + e]), cstp[4 * q + e]);
         if (Q32) {                                        // eight consecutive mixtures of (frame col, the lane's state): 32 bytes
 #pragma unroll
             for (int q = 0; q < 2; ++q)
@@ -589,7 +691,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int cur = (int)((tile - tile0) & 1);
         const bool has_next = tile + 1 < tile1;
         if (ABL == 6) ts = __builtin_amdgcn_s_memtime();
-        if (has_next) load_tile(tile + 1);
+        if (has_next) load_tile(tile + 1, cur ^ 1);
         if (half == 0) matrix_phase(cur, tile);
         else if (tile > tile0) {
             lse_to(&ob[cur ^ 1][0]);
@@ -635,7 +737,18 @@ bool i8_emit_shape_ok(int Nv, int Mv, int D) {
     return units && D >= 1 && 2 * D <= 80;
 }
 
-// once per model (after prep_diag / centre_and_kappa): digit planes of the coefficients
+// The integer bank scores this model's batches of F frames: planes packed for the shape the fp64 bank was packed for, the
+// model's range within what seven planes hold (rho, above), a few thousand frames to amortise 36 KB of digit planes per
+// wave and four slabs of 16 states or more (128 states x 1000 frames: 0.018 against 0.016 ms for one utterance, 0.033 /
+// 0.036 for four, 0.36 / 0.41 for 64; 512,000 frames of 32 states: 0.87 / 0.83, of 48: 1.17 / 1.57, of 64: 1.46 / 1.59)
+bool i8_model_ok(const Model& md) {
+    return md.i8_NG > 0 && md.i8_NG == md.wpack_NG && !sw().no_i8emit && md.i8_rho <= sw().i8_rho_max;
+}
+bool i8_route(const Model& md, long F) {
+    return i8_model_ok(md) && (sw().i8_min_frames >= 0 ? F >= sw().i8_min_frames : (F >= 4096 && md.i8_NG >= 12));
+}
+
+// once per model (after prep_diag / centre_and_kappa): scales, the model's range, digit planes of the coefficients
 int pack_i8_model(lnasr_ctx* ctx, const double* mu_s, const double* iv_s, const double* gc_s, const double* lw_s, int Nv,
                   int Mv) {
     ctx->model.i8_logw = lw_s;
@@ -649,11 +762,22 @@ int pack_i8_model(lnasr_ctx* ctx, const double* mu_s, const double* iv_s, const 
     LN_TRY(md.i8_wq.reserve(units * 2 * kSlots * 64 * 16));
     LN_TRY(md.i8_const.reserve(NMv * 8));
     LN_TRY(md.i8_const_nw.reserve(NMv * 8));
-    LN_LAUNCH(ctx, "i8_row_scale", i8_row_scale_kernel, dim3(80), dim3(256), 0, mu_s, iv_s, (int)NMv, D, md.i8_g.as<int>(),
+    LN_TRY(md.i8_h.reserve(NMv * 4));
+    LN_TRY(md.flags.reserve(256));
+    unsigned long long* rbits = reinterpret_cast<unsigned long long*>(md.flags.as<char>() + 16);
+    LN_HIP(hipMemsetAsync(rbits, 0, 8, ctx->stream));
+    LN_LAUNCH(ctx, "i8_row_scale", i8_row_scale_kernel, dim3(D), dim3(256), 0, mu_s, iv_s, (int)NMv, D, md.i8_g.as<int>(),
               md.i8_pow2g.as<double>());
+    LN_LAUNCH(ctx, "i8_comp_scale", i8_comp_scale_kernel, dim3((unsigned)((NMv + 3) / 4)), dim3(256), 0, mu_s, iv_s,
+              (const int*)md.i8_g.as<int>(), (int)NMv, D, md.i8_h.as<int>(), rbits);
     const size_t total = units * 2 * kSlots * 64;
     LN_LAUNCH(ctx, "pack_wslice", pack_wslice_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, mu_s, iv_s, gc_s,
-              lw_s, (const int*)md.i8_g.as<int>(), md.i8_wq.as<int4_t>(), md.i8_const.as<double>(), md.i8_const_nw.as<double>(), Nv, D, Mv);
+              lw_s, (const int*)md.i8_g.as<int>(), (const int*)md.i8_h.as<int>(), md.i8_wq.as<int4_t>(),
+              md.i8_const.as<double>(), md.i8_const_nw.as<double>(), Nv, D, Mv);
+    unsigned long long rb = 0;
+    LN_HIP(hipMemcpyAsync(&rb, rbits, 8, hipMemcpyDeviceToHost, ctx->stream));
+    LN_HIP(hipStreamSynchronize(ctx->stream));
+    md.i8_rho = __builtin_bit_cast(double, rb);
     md.i8_NG = (Mv == 32 ? 2 * Nv : Nv) / 4;             // in units of four 16-mixture (virtual) states, like wpack_NG
     return 0;
 }
@@ -683,12 +807,12 @@ int emit_diag_i8_device(lnasr_ctx* ctx, const double* obs, long F, double* b, do
 #define LN_I8K(abl, rem, wbm, mixv, name)                                                                         \
     LN_LAUNCH(ctx, name, (emit_diag_i8<abl, rem, wbm, mixv, kS, false>), dim3((unsigned)grid), dim3(512), 0,         \
               (const int4_t*)Fs, (const int4_t*)md.i8_wq.as<int4_t>(),                                               \
-              (const double*)(wbm ? md.i8_const_nw.as<double>() : md.i8_const.as<double>()), md.i8_logw, b, bm, F,   \
-              Nk, GY, ntiles, (int)tpb, nchunks, dbg, (float*)nullptr)
+              (const double*)(wbm ? md.i8_const_nw.as<double>() : md.i8_const.as<double>()),                         \
+              (const int*)md.i8_h.as<int>(), md.i8_logw, b, bm, F, Nk, GY, ntiles, (int)tpb, nchunks, dbg, (float*)nullptr)
 #define LN_I8Q(rem, mixv, name)                                                                                   \
     LN_LAUNCH(ctx, name, (emit_diag_i8<0, rem, false, mixv, 4, true>), dim3((unsigned)grid), dim3(512), 0,           \
               (const int4_t*)Fs, (const int4_t*)md.i8_wq.as<int4_t>(), (const double*)md.i8_const.as<double>(),      \
-              md.i8_logw, b, (double*)nullptr, F, Nk, GY, ntiles, (int)tpb, nchunks, dbg, q32)
+              (const int*)md.i8_h.as<int>(), md.i8_logw, b, (double*)nullptr, F, Nk, GY, ntiles, (int)tpb, nchunks, dbg, q32)
     unsigned long long* dbg = nullptr;
 #ifdef LNASR_I8_STAMPS                                    // diagnostic build: in-kernel phase stamps (s_memtime), printed per launch
     if (getenv("LNASR_I8_STAMPS") && !bm && mix == 16) {

@@ -60,6 +60,7 @@ SIGNATURES = {
     "lnasr_hmm_upload": [_vp, _i, _vp, _vp],
     "lnasr_model_is_diag": [_vp, _P(_i)],
     "lnasr_model_conditioning": [_vp, _P(_dbl), _P(_i)],
+    "lnasr_model_range": [_vp, _P(_dbl), _P(_i)],
     "lnasr_discrete_map_b": [_vp, _vp, _i, _i, _vp, _i, _i, _i, _vp],
     "lnasr_gmm_logprob": [_vp, _vp, _i, _i, _vp, _i, _vp, _vp],
     "lnasr_gauss1d": [_vp, _vp, _sz, _dbl, _dbl, _i, _vp],
@@ -489,6 +490,13 @@ class Context:
         k, d = C.c_double(0), C.c_int(0)
         check(lib().lnasr_model_conditioning(self.handle, C.byref(k), C.byref(d)))
         return k.value, bool(d.value)
+
+    def model_range(self):
+        """(rho, integer_bank): the model's range as the integer matrix-core bank's fixed point sees it, and whether large
+        batches of this model take that bank (include/lnasr_hip.h)."""
+        r, d = C.c_double(0), C.c_int(0)
+        check(lib().lnasr_model_range(self.handle, C.byref(r), C.byref(d)))
+        return r.value, bool(d.value)
 
     # -- helpers ---------------------------------------------------------------------------
     def _out(self, like_device, shape, dtype):

@@ -110,6 +110,7 @@ calls = {
     "lnasr_model_upload": (null, 2, 2, 2, buf, buf, buf, buf, buf, 1),
     "lnasr_model_upload_full": (null, 2, 2, 2, buf, buf, buf, buf, buf), "lnasr_hmm_upload": (null, 2, buf, buf),
     "lnasr_model_is_diag": (null, C.byref(ci)), "lnasr_model_conditioning": (null, C.byref(dbl), C.byref(ci)),
+    "lnasr_model_range": (null, C.byref(dbl), C.byref(ci)),
     "lnasr_discrete_map_b": (null, buf, 2, 2, ibuf, 1, 2, 0, buf), "lnasr_gmm_logprob": (null, buf, 1, 2, null, 0, buf, null),
     "lnasr_gauss1d": (null, buf, 4, 0.0, 1.0, 1, buf), "lnasr_gauss_multi": (null, buf, 2, 2, buf, buf, 1, buf),
     "lnasr_gauss_mixture": (null, buf, 2, buf, 2, 2, buf, buf, 1, buf),

