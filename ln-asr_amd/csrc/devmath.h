@@ -27,19 +27,26 @@ __device__ __forceinline__ void alternate_priority(unsigned block_class) {
 // the kernel's duration alone hides (it found the MFCC kernel's 20 % tail: DESIGN 4.6).
 #ifdef LNASR_BLOCK_TIMES
 static __device__ unsigned long long g_block_times[2 * 16384];
-#define LN_BLOCK_T0 const unsigned long long bt0__ = __builtin_amdgcn_s_memrealtime()
+static __device__ unsigned long long g_block_cycles[16384];      // shader-clock cycles of the block's life (s_memtime):
+#define LN_BLOCK_T0                                                      /* cycles / ticks * 100 MHz = its clock */ \
+    const unsigned long long bt0__ = __builtin_amdgcn_s_memrealtime(), bc0__ = __builtin_amdgcn_s_memtime()
 #define LN_BLOCK_T1                                                                  \
     do {                                                                             \
         const unsigned bid__ = blockIdx.x + gridDim.x * blockIdx.y;                  \
         if (threadIdx.x == 0 && bid__ < 16384) {                                     \
             g_block_times[2 * bid__] = bt0__;                                        \
             g_block_times[2 * bid__ + 1] = __builtin_amdgcn_s_memrealtime();         \
+            g_block_cycles[bid__] = __builtin_amdgcn_s_memtime() - bc0__;            \
         }                                                                            \
     } while (0)
 #define LN_BLOCK_TIMES_EXPORT(fn)                                                    \
     extern "C" int fn(unsigned long long* out) {                                     \
         if (hipDeviceSynchronize() != hipSuccess) return -1;                         \
         return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_block_times), sizeof(g_block_times)) == hipSuccess ? 0 : -1; \
+    }                                                                                \
+    extern "C" int fn##_cycles(unsigned long long* out) {                            \
+        if (hipDeviceSynchronize() != hipSuccess) return -1;                         \
+        return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_block_cycles), sizeof(g_block_cycles)) == hipSuccess ? 0 : -1; \
     }
 #else
 #define LN_BLOCK_T0

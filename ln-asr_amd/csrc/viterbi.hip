@@ -223,7 +223,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
     unsigned nan_epoch) {
     constexpr int NP = 64 * CPT;
     __shared__ double Vs[3][UB][NP];
-    unsigned long long saw_nan = 0;
+    bool nan0 = false;                             // CHKB, frame 0: per lane, folded into the scalar ballot word below
     LN_BLOCK_T0;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int u0 = blockIdx.x * UB;
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
             if (j < N && len[k] > 0) {
                 size_t o = ((size_t)(u0 + k) * T) * N + j;
                 const double b0 = ld(b, o);
-                if (CHKB && b0 != b0) saw_nan = 1;             // frame 0 (per-lane: merged into the ballot word below)
+                if (CHKB && b0 != b0) nan0 = true;
                 val = rnd<TS>(pi[j] + b0);
                 st(v, o, val);
             }
@@ -289,6 +289,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
     // store duty: (utterance, column block) q = w + jj*NW written to global one frame late
     constexpr int NJOB = CPT * UB;
     __syncthreads();
+    // (formed HERE, outside the divergent set-up loop: the word is wave-uniform and stays in scalar registers through the frames)
+    unsigned long long saw_nan = CHKB ? __ballot(nan0) : 0ull;
 
     int cur = 0;                                   // buffer holding v[t-1]
     for (int t = 1; t < maxlen; ++t) {
@@ -316,13 +318,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
                     bnext[k][c] = ld(row, jcol[c]);
                 }
             }
-        }
-        if (CHKB && w == 0) {                      // wave-uniform: one wave looks at the frame's emissions for the block
-#pragma unroll
-            for (int k = 0; k < UB; ++k)
-#pragma unroll
-                for (int c = 0; c < CPT; ++c)
-                    saw_nan |= __ballot(bcur[k][c] != bcur[k][c] && t < len[k] && lane + 64 * c < N);
         }
         // v[t-1] of the columns this wave stores to global (complete since the last barrier): read now, with the other LDS
         // reads of the turn, stored AFTER the arithmetic -- the store's wait for its LDS read sat at the top of the frame of the
@@ -365,9 +360,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
 #pragma unroll
         for (int k = 0; k < UB; ++k)
 #pragma unroll
-            for (int c = 0; c < CPT; ++c)
-                __hip_atomic_fetch_max(&Vs[nxt][k][lane + 64 * c], rnd<TS>(acc[k][c] + bcur[k][c]), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int c = 0; c < CPT; ++c) {
+                const double cand = rnd<TS>(acc[k][c] + bcur[k][c]);
+                // CHKB: one wave looks at the frame's candidates for the block -- v never holds a NaN (the atomic maximum drops
+                // one), so a NaN candidate is a NaN emission (columns past N repeat column N - 1: no mask needed); tested HERE,
+                // on a value that is live anyway (tested on bcur at the top of the frame the instantiation spilled 14 registers
+                // into the loop: 2.07 ms against 1.25 for the metric shard, round 6)
+                if (CHKB) saw_nan |= __ballot(cand != cand) & (t < len[k] ? ~0ull : 0ull);
+                __hip_atomic_fetch_max(&Vs[nxt][k][lane + 64 * c], cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
         if constexpr (LAT) {
             if (duty) st(v, ((size_t)(u0 + w / CPT) * T + (t - 1)) * N + lane + 64 * (w % CPT), vst);
         }
