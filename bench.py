@@ -7,20 +7,19 @@ final RCCL all-gather of the decoded state paths).
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
 With --gpus N > 1 and no launcher environment (WORLD_SIZE unset) this process touches no GPU: it
-starts N fresh ranks, one per GPU, as a child
-
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
-
-forwards their output and returns the launcher's exit code.  Started by such a launcher (the
-driver's own command line is the one above) the process is one rank; whoever launched it, the
-environment defaults a rank needs on this pool are set below, at import.
+starts N fresh ranks of itself, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
+MASTER_PORT in their environment), forwards their output and returns the largest exit code.
+Started by somebody else's launcher (the driver uses an elastic launcher with --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1 --master-port P in front of `bench.py --gpus N ...`)
+the process is one rank and reads the same variables; whoever launched it, the environment
+defaults a rank needs on this pool are set below, at import.  No ML framework anywhere in this
+file or in the package: the ranks meet through lnasr/rendezvous.py (loopback TCP; the 128-byte
+ncclUniqueId, the barriers and the max-over-ranks of the timing travel there).
 
 A step = one pass of the hot path (fp64-MFMA emission -> Viterbi trellis -> backtrace, then for
 N > 1 the RCCL gather of paths) over this rank's 1024 utterances, with the observations already
 resident in HBM.  Rank 0 prints ONE JSON line.  The compute path is liblnasr_hip.so through ctypes
-and the collectives are RCCL inside that library; with one rank no torch module is imported at all,
-with N > 1 torch.distributed (gloo, CPU) carries rendezvous / barrier / max-over-ranks only.
+and the collectives are RCCL inside that library.
 
 Before anything is timed EVERY rank decodes the first N_CHECK utterances of its own shard with the
 CPU oracle and compares the paths bit for bit; a mismatch, a failed communicator or a failed
@@ -33,22 +32,25 @@ Besides the headline the line carries
                same from pageable memory through the pinned staging ring; PCIe-inclusive, never `value`;
   baum_welch   BASELINE configs[4]: one statistics pass per rank (N=256, M=32, T=2000, 64 utterances:
                emission + forward/backward + accumulation) and the RCCL all-reduce of the packed
-               sufficient statistics (the second collective of the path), timed separately;
+               sufficient statistics (the second collective of the path), timed separately; `roofline`: the
+               pass's algorithmic FLOP over its time against the fp64 / fp32 peak + its three
+               dominant kernels;
+  configs3_one_gpu  (one rank only) all 8192 utterances of BASELINE configs[3] on this one GPU, same resident step;
   reference_api  (one rank only) the reference's own method names on ONE utterance through the mirror
                classes -- GMMHMM.decode / calc_prob / _viterbi / _forward / train(iters=1) at the metric
                shape with si as [N,M,D,D]: wall, device and host ms per call (tools/refapi.py).
 
-    --dry-launch    CPU rehearsal of the launch path (tests): the ranks rendezvous over gloo, shard
-                    a toy batch, gather toy paths through the gloo transport and rank 0 prints a
+    --dry-launch    CPU rehearsal of the launch path (tests): the ranks rendezvous, shard a toy batch,
+                    gather toy paths through the CPU transport (lnasr.dist.TcpComm) and rank 0 prints a
                     {"dry_launch": true, "n_ranks": N, ...} line.  No GPU call, no timing.
 """
 import os
 
-# Defaults every rank needs, whoever started it (bench.py's own launcher, the driver's torch.distributed.run, a
+# Defaults every rank needs, whoever started it (bench.py's own launcher, the driver's elastic launcher, a
 # test): set at import, before anything reads them.
 _ENV_DEFAULTS = {
     "HSA_ENABLE_IPC_MODE_LEGACY": "0",      # dmabuf IPC: RCCL across processes fails without it on this pool
-    "GLOO_SOCKET_IFNAME": "lo",             # one node: never depend on the hostname resolving ...
+    "GLOO_SOCKET_IFNAME": "lo",             # one node: never depend on the hostname resolving (a foreign launcher's gloo) ...
     "NCCL_SOCKET_IFNAME": "lo",             # ... nor on which interface RCCL's bootstrap would pick
     "MASTER_ADDR": "127.0.0.1",
     "OMP_NUM_THREADS": "1", "OPENBLAS_NUM_THREADS": "1", "MKL_NUM_THREADS": "1",   # CPU baseline: 1 BLAS thread / worker
@@ -74,6 +76,7 @@ FLOP_TRELLIS = 2 * N_STATES * N_STATES              # 32,768 per frame
 FLOP_DECODE = FLOP_EMIT + FLOP_TRELLIS              # 272,384 per frame
 BYTES_DECODE = 8 * N_DIM + 4                        # 316 B per frame (obs in, path out)
 PEAK_FP64_TFLOPS = 78.6                             # MI355X fp64 matrix = vector peak (MI355X_MICROARCH.md)
+PEAK_FP32_TFLOPS = 157.3                            # fp32 vector / matrix peak (same guide)
 PEAK_HBM_GBS = 8000.0
 PEAK_I8_TOPS = 5000.0                               # dense int8 matrix peak: 2 x the bf16 rate per clock (same guide)
 METRIC = "frames/sec Viterbi decode, 128-state 16-mix GMM-HMM, D=39 MFCC"
@@ -110,15 +113,34 @@ def _free_port():
 
 
 def launch_ranks(args, argv):
-    """Start N fresh ranks (one per GPU) from a parent that has made no GPU call, wait, return their exit code."""
-    env = dict(os.environ)
+    """Start N fresh ranks (one per GPU) from a parent that has made no GPU call, wait, return the largest exit code.
+    A rank that fails takes the others with it after a grace period (they would wait for it in the rendezvous)."""
+    base = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_PORT"):
-        env.pop(k, None)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
-    sys.stderr.write("[bench] starting %d ranks: %s\n" % (args.gpus, " ".join(cmd)))
+        base.pop(k, None)
+    port = _free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    sys.stderr.write("[bench] started %d ranks of %s %s (pids %s), rendezvous key 127.0.0.1:%d\n"
+                     % (args.gpus, os.path.basename(__file__), " ".join(argv), [p.pid for p in procs], port))
     sys.stderr.flush()
-    return subprocess.call(cmd, env=env)
+    codes, failed_at = [None] * len(procs), None
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+                if codes[i] not in (None, 0) and failed_at is None:
+                    failed_at = time.time()
+        if failed_at is not None and time.time() - failed_at > 30.0:
+            for i, p in enumerate(procs):                          # exactly the processes started above
+                if codes[i] is None:
+                    p.kill()
+                    codes[i] = p.wait()
+        time.sleep(0.05)
+    return max(abs(c) for c in codes)
 
 
 # ---- CPU baseline (rank 0, N=1 only): the oracle timed on the host cores ------------------------------
@@ -253,84 +275,83 @@ def cpu_baseline():
 
 
 def _pmc_traffic(kernel):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-    (profiles/pmc_traffic.json, corrected as MI355X_MICROARCH.md section HBM prescribes)."""
+    """(HBM bytes per launch, where the figure comes from) of the dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/pmc_traffic.json, corrected as MI355X_MICROARCH.md section HBM prescribes).  The counters are collected in
+    their own profiler passes, not in this run: the entry names the profile (tag, date) and carries a hash of the source
+    the counted kernel was built from (tools/prof_summary.py) -- a kernel whose source has changed since gets NO figure."""
+    import hashlib
     p = os.path.join(REPO, "profiles", "pmc_traffic.json")
     try:
         with open(p) as fp:
-            return json.load(fp).get(kernel, {}).get("hbm_bytes_per_launch")
-    except Exception:                                                  # noqa: BLE001
-        return None
+            ent = json.load(fp).get(kernel)
+        if not ent:
+            return None, "no entry for %s in profiles/pmc_traffic.json" % kernel
+        if "source_sha16" not in ent:
+            return None, "profiles/pmc_traffic.json entry predates source tracking: not used"
+        h = hashlib.sha256()
+        for f in (os.path.basename(ent["source"]), "devmath.h", "common.h"):
+            with open(os.path.join(REPO, "ln-asr_amd", "csrc", f), "rb") as fp:
+                h.update(fp.read())
+        if h.hexdigest()[:16] != ent["source_sha16"]:
+            return None, "STALE: %s changed after profile %s (%s); re-run tools/profile_round.sh" % (
+                ent["source"], ent.get("tag"), ent.get("date"))
+        return ent.get("hbm_bytes_per_launch"), "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, profile %s (%s), %s unchanged since" % (
+            ent.get("tag"), ent.get("date"), ent["source"])
+    except Exception as e:                                             # noqa: BLE001
+        return None, "unreadable: %s" % e
 
 
 # ---- --dry-launch: the launch path on CPU ----------------------------------------------------------------
 def dry_launch(rank, world):
-    import torch.distributed as dist
     from lnasr import dist as ldist
-    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    from lnasr import rendezvous
+    grp = rendezvous.TcpGroup(rank, world)
     try:
         U, T = 4 * world + 1, 8                                           # ragged shards
         lo, hi = ldist.shard_range(U, rank, world)
         truth = (np.arange(U * T, dtype=np.uint32).reshape(U, T) * 7) % N_STATES
-        comm = ldist.GlooComm(rank, world)
+        comm = ldist.TcpComm(grp)
         allp = ldist.gather_paths(comm, truth[lo:hi], U, T)
         ok = bool(np.array_equal(allp, truth))
-        seen = [None] * world
-        dist.all_gather_object(seen, (rank, int(os.environ.get("LOCAL_RANK", "-1")), os.getpid(),
-                                      {k: os.environ.get(k) for k in _ENV_DEFAULTS}))
+        seen = grp.allgather([rank, int(os.environ.get("LOCAL_RANK", "-1")), os.getpid(),
+                              {k: os.environ.get(k) for k in _ENV_DEFAULTS}])
         if rank == 0:
             print(json.dumps({"dry_launch": True, "n_ranks": world, "ranks": sorted(s[0] for s in seen),
                               "local_ranks": sorted(s[1] for s in seen), "distinct_pids": len({s[2] for s in seen}),
-                              "gather_ok": ok, "transport": "gloo (CPU rehearsal, nothing timed)",
+                              "gather_ok": ok, "transport": "loopback TCP (CPU rehearsal, nothing timed)",
                               "env": [s[3] for s in sorted(seen, key=lambda s: s[0])]}))
             sys.stdout.flush()
-        dist.barrier()
+        grp.barrier()
     finally:
-        dist.destroy_process_group()
+        grp.close()
     return 0 if ok else 1
 
 
 # ---- the rank ---------------------------------------------------------------------------------------------
 class Ranks:
-    """Rendezvous / barrier / reductions between ranks.  One rank: no-ops, and torch is never imported."""
+    """Rendezvous / barrier / reductions between ranks (lnasr/rendezvous.py).  One rank: no-ops, no socket."""
 
     def __init__(self, rank, world, use_comm):
-        self.rank, self.world, self.dist = rank, world, None
-        if use_comm:
-            import torch.distributed as dist
-            os.environ.setdefault("MASTER_PORT", str(_free_port()))       # one-rank rehearsal without a launcher
-            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-            self.dist = dist
+        from lnasr import rendezvous
+        self.rank, self.world = rank, world
+        self.grp = rendezvous.TcpGroup(rank, world) if use_comm else None
 
     def barrier(self):
-        if self.dist is not None:
-            self.dist.barrier()
+        if self.grp is not None:
+            self.grp.barrier()
 
     def max(self, x):
-        if self.dist is None:
-            return float(x)
-        import torch
-        t = torch.tensor([float(x)], dtype=torch.float64)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return float(t.item())
+        return float(x) if self.grp is None else self.grp.max(x)
 
     def gather(self, obj):
-        if self.dist is None:
-            return [obj]
-        out = [None] * self.world
-        self.dist.all_gather_object(out, obj)
-        return out
+        return [obj] if self.grp is None else self.grp.allgather(obj)
 
     def bcast(self, obj):
-        if self.dist is None:
-            return obj
-        box = [obj]
-        self.dist.broadcast_object_list(box, src=0)
-        return box[0]
+        return obj if self.grp is None else self.grp.bcast(obj)
 
     def close(self):
-        if self.dist is not None:
-            self.dist.destroy_process_group()
+        if self.grp is not None:
+            self.grp.close()
 
 
 def fail_line(rk, why):
@@ -490,12 +511,59 @@ def baum_welch(rk, ctx, use_rccl):
         m = ctx.bw_mstep(total)
         ok = ok and bool(np.allclose(np.exp(m["A"]).sum(axis=1), 1.0, atol=1e-9))
     out["frames_per_s"] = rk.world * frames / ((out["bw_pass_ms"] + (out["allreduce_ms"] or 0.0)) * 1e-3)
+    # roofline of the pass ("BW statistics (diag)"): emission 3 N M D + forward and backward 2 x 3 N^2 + xi N^2 +
+    # the mixture moments 4 N M D per frame -- algorithmic FLOP over the driver-timed pass, against the fp64 peak and, for the
+    # precision=float32 pass, the fp32 one; beside it the three kernels that take most of the pass (HIP events, one more pass)
+    flop = 3 * N * M * s["D"] + 2 * 3 * N * N + N * N + 4 * N * M * s["D"]
+    roof = {"bound": "mfma", "algorithmic_flop_per_frame": flop, "frames_per_pass": frames, "unit": "TFLOP/s",
+            "what": "3NMD (emission) + 2*3N^2 (forward, backward) + N^2 (xi) + 4NMD (moments) per frame, N=%d M=%d D=%d" % (N, M, s["D"])}
+    for tag, prec, peak, key in (("f64", np.float64, PEAK_FP64_TFLOPS, "bw_pass_ms"), ("f32", np.float32, PEAK_FP32_TFLOPS, "bw_pass_f32_ms")):
+        ach = flop * frames / (out[key] * 1e-3) / 1e12
+        ctx.device_sync()
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        ctx.bw_accumulate(d_obs, stats_out=d_stats, precision=prec)
+        ctx.device_sync()
+        ctx.prof_enable(False)
+        top = sorted(ctx.prof_report().items(), key=lambda kv: -kv[1][1])[:3]
+        roof[tag] = {"achieved": ach, "peak": peak, "frac": ach / peak, "pass_ms": out[key],
+                     "dominant_kernels_ms": {k: m for k, (n, m) in top}}
+    out["roofline"] = roof
     out["checks"] = "sum(gamma)=frames-U, sum(mix)=frames, counts%s: %s" % (
         ", all-reduced loglik = sum of the ranks', normalised M-step" if use_rccl else "", "ok" if ok else "FAILED")
     oks = rk.gather(bool(ok))
     d_obs.free()
     d_stats.free()
     return out, all(oks)
+
+
+def full_config3(ctx, mdl, first_shard_paths):
+    """BASELINE configs[3] in full on ONE GPU: all 8192 utterances (the eight shards' seeds, 2.6 GB of observations, 8.4 GB
+    each of b and v) through the same resident step, on the driver's clock.  Checks: shard 0 is the headline's shard, so its
+    paths must be the headline's bit for bit; every state index in range."""
+    from lnasr import synth, _ffi
+    shards, U, T = 8, UTT_PER_GPU, T_FRAMES
+    ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
+    d_obs = ctx.empty((shards * U, T, N_DIM), np.float64)
+    shard_bytes = U * T * N_DIM * 8
+    for k in range(shards):                                              # shard by shard: 320 MB of host memory at a time
+        x = synth.synth_obs(U, T, N_DIM, seed=1000 + k)
+        _ffi.check(_ffi.lib().lnasr_memcpy_h2d(ctx.handle, d_obs.ptr + k * shard_bytes, x.ctypes.data, shard_bytes))
+    d_path = ctx.empty((shards * U, T), np.uint32)
+
+    class _One:                                                          # timed() wants the rank helpers
+        def barrier(self): pass
+        def max(self, x): return float(x)
+    steps = 3
+    t = timed(_One(), ctx, lambda: ctx.decode(d_obs, path_out=d_path), steps, 1) / steps
+    p = d_path.to_host()
+    out = {"workload": "all %d utterances of BASELINE configs[3] on one GPU, same resident step" % (shards * U),
+           "utterances": shards * U, "steps": steps, "ms_per_step": t * 1e3, "value": shards * U * T / t, "unit": "frames/s",
+           "first_shard_paths_identical_to_headline": bool(np.array_equal(p[:U], first_shard_paths)),
+           "all_states_in_range": bool(p.max() < N_STATES)}
+    d_obs.free()
+    d_path.free()
+    return out, out["first_shard_paths_identical_to_headline"] and out["all_states_in_range"]
 
 
 def main():
@@ -556,6 +624,7 @@ def main():
 
     mdl = synth.synth_model(N_STATES, N_MIX, N_DIM, seed=1)
     ctx.upload_gmmhmm(mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"], diag=True)
+    model_range = ctx.model_range()                                 # (rho, integer bank admitted) of the metric's model
     d_obs = ctx.to_device(obs)
     d_path = ctx.empty((U, T), np.uint32)
     d_score = ctx.empty((U,), np.float64)
@@ -645,6 +714,17 @@ def main():
             # an extra section: its failure is reported IN the line, it never takes the headline with it
             sys.stderr.write("[rank %d] reference API section failed: %s: %s\n" % (rank, type(e).__name__, e))
             refapi = {"error": "%s: %s" % (type(e).__name__, e)}
+    full3 = None
+    if not args.no_extras and world == 1 and not use_comm and U == UTT_PER_GPU and T == 1000:
+        note("configs[3] in full on this GPU (8192 utterances)")
+        try:
+            full3, ok = full_config3(ctx, mdl, resident_paths)
+            if not ok:
+                sys.stderr.write("[rank %d] the 8192-utterance decode failed its checks\n" % rank)
+                rc = 1
+        except Exception as e:                                            # noqa: BLE001 -- an extra section, like reference_api
+            sys.stderr.write("[rank %d] 8192-utterance section failed: %s: %s\n" % (rank, type(e).__name__, e))
+            full3 = {"error": "%s: %s" % (type(e).__name__, e)}
     rc = int(max(rk.gather(rc)))
     note("done, rc=%d" % rc)
 
@@ -664,14 +744,18 @@ def main():
         achieved = flop * frames_launch / avg_s / 1e12
         extra = {}
         if name == "emit_diag_i8":
-            # the bank evaluates the fp64 quadratic form EXACTLY on the int8 matrix cores (csrc/gmm_i8.hip): 28 digit-plane
-            # products, 38 v_mfma_i32_16x16x64_i8 per 16 x 16 tile.  `achieved` / `frac` stay the ALGORITHMIC fp64 figure
+            # the bank evaluates the quadratic form as a 56-bit fixed-point product on the int8 matrix cores (csrc/gmm_i8.hip):
+            # 28 digit-plane products, 38 v_mfma_i32_16x16x64_i8 per 16 x 16 tile.  `achieved` / `frac` stay the ALGORITHMIC fp64 figure
             # against the fp64 matrix peak (the yardstick of every earlier round); the integer unit's own utilisation and
             # the digit-plane pass that precedes the bank (slice_features) are reported beside it.
             i8_ops = 38 * 64 * 2 * N_STATES * N_MIX                       # integer multiply-adds x 2 per frame
             sl = prof.get("slice_features")
             both = avg_s + (sl[1] / sl[0] * 1e-3 if sl else 0.0)
-            extra = {"matrix_unit": "int8 (v_mfma_i32_16x16x64_i8), exact: results are fp64 values",
+            rho, bank = model_range
+            extra = {"matrix_unit": "int8 (v_mfma_i32_16x16x64_i8): 56-bit fixed point with one binary scale per GEMM row, per component "
+                                    "and per frame; error ~3 * 2^-53 * rho on a component log-density at the frames it describes, "
+                                    "models with rho > 2048 take the fp64 matrix cores instead (lnasr_model_range)",
+                     "model_range_rho": rho, "integer_bank": bank,
                      "int8_ops_per_frame": i8_ops, "int8_achieved_tops": i8_ops * frames_launch / avg_s / 1e12,
                      "int8_peak_tops": PEAK_I8_TOPS, "int8_frac": i8_ops * frames_launch / avg_s / 1e12 / PEAK_I8_TOPS,
                      "with_slice_features": {"ms": both * 1e3, "achieved": flop * frames_launch / both / 1e12,
@@ -690,7 +774,7 @@ def main():
                        "inputs": "obs resident in HBM when the timed region starts (PCIe-inclusive: end_to_end)"},
             "roofline": {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": PEAK_FP64_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_TFLOPS,
-                         "traffic": _pmc_traffic(name),
+                         "traffic": _pmc_traffic(name)[0], "traffic_source": _pmc_traffic(name)[1],
                          "algorithmic_flop_per_frame": flop, "frames_per_launch": frames_launch,
                          "avg_launch_ms": avg_s * 1e3, **extra,
                          "whole_step": {"flop_per_frame": FLOP_DECODE,
@@ -705,6 +789,8 @@ def main():
             out["baum_welch"] = bw
         if refapi is not None:
             out["reference_api"] = refapi
+        if full3 is not None:
+            out["configs3_one_gpu"] = full3
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["cpu_baseline_reference_shaped"] = cpu_ref

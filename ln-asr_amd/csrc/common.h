@@ -39,7 +39,7 @@ int fail(int code, const char* fmt, ...);
     } while (0)
 
 // First statement of every C-ABI entry point that takes a context: the HIP "current device" is per thread, so a
-// call from a thread other than the one that created the context (or after torch moved the thread's device) would
+// call from a thread other than the one that created the context (or after another library moved the thread's device) would
 // otherwise allocate workspaces and launch on device 0.  hipSetDevice is a cheap thread-local store.
 #define LN_ENTER(ctx)                                          \
     do {                                                       \

@@ -3,9 +3,10 @@
 Utterances are independent for MFCC, scoring and every trellis, so they are block-partitioned
 over ranks and nothing is exchanged inside the time recursion.  Exactly two collectives exist:
 the all-gather of decoded state paths and the sum all-reduce of packed Baum-Welch statistics.
-On GPUs both run on RCCL over xGMI inside liblnasr_hip.so (`Context.comm_init`); the `gloo`
-transport below carries the same two calls over torch.distributed on CPU so that the sharding
-logic can be exercised without GPUs (tests, world_size 2).
+On GPUs both run on RCCL over xGMI inside liblnasr_hip.so (`Context.comm_init`); the ranks find
+each other through `lnasr.rendezvous` (loopback TCP, no framework).  `TcpComm` carries the same two
+calls over that rendezvous group on the CPU so that the sharding logic can be rehearsed without
+GPUs (`bench.py --dry-launch`, tests); the world-2 `gloo` test keeps its own transport under tests/.
 """
 import numpy as np
 
@@ -35,24 +36,19 @@ class RcclComm:
         return self.ctx.allreduce_f64(buf)
 
 
-class GlooComm:
-    """CPU transport over an initialised torch.distributed (gloo) group -- tests only."""
+class TcpComm:
+    """CPU transport over a lnasr.rendezvous.TcpGroup -- rehearsals and tests only (numpy, no framework)."""
 
-    def __init__(self, rank, world):
-        import torch.distributed as dist
-        self.dist, self.rank, self.world = dist, rank, world
+    def __init__(self, group):
+        self.group, self.rank, self.world = group, group.rank, group.world
 
     def allgather_u32(self, local):
-        import torch
-        t = torch.from_numpy(np.ascontiguousarray(local).astype(np.int64))
-        outs = [torch.empty_like(t) for _ in range(self.world)]
-        self.dist.all_gather(outs, t)
-        return np.stack([o.numpy() for o in outs]).astype(np.uint32)
+        parts = self.group.allgather(np.ascontiguousarray(local, dtype=np.uint32))
+        return np.stack(parts).astype(np.uint32)
 
     def allreduce_sum_f64(self, buf):
-        import torch
-        t = torch.from_numpy(buf)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        parts = self.group.allgather(np.ascontiguousarray(buf, dtype=np.float64))
+        buf[...] = np.sum(np.stack(parts), axis=0)          # same order on every rank: identical bits everywhere
         return buf
 
 

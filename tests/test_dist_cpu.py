@@ -1,5 +1,7 @@
-"""N > 1 path on CPU: world_size-2 gloo processes exercise the sharding + the two collectives
-(gather of paths, all-reduce of statistics) with the oracle standing in for the GPU compute."""
+"""N > 1 path on CPU: world_size-2 processes exercise the sharding + the two collectives (gather of paths, all-reduce of
+statistics) with the oracle standing in for the GPU compute -- once over gloo (the transport lives here, tests/_gloo_comm.py),
+once over the package's own framework-free rendezvous (lnasr/rendezvous.py + lnasr.dist.TcpComm), which is also what
+bench.py launches and meets its ranks with."""
 import os
 import socket
 import sys
@@ -7,7 +9,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import REPO, PKG_ROOT
+from conftest import REPO, PKG_ROOT, TESTS
 
 
 def _free_port():
@@ -18,23 +20,36 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, transport="gloo"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, PKG_ROOT)
+    sys.path.insert(0, TESTS)
     import importlib.util
-    import torch.distributed as dist
     spec = importlib.util.spec_from_file_location("lnasr_oracle", os.path.join(REPO, "oracle", "lnasr_oracle.py"))
     oracle = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(oracle)
     from lnasr import synth
     from lnasr import dist as ldist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class _Closer:
+        def __init__(self, fn):
+            self.destroy_process_group = fn
+
+    if transport == "gloo":
+        import torch.distributed as dist
+        from _gloo_comm import GlooComm
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        comm = GlooComm(rank, world)
+    else:
+        from lnasr import rendezvous
+        grp = rendezvous.TcpGroup(rank, world, timeout=120)
+        comm = ldist.TcpComm(grp)
+        dist = _Closer(grp.close)
     try:
         U, T, N, M, D = 5, 30, 6, 3, 4                      # 5 utterances over 2 ranks: ragged shards (3 + 2)
         mdl = synth.synth_model(N, M, D, seed=2)
         obs = synth.synth_obs(U, T, D, seed=42)
         lo, hi = ldist.shard_range(U, rank, world)
-        comm = ldist.GlooComm(rank, world)
         local = np.stack([oracle.decode_diag(obs[u], mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["var"])
                           for u in range(lo, hi)])
         allp = ldist.gather_paths(comm, local, U, T)
@@ -60,12 +75,13 @@ def test_shard_range():
     assert ldist.shard_sizes(8192, 8) == [1024] * 8
 
 
-def test_world2_gloo(oracle, synth):
-    import torch.multiprocessing as mp
+@pytest.mark.parametrize("transport", ["gloo", "tcp"])
+def test_world2(transport, oracle, synth):
+    import multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, transport)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=180) for _ in procs], key=lambda x: x[0])
@@ -94,16 +110,66 @@ def _run_bench(*argv, timeout=300):
     return r, lines
 
 
+NO_TORCH = os.path.join(TESTS, "_no_torch")       # a `torch` package that raises on import: proves nobody imports it
+
+
+def _poisoned(env):
+    env = dict(env)
+    env["PYTHONPATH"] = NO_TORCH + os.pathsep + env.get("PYTHONPATH", "")
+    return env
+
+
 def test_bench_self_launch_two_ranks():
-    """`bench.py --gpus 2` without a launcher starts two fresh ranks itself (torch.distributed.run), they
-    rendezvous on 127.0.0.1 and rank 0 prints one line; --dry-launch keeps the rehearsal on the CPU."""
-    r, lines = _run_bench("--gpus", "2", "--dry-launch")
+    """`bench.py --gpus 2` without a launcher starts two fresh ranks of itself, they meet through the package's loopback
+    rendezvous and rank 0 prints one line; --dry-launch keeps the rehearsal on the CPU.  Run with a `torch` that cannot be
+    imported: no framework on the launch / rendezvous path."""
+    import json
+    import subprocess
+    env = _poisoned({k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")})
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-launch"], capture_output=True,
+                       text=True, timeout=300, env=env)
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0, r.stderr[-2000:]
     assert len(lines) == 1
     out = lines[0]
     assert out["dry_launch"] and out["n_ranks"] == 2 and out["ranks"] == [0, 1] and out["local_ranks"] == [0, 1]
     assert out["distinct_pids"] == 2 and out["gather_ok"]
-    assert "torch.distributed.run" in r.stderr and "--nproc-per-node 2" in r.stderr
+    assert "started 2 ranks" in r.stderr
+
+
+def test_ranks_of_a_foreign_launcher_meet_although_master_port_is_taken():
+    """The driver starts the ranks with an elastic launcher whose own store LISTENS on MASTER_PORT.  The ranks must meet
+    anyway (they never bind that port: rank 0 publishes an ephemeral one in the rendezvous file), with four ranks and a
+    stale rendezvous file of an earlier run lying around."""
+    import json
+    import subprocess
+    sys.path.insert(0, PKG_ROOT)
+    from lnasr import rendezvous
+    squatter = socket.socket()
+    squatter.bind(("127.0.0.1", 0))
+    squatter.listen(8)
+    port = squatter.getsockname()[1]
+    stale = rendezvous.rendezvous_file("127.0.0.1", str(port))
+    with open(stale, "w") as fp:
+        fp.write("1 deadbeefdeadbeef\n")                         # nobody listens on port 1
+    base = _poisoned({k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")})
+    procs = []
+    try:
+        for rk in (3, 1, 2, 0):                                   # rank 0 last: the others poll a stale file meanwhile
+            env = dict(base, RANK=str(rk), LOCAL_RANK=str(rk), WORLD_SIZE="4", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       LNASR_RDZV_TIMEOUT="120")
+            procs.append((rk, subprocess.Popen([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4", "--dry-launch"],
+                                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)))
+        outs = {rk: p.communicate(timeout=300) + (p.returncode,) for rk, p in procs}
+    finally:
+        squatter.close()
+        for _, p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert all(o[2] == 0 for o in outs.values()), {rk: o[1][-500:] for rk, o in outs.items()}
+    line = [json.loads(l) for l in outs[0][0].splitlines() if l.startswith("{")][0]
+    assert line["n_ranks"] == 4 and line["ranks"] == [0, 1, 2, 3] and line["gather_ok"] and line["distinct_pids"] == 4
+    assert not os.path.exists(stale)                              # rank 0 removes its file on the way out
 
 
 def test_rank_started_by_a_foreign_launcher_gets_the_env_defaults():
@@ -118,7 +184,7 @@ def test_rank_started_by_a_foreign_launcher_gets_the_env_defaults():
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--dry-launch"],
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
-    assert "torch.distributed.run" not in r.stderr            # it did not start ranks of its own
+    assert "started" not in r.stderr                          # it did not start ranks of its own
     out = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")][0]
     seen = out["env"][0]
     assert seen["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
@@ -132,24 +198,21 @@ def test_rank_started_by_a_foreign_launcher_gets_the_env_defaults():
     assert out["env"][0]["NCCL_SOCKET_IFNAME"] == "eth9"
 
 
-def test_bench_n1_path_never_imports_torch():
-    """north_star: no PyTorch on the product path.  With one rank bench.py must not import torch at all (with N > 1
-    only torch.distributed over gloo, for rendezvous).  Checked on the source: every torch import sits inside the
-    Ranks / dry_launch helpers that a one-rank run without LNASR_BENCH_FORCE_COMM never enters."""
+def test_no_framework_import_anywhere_in_bench_or_package():
+    """north_star: no PyTorch.  Neither bench.py nor any module of the package imports torch (or any other framework) -- at
+    module level or inside a function; checked on the source of every file."""
     import ast
-    tree = ast.parse(open(os.path.join(REPO, "bench.py")).read())
-    allowed = {"dry_launch", "__init__", "max"}
-    for fn in ast.walk(tree):
-        if isinstance(fn, (ast.FunctionDef, ast.AsyncFunctionDef)):
-            for node in ast.walk(fn):
-                if isinstance(node, (ast.Import, ast.ImportFrom)):
-                    names = [a.name for a in node.names] + [getattr(node, "module", "") or ""]
-                    if any(n.split(".")[0] == "torch" for n in names):
-                        assert fn.name in allowed, fn.name
-    for node in tree.body:                                      # nothing at module level
-        if isinstance(node, (ast.Import, ast.ImportFrom)):
-            names = [a.name for a in node.names] + [getattr(node, "module", "") or ""]
-            assert not any(n.split(".")[0] == "torch" for n in names)
+    import glob
+    files = [os.path.join(REPO, "bench.py"), os.path.join(REPO, "__graft_entry__.py")] + \
+        sorted(glob.glob(os.path.join(PKG_ROOT, "**", "*.py"), recursive=True))
+    assert len(files) > 10
+    banned = {"torch", "jax", "tensorflow", "triton", "cupy"}
+    for f in files:
+        tree = ast.parse(open(f).read())
+        for node in ast.walk(tree):
+            if isinstance(node, (ast.Import, ast.ImportFrom)):
+                names = [a.name for a in node.names] + [getattr(node, "module", "") or ""]
+                assert not any(n.split(".")[0] in banned for n in names), (f, names)
 
 
 def test_bench_launch_fails_loudly_without_gpus():

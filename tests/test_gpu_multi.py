@@ -36,7 +36,8 @@ def _clean_env(**extra):
 def test_bench_failed_communicator_times_nothing():
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
                         "--utts", "8", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600,
-                       env=_clean_env(LNASR_BENCH_DEVICE="0", LNASR_COMM_TIMEOUT="90"))
+                       env=_clean_env(LNASR_BENCH_DEVICE="0", LNASR_COMM_TIMEOUT="90",
+                                      PYTHONPATH=os.path.join(REPO, "tests", "_no_torch") + os.pathsep + os.environ.get("PYTHONPATH", "")))
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode != 0, r.stdout[-2000:]
     assert len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])
@@ -46,12 +47,13 @@ def test_bench_failed_communicator_times_nothing():
 
 
 def test_bench_comm_path_one_rank_rehearsal():
-    """The N > 1 code path of bench.py with one rank (LNASR_BENCH_FORCE_COMM): gloo group, unique id, RCCL
-    communicator under the watchdog with torch already loaded in the process, RCCL gather inside the timed step,
-    n_gpus from ncclCommCount -- everything but the links."""
+    """The N > 1 code path of bench.py with one rank (LNASR_BENCH_FORCE_COMM): rendezvous group, unique id, RCCL
+    communicator under the watchdog, RCCL gather inside the timed step, n_gpus from ncclCommCount -- everything but the
+    links.  `torch` is made unimportable for the process: the path is framework-free."""
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "3", "--warmup", "1", "--utts", "64",
                         "--no-cpu-baseline"], capture_output=True, text=True, timeout=600,
-                       env=_clean_env(LNASR_BENCH_FORCE_COMM="1", LNASR_COMM_TIMEOUT="120"))
+                       env=_clean_env(LNASR_BENCH_FORCE_COMM="1", LNASR_COMM_TIMEOUT="120",
+                                      PYTHONPATH=os.path.join(REPO, "tests", "_no_torch") + os.pathsep + os.environ.get("PYTHONPATH", "")))
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -88,15 +90,12 @@ def _rank(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
     sys.path.insert(0, PKG_ROOT)
-    import torch.distributed as dist
-    from lnasr import _ffi, synth
+    from lnasr import _ffi, synth, rendezvous
     from lnasr import dist as ldist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    grp = rendezvous.TcpGroup(rank, world, timeout=240)         # the package's own rendezvous: no framework in a rank
     try:
         ctx = _ffi.Context(rank)
-        ids = [_ffi.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        comm = ldist.RcclComm(ctx, rank, world, ids[0])
+        comm = ldist.RcclComm(ctx, rank, world, grp.bcast(_ffi.comm_unique_id() if rank == 0 else None))
         out = {"info": ctx.comm_info()}
         N, M, D = 12, 4, 6
         mdl = synth.synth_model(N, M, D, seed=2)
@@ -121,10 +120,10 @@ def _rank(rank, world, port, q):
         out["hist"] = gh.train_batch(obs[lo:hi], iters=2, eps=0.0, verbose=False, comm=comm)
         out["A_after"] = np.asarray(gh.A)
         q.put((rank, out))
-        dist.barrier()
+        grp.barrier()
         ctx.close()
     finally:
-        dist.destroy_process_group()
+        grp.close()
 
 
 @pytest.mark.parametrize("world", [1, 2])
@@ -135,7 +134,7 @@ def test_rccl_gather_allreduce_and_training_loop(world, synth, oracle):
     from lnasr import _ffi
     if _ffi.device_count() < world:
         pytest.skip("needs a lease with %d GPUs (one rank per GPU)" % world)
-    import torch.multiprocessing as mp
+    import multiprocessing as mp
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
     port = _free_port()

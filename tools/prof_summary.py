@@ -9,7 +9,9 @@ two --pmc passes are given, profiles/<tag>_pmc.csv plus profiles/pmc_traffic.jso
 gfx950 (MI355X_MICROARCH.md, HBM); checked here against the known sizes of obs / b / v)."""
 import collections
 import csv
+import datetime
 import glob
+import hashlib
 import json
 import os
 import re
@@ -48,6 +50,16 @@ if len(sys.argv) >= 5:
                "viterbi_reg": "viterbi_reg_n128", "viterbi_reg1b": "viterbi_reg1b_n128",
                "backtrace_lds_kernel": "backtrace_lds"}
     traffic = {v: out[k] for k, v in key_map.items() if k in out}
+    # which source the counted kernel was built from: bench.py prints a traffic figure only while this still matches
+    src_of = {"emit_diag_mfma": "gmm.hip", "emit_diag_i8": "gmm_i8.hip", "slice_features": "gmm_i8.hip",
+              "viterbi_reg_n128": "viterbi.hip", "viterbi_reg1b_n128": "viterbi.hip", "backtrace_lds": "backtrace.hip"}
+    csrc = os.path.join(REPO, "ln-asr_amd", "csrc")
+    for name, ent in traffic.items():
+        h = hashlib.sha256()
+        for f in (src_of[name], "devmath.h", "common.h"):
+            h.update(open(os.path.join(csrc, f), "rb").read())
+        ent.update(tag=tag, date=datetime.date.today().isoformat(), source="ln-asr_amd/csrc/" + src_of[name],
+                   source_sha16=h.hexdigest()[:16])
     traffic["_source"] = "%s: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of bench.py (U=1024, T=1000)" % tag
     json.dump(traffic, open(os.path.join(REPO, "profiles", "pmc_traffic.json"), "w"), indent=1)
     print(open(os.path.join(REPO, "profiles", tag + "_pmc.csv")).read())
