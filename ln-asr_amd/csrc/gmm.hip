@@ -50,7 +50,9 @@ __global__ void transpose_exp_kernel(const double* __restrict__ A, double* __res
 __global__ void detect_offdiag_kernel(const double* __restrict__ S, int NM, int D, int* flag) {
     const int DD = D * D;
     for (int c = blockIdx.x; c < NM; c += gridDim.x) {
-        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;     // (block-uniform: one word)
+        // ONE thread reads the word and the block decides together: every wave reading it for itself could see another
+        // block's report between two waves' loads, and part of the block would walk into the barrier below without the rest
+        if (__syncthreads_or(threadIdx.x == 0 && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) return;
         const double* Sc = S + (size_t)c * DD;
         bool hit = false;
         for (int e = threadIdx.x; e < DD; e += blockDim.x) {

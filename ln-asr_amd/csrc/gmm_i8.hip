@@ -379,9 +379,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __shared__ double lws[WRITE_BM ? 256 : 1];
     __shared__ double csts[WRITE_BM ? 256 : 1];
     __shared__ int hs[WRITE_BM ? 256 : 1];
-    __shared__ double bms[WRITE_BM ? 2 * 16 * kBmRow : 1];
+    __shared__ __attribute__((aligned(32))) double bms[WRITE_BM ? 2 * 16 * kBmRow : 1];   // written / read as 32- and 16-byte vectors
     constexpr int kQRow = 16 * 16 + 8;                    // floats per frame of the q32 image (the block's 1 KB of a frame + pad)
-    __shared__ float qms[Q32 ? 2 * 16 * kQRow : 1];
+    __shared__ __attribute__((aligned(16))) float qms[Q32 ? 2 * 16 * kQRow : 1];          // ... as 16-byte vectors
     const long bid = blockIdx.x;
     const int xcd = (int)(bid & 7);
     const long bi = bid >> 3;

@@ -150,9 +150,18 @@ class GMMHMM(HMM):
         loop stops on `eps` after an E-step, `_map_b` leaves `self.b` / `self.bm` as that `calc_prob` would have."""
         if not self._fused_train_ok():
             return super().train(obs, iters, eps, verbose)
+        if iters <= 0:
+            return                                     # the reference's `for k in range(iters)` does nothing
         ctx = self.ctx
         obs = np.ascontiguousarray(obs, dtype=np.float64)
         d_obs = ctx.to_device(obs[None])
+        try:
+            self._train_fused_loop(obs, d_obs, iters, eps, verbose)
+        finally:
+            d_obs.free()                               # also when a kernel call raises or the user interrupts
+
+    def _train_fused_loop(self, obs, d_obs, iters, eps, verbose):
+        ctx = self.ctx
         N, M, D = self.n, self.m, self.d
         ll_at = N * N + 2 * N + N * M + N * M * D + N * M * D * D
 
@@ -179,7 +188,6 @@ class GMMHMM(HMM):
             before = after
         if stats is not None:                          # stopped on eps right after an E-step: the state calc_prob leaves
             self._map_b(d_obs.view(obs.shape))
-        d_obs.free()
 
     def _updatemodel(self, model):
         self._replaced = True

@@ -276,18 +276,24 @@ class HMM:
         """Run `fn` (emission + one trellis, the answer only) first on the model the device already holds, with the
         parameter check beside it, and again the checked way if the check says the parameters have changed."""
         self._speculating = True
+        first_error = None
         try:
             out = fn()
-        except Exception:
+        except Exception as e:                          # noqa: BLE001
             self._speculating = False
             if self._confirmed():
                 raise                                   # not a stale-model artefact: the caller's error
-            out = None
+            out, first_error = None, e
         finally:
             self._speculating = False
         if out is not None and self._confirmed():
             return out
-        return fn()
+        try:
+            return fn()
+        except Exception as e:                          # noqa: BLE001
+            if first_error is not None:                 # both attempts failed: say what the first one died of as well
+                raise e from first_error
+            raise
 
     def calc_prob(self, obs: np.ndarray) -> float:
         """log P(O | model) = lse(alpha[T-1])  (hmm.py:268-274).  alpha itself is not brought back unless a subclass
@@ -343,10 +349,19 @@ class HMM:
         iteration k + 1 -- the reference runs that forward pass twice over the same model (`calc_prob` at hmm.py:304, then
         `_forward` at :295), here it runs once.  `self.b` ends as the reference's closing `calc_prob` leaves it: the final
         model's emissions.  test/hmm-test.py's 48 iterations: 0.65 -> 0.3 ms each."""
+        if iters <= 0:
+            return                                           # the reference's `for k in range(iters)` does nothing
         ctx = self.ctx
         obs_i = np.ascontiguousarray(obs, dtype=np.int32)
         T, N = obs_i.shape[0], self.n
         d_obs = ctx.to_device(obs_i[None])
+        try:
+            self._train_fused_loop(d_obs, T, N, iters, eps, verbose)
+        finally:
+            d_obs.free()                                     # also when a kernel call raises or the user interrupts
+
+    def _train_fused_loop(self, d_obs, T, N, iters, eps, verbose):
+        ctx = self.ctx
         buf = {k: self._reuse_buffer("_train_" + k, shp)
                for k, shp in (("alpha", (1, T, N)), ("beta", (1, T, N)), ("xi", (1, T, N, N)), ("gamma", (1, T, N)))}
 
@@ -369,7 +384,6 @@ class HMM:
             if _report_iteration(k, before, after, verbose) < eps:
                 break
             before = after
-        d_obs.free()
 
     def _train_resident(self, obs, iters, eps, verbose):
         """The same iteration with every intermediate left in HBM (taken when no step is overridden): `_map_b`, forward, backward,
