@@ -229,8 +229,11 @@ __global__ void pack_wslice_kernel(const double* __restrict__ mu, const double* 
     }
 }
 
-// Digit planes of the features.  Block = 5 waves x 64 frames: wave `ch` owns the k-chunk 16 ch .. 16 ch + 15 of the block's 64
-// frames (every lane works; a plane row of a wave is 4 tiles x 256 contiguous bytes).
+// Digit planes of the features.  Block = 320 threads x 64 frames = 4 tiles: thread t owns (tile t / 80, k-chunk (t % 80) / 16,
+// frame t % 16) -- the 80 threads of a tile write 1280 contiguous bytes of every plane (a wave: runs of 256 B .. 1 KB).  The row
+// scales 2^g_k wait in the LDS: read per lane from global memory they were a third of the kernel (0.26 -> 0.20 ms per 1,024,000
+// frames, round 6; the store pattern -- one wave per k-chunk, four pieces of 256 B 9 KB apart per instruction, against this one --
+// measured the same: 0.2017 / 0.2001 ms).
 //   Fs[tile*kTileI4 + (plane*5 + chunk)*16 + frame]  (16 bytes: k = 16 chunk + byte),   then 16 doubles: 2^(e_f - 24)
 // (NaN for a frame with a NaN / infinite feature: every density of that frame comes out NaN, as the reference's does).
 __global__ __launch_bounds__(320) void slice_features_kernel(const double* __restrict__ obs, const double* __restrict__ centre,
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(320) void slice_features_kernel(const double* __res
                                                              long F, int D, unsigned* __restrict__ nan_flag,
                                                              unsigned nan_epoch) {
     const int tid = threadIdx.x;
-    const int ch = tid >> 6, fl = tid & 63;
+    const int ch = (tid % 80) >> 4, fl = (tid / 80) * 16 + (tid & 15);
     const long frame0 = (long)blockIdx.x * 64;
     const long frame = frame0 + fl;
     const bool live = frame < F;
@@ -246,6 +249,8 @@ __global__ __launch_bounds__(320) void slice_features_kernel(const double* __res
     __shared__ double xs[64 * 40];
     __shared__ double smax[kChunks][64];
     __shared__ int sbad[kChunks][64];
+    __shared__ double p2g[80];
+    if (tid < 80) p2g[tid] = pow2g[tid];
     {
         const long base = frame0 * D, lim = F * (long)D;
         for (int e = tid; e < 64 * D; e += 320) {
@@ -260,12 +265,12 @@ __global__ __launch_bounds__(320) void slice_features_kernel(const double* __res
     bool bad = false;
 #pragma unroll
     for (int by = 0; by < 16; ++by) {
-        const int k = 16 * ch + by;                       // wave-uniform
+        const int k = 16 * ch + by;
         double v = 0.0;
         if (k < 2 * D) {
             const double x = xf[k < D ? k : k - D];
             bad |= !__builtin_isfinite(x);
-            v = (k < D ? x * x : x) * pow2g[k];
+            v = (k < D ? x * x : x) * p2g[k];
         }
         val[by] = live ? v : 0.0;
         mx = fmax(mx, fabs(val[by]));
