@@ -356,3 +356,51 @@ def test_range_within_a_component_is_what_the_gate_measures(decades, accepted, s
     assert rel["default"] <= 1e-12 and rel["f64"] <= 1e-12, tag
     if accepted:
         assert rel["i8"] <= 1e-12, tag
+
+
+@pytest.mark.parametrize("seed", range(_lo, _lo + max(1, (_hi - _lo) * 24 // 16)))
+def test_range_gate_over_random_models(seed, ctx):
+    """The gate, empirically: seeded models whose variances combine a per-dimension scale (units: 1e-3 .. 1e3), a
+    per-component factor (up to 4 decades: sharp and broad components side by side) and a per-(component, dimension) factor (0
+    to 3 decades: range WITHIN a component, the one thing the fixed point does not hold), means spread by 0.3 .. 3 standard
+    deviations around a common offset; frames drawn from the components, 4352 of them so that the default dispatch takes the
+    integer bank whenever the model is admitted.  Against the reference's direct form in long double: whatever the default
+    route is it returns b to 1e-12 max(1, |b|), and whenever the model is admitted (rho <= 2048) so does the forced integer
+    bank -- the measured basis of kI8RhoMax."""
+    rng = np.random.default_rng(70000 + seed)
+    N, M = int(rng.choice([48, 64])), 16
+    D = int(rng.choice([14, 26, 33, 39]))
+    T = 4352
+    dim_scale = 10.0 ** rng.uniform(-3, 3, D) if seed % 3 else np.ones(D)
+    comp_dec = float(rng.choice([0.0, 1.0, 2.0, 4.0]))
+    cell_dec = float(rng.choice([0.0, 0.5, 1.0, 1.5, 2.0, 3.0]))
+    spread = float(rng.choice([0.3, 1.0, 3.0]))
+    offset = float(rng.choice([0.0, 0.0, 20.0]))
+    var = (0.5 + rng.random((N, M, D))) * 10.0 ** (-comp_dec * rng.random((N, M, 1))) * 10.0 ** (-cell_dec * rng.random((N, M, D)))
+    mu = spread * rng.standard_normal((N, M, D)) * np.sqrt(var.mean(axis=(0, 1)))[None, None, :] + offset
+    mu, var = mu * dim_scale, var * dim_scale ** 2
+    w = rng.random((N, M)) + 1e-3
+    w = np.log(w / w.sum(1, keepdims=True))
+    a = rng.random((N, N)) + 1e-3
+    mdl = {"A": np.log(a / a.sum(1, keepdims=True)), "pi": np.log(np.full(N, 1.0 / N)), "w": w, "mu": mu, "var": var}
+    comp = rng.integers(0, N * M, T)
+    obs = (mu.reshape(-1, D)[comp] + np.sqrt(var.reshape(-1, D)[comp]) * rng.standard_normal((T, D)))[None]
+    _, ref_b = _direct_longdouble(obs[0], w, mu, var)
+    out = {}
+    for name, env in (("default", {}), ("i8", dict(LNASR_I8_MIN_FRAMES=0, LNASR_I8_RHO_MAX=1e300))):
+        with env_switch(**env):
+            _upload(ctx, mdl)
+            rho, bank = ctx.model_range()
+            kappa, direct = ctx.model_conditioning()
+            b, names = _kernels_of(ctx, lambda: ctx.gmm_logprob(obs))
+            rel = float((np.abs(b[0].astype(np.longdouble) - ref_b) / np.maximum(1.0, np.abs(ref_b))).max())
+            out[name] = dict(rel=rel, rho=rho, bank=bank, direct=direct, i8=any(n.startswith("emit_diag_i8") for n in names))
+    tag = "seed=%d N=%d D=%d comp_dec=%g cell_dec=%g spread=%g offset=%g kappa=%.3g: %r" % (
+        seed, N, D, comp_dec, cell_dec, spread, offset, kappa, out)
+    print(tag)
+    assert out["default"]["rel"] <= 1e-12, tag
+    if out["default"]["bank"] and not out["default"]["direct"]:
+        assert out["i8"]["rel"] <= 1e-12, tag
+        assert out["default"]["i8"] or not tuned(), tag
+    if tuned():
+        assert not (out["default"]["i8"] and out["default"]["rho"] > 2048.0), tag
