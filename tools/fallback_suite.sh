@@ -3,6 +3,7 @@
 # under the tuned kernels is itself shown parity-green.   gpurun -- 'bash tools/fallback_suite.sh'
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
+echo "# commit $(head -1 .build_commit 2>/dev/null || echo unknown), $(sed -n 2p .build_commit 2>/dev/null || echo '?') uncommitted source file(s), $(date -u +%Y-%m-%dT%H:%MZ)"
 rc=0
 run() {
     echo "== $*"
