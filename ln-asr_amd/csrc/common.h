@@ -103,6 +103,10 @@ struct Model {
     // integer matrix-core bank (gmm_i8.hip): digit planes of the coefficients, row scales, component constants
     DevBuf i8_g, i8_pow2g, i8_h, i8_wq, i8_const, i8_const_nw;   // i8_h [Nv, mix] int: the components' exponents
     double i8_rho = 0.0;         // the model's range as the fixed point sees it (gmm_i8.hip); beyond kI8RhoMax: the fp64 bank
+    // full-covariance bank on the integer matrix cores (gmm_full_i8.hip): W planes in A-operand order, scales, constants
+    DevBuf fi8_gl, fi8_pow2gl, fi8_h, fi8_const, fi8_wq;
+    int fi8_nk = 0, fi8_Nv = 0;  // k-steps of 64 features (0: not packed), (virtual, padded) states
+    double fi8_rho = 0.0;
     const double* i8_logw = nullptr;   // the (padded) log weights the planes were packed with: [Nv,16]
     int i8_NG = 0;               // state groups packed (0: none)
     int i8_mix = 16;             // mixtures per (virtual) state of the packed planes: 16 or 8
@@ -136,7 +140,8 @@ struct Switches {
     long i8_min_frames = -1;      // LNASR_I8_MIN_FRAMES: the integer matrix-core bank from this many frames per launch (-1: measured rule)
     int fwd_one_maxu = -1;        // LNASR_FWD_ONE_MAXU: one utterance per block in the column-owned forward / backward up to this batch size
     double kappa_max = kKappaMax; // LNASR_KAPPA_MAX
-    double i8_rho_max = kI8RhoMax; // LNASR_I8_RHO_MAX
+    double i8_rho_max = kI8RhoMax; // LNASR_I8_RHO_MAX (set: it replaces the gates of BOTH integer banks, diagonal and full)
+    bool i8_rho_max_set = false;
     int h2d_threads = 4;          // LNASR_H2D_THREADS: host threads filling the pinned staging ring
     bool check_ptrs = false;      // LNASR_CHECK_PTRS: LN_DEVPTR verifies every pointer a launch helper is handed
     char emit = 0;                // LNASR_EMIT (ablation builds only)
@@ -279,6 +284,12 @@ bool i8_model_ok(const Model& md);          // planes packed, range within the g
 bool i8_route(const Model& md, long F);     // ... and a batch of F frames is large enough to take it
 int pack_i8_model(lnasr_ctx* ctx, const double* mu_s, const double* iv_s, const double* gc_s, const double* lw_s, int Nv, int Mv);
 int emit_diag_i8_device(lnasr_ctx* ctx, const double* obs, long F, double* b, double* bm, float* q32 = nullptr);
+// gmm_full_i8.hip: the full-covariance bank on the integer matrix cores (b only)
+bool full_i8_model_ok(const Model& md);
+bool full_i8_route(const Model& md, long F);
+int pack_full_i8_model(lnasr_ctx* ctx, const double* mu_p, const double* prec_p, const double* gconst_p, const double* logw_p,
+                       int Np, int Mp, int Nv);
+int emit_full_i8_device(lnasr_ctx* ctx, const double* obs, long F, double* b);
 // emit_device without the pass over non-finite frames; *scanned: the kernel tested the features it staged and raised
 // ctx->nan_flag itself (emit_batch runs the kernels chunk by chunk and the pass once)
 int emit_device_raw(lnasr_ctx* ctx, const double* obs, long F, int dtype, void* b, void* bm, bool* scanned,

@@ -49,7 +49,7 @@ void DevBuf::release() {
 }
 
 void Model::release() {
-    DevBuf* all[] = {&logA, &logAT, &logpi, &expA, &expAT, &logw, &mu, &ivar, &var, &prec, &gconst, &sigma_raw, &wpack, &wpack_nw, &wdirect, &pad_mu, &pad_ivar, &pad_gconst, &pad_logw, &pad_prec, &wfull, &wfull_nw, &pairtab, &flags, &centre, &mu_c, &wpack32, &lu_bad, &i8_g, &i8_pow2g, &i8_h, &i8_wq, &i8_const, &i8_const_nw};
+    DevBuf* all[] = {&logA, &logAT, &logpi, &expA, &expAT, &logw, &mu, &ivar, &var, &prec, &gconst, &sigma_raw, &wpack, &wpack_nw, &wdirect, &pad_mu, &pad_ivar, &pad_gconst, &pad_logw, &pad_prec, &wfull, &wfull_nw, &pairtab, &flags, &centre, &mu_c, &wpack32, &lu_bad, &i8_g, &i8_pow2g, &i8_h, &i8_wq, &i8_const, &i8_const_nw, &fi8_gl, &fi8_pow2gl, &fi8_h, &fi8_const, &fi8_wq};
     for (DevBuf* b : all) b->release();
     has_hmm = has_gmm = false;
 }
@@ -94,7 +94,10 @@ static void load_switches(Switches& s) {
     if (const char* e = getenv("LNASR_CHASE_MAXU")) s.chase_maxu = atoi(e);
     if (const char* e = getenv("LNASR_FWD_LAT_MAXU")) s.fwd_lat_maxu = atoi(e);
     if (const char* e = getenv("LNASR_KAPPA_MAX")) s.kappa_max = atof(e);
-    if (const char* e = getenv("LNASR_I8_RHO_MAX")) s.i8_rho_max = atof(e);
+    if (const char* e = getenv("LNASR_I8_RHO_MAX")) {
+        s.i8_rho_max = atof(e);
+        s.i8_rho_max_set = true;
+    }
     if (const char* e = getenv("LNASR_H2D_THREADS")) {
         s.h2d_threads = atoi(e);
         if (s.h2d_threads < 1) s.h2d_threads = 1;

@@ -431,7 +431,7 @@ int emit_device_f32(lnasr_ctx* ctx, const double* obs, long F, double* b, float*
     // batches the integer matrix-core bank takes (gmm_i8.hip): its four-plane instantiation hands over the same b + q32
     // (four planes keep 32 bits below the scales: ~3 * 2^-30 * rho on a component's log-density -- its own, tighter range gate)
     if (((md.i8_mix == 16 && virt == 1) || md.i8_mix == 32) && i8_route(md, F) &&
-        md.i8_rho <= (sw().i8_rho_max < kI8RhoMaxF32 ? sw().i8_rho_max : kI8RhoMaxF32))
+        md.i8_rho <= (sw().i8_rho_max_set ? sw().i8_rho_max : kI8RhoMaxF32))
         return emit_diag_i8_device(ctx, obs, F, b, nullptr, q32);
     LN_TRY(pack32(ctx));
     double* bv = b;

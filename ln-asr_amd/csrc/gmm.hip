@@ -1062,6 +1062,8 @@ static int model_upload_impl(lnasr_ctx* ctx, int N, int M, int D, const double* 
     md.wpack_Q = md.wpack_KS = 0;
     md.i8_NG = 0;
     md.i8_rho = 0.0;
+    md.fi8_nk = 0;
+    md.fi8_rho = 0.0;
     md.pad_N = md.pad_M = 0;
     md.wfull_Q = 0;
     if (diag) {
@@ -1618,8 +1620,9 @@ int lnasr_model_range(lnasr_ctx* ctx, double* rho, int* integer_bank) {
     LN_ENTER(ctx);
     LN_REQUIRE(ctx, "null ctx");
     if (!ctx->model.has_gmm) return fail(LNASR_E_NOMODEL, "no GMM-HMM model uploaded");
-    if (rho) *rho = ctx->model.i8_rho;
-    if (integer_bank) *integer_bank = i8_model_ok(ctx->model) ? 1 : 0;
+    const bool full = !ctx->model.diag;
+    if (rho) *rho = full ? ctx->model.fi8_rho : ctx->model.i8_rho;
+    if (integer_bank) *integer_bank = (full ? full_i8_model_ok(ctx->model) : i8_model_ok(ctx->model)) ? 1 : 0;
     return 0;
 }
 

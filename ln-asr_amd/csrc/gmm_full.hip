@@ -507,6 +507,10 @@ int pack_full_model(lnasr_ctx* ctx) {
     md.wfull_Q = Q;
     md.wfull_NCH = NCH;
     md.wfull_virt = virt;
+    // sixteen mixtures per (virtual) state: the same bank on the integer matrix cores for large batches (gmm_full_i8.hip)
+    md.fi8_nk = 0;
+    md.fi8_rho = 0.0;
+    if (Q == 4 && !sw().no_i8emit) LN_TRY(pack_full_i8_model(ctx, mu_s, pr_s, gc_s, lw_s, Np, Mp, Nv));
     return 0;
 }
 
@@ -557,7 +561,8 @@ int emit_full_mfma_device(lnasr_ctx* ctx, const double* obs, long F, double* b, 
         bmdst = ctx->ws_pad.as<double>();
     }
     int rc;
-    if (md.wfull_Q == 4) rc = launch_full<4>(ctx, obs, F, bdst, bmdst);
+    if (!bm && md.wfull_Q == 4 && md.fi8_Nv == Np * virt && full_i8_route(md, F)) rc = emit_full_i8_device(ctx, obs, F, bdst);
+    else if (md.wfull_Q == 4) rc = launch_full<4>(ctx, obs, F, bdst, bmdst);
     else if (md.wfull_Q == 2) rc = launch_full<2>(ctx, obs, F, bdst, bmdst);
     else rc = launch_full<1>(ctx, obs, F, bdst, bmdst);
     if (rc) return rc;
