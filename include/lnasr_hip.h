@@ -151,7 +151,9 @@ int lnasr_model_conditioning(lnasr_ctx* ctx, double* kappa, int* direct_form);
  * at frames within four standard deviations of the component's own mean: a component whose own variances (relative to the
  * model's scale in each dimension) span decades has a large rho, one sharp component among broad ones does not.
  * integer_bank = 1: the model's shape takes that bank and rho <= 2048 (error <= 1e-12); 0: large batches are scored by the
- * fp64 matrix-core bank as small ones are (shape not taken: rho = 0).  Replaces nothing in the reference, whose direct form
+ * fp64 matrix-core bank as small ones are (shape not taken: rho = 0).  A full-covariance model reports the same two values
+ * for its own integer bank (csrc/gmm_full_i8.hip: K = D (D + 1) / 2 + D features, gate 4096, measured in
+ * tests/test_gpu_full_i8.py).  Replaces nothing in the reference, whose direct form
  * (gmm.py:59-68) has no such limit -- this is how the limit of the fast path is made visible. */
 int lnasr_model_range(lnasr_ctx* ctx, double* rho, int* integer_bank);
 
