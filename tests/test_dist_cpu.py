@@ -224,3 +224,48 @@ def test_bench_launch_fails_loudly_without_gpus():
     r, lines = _run_bench("--gpus", "2", "--steps", "1", "--warmup", "0")
     assert r.returncode != 0
     assert not [l for l in lines if l.get("value")]
+
+
+def test_rendezvous_wire_format_and_failure_modes(tmp_path):
+    """The rendezvous of lnasr/rendezvous.py on its own: values survive the JSON wire format (bytes: the ncclUniqueId; numpy
+    arrays; nesting), a rank without a rank 0 gives up with TimeoutError after its timeout instead of hanging, and a stranger
+    talking nonsense to rank 0's port does not take a rank's place."""
+    import threading
+    import time
+    sys.path.insert(0, PKG_ROOT)
+    from lnasr import rendezvous as rz
+    val = {"id": bytes(range(128)), "x": np.arange(6, dtype=np.uint32).reshape(2, 3), "f": [1.5, None, "s", np.float64(2.0)]}
+    back = rz._dec(__import__("json").loads(__import__("json").dumps(rz._enc(val))))
+    assert back["id"] == val["id"] and back["x"].dtype == np.uint32 and np.array_equal(back["x"], val["x"])
+    assert back["f"] == [1.5, None, "s", 2.0]
+    os.environ["LNASR_RDZV_FILE"] = str(tmp_path / "rdzv")
+    try:
+        t0 = time.time()
+        with pytest.raises(TimeoutError):
+            rz.TcpGroup(1, 2, timeout=1.0)                        # nobody is rank 0
+        assert time.time() - t0 < 10
+        out = {}
+
+        def rank0():
+            g = rz.TcpGroup(0, 2, timeout=60)
+            out["gathered"] = g.allgather("zero")
+            out["max"] = g.max(1.0)
+            g.close()
+        th = threading.Thread(target=rank0)
+        th.start()
+        for _ in range(200):                                      # wait for rank 0's file, then be rude to its port
+            if os.path.exists(os.environ["LNASR_RDZV_FILE"]):
+                break
+            time.sleep(0.02)
+        port = int(open(os.environ["LNASR_RDZV_FILE"]).read().split()[0])
+        s = socket.create_connection(("127.0.0.1", port))
+        s.sendall(b"\x05\x00\x00\x00hello")                       # a well-formed frame that is not JSON
+        s.close()
+        g1 = rz.TcpGroup(1, 2, timeout=60)
+        assert g1.allgather("one") == ["zero", "one"] and g1.max(3.0) == 3.0
+        g1.close()
+        th.join(30)
+        assert out == {"gathered": ["zero", "one"], "max": 3.0}
+        assert not os.path.exists(os.environ["LNASR_RDZV_FILE"])
+    finally:
+        os.environ.pop("LNASR_RDZV_FILE", None)
