@@ -64,6 +64,22 @@ def test_full_integer_bank_equals_the_reference(N, M, D, U, T, synth, oracle, ct
     assert_close(b2, b64, 1e-13)
 
 
+def test_full_integer_bank_across_its_frame_chunks(synth, ctx):
+    """The feature planes are 5.8 KB per frame at D = 39, so a batch is scored in chunks of 131,072 frames: 140,000 frames of a
+    small model cross that boundary (and end in a ragged tile); every row equals the fp64 kernel's."""
+    N, M, D, T = 4, 16, 13, 140000
+    mdl = synth.synth_model(N, M, D, seed=77, full_cov=True)
+    obs = synth.synth_obs(1, T, D, seed=78)
+    _upload(ctx, mdl)
+    b, names = _kernels_of(ctx, lambda: ctx.gmm_logprob(obs))
+    assert "emit_full_i8" in names or not tuned()
+    with env_switch(LNASR_NO_I8EMIT=1):
+        _upload(ctx, mdl)
+        b64 = ctx.gmm_logprob(obs)
+    assert float((np.abs(b - b64) / np.maximum(1.0, np.abs(b64))).max()) <= 1e-13
+    assert np.isfinite(b[0, 131072 - 70:131072 + 70]).all() and np.isfinite(b[0, -40:]).all()
+
+
 def test_decode_and_bad_frames_over_the_full_integer_bank(synth, ctx):
     """Emission -> Viterbi -> back-trace over the integer bank gives the fp64 route's paths; a NaN and an infinite feature
     give the rows the fp64 route gives (the pass over non-finite frames re-scores them in the reference's arithmetic)."""
