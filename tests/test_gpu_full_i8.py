@@ -45,7 +45,7 @@ def test_full_integer_bank_equals_the_reference(N, M, D, U, T, synth, oracle, ct
         assert not ctx.model_is_diag()
         rho, bank = ctx.model_range()
         b, names = _kernels_of(ctx, lambda: ctx.gmm_logprob(obs))
-    assert bank and 0 < rho < 100, (rho, bank)
+    assert (bank and 0 < rho < 100) or not tuned(), (rho, bank)         # (planes are not packed under LNASR_NO_I8EMIT)
     assert "emit_full_i8" in names or not tuned(), names
     with env_switch(LNASR_NO_I8EMIT=1):
         _upload(ctx, mdl)
