@@ -269,3 +269,20 @@ def test_rendezvous_wire_format_and_failure_modes(tmp_path):
         assert not os.path.exists(os.environ["LNASR_RDZV_FILE"])
     finally:
         os.environ.pop("LNASR_RDZV_FILE", None)
+
+
+def test_the_drivers_own_launcher_starts_ranks_that_meet():
+    """The driver's command line: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...`.  That launcher's own store listens on P; the ranks it starts (which import no
+    framework themselves) must rendezvous all the same.  CPU rehearsal with --dry-launch."""
+    import json
+    import subprocess
+    pytest.importorskip("torch")                                   # the LAUNCHER is torch's; nothing of ours imports it
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr",
+                        "127.0.0.1", "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "3",
+                        "--dry-launch"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(out) == 1 and out[0]["n_ranks"] == 3 and out[0]["ranks"] == [0, 1, 2] and out[0]["gather_ok"]
+    assert out[0]["distinct_pids"] == 3
