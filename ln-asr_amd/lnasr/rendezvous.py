@@ -107,7 +107,8 @@ class TcpGroup:
             lst.listen(self.world)
             nonce = secrets.token_hex(8)
             tmp = "%s.%d.tmp" % (path, os.getpid())
-            with open(tmp, "w") as fp:
+            fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600)     # the nonce is for this user's ranks only
+            with os.fdopen(fd, "w") as fp:
                 fp.write("%d %s\n" % (lst.getsockname()[1], nonce))
             os.replace(tmp, path)                                 # atomic: a reader sees nothing or the whole line
             self._listener, self._file = lst, path
