@@ -19,6 +19,8 @@
 //     k-step s + 1 are in flight under the 112 matrix instructions of step s) and LDS -> registers by one ds_read_b128 each;
 //   * blockIdx is decoded so that an XCD owns a fixed group of component slabs (its W planes, 1.5 MB, stay in its L2) and
 //     the 32 blocks resident on it share 8 frame blocks' feature planes;
+//   * a block walks several consecutive frame blocks of its slab (about four blocks per CU in all): the tables are built once,
+//     and while the consumers run a tile's epilogue the loaders are already two steps into the next tile (-5 % at 131,072 frames);
 //   * epilogue once per tile: seven conversions and six FMAs per value (the pair join of gmm_i8.hip would overflow at
 //     K = 832), 2^(h_c + e_f), the constant, the 16-way log-sum-exp of gmm_i8.hip, b straight to global memory.
 // b only (bm: the fp64 kernel).  Kernels: full_coef / full_row_scale / full_comp_scale / full_pack_planes (once per model),
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(1024) void full_slice_features_kernel(const double*
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void emit_full_i8(
     const int4_t* __restrict__ fq, const double* __restrict__ fsc, const int4_t* __restrict__ wq,
     const double* __restrict__ constc, const int* __restrict__ hexp, double* __restrict__ b, long F, int Nv, int nk,
-    long nftiles, int slabs, int spx) {
+    long nftiles, int slabs, int spx, long fblocks, int tiles_pb) {
     __shared__ int4_t bufA[2][4 * kS * 64];                // [buffer][(cu, q)][plane][lane]: 28 KB each; W planes: from this XCD's L2
     __shared__ int4_t bufB[3][4 * kS * 64];                // [buffer][frame tile][plane][lane]; feature planes: from HBM / MALL, TWO steps ahead
     __shared__ double etab[kExpTabBig];
@@ -292,13 +294,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int xcd = (int)(bid & 7);
     const long inner = bid >> 3;
     const int slab = xcd + 8 * (int)(inner % spx);
-    const long fblock = inner / spx;
-    if (slab >= slabs) return;
+    const long fblock0 = (inner / spx) * tiles_pb;         // the block walks tiles_pb consecutive frame blocks of its slab: the
+    if (slab >= slabs || fblock0 >= fblocks) return;       // tables are built once, the loaders run ahead into the next tile
+    const int ntile = (int)(fblocks - fblock0 < tiles_pb ? fblocks - fblock0 : tiles_pb);    // while the consumers finish this one
+    const int nsteps = ntile * nk;                          // k-steps of the whole walk: step gs = tile gs / nk, k-step gs % nk
     exp_table_big_init(etab, tid, 512);
     log_table_init(ltab, tid, 512);
     const bool loader = w >= 4;
     const int cu = w & 1, fg = (w >> 1) & 1;
-    const long ft0 = fblock * 4;                            // the block's first frame tile
     // The 28 + 28 one-KB pieces of a k-step: loader wave lw moves pieces lw, lw + 4, ... (seven of each operand).  The W
     // planes of step s + 1 come from this XCD's L2 and land within a step; the feature planes are shared by the XCD's four
     // slabs only, so the first block to ask pays HBM / MALL latency (~2 us: with one step of lead every k-step took 3860
@@ -306,7 +309,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // COUNTED vmcnt (its seven newest requests may stay in flight across the barrier: a raw s_barrier, not __syncthreads,
     // whose fence would drain them).
     const int lw = w - 4;
-    auto load_A = [&](int ks) {
+    auto load_A = [&](int gs) {
+        const int ks = gs % nk;
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
             const int p = lw + 4 * i;                       // wave-uniform: 0 .. 27
@@ -314,11 +318,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const size_t ct = (size_t)(2 * slab + (t >> 1)) * 2 + (t & 1);
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void*)(wq + ((ct * nk + ks) * kS + pl) * 64 + lane),
-                (__attribute__((address_space(3))) void*)(&bufA[ks & 1][(t * kS + pl) * 64]), 16, 0, 0);
+                (__attribute__((address_space(3))) void*)(&bufA[gs & 1][(t * kS + pl) * 64]), 16, 0, 0);
         }
     };
-    auto load_B = [&](int ks) {
-        const int buf = ks % 3;
+    auto load_B = [&](int gs) {
+        const int buf = gs % 3, ks = gs % nk;
+        const long ft0 = (fblock0 + gs / nk) * 4;
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
             const int p = lw + 4 * i;
@@ -335,14 +340,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (loader) {
         load_A(0);
         load_B(0);
-        if (nk > 1) load_B(1);
-        for (int ks = 0; ks < nk; ++ks) {
-            // everything but the newest feature-plane requests (step ks + 1's, issued last) has landed
-            if (ks + 1 < nk) __builtin_amdgcn_s_waitcnt(0x0F77);    // vmcnt(7)
-            else __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0)
-            __builtin_amdgcn_s_barrier();                   // step ks is in the LDS; the consumers have read step ks - 1
-            if (ks + 1 < nk) load_A(ks + 1);
-            if (ks + 2 < nk) load_B(ks + 2);
+        if (nsteps > 1) load_B(1);
+        for (int gs = 0; gs < nsteps; ++gs) {
+            // everything but the newest feature-plane requests (step gs + 1's, issued last) has landed
+            if (gs + 1 < nsteps) __builtin_amdgcn_s_waitcnt(0x0F77);    // vmcnt(7)
+            else __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
+            __builtin_amdgcn_s_barrier();                   // step gs is in the LDS; the consumers have read step gs - 1
+            if (gs + 1 < nsteps) load_A(gs + 1);
+            if (gs + 2 < nsteps) load_B(gs + 2);
         }
         return;
     }
@@ -353,40 +358,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int q = 0; q < 2; ++q)
 #pragma unroll
             for (int t = 0; t < 2; ++t) acc[d][q][t] = int4_t{0, 0, 0, 0};
-    for (int ks = 0; ks < nk; ++ks) {
-        const int cur = ks & 1, curB = ks % 3;
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");     // the LDS reads below stay below the barrier
-        // Fragments are read in the order of use and the 28 plane pairs are walked by GROUPS g = max(i, j): group g needs the
-        // planes g of both operands and nothing newer, so the matrix instructions start behind the first four reads and the
-        // other 24 reads return under them (all A planes first, then B plane by plane: 650 cycles of every k-step exposed).
-        int4_t Af[2][kS], Bf[2][kS];
-#pragma unroll
-        for (int p = 0; p < kS; ++p) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q) Af[q][p] = bufA[cur][((2 * cu + q) * kS + p) * 64 + lane];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) Bf[t][p] = bufB[curB][((2 * fg + t) * kS + p) * 64 + lane];
-        }
-#define LN_PAIR(j, i)                                                                                           \
-    do {                                                                                                        \
-        if ((j) + (i) < kS) {                                                                                   \
-            _Pragma("unroll") for (int q = 0; q < 2; ++q) _Pragma("unroll") for (int t = 0; t < 2; ++t)         \
-                acc[(j) + (i)][q][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Af[q][j], Bf[t][i], acc[(j) + (i)][q][t], 0, 0, 0); \
-        }                                                                                                       \
-    } while (0)
-#pragma unroll
-        for (int g = 0; g < kS; ++g) {
-#pragma unroll
-            for (int o = 0; o < g; ++o) {                   // (o, g) and (g, o): A plane o with B plane g, A plane g with B plane o
-                LN_PAIR(o, g);
-                LN_PAIR(g, o);
-            }
-            LN_PAIR(g, g);
-        }
-#undef LN_PAIR
-    }
-    // epilogue: this lane holds, for frame tile t, frame col = lane & 15 and state 2 sp + (g & 1), the mixtures 8 (g >> 1) + 4 q + e
+    // epilogue constants: this lane holds, for frame tile t, frame col = lane & 15 and state 2 sp + (g & 1), the mixtures
+    // 8 (g >> 1) + 4 q + e
     const int g = lane >> 4, col = lane & 15;
     const int sp = 2 * slab + cu;
     const int state = 2 * sp + (g & 1), mb = 8 * (g >> 1);
@@ -407,6 +380,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(x), false, false);
         return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
     };
+    auto epilogue = [&](long ft0) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const long frame = (ft0 + 2 * fg + t) * 16 + col;
@@ -441,6 +415,49 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         s = swap_sum(s);
         const double res = (mx == LN_NEG_INF) ? mx : mx + log_sum(s, ltab);
         if (g < 2 && frame < F && state < Nv) b[frame * Nv + state] = res;
+    }
+    };
+    drain_vmem();
+    for (int gs = 0; gs < nsteps; ++gs) {
+        const int cur = gs & 1, curB = gs % 3;
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");     // the LDS reads below stay below the barrier
+        // Fragments are read in the order of use and the 28 plane pairs are walked by GROUPS g = max(i, j): group g needs the
+        // planes g of both operands and nothing newer, so the matrix instructions start behind the first four reads and the
+        // other 24 reads return under them (all A planes first, then B plane by plane: 650 cycles of every k-step exposed).
+        int4_t Af[2][kS], Bf[2][kS];
+#pragma unroll
+        for (int p = 0; p < kS; ++p) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) Af[q][p] = bufA[cur][((2 * cu + q) * kS + p) * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) Bf[t][p] = bufB[curB][((2 * fg + t) * kS + p) * 64 + lane];
+        }
+#define LN_PAIR(j, i)                                                                                           \
+    do {                                                                                                        \
+        if ((j) + (i) < kS) {                                                                                   \
+            _Pragma("unroll") for (int q = 0; q < 2; ++q) _Pragma("unroll") for (int t = 0; t < 2; ++t)         \
+                acc[(j) + (i)][q][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Af[q][j], Bf[t][i], acc[(j) + (i)][q][t], 0, 0, 0); \
+        }                                                                                                       \
+    } while (0)
+#pragma unroll
+        for (int g = 0; g < kS; ++g) {
+#pragma unroll
+            for (int o = 0; o < g; ++o) {                   // (o, g) and (g, o): A plane o with B plane g, A plane g with B plane o
+                LN_PAIR(o, g);
+                LN_PAIR(g, o);
+            }
+            LN_PAIR(g, g);
+        }
+#undef LN_PAIR
+        if ((gs + 1) % nk != 0) continue;                   // the tile's last k-step: its epilogue, then the next tile from zero
+        epilogue((fblock0 + gs / nk) * 4);
+#pragma unroll
+        for (int d = 0; d < kS; ++d)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[d][q][t] = int4_t{0, 0, 0, 0};
     }
     LN_BLOCK_T1;
 }
@@ -516,10 +533,16 @@ int emit_full_i8_device(lnasr_ctx* ctx, const double* obs, long F, double* b) {
         LN_LAUNCH(ctx, "full_slice_features", full_slice_features_kernel, dim3((unsigned)nftiles), dim3(16 * nk * 4), shm,
                   obs + (size_t)f0 * D, (const double*)md.centre.as<double>(), (const double*)md.fi8_pow2gl.as<double>(), fq, fsc,
                   Fc, D, nk);
-        const long grid = 8L * spx * fblocks;
+        // a block walks `tiles_pb` consecutive frame blocks of its slab: about four blocks per CU in all
+        const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+        long tiles_pb = (long)slabs * fblocks / (4L * cus);
+        if (tiles_pb < 1) tiles_pb = 1;
+        if (tiles_pb > 64) tiles_pb = 64;
+        const long walks = (fblocks + tiles_pb - 1) / tiles_pb;
+        const long grid = 8L * spx * walks;
         LN_LAUNCH(ctx, "emit_full_i8", emit_full_i8, dim3((unsigned)grid), dim3(512), 0, (const int4_t*)fq, (const double*)fsc,
                   (const int4_t*)md.fi8_wq.as<int4_t>(), (const double*)md.fi8_const.as<double>(),
-                  (const int*)md.fi8_h.as<int>(), b + (size_t)f0 * Nv, Fc, Nv, nk, nftiles, slabs, spx);
+                  (const int*)md.fi8_h.as<int>(), b + (size_t)f0 * Nv, Fc, Nv, nk, nftiles, slabs, spx, fblocks, (int)tiles_pb);
     }
     return 0;
 }

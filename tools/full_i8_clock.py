@@ -36,7 +36,7 @@ for _ in range(3):
     ctx.gmm_logprob(d_obs, b_out=b)
 ctx.sync()
 raw = _ffi.lib()
-nblocks = 8000
+nblocks = 16384                                        # (every slot; the blocks that ran have a later end than start)
 tbuf = (C.c_ulonglong * (2 * 16384))()
 cbuf = (C.c_ulonglong * 16384)()
 assert raw.lnasr_dbg_block_times_full_i8(tbuf) == 0 and raw.lnasr_dbg_block_times_full_i8_cycles(cbuf) == 0
@@ -45,5 +45,6 @@ cyc = np.array(cbuf[:nblocks], dtype=np.float64)
 ok = t[:, 1] > t[:, 0]
 life = (t[:, 1] - t[:, 0])[ok]
 ghz = cyc[ok] / life / 1e3
+ksteps = 250 * 32 * 13 / max(1, ok.sum())              # 8000 tiles of 13 k-steps, shared by the blocks that ran
 print("blocks %d  span %.3f ms  life mean %.2f us (min %.2f max %.2f)  clock mean %.3f GHz (min %.3f max %.3f)  cycles per block %.0f = %.0f per k-step" % (
-    ok.sum(), (t[ok, 1].max() - t[ok, 0].min()) / 1e3, life.mean(), life.min(), life.max(), ghz.mean(), ghz.min(), ghz.max(), cyc[ok].mean(), cyc[ok].mean() / 13))
+    ok.sum(), (t[ok, 1].max() - t[ok, 0].min()) / 1e3, life.mean(), life.min(), life.max(), ghz.mean(), ghz.min(), ghz.max(), cyc[ok].mean(), cyc[ok].mean() / ksteps))
