@@ -152,3 +152,48 @@ def test_full_range_gate(floor, accepted, ctx):
         assert out["default"]["bank"] == accepted and out["default"]["i8"] == accepted, tag
     if accepted:
         assert out["i8"]["rel"] <= 1e-12, tag
+
+
+import os
+_lo, _hi = (int(x) for x in os.environ.get("LNASR_TEST_SEEDS", "0:16").split(":"))
+
+
+@pytest.mark.parametrize("seed", range(_lo, _lo + max(1, (_hi - _lo) * 12 // 16)))
+def test_full_integer_bank_over_seeded_shapes(seed, ctx):
+    """Seeded shapes (N 2 .. 40, M = 16 / 32 / 10 / 12, D 2 .. 39: one to thirteen k-steps, padded and virtual states, slabs
+    that leave XCDs idle), covariances = a scaled scatter of a few frames + a floor (conditioning 2 .. ~1000), a common
+    offset, frame counts that end in ragged tiles: the forced integer bank against the fp64 kernel to 1e-12 max(1, |b|)
+    whenever the model is admitted, decode paths identical."""
+    rng = np.random.default_rng(50000 + seed)
+    N = int(rng.integers(2, 41))
+    M = int(rng.choice([16, 16, 32, 10, 12]))
+    D = int(rng.integers(2, 40))
+    U, T = int(rng.integers(1, 3)), int(rng.integers(1, 200))
+    floor = float(rng.choice([1.0, 0.3, 0.05, 0.01]))
+    npts = int(rng.integers(max(2, D // 2), 2 * D + 2))
+    offset = float(rng.choice([0.0, 0.0, 10.0]))
+    mu = offset + rng.uniform(-0.5, 0.5, (N, M, D))
+    pts = rng.standard_normal((N, M, npts, D))
+    si = np.einsum("nmpd,nmpe->nmde", pts, pts) / npts + floor * np.eye(D)
+    w = rng.random((N, M)) + 1e-3
+    w = np.log(w / w.sum(1, keepdims=True))
+    a = rng.random((N, N)) + 1e-3
+    mdl = {"A": np.log(a / a.sum(1, keepdims=True)), "pi": np.log(np.full(N, 1.0 / N)), "w": w, "mu": mu, "si": si}
+    comp = rng.integers(0, N * M, (U, T))
+    L = np.linalg.cholesky(si.reshape(-1, D, D))
+    obs = mu.reshape(-1, D)[comp] + np.einsum("utde,ute->utd", L[comp], rng.standard_normal((U, T, D)))
+    out = {}
+    for name, env in (("i8", dict(LNASR_I8_MIN_FRAMES=0)), ("f64", dict(LNASR_NO_I8EMIT=1))):
+        with env_switch(**env):
+            _upload(ctx, mdl)
+            rho, bank = ctx.model_range()
+            kappa, direct = ctx.model_conditioning()
+            b, names = _kernels_of(ctx, lambda: ctx.gmm_logprob(obs))
+            out[name] = (b, names, np.asarray(ctx.decode(obs)), rho, bank, direct)
+    tag = "seed=%d N=%d M=%d D=%d U=%d T=%d floor=%g npts=%d offset=%g rho=%.0f bank=%d direct=%d i8=%d" % (
+        seed, N, M, D, U, T, floor, npts, offset, out["i8"][3], out["i8"][4], out["i8"][5], "emit_full_i8" in out["i8"][1])
+    bi, bf = out["i8"][0], out["f64"][0]
+    assert float((np.abs(bi - bf) / np.maximum(1.0, np.abs(bf))).max()) <= 1e-12, tag
+    assert np.array_equal(out["i8"][2], out["f64"][2]), tag
+    if tuned() and out["i8"][4] and not out["i8"][5] and M in (16, 32):
+        assert "emit_full_i8" in out["i8"][1], tag
