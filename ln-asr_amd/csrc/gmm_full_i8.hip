@@ -18,11 +18,15 @@
 //     seven lane-linear 1 KB pieces that go HBM / L2 -> LDS by global_load_lds_dwordx4 (double buffered: the pieces of
 //     k-step s + 1 are in flight under the 112 matrix instructions of step s) and LDS -> registers by one ds_read_b128 each;
 //   * blockIdx is decoded so that an XCD owns a fixed group of component slabs (its W planes, 1.5 MB, stay in its L2) and
-//     the 32 blocks resident on it share 8 frame blocks' feature planes;
+//     the 32 blocks resident on it share 8 frame blocks' feature planes; W planes arrive one k-step ahead, feature planes
+//     (HBM / MALL for the first block that asks) two steps ahead in a third buffer: counted vmcnt, raw s_barrier;
 //   * a block walks several consecutive frame blocks of its slab (about four blocks per CU in all): the tables are built once,
 //     and while the consumers run a tile's epilogue the loaders are already two steps into the next tile (-5 % at 131,072 frames);
 //   * epilogue once per tile: seven conversions and six FMAs per value (the pair join of gmm_i8.hip would overflow at
 //     K = 832), 2^(h_c + e_f), the constant, the 16-way log-sum-exp of gmm_i8.hip, b straight to global memory.
+// Measured (N M = 2048, D = 39; tools/full_i8_try.py, full_i8_clock.py): 0.65-0.70 ms per 16,000 frames against 0.99 for
+// emit_full_mfma, 4.78 against 7.05 per 131,072; in-kernel clock 1.73 GHz -- the integer matrix unit is power-limited on these
+// boxes at about half its nominal rate, which is what separates this from the 0.43 ms its instruction counts promise.
 // b only (bm: the fp64 kernel).  Kernels: full_coef / full_row_scale / full_comp_scale / full_pack_planes (once per model),
 // full_slice_features (per batch, in chunks of kFullChunkFrames frames: 5.8 KB of planes per frame), emit_full_i8.
 #include <cstdio>
@@ -424,7 +428,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");     // the LDS reads below stay below the barrier
         // Fragments are read in the order of use and the 28 plane pairs are walked by GROUPS g = max(i, j): group g needs the
         // planes g of both operands and nothing newer, so the matrix instructions start behind the first four reads and the
-        // other 24 reads return under them (all A planes first, then B plane by plane: 650 cycles of every k-step exposed).
+        // other 24 reads return under them.
         int4_t Af[2][kS], Bf[2][kS];
 #pragma unroll
         for (int p = 0; p < kS; ++p) {
