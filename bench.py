@@ -26,7 +26,8 @@ CPU oracle and compares the paths bit for bit; a mismatch, a failed communicator
 rehearsal gather means NOTHING is timed: rank 0 prints the line with "value": null and the reason,
 and every rank exits non-zero.
 
-Besides the headline the line carries
+Besides the headline the line carries (inside `roofline`: `traffic` with its provenance, `shader_clock` = the clock the chip is
+left at behind the emission kernel, behind an fp64 kernel and idle)
   end_to_end   host numpy observations in -> host paths out (the reference's decode(), hmm.py:276-283,
                takes host arrays): page-locked buffers through the chunked upload pipeline, and the
                same from pageable memory through the pinned staging ring; PCIe-inclusive, never `value`;
@@ -289,7 +290,7 @@ def _pmc_traffic(kernel):
         if "source_sha16" not in ent:
             return None, "profiles/pmc_traffic.json entry predates source tracking: not used"
         h = hashlib.sha256()
-        for f in (os.path.basename(ent["source"]), "devmath.h", "common.h"):
+        for f in (os.path.basename(ent["source"]), "devmath.h"):
             with open(os.path.join(REPO, "ln-asr_amd", "csrc", f), "rb") as fp:
                 h.update(fp.read())
         if h.hexdigest()[:16] != ent["source_sha16"]:
@@ -690,6 +691,23 @@ def main():
             rc = 1
 
     step_s = elapsed / args.steps
+    # the shader clock the chip is left at (lnasr_debug_clock: a 20 us one-wave probe directly behind the kernel): the integer
+    # matrix kernel is power-limited, and what follows it -- the Viterbi kernel, 1.3 ms -- inherits its clock
+    clocks = None
+    try:
+        b_tmp = ctx.empty((U, T, N_STATES), np.float64)
+        ctx.gmm_logprob(d_obs, b_out=b_tmp)
+        ck_emit = ctx.debug_clock()
+        ctx.forward(b_tmp, want_alpha=False, want_loglik=True)
+        ck_f64 = ctx.debug_clock()
+        ctx.device_sync()
+        time.sleep(0.05)
+        clocks = {"behind_the_emission_kernel_ghz": ck_emit, "behind_an_fp64_vector_kernel_ghz": ck_f64,
+                  "after_50_ms_idle_ghz": ctx.debug_clock(),
+                  "what": "lnasr_debug_clock directly behind gmm_logprob (the dominant kernel) / forward on the same batch / idle"}
+        b_tmp.free()
+    except Exception as e:                                                # noqa: BLE001 -- a diagnostic, never the headline
+        clocks = {"error": "%s: %s" % (type(e).__name__, e)}
     e2e = bw = None
     if not args.no_extras:
         note("end-to-end (host in, host out)")
@@ -776,7 +794,7 @@ def main():
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_TFLOPS,
                          "traffic": _pmc_traffic(name)[0], "traffic_source": _pmc_traffic(name)[1],
                          "algorithmic_flop_per_frame": flop, "frames_per_launch": frames_launch,
-                         "avg_launch_ms": avg_s * 1e3, **extra,
+                         "avg_launch_ms": avg_s * 1e3, "shader_clock": clocks, **extra,
                          "whole_step": {"flop_per_frame": FLOP_DECODE,
                                         "achieved_tflops": FLOP_DECODE * n_ranks_rccl * U * T / step_s / 1e12,
                                         "frac_of_fp64_peak": FLOP_DECODE * U * T / step_s / 1e12 / PEAK_FP64_TFLOPS,

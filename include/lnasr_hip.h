@@ -105,6 +105,11 @@ int lnasr_debug_require_device_ptr(const void* p);
  * the parity suite uses it to pin that emissions whose size jumps from frame to frame -- data a model does not fit -- stay
  * on the fast path (tests/test_gpu_trellis.py). */
 int lnasr_debug_fallback_columns(lnasr_ctx* ctx, unsigned* count);
+/* Diagnostic: the shader clock (GHz) directly behind whatever the context's stream ran last -- a one-wave kernel counts
+ * shader-clock cycles over 20 us of the constant 100 MHz counter.  bench.py reports it behind the integer emission kernel,
+ * behind an fp64 kernel and after idling: the integer matrix kernels are power-limited and leave the chip at a lower
+ * clock.  Nothing in the reference corresponds to it. */
+int lnasr_debug_clock(lnasr_ctx* ctx, double* ghz);
 
 /* 128-bit fingerprint of a HOST buffer (no context, no device).  The reference's methods re-read self.A / self.mu /
  * self.si on every call (hmm.py:82-99, gmmhmm.py:58-67): the mirror classes fingerprint the parameters per call and

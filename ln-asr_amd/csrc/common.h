@@ -181,6 +181,7 @@ struct lnasr_ctx {
     lnasr::DevBuf ws_lvl, ws_lvl2;                         // emission-row levels of the N > 256 forward / backward kernels (bign.hip)
     lnasr::DevBuf ws_fs;                                   // digit planes of the features (gmm_i8.hip)
     lnasr::DevBuf ws_btb;                                  // byte back-pointer rows of the small-batch back-trace (backtrace.hip)
+    lnasr::DevBuf ws_clock;                                // two words of the clock probe (lnasr_debug_clock)
     // non-finite data (nanfix.hip): a device word the hot kernels set to the running call's epoch when they meet a NaN or
     // an infinity, and the per-utterance slots of the scan that follows
     lnasr::DevBuf nan_flag, nan_slots;

@@ -303,7 +303,7 @@ void lnasr_ctx_destroy(lnasr_ctx* ctx) {
     ctx->model.release();
     DevBuf* all[] = {&ctx->ws_in, &ctx->ws_in2, &ctx->ws_in3, &ctx->ws_in4, &ctx->ws_in5, &ctx->ws_out, &ctx->ws_out2,
                      &ctx->ws_out3, &ctx->ws_b, &ctx->ws_bm, &ctx->ws_v, &ctx->ws_alpha, &ctx->ws_beta,
-                     &ctx->ws_misc, &ctx->ws_misc2, &ctx->ws_lens, &ctx->ws_stats, &ctx->ws_p, &ctx->ws_q, &ctx->ws_raw, &ctx->ws_w1, &ctx->ws_w2, &ctx->ws_w3, &ctx->ws_pad, &ctx->ws_bp, &ctx->ws_btb, &ctx->ws_fs, &ctx->ws_lvl, &ctx->ws_lvl2, &ctx->mfcc_const, &ctx->nan_flag, &ctx->nan_slots};
+                     &ctx->ws_misc, &ctx->ws_misc2, &ctx->ws_lens, &ctx->ws_stats, &ctx->ws_p, &ctx->ws_q, &ctx->ws_raw, &ctx->ws_w1, &ctx->ws_w2, &ctx->ws_w3, &ctx->ws_pad, &ctx->ws_bp, &ctx->ws_btb, &ctx->ws_clock, &ctx->ws_fs, &ctx->ws_lvl, &ctx->ws_lvl2, &ctx->mfcc_const, &ctx->nan_flag, &ctx->nan_slots};
     for (DevBuf* b : all) b->release();
     for (auto& r : ctx->prof_recs) {
         (void)hipEventDestroy(r.e0);
@@ -355,6 +355,35 @@ int lnasr_debug_fallback_columns(lnasr_ctx* ctx, unsigned* out) {
     LN_HIP(hipStreamSynchronize(ctx->stream2));
     LN_HIP(hipMemcpy(out, word, 4, hipMemcpyDeviceToHost));
     LN_HIP(hipMemset(word, 0, 4));
+    return 0;
+}
+
+// Shader clock right now, as the GPU counts it: one wave spins for 20 us of the constant 100 MHz counter (s_memrealtime) and
+// reports how many shader-clock cycles (s_memtime) went by.  Enqueued on the context's stream, so it runs directly behind
+// whatever was launched last: the clock a kernel LEAVES the chip at (the power-limited integer kernels leave it
+// lower than the fp64 ones).
+__global__ void clock_probe_kernel(unsigned long long* out) {
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < 2000ull) r1 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) {
+        out[0] = c1 - c0;
+        out[1] = r1 - r0;
+    }
+}
+
+int lnasr_debug_clock(lnasr_ctx* ctx, double* ghz) {
+    LN_ENTER(ctx);
+    LN_REQUIRE(ctx && ghz, "null argument");
+    LN_TRY(ctx->ws_clock.reserve(64));
+    unsigned long long* d = ctx->ws_clock.as<unsigned long long>();
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, ctx->stream, d);
+    LN_HIP(hipGetLastError());
+    unsigned long long h[2] = {0, 0};
+    LN_HIP(hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, ctx->stream));
+    LN_HIP(hipStreamSynchronize(ctx->stream));
+    *ghz = h[1] ? (double)h[0] / (double)h[1] * 0.1 : 0.0;
     return 0;
 }
 

@@ -46,6 +46,7 @@ SIGNATURES = {
     "lnasr_hash128_end": [_vp, _P(C.c_uint64)],
     "lnasr_debug_require_device_ptr": [_vp],
     "lnasr_debug_fallback_columns": [_vp, _P(C.c_uint)],
+    "lnasr_debug_clock": [_vp, _P(_dbl)],
     "lnasr_dev_alloc": [_vp, _sz, _P(_vp)],
     "lnasr_dev_free": [_vp, _vp],
     "lnasr_memcpy_h2d": [_vp, _vp, _vp, _sz],
@@ -349,6 +350,12 @@ class Context:
         n = C.c_uint(0)
         check(lib().lnasr_debug_fallback_columns(self.handle, C.byref(n)))
         return n.value
+
+    def debug_clock(self):
+        """Shader clock (GHz) directly behind whatever this context's stream ran last (lnasr_debug_clock)."""
+        g = C.c_double(0)
+        check(lib().lnasr_debug_clock(self.handle, C.byref(g)))
+        return g.value
 
     def prof_enable(self, on=True):
         check(lib().lnasr_prof_enable(self.handle, 1 if on else 0))

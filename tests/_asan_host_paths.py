@@ -128,7 +128,7 @@ calls = {
     "lnasr_pad_rows": (null, buf, off, 1, 2, 8, buf), "lnasr_comm_init": (null, buf, 0, 1),
     "lnasr_comm_info": (null, C.byref(ci), C.byref(ci)), "lnasr_allgather_u32": (null, u32, 4, u32),
     "lnasr_allgather_paths": (null, u32, 4, 8, u32), "lnasr_allreduce_f64": (null, buf, 4),
-    "lnasr_debug_fallback_columns": (null, u32),
+    "lnasr_debug_fallback_columns": (null, u32), "lnasr_debug_clock": (null, C.byref(dbl)),
 }
 no_ctx = {"lnasr_abi_version", "lnasr_last_error", "lnasr_device_count", "lnasr_ctx_create", "lnasr_ctx_destroy",
           "lnasr_num_frames", "lnasr_reload_switches", "lnasr_comm_unique_id", "lnasr_comm_destroy", "lnasr_hash128",

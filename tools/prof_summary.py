@@ -56,7 +56,7 @@ if len(sys.argv) >= 5:
     csrc = os.path.join(REPO, "ln-asr_amd", "csrc")
     for name, ent in traffic.items():
         h = hashlib.sha256()
-        for f in (src_of[name], "devmath.h", "common.h"):
+        for f in (src_of[name], "devmath.h"):                 # the kernel's source and the device math it inlines
             h.update(open(os.path.join(csrc, f), "rb").read())
         ent.update(tag=tag, date=datetime.date.today().isoformat(), source="ln-asr_amd/csrc/" + src_of[name],
                    source_sha16=h.hexdigest()[:16])
