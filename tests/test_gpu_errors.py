@@ -103,3 +103,13 @@ def test_launch_helpers_get_device_pointers_only(synth):
         g32 = GMMHMM(5, 3, 2, mdl["A"], mdl["pi"], mdl["w"], mdl["mu"], mdl["si"], precision=np.float32)
         g32.train(o, iters=2, verbose=False)
         assert g.decode(o).shape == (30,)
+
+
+def test_clock_probe_reads_a_plausible_shader_clock():
+    """lnasr_debug_clock: a one-wave kernel counts shader-clock cycles over 20 us of the 100 MHz counter, directly behind whatever
+    the stream ran last.  Any MI355X clock lies between 0.3 and 3 GHz; two probes in a row agree to a few per cent."""
+    from lnasr import _ffi
+    ctx = _ffi.default_ctx()
+    a, b = ctx.debug_clock(), ctx.debug_clock()
+    assert 0.3 < a < 3.0 and 0.3 < b < 3.0, (a, b)
+    assert abs(a - b) < 0.3 * max(a, b), (a, b)
